@@ -1,0 +1,236 @@
+"""CPU ORACLE — TEST INFRASTRUCTURE ONLY.
+
+A functional, pure-torch fp32 restatement of the reference's VAE training-step arithmetic
+(Strong-AI-Lab/ct-vae).  It exists to *check* the HIP path; nothing under ``ct-vae_amd/`` may
+import it.  Allowed importers: ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py``.
+
+Parity status: PINNED.  ``tests/golden/*.npz`` were produced by importing the reference's own
+unmodified ``models/{types_,base,vanilla_vae,vq_vae,mcq_vae}.py`` in the build container
+(``oracle/gen_golden.py``) and ``tests/test_oracle_golden.py`` checks every function below against
+them.  Exception: ``CausalTransition`` (ct_mcq_vae.py:42-333) depends on torch_geometric 2.2.0,
+which is absent -> that part is restated in ``oracle/causal_cpu.py`` and is "parity unpinned".
+
+Everything here works on an ordered ``state_dict``-shaped mapping ``sd`` whose keys and PyTorch
+layouts equal the reference's (Conv2d [Co,Ci,kh,kw], ConvTranspose2d [Ci,Co,kh,kw], Linear
+[out,in]) so that the same tensors can be loaded into the reference modules.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+LEAKY = 0.01          # nn.LeakyReLU() default slope, every site (vanilla_vae.py:31, mcq_vae.py:172 ...)
+BN_EPS = 1e-5         # nn.BatchNorm2d defaults (vanilla_vae.py:30)
+BN_MOMENTUM = 0.1
+
+
+# --------------------------------------------------------------------------------------------
+# VanillaVAE  (models/vanilla_vae.py:8-173)
+# --------------------------------------------------------------------------------------------
+def _bn_lrelu(sd, pfx, y, training, new_buffers):
+    """BatchNorm2d (train: biased batch var; running stats momentum .1 with unbiased var) + LeakyReLU."""
+    rm = sd[pfx + ".running_mean"].detach().clone()
+    rv = sd[pfx + ".running_var"].detach().clone()
+    out = F.batch_norm(y, rm, rv, sd[pfx + ".weight"], sd[pfx + ".bias"], training, BN_MOMENTUM, BN_EPS)
+    if training and new_buffers is not None:
+        new_buffers[pfx + ".running_mean"] = rm
+        new_buffers[pfx + ".running_var"] = rv
+        new_buffers[pfx + ".num_batches_tracked"] = sd[pfx + ".num_batches_tracked"] + 1
+    return F.leaky_relu(out, LEAKY)
+
+
+def vanilla_encode(sd, x, training=True, new_buffers=None, n_layers=5):
+    """vanilla_vae.py:77-92: 5 x [Conv k3 s2 p1 -> BN -> LeakyReLU], NCHW flatten, two Linear heads."""
+    h = x
+    for i in range(n_layers):
+        h = F.conv2d(h, sd[f"encoder.{i}.0.weight"], sd[f"encoder.{i}.0.bias"], stride=2, padding=1)
+        h = _bn_lrelu(sd, f"encoder.{i}.1", h, training, new_buffers)
+    flat = torch.flatten(h, start_dim=1)
+    mu = F.linear(flat, sd["fc_mu.weight"], sd["fc_mu.bias"])
+    log_var = F.linear(flat, sd["fc_var.weight"], sd["fc_var.bias"])
+    return mu, log_var
+
+
+def vanilla_reparameterize(mu, log_var, eps):
+    """vanilla_vae.py:107-117 with the noise injected."""
+    return eps * torch.exp(0.5 * log_var) + mu
+
+
+def vanilla_decode(sd, z, training=True, new_buffers=None, n_layers=4):
+    """vanilla_vae.py:94-105: Linear -> view(-1,512,2,2) -> 4 x [ConvT k3 s2 p1 op1 -> BN -> LReLU] -> final_layer."""
+    h = F.linear(z, sd["decoder_input.weight"], sd["decoder_input.bias"]).view(-1, 512, 2, 2)
+    for i in range(n_layers):
+        h = F.conv_transpose2d(h, sd[f"decoder.{i}.0.weight"], sd[f"decoder.{i}.0.bias"],
+                               stride=2, padding=1, output_padding=1)
+        h = _bn_lrelu(sd, f"decoder.{i}.1", h, training, new_buffers)
+    h = F.conv_transpose2d(h, sd["final_layer.0.weight"], sd["final_layer.0.bias"],
+                           stride=2, padding=1, output_padding=1)
+    h = _bn_lrelu(sd, "final_layer.1", h, training, new_buffers)
+    h = F.conv2d(h, sd["final_layer.3.weight"], sd["final_layer.3.bias"], padding=1)
+    return torch.tanh(h)
+
+
+def vanilla_forward(sd, x, eps, training=True, new_buffers=None):
+    """vanilla_vae.py:119-122 -> [recons, input, mu, log_var]."""
+    mu, log_var = vanilla_encode(sd, x, training, new_buffers)
+    z = vanilla_reparameterize(mu, log_var, eps)
+    return [vanilla_decode(sd, z, training, new_buffers), x, mu, log_var]
+
+
+def vanilla_loss(recons, x, mu, log_var, M_N):
+    """vanilla_vae.py:124-146 (note 'KLD' is returned with flipped sign)."""
+    recons_loss = F.mse_loss(recons, x)
+    kld = torch.mean(-0.5 * torch.sum(1 + log_var - mu ** 2 - log_var.exp(), dim=1), dim=0)
+    return {"loss": recons_loss + M_N * kld, "Reconstruction_Loss": recons_loss.detach(), "KLD": -kld.detach()}
+
+
+# --------------------------------------------------------------------------------------------
+# Vector quantisers  (models/mcq_vae.py:7-137)
+# --------------------------------------------------------------------------------------------
+def vq_compute_inds(codebook, latents):
+    """mcq_vae.py:26-39: expanded-form distances, first-min argmin.  latents [B,Dc,H,W] -> [B,H,W] i64."""
+    lat = latents.permute(0, 2, 3, 1).contiguous()
+    flat = lat.view(-1, codebook.shape[1])
+    dist = torch.sum(flat ** 2, dim=1, keepdim=True) + torch.sum(codebook ** 2, dim=1) \
+        - 2 * torch.matmul(flat, codebook.t())
+    return torch.argmin(dist, dim=1).view(lat.shape[:3])
+
+
+def vq_compute_latents(codebook, latents, inds, beta):
+    """mcq_vae.py:41-64: row gather, beta*commitment + embedding loss, straight-through x + (q - x)."""
+    lat = latents.permute(0, 2, 3, 1).contiguous()
+    q = codebook[inds.reshape(-1)].view(lat.shape)
+    commitment = F.mse_loss(q.detach(), lat)
+    embedding = F.mse_loss(q, lat.detach())
+    vq_loss = commitment * beta + embedding
+    q = lat + (q - lat).detach()
+    return q.permute(0, 3, 1, 2).contiguous(), vq_loss
+
+
+def mcq_compute_inds(sd, latents, codebooks, pfx="vq_layer"):
+    """mcq_vae.py:100-110, including the slice-offset quirk latents[:, i:i+D/C]."""
+    dc = latents.shape[1] // codebooks
+    out = [vq_compute_inds(sd[f"{pfx}.quantizers.{i}.embedding.weight"], latents[:, i:i + dc]) for i in range(codebooks)]
+    return torch.stack(out, 1)
+
+
+def mcq_compute_latents(sd, latents, inds, codebooks, beta, pfx="vq_layer"):
+    """mcq_vae.py:112-127."""
+    dc = latents.shape[1] // codebooks
+    qs, losses = [], []
+    for i in range(codebooks):
+        q, l = vq_compute_latents(sd[f"{pfx}.quantizers.{i}.embedding.weight"], latents[:, i:i + dc], inds[:, i], beta)
+        qs.append(q)
+        losses.append(l)
+    return torch.cat(qs, 1), sum(losses)
+
+
+# --------------------------------------------------------------------------------------------
+# MCQVAE and the conv/VQ path of CTMCQVAE  (models/mcq_vae.py:142-317, ct_mcq_vae.py:365-469)
+# --------------------------------------------------------------------------------------------
+def _res(sd, pfx, x):
+    """vq_vae.py:57-70: x + Conv1x1(ReLU(Conv3x3(x))), both bias-free."""
+    h = F.relu(F.conv2d(x, sd[pfx + ".resblock.0.weight"], None, padding=1))
+    return x + F.conv2d(h, sd[pfx + ".resblock.2.weight"], None)
+
+
+def mcq_encode(sd, x, n_down=3):
+    """mcq_vae.py:166-193."""
+    h = x
+    for i in range(n_down):
+        h = F.leaky_relu(F.conv2d(h, sd[f"encoder.{i}.0.weight"], sd[f"encoder.{i}.0.bias"], stride=2, padding=1), LEAKY)
+    h = F.leaky_relu(F.conv2d(h, sd[f"encoder.{n_down}.0.weight"], sd[f"encoder.{n_down}.0.bias"], padding=1), LEAKY)
+    for j in range(6):
+        h = _res(sd, f"encoder.{n_down + 1 + j}", h)
+    h = F.leaky_relu(h, LEAKY)
+    k = n_down + 8
+    return F.leaky_relu(F.conv2d(h, sd[f"encoder.{k}.0.weight"], sd[f"encoder.{k}.0.bias"]), LEAKY)
+
+
+def mcq_decode(sd, q, n_down=3):
+    """mcq_vae.py:201-239."""
+    h = F.leaky_relu(F.conv2d(q, sd["decoder.0.0.weight"], sd["decoder.0.0.bias"], padding=1), LEAKY)
+    for j in range(6):
+        h = _res(sd, f"decoder.{1 + j}", h)
+    h = F.leaky_relu(h, LEAKY)
+    for i in range(n_down - 1):
+        h = F.leaky_relu(F.conv_transpose2d(h, sd[f"decoder.{8 + i}.0.weight"], sd[f"decoder.{8 + i}.0.bias"],
+                                            stride=2, padding=1), LEAKY)
+    k = 8 + n_down - 1
+    return torch.tanh(F.conv_transpose2d(h, sd[f"decoder.{k}.0.weight"], sd[f"decoder.{k}.0.bias"], stride=2, padding=1))
+
+
+def mcq_forward(sd, x, codebooks, beta, n_down=3, return_aux=False):
+    """mcq_vae.py:262-265 -> [recons, input, vq_loss]."""
+    lat = mcq_encode(sd, x, n_down)
+    inds = mcq_compute_inds(sd, lat, codebooks)
+    q, vq_loss = mcq_compute_latents(sd, lat, inds, codebooks, beta)
+    out = [mcq_decode(sd, q, n_down), x, vq_loss]
+    return (out, {"latents": lat, "inds": inds, "quantized": q}) if return_aux else out
+
+
+def mcq_loss(recons, x, vq_loss):
+    """mcq_vae.py:267-284 (values are NOT detached)."""
+    recons_loss = F.mse_loss(recons, x)
+    return {"loss": recons_loss + vq_loss, "Reconstruction_Loss": recons_loss, "VQ_Loss": vq_loss}
+
+
+def ct_forward_conv_path(sd, x, y, codebooks, beta, n_down=3):
+    """Conv+VQ+decoder part of CTMCQVAE.forward_action (ct_mcq_vae.py:525-546) with the causal layer
+    replaced by identity on the indices (== skip_transition=True data flow): encoder on x (with grad),
+    encoder on y (indices only, no grad path), decoder once, recon compared with y, vq_loss forced 0."""
+    lat = mcq_encode(sd, x, n_down)
+    inds = mcq_compute_inds(sd, lat, codebooks)
+    with torch.no_grad():
+        inds_y = mcq_compute_inds(sd, mcq_encode(sd, y, n_down), codebooks)
+    q, _ = mcq_compute_latents(sd, lat, inds, codebooks, beta)
+    return [mcq_decode(sd, q, n_down), y, torch.tensor(0.0)], {"inds": inds, "inds_y": inds_y}
+
+
+# --------------------------------------------------------------------------------------------
+# step helpers used by tests / the CPU baseline
+# --------------------------------------------------------------------------------------------
+def leafify(sd):
+    """Detached float leaves with requires_grad (integer buffers are passed through)."""
+    out = OrderedDict()
+    for k, v in sd.items():
+        if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            out[k] = v.detach().clone().requires_grad_(True)
+        else:
+            out[k] = v.detach().clone()
+    return out
+
+
+def vanilla_step(sd, x, eps, M_N):
+    """forward + loss + backward.  Returns (loss dict, grads dict, new BN buffers, outputs)."""
+    sd = leafify(sd)
+    nb = OrderedDict()
+    recons, _, mu, log_var = vanilla_forward(sd, x, eps, True, nb)
+    losses = vanilla_loss(recons, x, mu, log_var, M_N)
+    losses["loss"].backward()
+    grads = OrderedDict((k, v.grad) for k, v in sd.items() if v.requires_grad)
+    return losses, grads, nb, {"recons": recons.detach(), "mu": mu.detach(), "log_var": log_var.detach()}
+
+
+def mcq_step(sd, x, codebooks, beta, n_down=3):
+    sd = leafify(sd)
+    (recons, _, vq_loss), aux = mcq_forward(sd, x, codebooks, beta, n_down, return_aux=True)
+    losses = mcq_loss(recons, x, vq_loss)
+    losses["loss"].backward()
+    grads = OrderedDict((k, (v.grad if v.grad is not None else torch.zeros_like(v))) for k, v in sd.items() if v.requires_grad)
+    aux = {k: v.detach() for k, v in aux.items()}
+    aux["recons"] = recons.detach()
+    return {k: v.detach() for k, v in losses.items()}, grads, aux
+
+
+def adam_steps(params, grads_fn, n_steps, lr, weight_decay=0.0, gamma=None):
+    """experiment.py:152-187: optim.Adam(lr, weight_decay) default betas/eps; grads_fn(params)->grads."""
+    ps = [p.detach().clone().requires_grad_(True) for p in params]
+    opt = torch.optim.Adam(ps, lr=lr, weight_decay=weight_decay)
+    for _ in range(n_steps):
+        gs = grads_fn(ps)
+        for p, g in zip(ps, gs):
+            p.grad = g.clone()
+        opt.step()
+    return [p.detach() for p in ps]

@@ -1,0 +1,82 @@
+"""Shared test helpers: model configs, state construction, checksum comparison."""
+import numpy as np
+import torch
+
+from ctvae_amd import filler
+
+MCQ_CFG = dict(in_channels=3, embedding_dim=128, hidden_dims=[64, 128, 256], num_embeddings=64, img_size=64,
+               codebooks=4, beta=0.25)
+CT_CONV_CFG = dict(in_channels=3, embedding_dim=128, hidden_dims=[64, 128, 256], num_embeddings=64, img_size=64,
+                   codebooks=1, beta=0.1)
+SEEDS = {"vanilla": 1265, "mcq": 1320, "ctconv": 1250}
+
+
+def vanilla_specs():
+    """state_dict keys/shapes of VanillaVAE(in_channels=3, latent_dim=128) (vanilla_vae.py:11-75)."""
+    s = []
+    f32, i64 = torch.float32, torch.int64
+
+    def bn(p, c):
+        s.extend([(p + ".weight", (c,), f32), (p + ".bias", (c,), f32), (p + ".running_mean", (c,), f32),
+                  (p + ".running_var", (c,), f32), (p + ".num_batches_tracked", (), i64)])
+
+    ci = 3
+    for i, c in enumerate([32, 64, 128, 256, 512]):
+        s.extend([(f"encoder.{i}.0.weight", (c, ci, 3, 3), f32), (f"encoder.{i}.0.bias", (c,), f32)])
+        bn(f"encoder.{i}.1", c)
+        ci = c
+    s.extend([("fc_mu.weight", (128, 2048), f32), ("fc_mu.bias", (128,), f32),
+              ("fc_var.weight", (128, 2048), f32), ("fc_var.bias", (128,), f32),
+              ("decoder_input.weight", (2048, 128), f32), ("decoder_input.bias", (2048,), f32)])
+    hd = [512, 256, 128, 64, 32]
+    for i in range(4):
+        s.extend([(f"decoder.{i}.0.weight", (hd[i], hd[i + 1], 3, 3), f32), (f"decoder.{i}.0.bias", (hd[i + 1],), f32)])
+        bn(f"decoder.{i}.1", hd[i + 1])
+    s.extend([("final_layer.0.weight", (32, 32, 3, 3), f32), ("final_layer.0.bias", (32,), f32)])
+    bn("final_layer.1", 32)
+    s.extend([("final_layer.3.weight", (3, 32, 3, 3), f32), ("final_layer.3.bias", (3,), f32)])
+    return s
+
+
+def mcq_specs(cfg):
+    """state_dict keys/shapes of MCQVAE(**cfg) (mcq_vae.py:144-239)."""
+    s = []
+    f32 = torch.float32
+    hd = list(cfg["hidden_dims"])
+    n = len(hd)
+    D, K, C = cfg["embedding_dim"], cfg["num_embeddings"], cfg["codebooks"]
+    ci = cfg["in_channels"]
+    for i, c in enumerate(hd):
+        s.extend([(f"encoder.{i}.0.weight", (c, ci, 4, 4), f32), (f"encoder.{i}.0.bias", (c,), f32)])
+        ci = c
+    s.extend([(f"encoder.{n}.0.weight", (ci, ci, 3, 3), f32), (f"encoder.{n}.0.bias", (ci,), f32)])
+    for j in range(6):
+        s.extend([(f"encoder.{n + 1 + j}.resblock.0.weight", (ci, ci, 3, 3), f32),
+                  (f"encoder.{n + 1 + j}.resblock.2.weight", (ci, ci, 1, 1), f32)])
+    s.extend([(f"encoder.{n + 8}.0.weight", (D, ci, 1, 1), f32), (f"encoder.{n + 8}.0.bias", (D,), f32)])
+    for i in range(C):
+        s.append((f"vq_layer.quantizers.{i}.embedding.weight", (K, D // C), f32))
+    s.extend([("decoder.0.0.weight", (ci, D, 3, 3), f32), ("decoder.0.0.bias", (ci,), f32)])
+    for j in range(6):
+        s.extend([(f"decoder.{1 + j}.resblock.0.weight", (ci, ci, 3, 3), f32),
+                  (f"decoder.{1 + j}.resblock.2.weight", (ci, ci, 1, 1), f32)])
+    rev = hd[::-1]
+    for i in range(n - 1):
+        s.extend([(f"decoder.{8 + i}.0.weight", (rev[i], rev[i + 1], 4, 4), f32), (f"decoder.{8 + i}.0.bias", (rev[i + 1],), f32)])
+    k = 8 + n - 1
+    s.extend([(f"decoder.{k}.0.weight", (rev[-1], cfg["in_channels"], 4, 4), f32), (f"decoder.{k}.0.bias", (cfg["in_channels"],), f32)])
+    return s
+
+
+def cks(t):
+    t = t.detach().double().cpu()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()], dtype=np.float64)
+
+
+def assert_cks_close(got, want, rtol, atol, what=""):
+    """Compare (sum, abs-sum, sq-sum) triples: abs-sum and sq-sum relative, plain sum against abs-sum scale."""
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    scale = max(want[1], atol)
+    assert abs(got[0] - want[0]) <= rtol * scale + atol, f"{what}: sum {got[0]} vs {want[0]}"
+    assert abs(got[1] - want[1]) <= rtol * scale + atol, f"{what}: abs-sum {got[1]} vs {want[1]}"
+    assert abs(got[2] - want[2]) <= 2 * rtol * max(want[2], atol) + atol, f"{what}: sq-sum {got[2]} vs {want[2]}"

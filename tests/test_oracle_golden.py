@@ -1,0 +1,93 @@
+"""CPU: the oracle restatement (oracle/vae_cpu.py) against golden vectors produced by the reference's
+own modules (oracle/gen_golden.py).  This is what pins the oracle (tier rule 3)."""
+import numpy as np
+import pytest
+import torch
+
+from ctvae_amd import filler
+from oracle import vae_cpu as O
+from tests import helpers as H
+
+TOL = 1e-4      # north_star: outputs match the reference CPU path within 1e-4 fp32
+
+
+@pytest.mark.parametrize("B", [2, 4])
+def test_vanilla_forward_loss_grads(golden, B):
+    g = golden(f"vanilla_b{B}")
+    sd = filler.fill_state(H.vanilla_specs(), int(g["seed"]) + 1)
+    x, eps = filler.synthetic_batch(int(g["seed"]), B)
+    np.testing.assert_allclose(H.cks(x), g["x_cks"], rtol=1e-12)
+    np.testing.assert_allclose(H.cks(eps), g["eps_cks"], rtol=1e-12)
+    losses, grads, nb, out = O.vanilla_step(sd, x, eps, float(g["M_N"]))
+    np.testing.assert_allclose(out["mu"].numpy(), g["mu"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(out["log_var"].numpy(), g["log_var"], atol=TOL, rtol=0)
+    if B <= 2:
+        np.testing.assert_allclose(out["recons"].numpy(), g["recons"], atol=TOL, rtol=0)
+    else:
+        np.testing.assert_allclose(out["recons"][:, :, ::4, ::4].numpy(), g["recons_strided"], atol=TOL, rtol=0)
+    for k in ("loss", "Reconstruction_Loss", "KLD"):
+        assert abs(losses[k].item() - float(g["loss." + k])) <= TOL * max(1.0, abs(float(g["loss." + k])))
+    for k, gr in grads.items():
+        H.assert_cks_close(H.cks(gr), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
+    for k in ("fc_mu.bias", "encoder.0.0.weight", "final_layer.3.weight", "decoder.3.1.weight", "encoder.4.1.bias"):
+        np.testing.assert_allclose(grads[k].numpy(), g["grad." + k], atol=TOL, rtol=1e-3)
+    for k, v in nb.items():
+        np.testing.assert_allclose(v.numpy(), g["buf1." + k], atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("tag,cfg", [("mcq", H.MCQ_CFG), ("ctconv", H.CT_CONV_CFG)])
+@pytest.mark.parametrize("B", [2, 4])
+def test_mcq_forward_loss_grads(golden, tag, cfg, B):
+    g = golden(f"{tag}_b{B}")
+    sd = filler.fill_state(H.mcq_specs(cfg), int(g["seed"]) + 1)
+    x, _ = filler.synthetic_batch(int(g["seed"]), B)
+    np.testing.assert_allclose(H.cks(x), g["x_cks"], rtol=1e-12)
+    losses, grads, aux = O.mcq_step(sd, x, cfg["codebooks"], cfg["beta"], len(cfg["hidden_dims"]))
+    inds = aux["inds"].numpy()
+    bad = inds != g["inds"]
+    assert not (bad & (g["margin"] > 1e-5)).any(), "index mismatch on a row whose margin is not a near-tie (SURVEY N2)"
+    if B <= 2:
+        np.testing.assert_allclose(aux["latents"].numpy(), g["latents"], atol=TOL, rtol=0)
+        np.testing.assert_allclose(aux["recons"].numpy(), g["recons"], atol=TOL, rtol=0)
+    else:
+        np.testing.assert_allclose(aux["recons"][:, :, ::4, ::4].numpy(), g["recons_strided"], atol=TOL, rtol=0)
+    for k in ("loss", "Reconstruction_Loss", "VQ_Loss"):
+        assert abs(losses[k].item() - float(g["loss." + k])) <= TOL
+    for k, gr in grads.items():
+        H.assert_cks_close(H.cks(gr), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
+    for k in [k[5:] for k in g if k.startswith("grad.")]:
+        np.testing.assert_allclose(grads[k].numpy(), g["grad." + k], atol=TOL, rtol=1e-3)
+
+
+def test_slice_offset_quirk():
+    """mcq_vae.py:104,117: codebook i reads channels [i, i+D/C) -> channels >= C-1+D/C never get gradient."""
+    cfg = H.MCQ_CFG
+    sd = filler.fill_state(H.mcq_specs(cfg), 7)
+    lat = torch.randn(2, 128, 8, 8, generator=torch.Generator().manual_seed(3)).requires_grad_(True)
+    inds = O.mcq_compute_inds(sd, lat, 4)
+    q, loss = O.mcq_compute_latents(sd, lat, inds, 4, 0.25)
+    (q.sum() + loss).backward()
+    assert lat.grad[:, 35:].abs().max().item() == 0.0
+    assert lat.grad[:, :35].abs().min().item() > 0.0
+
+
+def test_vanilla_adam_steps(golden):
+    """experiment.py:158-160 Adam; 3 steps on one batch: the loss trajectory is the well-conditioned observable."""
+    g = golden("vanilla_b2")
+    sd = filler.fill_state(H.vanilla_specs(), int(g["seed"]) + 1)
+    x, eps = filler.synthetic_batch(int(g["seed"]), 2)
+    cur = O.leafify(sd)
+    params = [k for k, v in cur.items() if v.requires_grad]
+    opt = torch.optim.Adam([cur[k] for k in params], lr=float(g["lr"]))
+    got = []
+    for step in range(3):
+        opt.zero_grad()
+        nb = {}
+        r = O.vanilla_forward(cur, x, eps, True, nb)
+        l = O.vanilla_loss(*r, float(g["M_N"]))
+        l["loss"].backward()
+        opt.step()
+        for k, v in nb.items():
+            cur[k] = v
+        got.append(l["loss"].item())
+    np.testing.assert_allclose(got, g["adam_losses"], rtol=2e-3, atol=1e-4)
