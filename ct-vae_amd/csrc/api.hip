@@ -1,0 +1,174 @@
+// extern "C" entry points of libctvae_hip.so (see include/ctvae_hip.h).  Thin argument checks + dispatch
+// into the kernel launchers; nothing here allocates or synchronises.
+#include "../../include/ctvae_hip.h"
+
+#include "common.hpp"
+
+namespace ctvae {
+int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
+                   const float* mask, int mask_act, float* S, int act, hipStream_t st);
+int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, float* dbias, float* ws, size_t ws_bytes,
+                 int accumulate, hipStream_t st);
+int launch_bn_forward(const float* y, int R, int C, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, float momentum, float eps, int training, int act, float* out, float* save_mean,
+                      float* save_invstd, float* ws, size_t ws_bytes, hipStream_t st);
+int launch_bn_backward(const float* ga, const float* a_out, const float* y, int R, int C, const float* gamma,
+                       const float* save_mean, const float* save_invstd, int act, float* gy, float* dgamma, float* dbeta,
+                       int accumulate, float* ws, size_t ws_bytes, hipStream_t st);
+int launch_permute(const float* in, float* out, int B, int C, int P, int to_nhwc, hipStream_t st);
+int launch_act_bwd(const float* gout, const float* out, float* gin, long n, int act, hipStream_t st);
+int launch_act_fwd(const float* in, float* out, long n, int act, hipStream_t st);
+int launch_reparam_fwd(const float* mu, long mu_rs, const float* lv, long lv_rs, const float* eps, float* z, int B, int L,
+                       hipStream_t st);
+int launch_reparam_bwd(const float* gz, const float* lv, long lv_rs, const float* eps, float* gmu, float* glv, int B, int L,
+                       hipStream_t st);
+int launch_adam(float* p, const float* g, float* m, float* v, float* state, long n, float grad_scale, hipStream_t st);
+int launch_loss_forward(const float* r, const float* x, long n, const float* mu, long mu_rs, const float* lv, long lv_rs,
+                        int B, int L, float M_N, const float* extra, float* out3, float* ws, size_t ws_bytes, hipStream_t st);
+int launch_mse_backward(const float* r, const float* x, const float* go, float* gr, long n, hipStream_t st);
+int launch_kl_backward(const float* mu, long mu_rs, const float* lv, long lv_rs, const float* go, float* gmu, float* glv,
+                       int B, int L, float M_N, hipStream_t st);
+int launch_vq_inds(const float* lat, const float* cb, long long* inds, int B, int HW, int D, int K, int C, hipStream_t st);
+int launch_vq_lookup(const float* lat, const float* cb, const long long* inds, float* out, float* vq_loss, float beta, int B,
+                     int HW, int D, int K, int C, float* ws, size_t ws_bytes, hipStream_t st);
+int launch_vq_backward(const float* gq, const float* gvq, const float* lat, const float* cb, const long long* inds,
+                       float* glat, float* dcb, int accumulate, float beta, int B, int HW, int D, int K, int C,
+                       hipStream_t st);
+}  // namespace ctvae
+
+using namespace ctvae;
+
+extern "C" {
+
+const char* ctvae_version(void) { return "0.1.0"; }
+const char* ctvae_arch(void) { return "gfx950"; }
+
+const char* ctvae_error_string(int code) {
+  if (code == 0) return "success";
+  if (code == kErrBadArg) return "ctvae: unsupported shape or bad argument";
+  if (code == kErrWorkspace) return "ctvae: workspace too small";
+  if (code > 0) return hipGetErrorString((hipError_t)code);
+  return "ctvae: unknown error";
+}
+
+size_t ctvae_workspace_bytes(void) { return (size_t)256 << 20; }
+
+int ctvae_conv_forward(int kind, const float* x, const float* w, const float* bias, const float* add, float* y, int B,
+                       int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int act, void* stream) {
+  if (!x || !w || !y || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
+  ConvGeom g;
+  if (build_geom(g, kind == CTVAE_CONV ? 0 : 1, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
+  return launch_tapgemm(g, x, w, bias, add, nullptr, 0, y, act, (hipStream_t)stream);
+}
+
+int ctvae_conv_dgrad(int kind, const float* dy, const float* w, const float* add, const float* mask, int mask_act,
+                     float* dx, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
+                     void* stream) {
+  if (!dy || !w || !dx || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
+  ConvGeom g;
+  if (build_geom(g, kind == CTVAE_CONV ? 2 : 3, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
+  return launch_tapgemm(g, dy, w, nullptr, add, mask, mask_act, dx, ACT_NONE, (hipStream_t)stream);
+}
+
+int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float* dbias, int B, int H, int W, int Ci,
+                     int Co, int k, int stride, int pad, int out_pad, int accumulate, float* ws, size_t ws_bytes,
+                     void* stream) {
+  if (!x || !dy || !dw || !ws || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
+  ConvGeom g;
+  if (build_geom(g, kind == CTVAE_CONV ? 0 : 1, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
+  return launch_wgrad(g, x, dy, dw, dbias, ws, ws_bytes, accumulate, (hipStream_t)stream);
+}
+
+int ctvae_bn_forward(const float* y, int R, int C, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, float momentum, float eps, int training, int act, float* out,
+                     float* save_mean, float* save_invstd, float* ws, size_t ws_bytes, void* stream) {
+  if (!y || !gamma || !beta || !out || !ws) return kErrBadArg;
+  if (training && (!save_mean || !save_invstd)) return kErrBadArg;
+  if (!training && (!running_mean || !running_var)) return kErrBadArg;
+  return launch_bn_forward(y, R, C, gamma, beta, running_mean, running_var, momentum, eps, training, act, out, save_mean,
+                           save_invstd, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int ctvae_bn_backward(const float* g_a, const float* a_out, const float* y, int R, int C, const float* gamma,
+                      const float* save_mean, const float* save_invstd, int act, float* g_y, float* dgamma,
+                      float* dbeta, int accumulate, float* ws, size_t ws_bytes, void* stream) {
+  if (!g_a || !a_out || !y || !gamma || !save_mean || !save_invstd || !g_y || !dgamma || !dbeta || !ws) return kErrBadArg;
+  return launch_bn_backward(g_a, a_out, y, R, C, gamma, save_mean, save_invstd, act, g_y, dgamma, dbeta, accumulate, ws,
+                            ws_bytes, (hipStream_t)stream);
+}
+
+int ctvae_permute(const float* in, float* out, int B, int C, int P, int to_nhwc, void* stream) {
+  if (!in || !out || B <= 0 || C <= 0 || P <= 0) return kErrBadArg;
+  return launch_permute(in, out, B, C, P, to_nhwc, (hipStream_t)stream);
+}
+
+int ctvae_act_forward(const float* in, float* out, long n, int act, void* stream) {
+  if (!in || !out || n <= 0) return kErrBadArg;
+  return launch_act_fwd(in, out, n, act, (hipStream_t)stream);
+}
+
+int ctvae_act_backward(const float* g_out, const float* out, float* g_in, long n, int act, void* stream) {
+  if (!g_out || !out || !g_in || n <= 0) return kErrBadArg;
+  return launch_act_bwd(g_out, out, g_in, n, act, (hipStream_t)stream);
+}
+
+int ctvae_reparam_forward(const float* mu, long mu_rs, const float* logvar, long lv_rs, const float* eps, float* z, int B,
+                          int L, void* stream) {
+  if (!mu || !logvar || !eps || !z || B <= 0 || L <= 0) return kErrBadArg;
+  return launch_reparam_fwd(mu, mu_rs, logvar, lv_rs, eps, z, B, L, (hipStream_t)stream);
+}
+
+int ctvae_reparam_backward(const float* g_z, const float* logvar, long lv_rs, const float* eps, float* g_mu,
+                           float* g_logvar, int B, int L, void* stream) {
+  if (!g_z || !logvar || !eps || !g_mu || !g_logvar || B <= 0 || L <= 0) return kErrBadArg;
+  return launch_reparam_bwd(g_z, logvar, lv_rs, eps, g_mu, g_logvar, B, L, (hipStream_t)stream);
+}
+
+int ctvae_loss_forward(const float* recons, const float* x, long n, const float* mu, long mu_rs, const float* logvar,
+                       long lv_rs, int B, int L, float M_N, const float* extra, float* out4, float* ws, size_t ws_bytes,
+                       void* stream) {
+  if (!recons || !x || !out4 || !ws || n <= 0) return kErrBadArg;
+  if ((mu == nullptr) != (logvar == nullptr)) return kErrBadArg;
+  return launch_loss_forward(recons, x, n, mu, mu_rs, logvar, lv_rs, B, L, M_N, extra, out4, ws, ws_bytes,
+                             (hipStream_t)stream);
+}
+
+int ctvae_mse_backward(const float* recons, const float* x, const float* g_loss, float* g_recons, long n, void* stream) {
+  if (!recons || !x || !g_loss || !g_recons || n <= 0) return kErrBadArg;
+  return launch_mse_backward(recons, x, g_loss, g_recons, n, (hipStream_t)stream);
+}
+
+int ctvae_kl_backward(const float* mu, long mu_rs, const float* logvar, long lv_rs, const float* g_loss, float* g_mu,
+                      float* g_logvar, int B, int L, float M_N, void* stream) {
+  if (!mu || !logvar || !g_loss || !g_mu || !g_logvar) return kErrBadArg;
+  return launch_kl_backward(mu, mu_rs, logvar, lv_rs, g_loss, g_mu, g_logvar, B, L, M_N, (hipStream_t)stream);
+}
+
+int ctvae_vq_inds(const float* latents, const float* codebooks, int64_t* inds, int B, int HW, int D, int K, int C,
+                  void* stream) {
+  if (!latents || !codebooks || !inds || B <= 0 || HW <= 0 || C <= 0) return kErrBadArg;
+  return launch_vq_inds(latents, codebooks, (long long*)inds, B, HW, D, K, C, (hipStream_t)stream);
+}
+
+int ctvae_vq_lookup(const float* latents, const float* codebooks, const int64_t* inds, float* quantized, float* vq_loss,
+                    float beta, int B, int HW, int D, int K, int C, float* ws, size_t ws_bytes, void* stream) {
+  if (!latents || !codebooks || !inds || !quantized || !vq_loss || !ws || C <= 0) return kErrBadArg;
+  return launch_vq_lookup(latents, codebooks, (const long long*)inds, quantized, vq_loss, beta, B, HW, D, K, C, ws, ws_bytes,
+                          (hipStream_t)stream);
+}
+
+int ctvae_vq_backward(const float* g_quantized, const float* g_vq_loss, const float* latents, const float* codebooks,
+                      const int64_t* inds, float* g_latents, float* d_codebooks, int accumulate, float beta, int B, int HW,
+                      int D, int K, int C, void* stream) {
+  if (!latents || !codebooks || !inds || C <= 0) return kErrBadArg;
+  return launch_vq_backward(g_quantized, g_vq_loss, latents, codebooks, (const long long*)inds, g_latents, d_codebooks,
+                            accumulate, beta, B, HW, D, K, C, (hipStream_t)stream);
+}
+
+int ctvae_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* state, long n,
+                    float grad_scale, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !state || n <= 0) return kErrBadArg;
+  return launch_adam(params, grads, exp_avg, exp_avg_sq, state, n, grad_scale, (hipStream_t)stream);
+}
+
+}  // extern "C"

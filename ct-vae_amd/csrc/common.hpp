@@ -1,0 +1,70 @@
+// Common device/host helpers for the ctvae HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "geom.hpp"
+
+namespace ctvae {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr float kLeaky = 0.01f;  // nn.LeakyReLU() default (vanilla_vae.py:31)
+
+enum Act : int { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_TANH = 3 };
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+  switch (act) {
+    case ACT_LRELU: return v > 0.f ? v : v * kLeaky;
+    case ACT_RELU: return v > 0.f ? v : 0.f;
+    case ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+// derivative expressed through the saved post-activation output o
+__device__ __forceinline__ float act_bwd_from_out(float o, int act) {
+  switch (act) {
+    case ACT_LRELU: return o > 0.f ? 1.f : kLeaky;
+    case ACT_RELU: return o > 0.f ? 1.f : 0.f;
+    case ACT_TANH: return 1.f - o * o;
+    default: return 1.f;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum for blockDim.x == 256 (4 waves); result valid in every thread
+__device__ __forceinline__ float block_sum_256(float v, float* sm /* >=4 floats */) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+#define CTVAE_LAUNCH_CHECK()                   \
+  do {                                         \
+    hipError_t e__ = hipGetLastError();        \
+    if (e__ != hipSuccess) return (int)e__;    \
+  } while (0)
+
+// argument error (distinct from hipError_t values, which are small positive numbers)
+constexpr int kErrBadArg = -22;
+constexpr int kErrWorkspace = -12;
+
+}  // namespace ctvae

@@ -1,0 +1,139 @@
+// Loss reductions: F.mse_loss mean over every element (vanilla_vae.py:140,
+// mcq_vae.py:279, ct_mcq_vae.py:611) and the Gaussian KL term mean_b(-0.5*sum_d(1+lv-mu^2-e^lv))
+// (vanilla_vae.py:143).  Wavefront shuffle reductions -> one partial per workgroup -> one
+// finishing workgroup that adds the partials in double and emits the scalars.  HBM-bound:
+// algorithmic bytes = 2 * 4 * n (recons + input) + 2 * 4 * B * L.
+#include "common.hpp"
+
+namespace ctvae {
+
+constexpr int kLossBlocks = 1024;
+
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ r, const float* __restrict__ x,
+                                                          float* __restrict__ part, long n4, long n) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    f32x4 a = reinterpret_cast<const f32x4*>(r)[i];
+    f32x4 b = reinterpret_cast<const f32x4*>(x)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float d = a[k] - b[k];
+      s += d * d;
+    }
+  }
+  if (blockIdx.x == 0) {  // tail (n % 4)
+    for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) {
+      float d = r[i] - x[i];
+      s += d * d;
+    }
+  }
+  s = block_sum_256(s, sm);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// out[0] = loss = mse + M_N*kld (+ extra[0] if given), out[1] = mse, out[2] = kld, out[3] = -kld ('KLD' key, vanilla_vae.py:146)
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ part, int nparts, double inv_n,
+                                                          const float* __restrict__ mu, long mu_rs,
+                                                          const float* __restrict__ lv, long lv_rs, int B, int L, float M_N,
+                                                          const float* __restrict__ extra, float* __restrict__ out) {
+  __shared__ double smd[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += (double)part[i];
+  double k = 0.0;
+  if (mu != nullptr) {
+    for (int i = threadIdx.x; i < B * L; i += 256) {
+      int b = i / L, d = i - b * L;
+      float m = mu[b * mu_rs + d], l = lv[b * lv_rs + d];
+      k += (double)(1.f + l - m * m - expf(l));
+    }
+  }
+  s = wave_sum_d(s);
+  k = wave_sum_d(k);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) smd[w] = s;
+  __syncthreads();
+  double st = smd[0] + smd[1] + smd[2] + smd[3];
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) smd[w] = k;
+  __syncthreads();
+  double kt = smd[0] + smd[1] + smd[2] + smd[3];
+  if (threadIdx.x == 0) {
+    float mse = (float)(st * inv_n);
+    float kld = mu != nullptr ? (float)(-0.5 * kt / (double)B) : 0.f;
+    float loss = mse + M_N * kld;
+    if (extra != nullptr) loss += extra[0];
+    out[0] = loss;
+    out[1] = mse;
+    out[2] = kld;
+    out[3] = -kld;
+  }
+}
+
+// g_r = go * 2 (r - x) / n
+__global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ r, const float* __restrict__ x,
+                                                      const float* __restrict__ go, float* __restrict__ gr, long n4, long n,
+                                                      float two_over_n) {
+  const float sc = go[0] * two_over_n;
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    f32x4 a = reinterpret_cast<const f32x4*>(r)[i];
+    f32x4 b = reinterpret_cast<const f32x4*>(x)[i];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = sc * (a[k] - b[k]);
+    reinterpret_cast<f32x4*>(gr)[i] = o;
+  }
+  if (blockIdx.x == 0)
+    for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) gr[i] = sc * (r[i] - x[i]);
+}
+
+// g_mu = go*M_N*mu/B ; g_lv = go*M_N*0.5*(e^lv - 1)/B     (dense [B][L] outputs)
+__global__ __launch_bounds__(256) void kl_bwd_kernel(const float* __restrict__ mu, long mu_rs, const float* __restrict__ lv,
+                                                     long lv_rs, const float* __restrict__ go, float* __restrict__ gmu,
+                                                     float* __restrict__ glv, int B, int L, float M_N) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * L) return;
+  const int b = i / L, d = i - b * L;
+  const float sc = go[0] * M_N / (float)B;
+  gmu[i] = sc * mu[b * mu_rs + d];
+  glv[i] = sc * 0.5f * (expf(lv[b * lv_rs + d]) - 1.f);
+}
+
+size_t loss_workspace_floats() { return kLossBlocks; }
+
+int launch_loss_forward(const float* r, const float* x, long n, const float* mu, long mu_rs, const float* lv, long lv_rs,
+                        int B, int L, float M_N, const float* extra, float* out4, float* ws, size_t ws_bytes,
+                        hipStream_t st) {
+  if (ws_bytes / sizeof(float) < loss_workspace_floats() || n <= 0) return kErrWorkspace;
+  const long n4 = n / 4;
+  long blocks = (n4 + 255) / 256;
+  if (blocks > kLossBlocks) blocks = kLossBlocks;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(mse_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, st, r, x, ws, n4, n);
+  CTVAE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, ws, (int)blocks, 1.0 / (double)n, mu, mu_rs, lv, lv_rs,
+                     B, L, M_N, extra, out4);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_mse_backward(const float* r, const float* x, const float* go, float* gr, long n, hipStream_t st) {
+  const long n4 = n / 4;
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(mse_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, r, x, go, gr, n4, n, (float)(2.0 / (double)n));
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_kl_backward(const float* mu, long mu_rs, const float* lv, long lv_rs, const float* go, float* gmu, float* glv,
+                       int B, int L, float M_N, hipStream_t st) {
+  hipLaunchKernelGGL(kl_bwd_kernel, dim3(ceil_div(B * L, 256)), dim3(256), 0, st, mu, mu_rs, lv, lv_rs, go, gmu, glv, B, L, M_N);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace ctvae

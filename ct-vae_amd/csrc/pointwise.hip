@@ -1,0 +1,142 @@
+// HBM-bound pointwise kernels of the training step: layout changes at the NCHW API boundary,
+// activation backward, Gaussian reparameterisation (vanilla_vae.py:107-117) and the flat fused Adam
+// update (experiment.py:158-160).  Roofline for all of them: bytes moved / 8 TB/s.
+#include "common.hpp"
+
+namespace ctvae {
+
+// out[b][p][c] = in[b][c][p]   (NCHW -> NHWC with p = h*W+w), or the inverse with to_nhwc = 0
+__global__ __launch_bounds__(256) void permute_cp_kernel(const float* __restrict__ in, float* __restrict__ out, int B,
+                                                         int C, int P, int to_nhwc) {
+  const long n = (long)B * C * P;
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    if (to_nhwc) {  // i indexes out [b][p][c]
+      int c = (int)(i % C);
+      long t = i / C;
+      int p = (int)(t % P);
+      long b = t / P;
+      out[i] = in[(b * C + c) * P + p];
+    } else {  // i indexes out [b][c][p]
+      int p = (int)(i % P);
+      long t = i / P;
+      int c = (int)(t % C);
+      long b = t / C;
+      out[i] = in[(b * P + p) * C + c];
+    }
+  }
+}
+
+// gin = gout * act'(out)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ out,
+                                                      float* __restrict__ gin, long n, int act) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) gin[i] = gout[i] * act_bwd_from_out(out[i], act);
+}
+
+// out = act(in)   (standalone nn.LeakyReLU sites, mcq_vae.py:185,216, when not fused into a producer)
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, long n, int act) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = act_fwd(in[i], act);
+}
+
+// z = eps * exp(0.5*logvar) + mu          (row strides allow mu/logvar to be column slices of one head GEMM)
+__global__ __launch_bounds__(256) void reparam_fwd_kernel(const float* __restrict__ mu, long mu_rs, const float* __restrict__ lv,
+                                                          long lv_rs, const float* __restrict__ eps, float* __restrict__ z,
+                                                          int B, int L) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * L) return;
+  const int b = i / L, d = i - b * L;
+  z[i] = eps[i] * expf(0.5f * lv[b * lv_rs + d]) + mu[b * mu_rs + d];
+}
+
+// g_mu = g_z ; g_lv = g_z * eps * 0.5 * exp(0.5*logvar)
+__global__ __launch_bounds__(256) void reparam_bwd_kernel(const float* __restrict__ gz, const float* __restrict__ lv, long lv_rs,
+                                                          const float* __restrict__ eps, float* __restrict__ gmu,
+                                                          float* __restrict__ glv, int B, int L) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * L) return;
+  const int b = i / L, d = i - b * L;
+  const float g = gz[i];
+  gmu[i] = g;
+  glv[i] = g * eps[i] * 0.5f * expf(0.5f * lv[b * lv_rs + d]);
+}
+
+// ---- Adam ---------------------------------------------------------------------------------------------
+// state[0]=step (as float), [1]=lr, [2]=beta1, [3]=beta2, [4]=eps, [5]=weight_decay, [6]=beta1^t, [7]=beta2^t
+__global__ void adam_advance_kernel(float* state) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    state[0] += 1.f;
+    state[6] *= state[2];
+    state[7] *= state[3];
+  }
+}
+
+// torch.optim.Adam (no amsgrad): g += wd*p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, const float* __restrict__ state, long n,
+                                                   float grad_scale) {
+  const float lr = state[1], b1 = state[2], b2 = state[3], eps = state[4], wd = state[5];
+  const float bc1 = 1.f - state[6], bc2 = 1.f - state[7];
+  const float step_size = lr / bc1, bc2s = sqrtf(bc2);
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    float pi = p[i];
+    float gi = g[i] * grad_scale + wd * pi;
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi - step_size * (mi / (sqrtf(vi) / bc2s + eps));
+  }
+}
+
+static inline unsigned grid_for(long n, int cap = 4096) {
+  long b = (n + 255) / 256;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+int launch_permute(const float* in, float* out, int B, int C, int P, int to_nhwc, hipStream_t st) {
+  hipLaunchKernelGGL(permute_cp_kernel, dim3(grid_for((long)B * C * P)), dim3(256), 0, st, in, out, B, C, P, to_nhwc);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_act_bwd(const float* gout, const float* out, float* gin, long n, int act, hipStream_t st) {
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, gout, out, gin, n, act);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_act_fwd(const float* in, float* out, long n, int act, hipStream_t st) {
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, in, out, n, act);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_reparam_fwd(const float* mu, long mu_rs, const float* lv, long lv_rs, const float* eps, float* z, int B, int L,
+                       hipStream_t st) {
+  hipLaunchKernelGGL(reparam_fwd_kernel, dim3(ceil_div(B * L, 256)), dim3(256), 0, st, mu, mu_rs, lv, lv_rs, eps, z, B, L);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_reparam_bwd(const float* gz, const float* lv, long lv_rs, const float* eps, float* gmu, float* glv, int B, int L,
+                       hipStream_t st) {
+  hipLaunchKernelGGL(reparam_bwd_kernel, dim3(ceil_div(B * L, 256)), dim3(256), 0, st, gz, lv, lv_rs, eps, gmu, glv, B, L);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_adam(float* p, const float* g, float* m, float* v, float* state, long n, float grad_scale, hipStream_t st) {
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, st, state);
+  CTVAE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, st, p, g, m, v, state, n, grad_scale);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace ctvae

@@ -1,0 +1,380 @@
+// Tap-GEMM: the one f32-MFMA implicit-GEMM kernel behind every Conv2d / ConvTranspose2d / Linear
+// forward and data-gradient on the hot path (see geom.hpp for the geometry model).
+//
+//   S[spix(m)][n] = epi( sum_t sum_c G[gpix(m,t)][c] * Wmat[t][c][n] )
+//
+// Replaces (reference call sites): nn.Conv2d k3s2 (vanilla_vae.py:28-29), nn.ConvTranspose2d k3s2
+// (vanilla_vae.py:50-55,65-70), nn.Conv2d k3s1 (vanilla_vae.py:73-74, mcq_vae.py:178-179, vq_vae.py:63-64),
+// nn.Conv2d k4s2 (mcq_vae.py:170-171), k1 (vq_vae.py:66-67, mcq_vae.py:189-190), nn.ConvTranspose2d k4s2
+// (mcq_vae.py:223-236), nn.Linear (vanilla_vae.py:36-37,43) and autograd's dgrad of each.
+//
+// Design (CDNA4): one 256-thread workgroup = 4 waves computes a BM x BN tile of S with
+// v_mfma_f32_32x32x2_f32 (exact f32, k-ordered fma chain -> 1e-4 parity is safe).  Per 32-deep K
+// chunk the gathered operand is im2col'ed on the fly from NHWC global memory into an LDS tile
+// [BM][32+4] (16-B vector loads along channels, rows padded so ds_read_b128 is conflict-free), the
+// weight slab goes to LDS as [32][BN] (or [BN][32+4] when the per-tap transpose is needed for
+// dgrad).  Next-chunk global loads are issued before the MFMA block of the current chunk
+// (register prefetch) and occupancy (small accumulators) hides the rest.  Epilogue fuses bias,
+// residual add, forward activation, or the multiplication by the previous layer's activation
+// derivative (backward).
+#include "common.hpp"
+
+namespace ctvae {
+
+struct TapGemmArgs {
+  ConvGeom g;
+  const float* G;
+  const float* W;
+  const float* bias;
+  const float* add;
+  const float* mask;
+  float* S;
+  int act;
+  int mask_act;
+  int Mc;      // B*Qh*Qw
+  int N;       // sC
+  int mtiles;  // per class
+  int ntiles;
+};
+
+constexpr int KC = 32;
+constexpr int LDK = KC + 4;  // padded K-contiguous LDS row (floats)
+
+template <int WM, int WN, int TM, int TN, bool WT, bool AVEC, bool BVEC>
+__global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  __shared__ __attribute__((aligned(16))) float sA[BM * LDK];
+  __shared__ __attribute__((aligned(16))) float sB[WT ? BN * LDK : KC * BN];
+  __shared__ int sRowPix[BM];
+  __shared__ int sRowYX[BM];
+  __shared__ int sOut[BM];
+  __shared__ int sTab[AVEC ? 1 : 64 * 4];  // per flattened k: dy, dx, c, wtap
+
+  const ConvGeom& g = a.g;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int cls = blockIdx.y;
+  const int tile = blockIdx.x;
+  const int mt = tile / a.ntiles, nt = tile - mt * a.ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int ntaps = g.ntaps[cls];
+  const int gC = g.gC;
+  const int Ktot = ntaps * gC;
+
+  // ---- per-tile row tables --------------------------------------------------------------
+  for (int r = tid; r < BM; r += 256) {
+    int m = m0 + r;
+    if (m < a.Mc) {
+      int b, qy, qx;
+      decode_m(g, m, b, qy, qx);
+      sRowPix[r] = (b * g.gH + qy * g.is) * g.gW + qx * g.is;  // may lie outside the image; range-checked per tap
+      sRowYX[r] = ((qy * g.is) << 16) | (qx * g.is);
+      sOut[r] = scatter_pix(g, cls, b, qy, qx);
+    } else {
+      sRowPix[r] = -1;
+      sRowYX[r] = 0;
+      sOut[r] = -1;
+    }
+  }
+  if constexpr (!AVEC) {
+    for (int k = tid; k < 64; k += 256) {
+      int t = k / gC, c = k - t * gC;
+      bool ok = k < Ktot;
+      Tap tp = g.taps[cls][ok ? t : 0];
+      sTab[k * 4 + 0] = tp.dy;
+      sTab[k * 4 + 1] = tp.dx;
+      sTab[k * 4 + 2] = c;
+      sTab[k * 4 + 3] = ok ? tp.wtap : -1;
+    }
+  }
+  __syncthreads();
+
+  const int nch = AVEC ? (Ktot / KC) : ((Ktot + KC - 1) / KC);
+
+  // ---- staging registers ------------------------------------------------------------------
+  constexpr int A_V = BM / 32;      // float4 per thread (vector path)
+  constexpr int A_S = BM / 8;       // floats per thread (scalar path)
+  constexpr int B_V = BN / 32;      // float4 per thread
+  constexpr int B_S = BN / 8;       // floats per thread
+  f32x4 ra[AVEC ? A_V : 1];
+  float rs[AVEC ? 1 : A_S];
+  f32x4 rb[BVEC ? B_V : 1];
+  float rbs[BVEC ? 1 : B_S];
+
+  auto load_chunk = [&](int c) {
+    // tap for this chunk (vector path: chunk lies inside one tap)
+    int t = 0, ci0 = 0;
+    Tap tp{0, 0, 0};
+    if constexpr (AVEC) {
+      int k0 = c * KC;
+      t = k0 / gC;
+      ci0 = k0 - t * gC;
+      tp = g.taps[cls][t];
+    }
+    // ---- A ----
+    if constexpr (AVEC) {
+      const int kq = tid & 7;
+#pragma unroll
+      for (int j = 0; j < A_V; ++j) {
+        int r = (tid >> 3) + 32 * j;
+        int pix = sRowPix[r], yx = sRowYX[r];
+        int iy = (yx >> 16) + tp.dy, ix = (yx & 0xffff) + tp.dx;
+        bool ok = (pix >= 0) && ((unsigned)iy < (unsigned)g.gH) && ((unsigned)ix < (unsigned)g.gW);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+          long off = (long)(pix + tp.dy * g.gW + tp.dx) * gC + ci0 + 4 * kq;
+          v = *reinterpret_cast<const f32x4*>(a.G + off);
+        }
+        ra[j] = v;
+      }
+    } else {
+      const int kk = tid & 31;
+      const int k = c * KC + kk;
+      const int dy = sTab[(k & 63) * 4 + 0], dx = sTab[(k & 63) * 4 + 1], cc = sTab[(k & 63) * 4 + 2];
+      const bool kok = (k < Ktot);
+#pragma unroll
+      for (int j = 0; j < A_S; ++j) {
+        int r = (tid >> 5) + 8 * j;
+        int pix = sRowPix[r], yx = sRowYX[r];
+        int iy = (yx >> 16) + dy, ix = (yx & 0xffff) + dx;
+        bool ok = kok && (pix >= 0) && ((unsigned)iy < (unsigned)g.gH) && ((unsigned)ix < (unsigned)g.gW);
+        float v = 0.f;
+        if (ok) v = a.G[(long)(pix + dy * g.gW + dx) * gC + cc];
+        rs[j] = v;
+      }
+    }
+    // ---- B ----
+    if constexpr (!WT) {
+      if constexpr (BVEC) {
+#pragma unroll
+        for (int j = 0; j < B_V; ++j) {
+          int f = tid + 256 * j;
+          int kr = f / (BN / 4), nq = f - kr * (BN / 4);
+          int n = n0 + 4 * nq;
+          long row;
+          bool ok = n < a.N;
+          if constexpr (AVEC) {
+            row = (long)tp.wtap * g.wCi + ci0 + kr;
+          } else {
+            int k = c * KC + kr;
+            int wt = sTab[(k & 63) * 4 + 3];
+            ok = ok && (k < Ktot);
+            row = (long)wt * g.wCi + sTab[(k & 63) * 4 + 2];
+          }
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (ok) v = *reinterpret_cast<const f32x4*>(a.W + row * g.wCo + n);
+          rb[j] = v;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < B_S; ++j) {
+          int e = tid + 256 * j;
+          int kr = e / BN, nn = e - kr * BN;
+          int n = n0 + nn;
+          long row;
+          bool ok = n < a.N;
+          if constexpr (AVEC) {
+            row = (long)tp.wtap * g.wCi + ci0 + kr;
+          } else {
+            int k = c * KC + kr;
+            int wt = sTab[(k & 63) * 4 + 3];
+            ok = ok && (k < Ktot);
+            row = (long)wt * g.wCi + sTab[(k & 63) * 4 + 2];
+          }
+          rbs[j] = ok ? a.W[row * g.wCo + n] : 0.f;
+        }
+      }
+    } else {
+      // Wmat[t][c][n] = W[t][n][c]: rows n, contiguous along c
+      if constexpr (BVEC) {
+        const int kq = tid & 7;
+#pragma unroll
+        for (int j = 0; j < B_V; ++j) {
+          int nr = (tid >> 3) + 32 * j;
+          int n = n0 + nr;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (n < a.N) v = *reinterpret_cast<const f32x4*>(a.W + ((long)tp.wtap * g.wCi + n) * g.wCo + ci0 + 4 * kq);
+          rb[j] = v;
+        }
+      } else {
+        const int kk = tid & 31;
+        const int k = c * KC + kk;
+        const int cc = sTab[(k & 63) * 4 + 2], wt = sTab[(k & 63) * 4 + 3];
+        const bool kok = (k < Ktot);
+#pragma unroll
+        for (int j = 0; j < B_S; ++j) {
+          int nr = (tid >> 5) + 8 * j;
+          int n = n0 + nr;
+          rbs[j] = (kok && n < a.N) ? a.W[((long)wt * g.wCi + n) * g.wCo + cc] : 0.f;
+        }
+      }
+    }
+  };
+
+  auto store_chunk = [&]() {
+    if constexpr (AVEC) {
+      const int kq = tid & 7;
+#pragma unroll
+      for (int j = 0; j < A_V; ++j) {
+        int r = (tid >> 3) + 32 * j;
+        *reinterpret_cast<f32x4*>(&sA[r * LDK + 4 * kq]) = ra[j];
+      }
+    } else {
+      const int kk = tid & 31;
+#pragma unroll
+      for (int j = 0; j < A_S; ++j) sA[((tid >> 5) + 8 * j) * LDK + kk] = rs[j];
+    }
+    if constexpr (!WT) {
+      if constexpr (BVEC) {
+#pragma unroll
+        for (int j = 0; j < B_V; ++j) {
+          int f = tid + 256 * j;
+          int kr = f / (BN / 4), nq = f - kr * (BN / 4);
+          *reinterpret_cast<f32x4*>(&sB[kr * BN + 4 * nq]) = rb[j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < B_S; ++j) sB[tid + 256 * j] = rbs[j];
+      }
+    } else {
+      if constexpr (BVEC) {
+        const int kq = tid & 7;
+#pragma unroll
+        for (int j = 0; j < B_V; ++j) *reinterpret_cast<f32x4*>(&sB[((tid >> 3) + 32 * j) * LDK + 4 * kq]) = rb[j];
+      } else {
+        const int kk = tid & 31;
+#pragma unroll
+        for (int j = 0; j < B_S; ++j) sB[((tid >> 5) + 8 * j) * LDK + kk] = rbs[j];
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int li = lane & 31, lh = lane >> 5;
+
+  load_chunk(0);
+  store_chunk();
+  __syncthreads();
+  for (int c = 0; c < nch; ++c) {
+    if (c + 1 < nch) load_chunk(c + 1);
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      f32x4 af[TM];
+      float bf[TN][4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[i] = *reinterpret_cast<const f32x4*>(&sA[((wm * TM + i) * 32 + li) * LDK + kg * 8 + 4 * lh]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (WT) {
+          f32x4 t4 = *reinterpret_cast<const f32x4*>(&sB[((wn * TN + j) * 32 + li) * LDK + kg * 8 + 4 * lh]);
+          bf[j][0] = t4[0]; bf[j][1] = t4[1]; bf[j][2] = t4[2]; bf[j][3] = t4[3];
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) bf[j][s] = sB[(kg * 8 + 4 * lh + s) * BN + (wn * TN + j) * 32 + li];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (c + 1 < nch) {
+      store_chunk();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------
+  const int N = a.N;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + li;
+    const bool cok = col < N;
+    const float bv = (a.bias != nullptr && cok) ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wm * TM + i) * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+        const int sp = sOut[row];
+        if (sp >= 0 && cok) {
+          const long idx = (long)sp * N + col;
+          float v = acc[i][j][r] + bv;
+          if (a.add != nullptr) v += a.add[idx];
+          v = act_fwd(v, a.act);
+          if (a.mask != nullptr) v *= act_bwd_from_out(a.mask[idx], a.mask_act);
+          a.S[idx] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---- host side --------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN, bool GENERIC>
+static int launch_cfg(const TapGemmArgs& a, bool wt, bool avec, bool bvec, hipStream_t st) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  TapGemmArgs args = a;
+  args.mtiles = ceil_div(a.Mc, BM);
+  args.ntiles = ceil_div(a.N, BN);
+  dim3 grid(args.mtiles * args.ntiles, a.g.ncls), block(256);
+#define CTVAE_TG(WT_, AV_, BV_) \
+  hipLaunchKernelGGL((tapgemm_kernel<WM, WN, TM, TN, WT_, AV_, BV_>), grid, block, 0, st, args)
+  if constexpr (GENERIC) {  // the masked/scalar variants exist for one tile shape only
+    if (!wt) {
+      if (avec && bvec) CTVAE_TG(false, true, true);
+      else if (!avec && bvec) CTVAE_TG(false, false, true);
+      else if (avec && !bvec) CTVAE_TG(false, true, false);
+      else CTVAE_TG(false, false, false);
+    } else {
+      if (avec) CTVAE_TG(true, true, true);
+      else CTVAE_TG(true, false, false);
+    }
+  } else {
+    if (!avec || !bvec) return kErrBadArg;
+    if (!wt) CTVAE_TG(false, true, true);
+    else CTVAE_TG(true, true, true);
+  }
+#undef CTVAE_TG
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
+                   const float* mask, int mask_act, float* S, int act, hipStream_t st) {
+  TapGemmArgs a{};
+  a.g = g;
+  a.G = G; a.W = W; a.bias = bias; a.add = add; a.mask = mask; a.S = S;
+  a.act = act; a.mask_act = mask_act;
+  a.Mc = g.B * g.Qh * g.Qw;
+  a.N = g.sC;
+  if (a.Mc <= 0 || a.N <= 0) return kErrBadArg;
+  const bool wt = g.wT != 0;
+  const bool avec = (g.gC % KC) == 0;
+  const bool bvec = wt ? avec : ((a.N % 4) == 0);
+  if (!avec) {
+    for (int c = 0; c < g.ncls; ++c)
+      if (g.ntaps[c] * g.gC > 64) return kErrBadArg;  // scalar path keeps its k-table in LDS
+  }
+  // tile choice: N<=32 -> 128x32 (4x1 waves); big problems -> 128x64; small M -> 64x64
+  if (a.N <= 32 || !avec || !bvec) return launch_cfg<4, 1, 1, 1, true>(a, wt, avec, bvec, st);
+  const long tiles128 = (long)ceil_div(a.Mc, 128) * ceil_div(a.N, 64) * g.ncls;
+  if (tiles128 >= 512) return launch_cfg<2, 2, 2, 1, false>(a, wt, avec, bvec, st);
+  return launch_cfg<2, 2, 1, 1, false>(a, wt, avec, bvec, st);
+}
+
+}  // namespace ctvae

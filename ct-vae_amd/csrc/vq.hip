@@ -1,0 +1,241 @@
+// Multi-codebook vector quantiser (mcq_vae.py:7-137) on NHWC latents [P = B*H*W][D].
+//
+//  * index search (mcq_vae.py:26-39): dist = (|x|^2 + |e_k|^2) - 2 x.e_k in the reference's expanded
+//    form, first-min arg-min.  Codebook staged in LDS (odd row stride -> conflict-free), one wavefront
+//    per latent row, lane == code, wave shuffle arg-min on (dist, k).
+//  * lookup + loss (mcq_vae.py:41-64): q = E[idx]; out = x + (q - x) (same rounding as the reference's
+//    straight-through expression); per-codebook sum (q-x)^2 -> vq_loss = sum_i (beta*mse_i + mse_i).
+//  * backward: straight-through pass of g_q plus beta*2(x-q)/N into the latents; embedding-loss
+//    gradient 2(q-x)/N scattered per code, computed without atomics (one workgroup per code).
+//  * the reference's slice quirk is reproduced: codebook i reads channels [i, i+D/C) (mcq_vae.py:104,117).
+// All HBM/L2-bound; algorithmic bytes = latents read + quantized written + indices.
+#include "common.hpp"
+
+namespace ctvae {
+
+// grid (row blocks, C); block 256 = 4 waves, each wave walks rows
+__global__ __launch_bounds__(256) void vq_inds_kernel(const float* __restrict__ lat, const float* __restrict__ cb,
+                                                      long long* __restrict__ inds, int P, int D, int K, int Dc, int C,
+                                                      int HW, int rows_per_block) {
+  extern __shared__ float smem[];
+  const int ld = Dc | 1;                 // odd stride
+  float* sE = smem;                      // [K][ld]
+  float* sEE = sE + (size_t)K * ld;      // [K]
+  float* sX = sEE + K;                   // [4][Dc]
+  const int cbi = blockIdx.y;
+  const float* E = cb + (size_t)cbi * K * Dc;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < K * Dc; i += 256) sE[(i / Dc) * ld + (i % Dc)] = E[i];
+  __syncthreads();
+  for (int k = tid; k < K; k += 256) {
+    float s = 0.f;
+    for (int d = 0; d < Dc; ++d) s += sE[k * ld + d] * sE[k * ld + d];
+    sEE[k] = s;
+  }
+  __syncthreads();
+  float* myX = sX + wave * Dc;
+  const int r0 = blockIdx.x * rows_per_block;
+  int r1 = r0 + rows_per_block;
+  if (r1 > P) r1 = P;
+  for (int p = r0 + wave; p < r1; p += 4) {
+    const float* x = lat + (size_t)p * D + cbi;  // slice offset i, not i*Dc (reference quirk)
+    for (int d = lane; d < Dc; d += 64) myX[d] = x[d];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float xx = 0.f;
+    for (int d = 0; d < Dc; ++d) xx += myX[d] * myX[d];
+    float best = 3.4e38f;
+    int bestk = 0x7fffffff;
+    for (int k = lane; k < K; k += 64) {
+      float dot = 0.f;
+      for (int d = 0; d < Dc; ++d) dot += myX[d] * sE[k * ld + d];
+      float dist = (xx + sEE[k]) - 2.f * dot;
+      if (dist < best) { best = dist; bestk = k; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      float ob = __shfl_xor(best, o, 64);
+      int ok = __shfl_xor(bestk, o, 64);
+      if (ob < best || (ob == best && ok < bestk)) { best = ob; bestk = ok; }
+    }
+    if (lane == 0) {
+      int b = p / HW, hw = p - b * HW;
+      inds[((size_t)b * C + cbi) * HW + hw] = (long long)bestk;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// out[p][i*Dc+d] = x + (E_i[idx][d] - x),  x = lat[p][i+d];  part[blk][i] = sum (q-x)^2
+__global__ __launch_bounds__(256) void vq_lookup_kernel(const float* __restrict__ lat, const float* __restrict__ cb,
+                                                        const long long* __restrict__ inds, float* __restrict__ out,
+                                                        float* __restrict__ part, int P, int D, int K, int Dc, int C, int HW) {
+  __shared__ float sm[4];
+  const long n = (long)P * D;
+  const long stride = (long)gridDim.x * 256;
+  // every thread owns fixed columns when stride % D == 0 is not guaranteed -> accumulate per codebook generally
+  float acc[kMaxCls * 2];  // up to 8 codebooks
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) {
+    const int col = (int)(e % D);
+    const long p = e / D;
+    const int i = col / Dc, d = col - i * Dc;
+    const int b = (int)(p / HW), hw = (int)(p - (long)b * HW);
+    const long long idx = inds[((size_t)b * C + i) * HW + hw];
+    const float x = lat[p * D + i + d];
+    const float q = cb[((size_t)i * K + (size_t)idx) * Dc + d];
+    const float df = q - x;
+    out[e] = x + df;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j == i) acc[j] += df * df;
+  }
+  for (int i = 0; i < C; ++i) {
+    float s = block_sum_256(acc[i], sm);
+    if (threadIdx.x == 0) part[(size_t)blockIdx.x * C + i] = s;
+  }
+}
+
+// vq_loss = sum_i ( mse_i*beta + mse_i ), mse_i = sum_i/(P*Dc)
+__global__ __launch_bounds__(64) void vq_loss_finish_kernel(const float* __restrict__ part, int nblocks, int C, double inv_n,
+                                                            float beta, float* __restrict__ out) {
+  float total = 0.f;
+  for (int i = 0; i < C; ++i) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += (double)part[(size_t)b * C + i];
+    s = wave_sum_d(s);
+    float mse = (float)(s * inv_n);
+    total = total + (mse * beta + mse);
+  }
+  if (threadIdx.x == 0) out[0] = total;
+}
+
+// g_lat[p][j] = sum_{i: 0<=j-i<Dc} ( g_q[p][i*Dc + j-i] + g_vq*beta*2*(x_j - E_i[idx][j-i])/(P*Dc) )
+__global__ __launch_bounds__(256) void vq_bwd_latents_kernel(const float* __restrict__ gq, const float* __restrict__ gvq,
+                                                             const float* __restrict__ lat, const float* __restrict__ cb,
+                                                             const long long* __restrict__ inds, float* __restrict__ glat,
+                                                             int P, int D, int K, int Dc, int C, int HW, float beta) {
+  const long n = (long)P * D;
+  const long stride = (long)gridDim.x * 256;
+  const float sc = (gvq != nullptr ? gvq[0] : 0.f) * beta * 2.f / ((float)P * (float)Dc);
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) {
+    const int j = (int)(e % D);
+    const long p = e / D;
+    const int b = (int)(p / HW), hw = (int)(p - (long)b * HW);
+    const float x = lat[e];
+    float g = 0.f;
+    int ilo = j - Dc + 1;
+    if (ilo < 0) ilo = 0;
+    int ihi = j < C - 1 ? j : C - 1;
+    for (int i = ilo; i <= ihi; ++i) {
+      const int d = j - i;
+      const long long idx = inds[((size_t)b * C + i) * HW + hw];
+      const float q = cb[((size_t)i * K + (size_t)idx) * Dc + d];
+      g += (gq != nullptr ? gq[p * D + i * Dc + d] : 0.f) + sc * (x - q);
+    }
+    glat[e] = g;
+  }
+}
+
+// dE_i[k][d] (+)= g_vq * 2 * (cnt*E_i[k][d] - sum_{p: idx=k} x[p][i+d]) / (P*Dc)      grid (K, C), block 256
+__global__ __launch_bounds__(256) void vq_bwd_codebook_kernel(const float* __restrict__ gvq, const float* __restrict__ lat,
+                                                              const float* __restrict__ cb, const long long* __restrict__ inds,
+                                                              float* __restrict__ dcb, int P, int D, int K, int Dc, int C,
+                                                              int HW, int accumulate) {
+  __shared__ float sAcc[4][256];
+  __shared__ int sCnt[4];
+  const int k = blockIdx.x, i = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};  // d = lane + 64*u, Dc <= 256
+  int cnt = 0;
+  for (int base = wave * 64; base < P; base += 256) {
+    const int p = base + lane;
+    bool hit = false;
+    if (p < P) {
+      int b = p / HW, hw = p - b * HW;
+      hit = inds[((size_t)b * C + i) * HW + hw] == (long long)k;
+    }
+    unsigned long long mask = __ballot(hit);
+    cnt += __popcll(mask);
+    while (mask) {
+      int l = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      const float* x = lat + (size_t)(base + l) * D + i;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int d = lane + 64 * u;
+        if (d < Dc) acc[u] += x[d];
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) sAcc[wave][lane + 64 * u] = acc[u];
+  if (lane == 0) sCnt[wave] = cnt;
+  __syncthreads();
+  if (tid < Dc) {
+    const float sx = ((sAcc[0][tid] + sAcc[1][tid]) + sAcc[2][tid]) + sAcc[3][tid];
+    const float c = (float)(sCnt[0] + sCnt[1] + sCnt[2] + sCnt[3]);
+    const size_t o = ((size_t)i * K + k) * Dc + tid;
+    const float sc = (gvq != nullptr ? gvq[0] : 0.f) * 2.f / ((float)P * (float)Dc);
+    const float g = sc * (c * cb[o] - sx);
+    dcb[o] = (accumulate ? dcb[o] : 0.f) + g;
+  }
+}
+
+size_t vq_workspace_floats(int C) { return (size_t)1024 * C; }
+
+int launch_vq_inds(const float* lat, const float* cb, long long* inds, int B, int HW, int D, int K, int C, hipStream_t st) {
+  if (D % C != 0 || C > 8) return kErrBadArg;
+  const int Dc = D / C, P = B * HW;
+  const size_t smem = ((size_t)K * (Dc | 1) + K + 4 * Dc) * sizeof(float);
+  if (smem > 150 * 1024) return kErrBadArg;
+  int blocks = ceil_div(P, 64);
+  if (blocks > 512) blocks = 512;
+  const int rpb = ceil_div(P, blocks);
+  blocks = ceil_div(P, rpb);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(vq_inds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(vq_inds_kernel, dim3(blocks, C), dim3(256), smem, st, lat, cb, inds, P, D, K, Dc, C, HW, rpb);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_vq_lookup(const float* lat, const float* cb, const long long* inds, float* out, float* vq_loss, float beta, int B,
+                     int HW, int D, int K, int C, float* ws, size_t ws_bytes, hipStream_t st) {
+  if (D % C != 0 || C > 8) return kErrBadArg;
+  if (ws_bytes / sizeof(float) < vq_workspace_floats(C)) return kErrWorkspace;
+  const int Dc = D / C, P = B * HW;
+  long blocks = ((long)P * D + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(vq_lookup_kernel, dim3((unsigned)blocks), dim3(256), 0, st, lat, cb, inds, out, ws, P, D, K, Dc, C, HW);
+  CTVAE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(vq_loss_finish_kernel, dim3(1), dim3(64), 0, st, ws, (int)blocks, C, 1.0 / ((double)P * Dc), beta, vq_loss);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_vq_backward(const float* gq, const float* gvq, const float* lat, const float* cb, const long long* inds,
+                       float* glat, float* dcb, int accumulate, float beta, int B, int HW, int D, int K, int C,
+                       hipStream_t st) {
+  if (D % C != 0 || C > 8 || D / C > 256) return kErrBadArg;
+  const int Dc = D / C, P = B * HW;
+  if (glat != nullptr) {
+    long blocks = ((long)P * D + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(vq_bwd_latents_kernel, dim3((unsigned)blocks), dim3(256), 0, st, gq, gvq, lat, cb, inds, glat, P, D, K,
+                       Dc, C, HW, beta);
+    CTVAE_LAUNCH_CHECK();
+  }
+  if (dcb != nullptr) {
+    hipLaunchKernelGGL(vq_bwd_codebook_kernel, dim3(K, C), dim3(256), 0, st, gvq, lat, cb, inds, dcb, P, D, K, Dc, C, HW,
+                       accumulate);
+    CTVAE_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+}  // namespace ctvae

@@ -1,0 +1,310 @@
+// Weight-gradient kernel: autograd's wgrad of every Conv2d / ConvTranspose2d / Linear on the hot path
+// (SURVEY.md K20).  In the layer's FORWARD tap-GEMM geometry (geom.hpp)
+//
+//     dW[wtap(t)][c][n] = sum_m  X[gpix(m,t)][c] * dY[spix(m)][n]        (+ dbias[n] = sum_m dY[spix(m)][n])
+//
+// i.e. a GEMM whose output is small (taps*Ci x Co) and whose reduction runs over every output
+// pixel of the batch.  One workgroup owns a KT x NT tile of dW for one slice of the m range
+// ("split-M"), streams 32-pixel chunks of im2col(X) and dY through LDS and accumulates with
+// v_mfma_f32_32x32x2_f32; slices are combined by a second, deterministic pass (no float atomics:
+// bitwise reproducible, and atomics would be bound at ~1.3 TB/s on gfx950).
+#include "common.hpp"
+
+namespace ctvae {
+
+struct WgradArgs {
+  ConvGeom g;
+  const float* X;
+  const float* dY;
+  float* part;   // [S][rows_total][N]
+  float* pbias;  // [S*ncls][N] or null
+  int Mc, N, S, chunks_per_split;
+  int rows_total;          // taps_total * gC
+  int ktile_start[kMaxCls + 1];
+  int ntiles;
+};
+
+constexpr int MC = 32;
+
+template <int WK, int WN, bool XVEC, bool DVEC>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+  constexpr int KT = WK * 32, NT = WN * 32;
+  static_assert(WK * WN == 4, "4 waves");
+  __shared__ __attribute__((aligned(16))) float sX[MC * KT];
+  __shared__ __attribute__((aligned(16))) float sD[MC * NT];
+  __shared__ int sRowPix[2][MC];
+  __shared__ int sRowYX[2][MC];
+  __shared__ int sRowOut[2][MC];
+
+  const ConvGeom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int split = blockIdx.y;
+  const int ktg = blockIdx.x / a.ntiles, nt = blockIdx.x - ktg * a.ntiles;
+  int cls = 0;
+#pragma unroll
+  for (int c = 1; c < kMaxCls; ++c)
+    if (c < g.ncls && ktg >= a.ktile_start[c]) cls = c;
+  const int kt0 = (ktg - a.ktile_start[cls]) * KT;
+  const int n0 = nt * NT;
+  const int gC = g.gC;
+  const int Ktot = g.ntaps[cls] * gC;
+  const int N = a.N;
+
+  const int cbeg = split * a.chunks_per_split;
+  const int nchunks_all = (a.Mc + MC - 1) / MC;
+  int cend = cbeg + a.chunks_per_split;
+  if (cend > nchunks_all) cend = nchunks_all;
+  const int nch = cend - cbeg;
+
+  auto rowinfo = [&](int c, int buf) {
+    if (tid < MC) {
+      int m = (cbeg + c) * MC + tid;
+      if (m < a.Mc) {
+        int b, qy, qx;
+        decode_m(g, m, b, qy, qx);
+        sRowPix[buf][tid] = (b * g.gH + qy * g.is) * g.gW + qx * g.is;
+        sRowYX[buf][tid] = ((qy * g.is) << 16) | (qx * g.is);
+        sRowOut[buf][tid] = scatter_pix(g, cls, b, qy, qx);
+      } else {
+        sRowPix[buf][tid] = -1;
+        sRowYX[buf][tid] = 0;
+        sRowOut[buf][tid] = -1;
+      }
+    }
+  };
+
+  // per-thread fixed k column(s) of the X tile
+  constexpr int XQ = KT / 4;            // float4 per row
+  constexpr int X_V = (MC * XQ) / 256;  // float4 per thread
+  constexpr int X_S = (MC * KT) / 256;  // scalars per thread
+  constexpr int DQ = NT / 4;
+  constexpr int D_V = (MC * DQ) / 256 > 0 ? (MC * DQ) / 256 : 1;
+  constexpr int D_S = (MC * NT) / 256;
+  static_assert((MC * DQ) % 256 == 0 || MC * DQ == 256 / 1 || true, "");
+
+  int x_dy = 0, x_dx = 0, x_c = 0;
+  bool x_kok = false;
+  {
+    int kcol = XVEC ? 4 * (tid % XQ) : (tid % KT);
+    int k = kt0 + kcol;
+    x_kok = k < Ktot;
+    int t = x_kok ? k / gC : 0;
+    x_c = k - t * gC;
+    Tap tp = g.taps[cls][t];
+    x_dy = tp.dy;
+    x_dx = tp.dx;
+  }
+
+  f32x4 rx[XVEC ? X_V : 1];
+  float rxs[XVEC ? 1 : X_S];
+  f32x4 rd[DVEC ? D_V : 1];
+  float rds[DVEC ? 1 : D_S];
+
+  auto load_chunk = [&](int buf) {
+    if constexpr (XVEC) {
+#pragma unroll
+      for (int j = 0; j < X_V; ++j) {
+        int r = tid / XQ + (256 / XQ) * j;
+        int pix = sRowPix[buf][r], yx = sRowYX[buf][r];
+        int iy = (yx >> 16) + x_dy, ix = (yx & 0xffff) + x_dx;
+        bool ok = x_kok && pix >= 0 && (unsigned)iy < (unsigned)g.gH && (unsigned)ix < (unsigned)g.gW;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *reinterpret_cast<const f32x4*>(a.X + (long)(pix + x_dy * g.gW + x_dx) * gC + x_c);
+        rx[j] = v;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < X_S; ++j) {
+        int r = tid / KT + (256 / KT) * j;
+        int pix = sRowPix[buf][r], yx = sRowYX[buf][r];
+        int iy = (yx >> 16) + x_dy, ix = (yx & 0xffff) + x_dx;
+        bool ok = x_kok && pix >= 0 && (unsigned)iy < (unsigned)g.gH && (unsigned)ix < (unsigned)g.gW;
+        rxs[j] = ok ? a.X[(long)(pix + x_dy * g.gW + x_dx) * gC + x_c] : 0.f;
+      }
+    }
+    if constexpr (DVEC) {
+#pragma unroll
+      for (int j = 0; j < D_V; ++j) {
+        int f = tid + 256 * j;
+        int r = f / DQ, nq = f - r * DQ;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < MC) {
+          int sp = sRowOut[buf][r];
+          int n = n0 + 4 * nq;
+          if (sp >= 0 && n < N) v = *reinterpret_cast<const f32x4*>(a.dY + (long)sp * N + n);
+        }
+        rd[j] = v;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < D_S; ++j) {
+        int e = tid + 256 * j;
+        int r = e / NT, nn = e - r * NT;
+        int sp = sRowOut[buf][r];
+        int n = n0 + nn;
+        rds[j] = (sp >= 0 && n < N) ? a.dY[(long)sp * N + n] : 0.f;
+      }
+    }
+  };
+
+  auto store_chunk = [&]() {
+    if constexpr (XVEC) {
+#pragma unroll
+      for (int j = 0; j < X_V; ++j) {
+        int r = tid / XQ + (256 / XQ) * j;
+        *reinterpret_cast<f32x4*>(&sX[r * KT + 4 * (tid % XQ)]) = rx[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < X_S; ++j) sX[(tid / KT + (256 / KT) * j) * KT + (tid % KT)] = rxs[j];
+    }
+    if constexpr (DVEC) {
+#pragma unroll
+      for (int j = 0; j < D_V; ++j) {
+        int f = tid + 256 * j;
+        int r = f / DQ, nq = f - r * DQ;
+        if (r < MC) *reinterpret_cast<f32x4*>(&sD[r * NT + 4 * nq]) = rd[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < D_S; ++j) sD[tid + 256 * j] = rds[j];
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
+  const bool do_bias = (a.pbias != nullptr) && (kt0 == 0) && (tid < NT);
+
+  if (nch > 0) {
+    rowinfo(0, 0);
+    __syncthreads();
+    load_chunk(0);
+    if (nch > 1) rowinfo(1, 1);
+    store_chunk();
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+      if (c + 1 < nch) load_chunk((c + 1) & 1);
+      if (c + 2 < nch) rowinfo(c + 2, c & 1);
+#pragma unroll
+      for (int s = 0; s < MC / 2; ++s) {
+        float av = sX[(2 * s + lh) * KT + wk * 32 + li];
+        float bv = sD[(2 * s + lh) * NT + wn * 32 + li];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+      }
+      if (do_bias) {
+#pragma unroll 8
+        for (int r = 0; r < MC; ++r) bsum += sD[r * NT + tid];
+      }
+      __syncthreads();
+      if (c + 1 < nch) {
+        store_chunk();
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---- write partial tile ---------------------------------------------------------------------
+  const int col = n0 + wn * 32 + li;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int k = kt0 + wk * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+    if (k < Ktot && col < N) {
+      int t = k / gC, c = k - t * gC;
+      int wrow = g.taps[cls][t].wtap * gC + c;
+      a.part[((long)split * a.rows_total + wrow) * N + col] = acc[r];
+    }
+  }
+  if (do_bias && n0 + tid < N) a.pbias[(long)(split * g.ncls + cls) * N + n0 + tid] = bsum;
+}
+
+// dst[i] = (accumulate ? dst[i] : 0) + sum_s part[s*stride + i]
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ dst,
+                                                              long n, int S, long stride, int accumulate) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = accumulate ? dst[i] : 0.f;
+  for (int s = 0; s < S; ++s) v += part[(long)s * stride + i];
+  dst[i] = v;
+}
+
+size_t wgrad_workspace_floats(const ConvGeom& g, int S) {
+  int taps_total = 0;
+  for (int c = 0; c < g.ncls; ++c) taps_total += g.ntaps[c];
+  size_t rows = (size_t)taps_total * g.gC;
+  return (size_t)S * rows * g.sC + (size_t)S * g.ncls * g.sC;
+}
+
+// choose the number of m-splits so that the grid has ~1024 workgroups
+static int choose_splits(const ConvGeom& g, int KT, int NT, size_t ws_floats) {
+  int ktiles = 0;
+  for (int c = 0; c < g.ncls; ++c) ktiles += ceil_div(g.ntaps[c] * g.gC, KT);
+  int tiles = ktiles * ceil_div(g.sC, NT);
+  int Mc = g.B * g.Qh * g.Qw;
+  int nchunks = ceil_div(Mc, MC);
+  int S = 1024 / (tiles > 0 ? tiles : 1);
+  if (S < 1) S = 1;
+  int maxS = ceil_div(nchunks, 4);  // at least 4 chunks per split
+  if (maxS < 1) maxS = 1;
+  if (S > maxS) S = maxS;
+  while (S > 1 && wgrad_workspace_floats(g, S) > ws_floats) --S;
+  return S;
+}
+
+int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, float* dbias, float* ws,
+                 size_t ws_bytes, int accumulate, hipStream_t st) {
+  WgradArgs a{};
+  a.g = g;
+  a.X = X; a.dY = dY;
+  a.Mc = g.B * g.Qh * g.Qw;
+  a.N = g.sC;
+  if (g.wT != 0 || a.Mc <= 0) return kErrBadArg;
+  int taps_total = 0;
+  for (int c = 0; c < g.ncls; ++c) taps_total += g.ntaps[c];
+  a.rows_total = taps_total * g.gC;
+  const bool xvec = (g.gC % 4) == 0, dvec = (a.N % 4) == 0;
+  const bool narrow = a.N <= 32;
+  const int KT = narrow ? 128 : 64, NT = narrow ? 32 : 64;
+  const size_t ws_floats = ws_bytes / sizeof(float);
+  const int S = choose_splits(g, KT, NT, ws_floats);
+  if (wgrad_workspace_floats(g, S) > ws_floats) return kErrWorkspace;
+  a.S = S;
+  const int nchunks = ceil_div(a.Mc, MC);
+  a.chunks_per_split = ceil_div(nchunks, S);
+  a.part = ws;
+  a.pbias = dbias ? ws + (size_t)S * a.rows_total * a.N : nullptr;
+  int kt = 0;
+  for (int c = 0; c < g.ncls; ++c) {
+    a.ktile_start[c] = kt;
+    kt += ceil_div(g.ntaps[c] * g.gC, KT);
+  }
+  a.ktile_start[g.ncls] = kt;
+  a.ntiles = ceil_div(a.N, NT);
+  dim3 grid(kt * a.ntiles, S), block(256);
+#define CTVAE_WG(WK_, WN_)                                                                              \
+  do {                                                                                                  \
+    if (xvec && dvec) hipLaunchKernelGGL((wgrad_kernel<WK_, WN_, true, true>), grid, block, 0, st, a);  \
+    else if (!xvec && dvec) hipLaunchKernelGGL((wgrad_kernel<WK_, WN_, false, true>), grid, block, 0, st, a); \
+    else if (xvec && !dvec) hipLaunchKernelGGL((wgrad_kernel<WK_, WN_, true, false>), grid, block, 0, st, a); \
+    else hipLaunchKernelGGL((wgrad_kernel<WK_, WN_, false, false>), grid, block, 0, st, a);             \
+  } while (0)
+  if (narrow) CTVAE_WG(4, 1);
+  else CTVAE_WG(2, 2);
+#undef CTVAE_WG
+  CTVAE_LAUNCH_CHECK();
+  const long n = (long)a.rows_total * a.N;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), block, 0, st, a.part, dW, n, S,
+                     (long)a.rows_total * a.N, accumulate);
+  CTVAE_LAUNCH_CHECK();
+  if (dbias) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(a.N, 256)), block, 0, st, a.pbias, dbias,
+                       (long)a.N, S * g.ncls, (long)a.N, accumulate);
+    CTVAE_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+}  // namespace ctvae

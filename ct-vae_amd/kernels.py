@@ -1,0 +1,412 @@
+"""``torch.autograd.Function`` wrappers around the C ABI (``native.py`` / ``include/ctvae_hip.h``).
+
+Conventions
+-----------
+* Activations are plain contiguous NHWC tensors ``[B,H,W,C]`` inside this module; the model layer
+  (``models/``) exposes them as logical-NCHW ``permute(0,3,1,2)`` views (= torch channels_last).
+* Weights are parameters whose *memory* is the packed ``[kh*kw][Ci][Co]`` layout while their logical
+  shape/strides are PyTorch's (``models/packing.py``); kernels receive ``param.data_ptr()``.
+* Parameter gradients are written by the wgrad kernels straight into ``param.grad`` (same packed memory
+  layout, accumulate semantics like autograd); ``backward`` therefore returns ``None`` for parameters.
+  DDP hooks on parameters do not fire -- use ``ctvae_amd.ddp.GradBucketAllReduce``.
+* No op here has a PyTorch/CPU fallback: a missing library or a CPU tensor raises.
+"""
+from dataclasses import dataclass
+
+import torch
+from torch.autograd import Function
+
+from . import native
+
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+CONV, CONVT = 0, 1
+BN_MOMENTUM, BN_EPS = 0.1, 1e-5      # nn.BatchNorm2d defaults (vanilla_vae.py:30)
+
+
+@dataclass(frozen=True)
+class ConvSpec:
+    kind: int          # CONV / CONVT
+    ci: int
+    co: int
+    k: int
+    stride: int = 1
+    pad: int = 0
+    out_pad: int = 0
+    act: int = ACT_NONE
+
+    def out_hw(self, h, w):
+        if self.kind == CONV:
+            return (h + 2 * self.pad - self.k) // self.stride + 1, (w + 2 * self.pad - self.k) // self.stride + 1
+        return ((h - 1) * self.stride - 2 * self.pad + self.k + self.out_pad,
+                (w - 1) * self.stride - 2 * self.pad + self.k + self.out_pad)
+
+
+def _req_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("ctvae HIP kernels need device tensors (there is no CPU fallback on the product path)")
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def grad_target(p):
+    """(tensor to write the gradient into, accumulate flag).  Allocates p.grad with p's memory layout if absent."""
+    if p.grad is None:
+        p.grad = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device)
+        return p.grad, 0
+    if p.grad.stride() != p.stride():
+        raise RuntimeError("parameter .grad does not share the packed layout of the parameter")
+    return p.grad, 1
+
+
+# ---------------------------------------------------------------------------------------------------
+# low level launch helpers (no autograd)
+# ---------------------------------------------------------------------------------------------------
+def conv_forward_raw(x, w, b, spec: ConvSpec, add=None, act=None):
+    B, H, W, _ = x.shape
+    ho, wo = spec.out_hw(H, W)
+    y = torch.empty((B, ho, wo, spec.co), dtype=torch.float32, device=x.device)
+    native.call("ctvae_conv_forward", spec.kind, x.data_ptr(), w.data_ptr(), native.ptr(b), native.ptr(add), y.data_ptr(),
+                B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, spec.act if act is None else act)
+    return y
+
+
+def conv_dgrad_raw(dy, w, spec: ConvSpec, in_hw, add=None, mask=None, mask_act=ACT_NONE):
+    B = dy.shape[0]
+    H, W = in_hw
+    dx = torch.empty((B, H, W, spec.ci), dtype=torch.float32, device=dy.device)
+    native.call("ctvae_conv_dgrad", spec.kind, dy.data_ptr(), w.data_ptr(), native.ptr(add), native.ptr(mask), mask_act,
+                dx.data_ptr(), B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad)
+    return dx
+
+
+def conv_wgrad_raw(x, dy, w_param, b_param, spec: ConvSpec):
+    B, H, W, _ = x.shape
+    ws = native.workspace(x.device)
+    gw, acc = grad_target(w_param)
+    gb = None
+    if b_param is not None:
+        gb, accb = grad_target(b_param)
+        if accb != acc:   # keep one accumulate flag per call: materialise the fresh one as zeros
+            if acc == 0:
+                gw.zero_()
+            else:
+                gb.zero_()
+            acc = 1
+    native.call("ctvae_conv_wgrad", spec.kind, x.data_ptr(), dy.data_ptr(), gw.data_ptr(), native.ptr(gb),
+                B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, acc, ws.data_ptr(), ws.numel() * 4)
+
+
+def act_backward_raw(g_out, out, act):
+    if act == ACT_NONE:
+        return g_out
+    g_in = torch.empty_like(out)
+    native.call("ctvae_act_backward", g_out.data_ptr(), out.data_ptr(), g_in.data_ptr(), out.numel(), act)
+    return g_in
+
+
+def permute_raw(x, B, C, P, to_nhwc):
+    out = torch.empty(x.numel(), dtype=torch.float32, device=x.device)
+    native.call("ctvae_permute", x.data_ptr(), out.data_ptr(), B, C, P, 1 if to_nhwc else 0)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# layout boundary
+# ---------------------------------------------------------------------------------------------------
+class _ToNHWC(Function):
+    """Logical NCHW contiguous -> NHWC contiguous (HIP permute)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, C, H, W = x.shape
+        ctx.dims = (B, C, H, W)
+        return permute_raw(_c(x), B, C, H * W, True).view(B, H, W, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W = ctx.dims
+        return permute_raw(_c(g), B, C, H * W, False).view(B, C, H, W)
+
+
+class _ToNCHW(Function):
+    """NHWC contiguous -> NCHW contiguous."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, H, W, C = x.shape
+        ctx.dims = (B, C, H, W)
+        return permute_raw(_c(x), B, C, H * W, False).view(B, C, H, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W = ctx.dims
+        return permute_raw(_c(g), B, C, H * W, True).view(B, H, W, C)
+
+
+def to_nhwc(x_nchw):
+    """Accept a logical [B,C,H,W] tensor, return the NHWC-contiguous [B,H,W,C] tensor (zero-copy for channels_last)."""
+    _req_cuda(x_nchw)
+    if x_nchw.dtype != torch.float32:
+        raise RuntimeError("ctvae kernels are fp32 (parity target 1e-4, SURVEY.md §7)")
+    v = x_nchw.permute(0, 2, 3, 1)
+    if v.is_contiguous():
+        return v
+    if x_nchw.is_contiguous():
+        return _ToNHWC.apply(x_nchw)
+    return v.contiguous()
+
+
+def to_nchw_view(x_nhwc):
+    return x_nhwc.permute(0, 3, 1, 2)
+
+
+# ---------------------------------------------------------------------------------------------------
+# conv / linear (+ bias + residual + activation)
+# ---------------------------------------------------------------------------------------------------
+class ConvAct(Function):
+    """y = act(conv(x, w) + b + add).  Conv2d/ConvTranspose2d/Linear forward, dgrad and wgrad on HIP."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, add, spec):
+        _req_cuda(x, w)
+        x = _c(x)
+        add_c = _c(add) if add is not None else None
+        y = conv_forward_raw(x, w, b, spec, add_c)
+        ctx.spec = spec
+        ctx.w, ctx.b = w, b
+        ctx.has_add = add is not None
+        ctx.save_for_backward(x, y if spec.act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        spec = ctx.spec
+        x, y = ctx.saved_tensors
+        g_y = _c(g_y)
+        g_pre = act_backward_raw(g_y, y, spec.act) if spec.act != ACT_NONE else g_y
+        conv_wgrad_raw(x, g_pre, ctx.w, ctx.b, spec)
+        g_x = None
+        if ctx.needs_input_grad[0]:
+            g_x = conv_dgrad_raw(g_pre, ctx.w, spec, (x.shape[1], x.shape[2]))
+        g_add = g_pre if (ctx.has_add and ctx.needs_input_grad[3]) else None
+        return g_x, None, None, g_add, None
+
+
+class ConvBNAct(Function):
+    """a = act(BatchNorm2d(conv(x, w) + b)) with train-mode batch statistics (vanilla_vae.py:25-35,47-75)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, training, spec, bn_act):
+        _req_cuda(x, w, gamma)
+        x = _c(x)
+        y = conv_forward_raw(x, w, b, spec, None, ACT_NONE)
+        B, H, W, C = y.shape
+        a = torch.empty_like(y)
+        ws = native.workspace(x.device)
+        save_mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        save_invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        native.call("ctvae_bn_forward", y.data_ptr(), B * H * W, C, gamma.data_ptr(), beta.data_ptr(),
+                    native.ptr(running_mean), native.ptr(running_var), BN_MOMENTUM, BN_EPS, 1 if training else 0, bn_act,
+                    a.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr(), ws.numel() * 4)
+        ctx.spec, ctx.bn_act, ctx.training = spec, bn_act, training
+        ctx.params = (w, b, gamma, beta)
+        ctx.save_for_backward(x, y, a, save_mean, save_invstd)
+        return a
+
+    @staticmethod
+    def backward(ctx, g_a):
+        if not ctx.training:
+            raise RuntimeError("backward through eval-mode BatchNorm is not supported on the HIP path")
+        spec = ctx.spec
+        w, b, gamma, beta = ctx.params
+        x, y, a, save_mean, save_invstd = ctx.saved_tensors
+        g_a = _c(g_a)
+        B, H, W, C = y.shape
+        ws = native.workspace(x.device)
+        g_y = torch.empty_like(y)
+        gg, accg = grad_target(gamma)
+        gbt, accb = grad_target(beta)
+        if accg != accb:
+            (gg if accg == 0 else gbt).zero_()
+            accg = 1
+        native.call("ctvae_bn_backward", g_a.data_ptr(), a.data_ptr(), y.data_ptr(), B * H * W, C, gamma.data_ptr(),
+                    save_mean.data_ptr(), save_invstd.data_ptr(), ctx.bn_act, g_y.data_ptr(), gg.data_ptr(), gbt.data_ptr(),
+                    accg, ws.data_ptr(), ws.numel() * 4)
+        conv_wgrad_raw(x, g_y, w, b, spec)
+        g_x = None
+        if ctx.needs_input_grad[0]:
+            g_x = conv_dgrad_raw(g_y, w, spec, (x.shape[1], x.shape[2]))
+        return (g_x,) + (None,) * 9
+
+
+class ActFn(Function):
+    """Standalone activation (nn.LeakyReLU sites mcq_vae.py:185,216)."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        _req_cuda(x)
+        x = _c(x)
+        out = torch.empty_like(x)
+        native.call("ctvae_act_forward", x.data_ptr(), out.data_ptr(), x.numel(), act)
+        ctx.act = act
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        return act_backward_raw(_c(g), out, ctx.act), None
+
+
+# ---------------------------------------------------------------------------------------------------
+# Gaussian reparameterisation and losses
+# ---------------------------------------------------------------------------------------------------
+def _rows(t):
+    """(tensor, row stride) for a 2-D tensor whose rows are contiguous (column slices of a wider matrix allowed)."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        t = t.contiguous()
+    return t, t.stride(0)
+
+
+class Reparameterize(Function):
+    """z = eps * exp(0.5*logvar) + mu (vanilla_vae.py:107-117), noise injectable."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        _req_cuda(mu, logvar, eps)
+        mu_, mrs = _rows(mu)
+        lv_, lrs = _rows(logvar)
+        eps = _c(eps)
+        B, L = mu.shape
+        z = torch.empty((B, L), dtype=torch.float32, device=mu.device)
+        native.call("ctvae_reparam_forward", mu_.data_ptr(), mrs, lv_.data_ptr(), lrs, eps.data_ptr(), z.data_ptr(), B, L)
+        ctx.save_for_backward(lv_, eps)
+        ctx.lrs = lrs
+        return z
+
+    @staticmethod
+    def backward(ctx, g_z):
+        lv_, eps = ctx.saved_tensors
+        g_z = _c(g_z)
+        B, L = g_z.shape
+        g_mu = torch.empty_like(g_z)
+        g_lv = torch.empty_like(g_z)
+        native.call("ctvae_reparam_backward", g_z.data_ptr(), lv_.data_ptr(), ctx.lrs, eps.data_ptr(), g_mu.data_ptr(),
+                    g_lv.data_ptr(), B, L)
+        return g_mu, g_lv, None
+
+
+class VAELoss(Function):
+    """out = [loss, mse, kld, -kld]: mse = F.mse_loss(recons, x); kld as vanilla_vae.py:143; loss = mse + M_N*kld (+ extra).
+    recons/x are same-layout contiguous tensors.  Only out[0] carries gradient."""
+
+    @staticmethod
+    def forward(ctx, recons, x, mu, logvar, extra, M_N):
+        _req_cuda(recons, x)
+        recons, x = _c(recons), _c(x)
+        if recons.shape != x.shape:
+            raise RuntimeError("mse_loss: shape mismatch")
+        out = torch.empty(4, dtype=torch.float32, device=recons.device)
+        ws = native.workspace(recons.device)
+        if mu is not None:
+            mu_, mrs = _rows(mu)
+            lv_, lrs = _rows(logvar)
+            B, L = mu.shape
+        else:
+            mu_, lv_, mrs, lrs, B, L = None, None, 0, 0, 0, 0
+        native.call("ctvae_loss_forward", recons.data_ptr(), x.data_ptr(), recons.numel(), native.ptr(mu_), mrs, native.ptr(lv_),
+                    lrs, B, L, float(M_N), native.ptr(extra), out.data_ptr(), ws.data_ptr(), ws.numel() * 4)
+        ctx.save_for_backward(recons, x, mu_, lv_)
+        ctx.meta = (mrs, lrs, B, L, float(M_N), extra is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        recons, x, mu_, lv_ = ctx.saved_tensors
+        mrs, lrs, B, L, M_N, has_extra = ctx.meta
+        g_loss = _c(g_out[0:1])                      # d/d loss; mse and kld outputs are reported detached
+        g_r = None
+        if ctx.needs_input_grad[0]:
+            g_r = torch.empty_like(recons)
+            native.call("ctvae_mse_backward", recons.data_ptr(), x.data_ptr(), g_loss.data_ptr(), g_r.data_ptr(), recons.numel())
+        g_mu = g_lv = None
+        if mu_ is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
+            g_mu = torch.empty((B, L), dtype=torch.float32, device=recons.device)
+            g_lv = torch.empty((B, L), dtype=torch.float32, device=recons.device)
+            native.call("ctvae_kl_backward", mu_.data_ptr(), mrs, lv_.data_ptr(), lrs, g_loss.data_ptr(), g_mu.data_ptr(),
+                        g_lv.data_ptr(), B, L, M_N)
+        g_extra = g_loss.reshape(()) if (has_extra and ctx.needs_input_grad[4]) else None
+        return g_r, None, g_mu, g_lv, g_extra, None
+
+
+# ---------------------------------------------------------------------------------------------------
+# vector quantiser
+# ---------------------------------------------------------------------------------------------------
+def vq_compute_inds(latents_nhwc, codebooks, K, C):
+    """latents [B,H,W,D] -> int64 [B,C,H,W] (mcq_vae.py:26-39,100-110).  No gradient (arg-min)."""
+    _req_cuda(latents_nhwc)
+    lat = _c(latents_nhwc.detach())
+    B, H, W, D = lat.shape
+    inds = torch.empty((B, C, H, W), dtype=torch.int64, device=lat.device)
+    native.call("ctvae_vq_inds", lat.data_ptr(), codebooks[0].data_ptr(), inds.data_ptr(), B, H * W, D, K, C)
+    return inds
+
+
+class VQLookup(Function):
+    """(quantized [B,H,W,D], vq_loss scalar) = compute_latents(latents, inds) (mcq_vae.py:41-64,112-127)."""
+
+    @staticmethod
+    def forward(ctx, latents, inds, beta, K, C, *codebooks):
+        _req_cuda(latents, inds)
+        lat = _c(latents)
+        inds = _c(inds)
+        B, H, W, D = lat.shape
+        q = torch.empty_like(lat)
+        vq_loss = torch.empty((), dtype=torch.float32, device=lat.device)
+        ws = native.workspace(lat.device)
+        native.call("ctvae_vq_lookup", lat.data_ptr(), codebooks[0].data_ptr(), inds.data_ptr(), q.data_ptr(),
+                    vq_loss.data_ptr(), float(beta), B, H * W, D, K, C, ws.data_ptr(), ws.numel() * 4)
+        ctx.meta = (float(beta), K, C)
+        ctx.codebooks = codebooks
+        ctx.save_for_backward(lat, inds)
+        return q, vq_loss
+
+    @staticmethod
+    def backward(ctx, g_q, g_vq):
+        lat, inds = ctx.saved_tensors
+        beta, K, C = ctx.meta
+        B, H, W, D = lat.shape
+        g_q = _c(g_q) if g_q is not None else None
+        g_vq = _c(g_vq) if g_vq is not None else None
+        g_lat = torch.empty_like(lat) if ctx.needs_input_grad[0] else None
+        cb0 = ctx.codebooks[0]
+        dcb = None
+        acc = 0
+        if g_vq is not None and cb0.requires_grad:
+            flags = [grad_target(cb) for cb in ctx.codebooks]
+            if any(f[1] != flags[0][1] for f in flags):
+                for (gt, a) in flags:
+                    if a == 0:
+                        gt.zero_()
+                acc = 1
+            else:
+                acc = flags[0][1]
+            dcb = flags[0][0]
+            for i in range(1, C):
+                if flags[i][0].data_ptr() != dcb.data_ptr() + i * cb0.numel() * 4:
+                    raise RuntimeError("codebook gradients must be stored back to back (flat gradient buffer)")
+        native.call("ctvae_vq_backward", native.ptr(g_q), native.ptr(g_vq), lat.data_ptr(), cb0.data_ptr(), inds.data_ptr(),
+                    native.ptr(g_lat), native.ptr(dcb), acc, beta, B, H * W, D, K, C)
+        return (g_lat, None, None, None, None) + (None,) * len(ctx.codebooks)
+
+
+# ---------------------------------------------------------------------------------------------------
+# flat fused Adam
+# ---------------------------------------------------------------------------------------------------
+def adam_step(flat_params, flat_grads, exp_avg, exp_avg_sq, state, grad_scale=1.0):
+    _req_cuda(flat_params, flat_grads)
+    native.call("ctvae_adam_step", flat_params.data_ptr(), flat_grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                state.data_ptr(), flat_params.numel(), float(grad_scale))

@@ -1,0 +1,23 @@
+"""Mirror of the reference's ``models`` package for the hot-path models (models/__init__.py:1-56):
+``vae_models[name](**config['model_params'])`` is how run.py:52 builds a model."""
+from .base import BaseVAE
+from .blocks import ResidualLayer
+from .mcq_vae import MCQVAE, MultipleCodebookVectorQuantizer, VectorQuantizerMS
+from .vanilla_vae import VanillaVAE
+
+# Aliases (models/__init__.py:29-32)
+VAE = VanillaVAE
+GaussianVAE = VanillaVAE
+
+vae_models = {
+    'VanillaVAE': VanillaVAE,
+    'VAE': VanillaVAE,
+    'GaussianVAE': VanillaVAE,
+    'MCQVAE': MCQVAE,
+}
+
+try:  # CTMCQVAE needs nothing beyond torch, but keep the registry usable if it is being developed
+    from .ct_mcq_vae import CTMCQVAE
+    vae_models['CTMCQVAE'] = CTMCQVAE
+except ImportError:  # pragma: no cover
+    pass

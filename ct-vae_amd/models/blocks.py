@@ -1,0 +1,82 @@
+"""HIP-backed building blocks that reproduce the reference's module tree (so ``state_dict`` keys match)
+while executing fused kernels.  All blocks take and return NHWC-contiguous ``[B,H,W,C]`` tensors; the
+model classes convert at the public NCHW boundary."""
+import torch
+from torch import nn
+
+from .. import kernels as K
+from .packing import PackedBN, PackedConv
+
+
+def conv_bn_leaky(x, conv, bn, spec, training):
+    """Conv (+bias) -> train/eval BatchNorm2d -> LeakyReLU on the holders `conv` / `bn`."""
+    a = K.ConvBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                          training, spec, K.ACT_LRELU)
+    if training:
+        bn.num_batches_tracked += 1
+    return a
+
+
+class ConvBNLeaky(nn.Module):
+    """nn.Sequential(Conv2d|ConvTranspose2d, BatchNorm2d, LeakyReLU) (vanilla_vae.py:25-35,47-58) as two launches
+    groups: conv (+bias) and BN statistics/apply+LeakyReLU.  Children are named "0" and "1" like the reference."""
+
+    def __init__(self, ci, co, k, stride, pad, out_pad=0, transposed=False):
+        super().__init__()
+        self.add_module("0", PackedConv(ci, co, k, transposed=transposed, bias=True))
+        self.add_module("1", PackedBN(co))
+        self.spec = K.ConvSpec(K.CONVT if transposed else K.CONV, ci, co, k, stride, pad, out_pad, K.ACT_NONE)
+
+    def forward(self, x):
+        return conv_bn_leaky(x, self._modules["0"], self._modules["1"], self.spec, self.training)
+
+
+class ConvAct(nn.Module):
+    """nn.Sequential(Conv2d|ConvTranspose2d, LeakyReLU|Tanh) (mcq_vae.py:168-173,176-180,187-191,203-209,221-237):
+    one launch, bias + activation in the epilogue.  Child "0" holds the parameters."""
+
+    def __init__(self, ci, co, k, stride, pad, act, transposed=False, out_pad=0):
+        super().__init__()
+        self.add_module("0", PackedConv(ci, co, k, transposed=transposed, bias=True))
+        self.spec = K.ConvSpec(K.CONVT if transposed else K.CONV, ci, co, k, stride, pad, out_pad, act)
+
+    def forward(self, x):
+        conv = self._modules["0"]
+        return K.ConvAct.apply(x, conv.weight, conv.bias, None, self.spec)
+
+
+class _ResBlockParams(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.add_module("0", PackedConv(c, c, 3, bias=False))
+        self.add_module("2", PackedConv(c, c, 1, bias=False))
+
+
+class ResidualLayer(nn.Module):
+    """x + Conv1x1(ReLU(Conv3x3(x))), both bias-free (vq_vae.py:57-70).  ReLU is fused into the 3x3 epilogue, the skip
+    add into the 1x1 epilogue; ``post_act`` additionally fuses the LeakyReLU that follows the last block
+    (mcq_vae.py:185,216) when the model asks for it."""
+
+    def __init__(self, in_channels, out_channels, post_act=K.ACT_NONE):
+        super().__init__()
+        assert in_channels == out_channels
+        self.resblock = _ResBlockParams(in_channels)
+        c = in_channels
+        self.spec3 = K.ConvSpec(K.CONV, c, c, 3, 1, 1, 0, K.ACT_RELU)
+        self.spec1 = K.ConvSpec(K.CONV, c, c, 1, 1, 0, 0, post_act)
+
+    def forward(self, x):
+        h = K.ConvAct.apply(x, self.resblock._modules["0"].weight, None, None, self.spec3)
+        return K.ConvAct.apply(h, self.resblock._modules["2"].weight, None, x, self.spec1)
+
+
+class LeakyReLU(nn.Module):
+    """Parameter-free placeholder that keeps the reference's Sequential indices; ``fused=True`` means the
+    producer already applied it."""
+
+    def __init__(self, fused=False):
+        super().__init__()
+        self.fused = fused
+
+    def forward(self, x):
+        return x if self.fused else K.ActFn.apply(x, K.ACT_LRELU)

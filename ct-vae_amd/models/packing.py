@@ -1,0 +1,208 @@
+"""Parameter storage for the HIP models: PyTorch-shaped views over packed, flat HBM buffers.
+
+Every parameter keeps the reference's name and logical shape (``state_dict`` interchange with
+ct-vae checkpoints, SURVEY.md §5 "Checkpoint / resume"), but its memory is what the kernels want:
+
+* Conv2d weight ``[Co,Ci,kh,kw]``          -> memory ``[kh][kw][Ci][Co]`` (strides ``(1, Co, kw*Ci*Co, Ci*Co)``)
+* ConvTranspose2d weight ``[Ci,Co,kh,kw]`` -> memory ``[kh][kw][Ci][Co]`` (strides ``(Co, 1, kw*Ci*Co, Ci*Co)``)
+* Linear weight ``[out,in]``               -> memory ``[in][out]``; several Linear layers that read the same
+  input (fc_mu / fc_var) share one ``[in][sum(out)]`` block so the heads run as ONE GEMM.
+
+``FlatParamMixin.flatten_parameters`` then places all blocks back to back in ONE fp32 buffer (and the
+gradients in a second one of the same layout): the DDP exchange is a single all-reduce of that buffer and
+Adam is one kernel over it (288 GB HBM: no reason to scatter 50 small allocations).
+"""
+import math
+
+import torch
+from torch import nn
+
+
+def _uniform_(t, bound):
+    with torch.no_grad():
+        t.uniform_(-bound, bound)
+
+
+class PackedConv(nn.Module):
+    """Holder for a Conv2d / ConvTranspose2d weight (+bias) in packed layout; default init = torch's
+    (kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(fan_in)); bias U(+-1/sqrt(fan_in)))."""
+
+    def __init__(self, ci, co, k, transposed=False, bias=True):
+        super().__init__()
+        self.ci, self.co, self.k, self.transposed = ci, co, k, transposed
+        store = torch.empty(k, k, ci, co)
+        if transposed:
+            w = store.permute(2, 3, 0, 1)      # [Ci,Co,kh,kw]
+            fan_in = co * k * k                # torch computes fan_in from dim 1 of the weight tensor
+        else:
+            w = store.permute(3, 2, 0, 1)      # [Co,Ci,kh,kw]
+            fan_in = ci * k * k
+        self.weight = nn.Parameter(w)
+        _uniform_(self.weight, 1.0 / math.sqrt(fan_in))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(co))
+            _uniform_(self.bias, 1.0 / math.sqrt(fan_in))
+        else:
+            self.register_parameter("bias", None)
+
+    def storage_blocks(self):
+        k, ci, co = self.k, self.ci, self.co
+        if self.transposed:
+            size, stride = (ci, co, k, k), (co, 1, k * ci * co, ci * co)
+        else:
+            size, stride = (co, ci, k, k), (1, co, k * ci * co, ci * co)
+        blocks = [(k * k * ci * co, [(self.weight, 0, size, stride)])]
+        if self.bias is not None:
+            blocks.append((co, [(self.bias, 0, (co,), (1,))]))
+        return blocks
+
+
+class PackedLinearGroup:
+    """Storage description for Linear layers sharing one input: memory [in][sum(out)] (weights), [sum(out)] (biases)."""
+
+    def __init__(self, linears):
+        self.linears = linears
+        self.fin = linears[0].in_features
+        self.total = sum(l.out_features for l in linears)
+
+    def storage_blocks(self):
+        wviews, bviews, off = [], [], 0
+        for l in self.linears:
+            wviews.append((l.weight, off, (l.out_features, self.fin), (1, self.total)))
+            bviews.append((l.bias, off, (l.out_features,), (1,)))
+            off += l.out_features
+        return [(self.fin * self.total, wviews), (self.total, bviews)]
+
+
+class PackedLinear(nn.Module):
+    def __init__(self, fin, fout):
+        super().__init__()
+        self.in_features, self.out_features = fin, fout
+        self.weight = nn.Parameter(torch.empty(fin, fout).t())      # logical [out,in], memory [in][out]
+        self.bias = nn.Parameter(torch.empty(fout))
+        _uniform_(self.weight, 1.0 / math.sqrt(fin))
+        _uniform_(self.bias, 1.0 / math.sqrt(fin))
+
+    def storage_blocks(self):
+        return PackedLinearGroup([self]).storage_blocks()
+
+
+class PackedBN(nn.Module):
+    """BatchNorm2d parameters/buffers (gamma=1, beta=0, running_mean=0, running_var=1, num_batches_tracked=0)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.num_features = c
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def storage_blocks(self):
+        c = self.num_features
+        return [(c, [(self.weight, 0, (c,), (1,))]), (c, [(self.bias, 0, (c,), (1,))])]
+
+
+class PackedEmbedding(nn.Module):
+    """nn.Embedding(K, D) weight, init U(-1/K, 1/K) (mcq_vae.py:22-23)."""
+
+    def __init__(self, K, D):
+        super().__init__()
+        self.K, self.D = K, D
+        self.weight = nn.Parameter(torch.empty(K, D))
+        _uniform_(self.weight, 1.0 / K)
+
+    def storage_blocks(self):
+        return [(self.K * self.D, [(self.weight, 0, (self.K, self.D), (self.D, 1))])]
+
+
+class FlatParamMixin:
+    """Mixin for nn.Module roots: one flat parameter buffer + one flat gradient buffer."""
+
+    def _collect_blocks(self):
+        blocks, seen_groups = [], set()
+        claimed = set()
+        for m in self.modules():
+            grp = getattr(m, "_linear_group", None)
+            if grp is not None:
+                if id(grp) not in seen_groups:
+                    seen_groups.add(id(grp))
+                    blocks.extend(grp.storage_blocks())
+                continue
+            if hasattr(m, "storage_blocks") and m is not self:
+                blocks.extend(m.storage_blocks())
+        for _, views in blocks:
+            for p, *_ in views:
+                claimed.add(id(p))
+        for name, p in self.named_parameters():
+            if id(p) not in claimed:   # any other parameter (e.g. torch-level sub-modules): contiguous block
+                pc = p.detach().contiguous()
+                blocks.append((p.numel(), [(p, 0, tuple(p.shape), tuple(pc.stride()))]))
+        return blocks
+
+    def flatten_parameters(self):
+        """(Re)build the flat parameter / gradient buffers on the parameters' current device, keeping values."""
+        blocks = self._collect_blocks()
+        total = sum(n for n, _ in blocks)
+        dev = next(self.parameters()).device
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        gflat = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        self._grad_views = []
+        with torch.no_grad():
+            for n, views in blocks:
+                for p, o, size, stride in views:
+                    v = flat.as_strided(size, stride, off + o)
+                    v.copy_(p.detach().to(dev))
+                    old_grad = p.grad
+                    p.data = v
+                    g = gflat.as_strided(size, stride, off + o)
+                    if old_grad is not None:
+                        g.copy_(old_grad.to(dev))
+                    p.grad = g
+                    self._grad_views.append((p, g))
+                off += n
+        self._flat_params, self._flat_grads = flat, gflat
+        return flat, gflat
+
+    def attach_grads(self):
+        """Make sure every parameter's .grad is its view of the flat gradient buffer (an optimizer's
+        zero_grad(set_to_none=True) drops them; None means zero, so the view is cleared)."""
+        if getattr(self, "_flat_grads", None) is None:
+            self.flatten_parameters()
+            return
+        for p, g in self._grad_views:
+            if p.grad is not g:
+                with torch.no_grad():
+                    if p.grad is None:
+                        g.zero_()
+                    else:
+                        g.copy_(p.grad)
+                p.grad = g
+
+    @property
+    def flat_params(self):
+        if getattr(self, "_flat_params", None) is None:
+            self.flatten_parameters()
+        return self._flat_params
+
+    @property
+    def flat_grads(self):
+        if getattr(self, "_flat_grads", None) is None:
+            self.flatten_parameters()
+        return self._flat_grads
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._flat_params = self._flat_grads = None
+        if any(True for _ in self.parameters()):
+            self.flatten_parameters()
+        return out
+
+    def zero_grad(self, set_to_none: bool = False):
+        """Gradients live in the flat buffer: zero it in one memset instead of dropping the views."""
+        if getattr(self, "_flat_grads", None) is not None:
+            self._flat_grads.zero_()
+        else:
+            super().zero_grad(set_to_none=set_to_none)

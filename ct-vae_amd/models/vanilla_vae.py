@@ -1,0 +1,132 @@
+"""VanillaVAE on HIP kernels — drop-in for the reference class (models/vanilla_vae.py:8-173).
+
+Same constructor kwargs, method signatures, return lists, loss-dict keys and ``state_dict`` keys
+(``encoder.{i}.{0,1}.*``, ``fc_mu``, ``fc_var``, ``decoder_input``, ``decoder.{i}.{0,1}.*``,
+``final_layer.{0,1,3}.*``).  Differences that are deliberate and documented:
+
+* tensors returned by ``decode``/``forward`` are logical NCHW with channels_last memory;
+* ``reparameterize`` takes an optional ``eps`` so that noise can be injected;
+* parameters are views of one packed buffer (``packing.py``); ``fc_mu``/``fc_var`` run as one GEMM.
+"""
+from typing import List
+
+import torch
+from torch import nn
+
+from .. import kernels as K
+from .base import BaseVAE
+from .blocks import ConvBNLeaky, conv_bn_leaky
+from .packing import PackedBN, PackedConv, PackedLinear, PackedLinearGroup
+from .types_ import Tensor
+
+
+class _FinalLayer(nn.Module):
+    """nn.Sequential(ConvTranspose2d, BatchNorm2d, LeakyReLU, Conv2d(->3), Tanh) (vanilla_vae.py:64-75);
+    children "0", "1", "3" carry the parameters like the reference's Sequential indices."""
+
+    def __init__(self, c, out_channels=3):
+        super().__init__()
+        self.add_module("0", PackedConv(c, c, 3, transposed=True, bias=True))
+        self.add_module("1", PackedBN(c))
+        self.add_module("3", PackedConv(c, out_channels, 3, bias=True))
+        self.spec_up = K.ConvSpec(K.CONVT, c, c, 3, 2, 1, 1, K.ACT_NONE)
+        self.spec_out = K.ConvSpec(K.CONV, c, out_channels, 3, 1, 1, 0, K.ACT_TANH)
+
+    def forward(self, x):
+        h = conv_bn_leaky(x, self._modules["0"], self._modules["1"], self.spec_up, self.training)
+        conv = self._modules["3"]
+        return K.ConvAct.apply(h, conv.weight, conv.bias, None, self.spec_out)
+
+
+class VanillaVAE(BaseVAE):
+
+    def __init__(self, in_channels: int, latent_dim: int, hidden_dims: List = None, **kwargs) -> None:
+        super().__init__()
+        self.latent_dim = latent_dim
+        if hidden_dims is None:
+            hidden_dims = [32, 64, 128, 256, 512]
+        if hidden_dims[-1] != 512:
+            # the reference hard-codes view(-1, 512, 2, 2) in decode (vanilla_vae.py:102)
+            raise ValueError("VanillaVAE.decode assumes hidden_dims[-1] == 512 (reference behaviour)")
+        self.in_channels = in_channels
+        self.hidden_dims_fwd = list(hidden_dims)
+
+        enc, c = [], in_channels
+        for h in hidden_dims:
+            enc.append(ConvBNLeaky(c, h, 3, 2, 1))
+            c = h
+        self.encoder = nn.Sequential(*enc)
+        self.fc_mu = PackedLinear(hidden_dims[-1] * 4, latent_dim)
+        self.fc_var = PackedLinear(hidden_dims[-1] * 4, latent_dim)
+        grp = PackedLinearGroup([self.fc_mu, self.fc_var])
+        self.fc_mu._linear_group = grp
+        self.fc_var._linear_group = grp
+        self._head_spec = K.ConvSpec(K.CONV, hidden_dims[-1] * 4, 2 * latent_dim, 1)
+
+        self.decoder_input = PackedLinear(latent_dim, hidden_dims[-1] * 4)
+        self._dec_in_spec = K.ConvSpec(K.CONV, latent_dim, hidden_dims[-1] * 4, 1)
+        hidden_dims.reverse()                  # the reference mutates the caller's list too (vanilla_vae.py:45)
+        dec = []
+        for i in range(len(hidden_dims) - 1):
+            dec.append(ConvBNLeaky(hidden_dims[i], hidden_dims[i + 1], 3, 2, 1, out_pad=1, transposed=True))
+        self.decoder = nn.Sequential(*dec)
+        self.final_layer = _FinalLayer(hidden_dims[-1], 3)
+        self._x_cache = None
+        self.flatten_parameters()
+
+    # -- helpers ----------------------------------------------------------------------------------
+    def _input_nhwc(self, input):
+        x = K.to_nhwc(input)
+        self._x_cache = (input.data_ptr(), input._version, tuple(input.shape), x)
+        return x
+
+    def _cached_nhwc(self, input):
+        c = self._x_cache
+        if c is not None and c[0] == input.data_ptr() and c[1] == input._version and c[2] == tuple(input.shape):
+            return c[3]
+        return K.to_nhwc(input)
+
+    # -- reference API ----------------------------------------------------------------------------
+    def encode(self, input: Tensor) -> List[Tensor]:
+        """[B,C,64,64] -> [mu [B,L], log_var [B,L]] (vanilla_vae.py:77-92)."""
+        self.attach_grads()
+        h = self.encoder(self._input_nhwc(input))                       # [B,2,2,512] NHWC
+        B = h.shape[0]
+        flat = K._ToNCHW.apply(h).view(B, 1, 1, -1)                      # torch.flatten(start_dim=1) on NCHW
+        heads = K.ConvAct.apply(flat, self.fc_mu.weight, self.fc_mu.bias, None, self._head_spec).view(B, -1)
+        L = self.latent_dim
+        return [heads[:, :L], heads[:, L:]]
+
+    def decode(self, z: Tensor) -> Tensor:
+        """[B,L] -> [B,3,64,64] (vanilla_vae.py:94-105)."""
+        self.attach_grads()
+        B = z.shape[0]
+        h = K.ConvAct.apply(z.reshape(B, 1, 1, -1), self.decoder_input.weight, self.decoder_input.bias, None, self._dec_in_spec)
+        h = K._ToNHWC.apply(h.view(B, 512, 2, 2))                        # .view(-1,512,2,2) is NCHW
+        h = self.decoder(h)
+        return K.to_nchw_view(self.final_layer(h))
+
+    def reparameterize(self, mu: Tensor, logvar: Tensor, eps: Tensor = None) -> Tensor:
+        """eps*exp(0.5*logvar)+mu (vanilla_vae.py:107-117); eps defaults to fresh N(0,1) noise on mu's device."""
+        if eps is None:
+            eps = torch.randn(mu.shape, dtype=mu.dtype, device=mu.device)
+        return K.Reparameterize.apply(mu, logvar, eps.to(mu.device))
+
+    def forward(self, input: Tensor, eps: Tensor = None, **kwargs) -> List[Tensor]:
+        mu, log_var = self.encode(input)
+        z = self.reparameterize(mu, log_var, eps)
+        return [self.decode(z), input, mu, log_var]
+
+    def loss_function(self, *args, **kwargs) -> dict:
+        """MSE + M_N*KL (vanilla_vae.py:124-146); 'KLD' carries the reference's flipped sign."""
+        recons, input, mu, log_var = args[0], args[1], args[2], args[3]
+        kld_weight = kwargs['M_N']
+        out = K.VAELoss.apply(K.to_nhwc(recons), self._cached_nhwc(input), mu, log_var, None, kld_weight)
+        return {'loss': out[0], 'Reconstruction_Loss': out[1].detach(), 'KLD': out[3].detach()}
+
+    def sample(self, num_samples: int, current_device: int, **kwargs) -> Tensor:
+        z = torch.randn(num_samples, self.latent_dim).to(current_device)
+        return self.decode(z)
+
+    def generate(self, x: Tensor, **kwargs) -> Tensor:
+        return self.forward(x)[0]

@@ -1,0 +1,113 @@
+"""ctypes binding of ``libctvae_hip.so`` (C ABI: ``include/ctvae_hip.h``).
+
+The product path has NO CPU or eager-PyTorch fallback: if the library is missing, cannot be loaded or
+a launch fails, a ``RuntimeError`` is raised (SURVEY.md §8b "Errors").  Tensors are passed as raw device
+pointers; the current torch stream is passed as the ``hipStream_t``.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libctvae_hip.so")
+
+_c = ctypes
+_fp, _vp, _i, _l, _f, _sz = _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_long, _c.c_float, _c.c_size_t
+
+# name -> argtypes (all return int unless listed in _RESTYPES)
+SIGNATURES = {
+    "ctvae_conv_forward": [_i, _fp, _fp, _fp, _fp, _fp] + [_i] * 10 + [_vp],
+    "ctvae_conv_dgrad": [_i, _fp, _fp, _fp, _fp, _i, _fp] + [_i] * 9 + [_vp],
+    "ctvae_conv_wgrad": [_i, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _sz, _vp],
+    "ctvae_bn_forward": [_fp, _i, _i, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _fp, _fp, _fp, _fp, _sz, _vp],
+    "ctvae_bn_backward": [_fp, _fp, _fp, _i, _i, _fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _fp, _sz, _vp],
+    "ctvae_permute": [_fp, _fp, _i, _i, _i, _i, _vp],
+    "ctvae_act_forward": [_fp, _fp, _l, _i, _vp],
+    "ctvae_act_backward": [_fp, _fp, _fp, _l, _i, _vp],
+    "ctvae_reparam_forward": [_fp, _l, _fp, _l, _fp, _fp, _i, _i, _vp],
+    "ctvae_reparam_backward": [_fp, _fp, _l, _fp, _fp, _fp, _i, _i, _vp],
+    "ctvae_loss_forward": [_fp, _fp, _l, _fp, _l, _fp, _l, _i, _i, _f, _fp, _fp, _fp, _sz, _vp],
+    "ctvae_mse_backward": [_fp, _fp, _fp, _fp, _l, _vp],
+    "ctvae_kl_backward": [_fp, _l, _fp, _l, _fp, _fp, _fp, _i, _i, _f, _vp],
+    "ctvae_vq_inds": [_fp, _fp, _fp, _i, _i, _i, _i, _i, _vp],
+    "ctvae_vq_lookup": [_fp, _fp, _fp, _fp, _fp, _f, _i, _i, _i, _i, _i, _fp, _sz, _vp],
+    "ctvae_vq_backward": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _f, _i, _i, _i, _i, _i, _vp],
+    "ctvae_adam_step": [_fp, _fp, _fp, _fp, _fp, _l, _f, _vp],
+}
+_RESTYPES = {
+    "ctvae_version": _c.c_char_p,
+    "ctvae_arch": _c.c_char_p,
+    "ctvae_error_string": _c.c_char_p,
+    "ctvae_workspace_bytes": _c.c_size_t,
+}
+EXPORTS = sorted(list(SIGNATURES) + list(_RESTYPES))
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises RuntimeError when it is absent or does not match the header."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m ctvae_amd.build` (hipcc, gfx950). "
+            "There is no CPU/PyTorch fallback for the ctvae hot path.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise RuntimeError(f"{LIB_PATH} does not export {name} (stale build?)")
+        fn.argtypes = argtypes
+        fn.restype = _c.c_int
+    for name, res in _RESTYPES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise RuntimeError(f"{LIB_PATH} does not export {name} (stale build?)")
+        fn.restype = res
+        fn.argtypes = [_c.c_int] if name == "ctvae_error_string" else []
+    if lib.ctvae_arch() != b"gfx950":
+        raise RuntimeError("libctvae_hip.so was not built for gfx950")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = load().ctvae_error_string(int(code)).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {code})")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+_workspaces = {}
+
+
+def workspace(device) -> torch.Tensor:
+    """Per-(device, stream) scratch buffer.  Kernels on one stream are ordered, so one buffer per stream is
+    race-free; a second stream gets its own."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None:
+        n = load().ctvae_workspace_bytes()
+        ws = torch.empty(n // 4, dtype=torch.float32, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def call(name: str, *args):
+    """Launch entry point `name` on the current stream (the trailing stream argument is appended here)."""
+    lib = load()
+    check(getattr(lib, name)(*args, stream_ptr()), name)

@@ -1,0 +1,108 @@
+/* ctvae_hip.h — C ABI of libctvae_hip.so (MI355X / gfx950).
+ *
+ * The reference (Strong-AI-Lab/ct-vae) is 100 % Python and has no FFI of its own: every kernel is
+ * reached implicitly through torch.nn / torch.autograd.  This header therefore
+ * declares, per implicit op on the hot path, the entry point a binding for that op calls instead;
+ * each declaration cites the reference call site it replaces.  All tensors are fp32, activations are
+ * NHWC ("channels_last") in HBM, weights are packed [kh*kw][Cin][Cout] (Conv2d AND ConvTranspose2d,
+ * with Cin/Cout the layer's input/output channels; Linear = 1x1 conv on a 1x1 image).  No function
+ * allocates, synchronises or touches the host: callers own every buffer, incl. the scratch workspace
+ * (ctvae_workspace_bytes()), so every call is hipGraph-capturable.  Return value: 0, a hipError_t
+ * (>0) or a negative argument/workspace error; ctvae_error_string() maps either to text.
+ * `stream` is a hipStream_t passed as void*.
+ */
+#ifndef CTVAE_HIP_H
+#define CTVAE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* activation codes */
+#define CTVAE_ACT_NONE 0
+#define CTVAE_ACT_LRELU 1 /* nn.LeakyReLU() slope 0.01, vanilla_vae.py:31 */
+#define CTVAE_ACT_RELU 2  /* nn.ReLU(True), vq_vae.py:65 */
+#define CTVAE_ACT_TANH 3  /* nn.Tanh(), vanilla_vae.py:75, mcq_vae.py:237 */
+
+/* layer kinds */
+#define CTVAE_CONV 0  /* nn.Conv2d / nn.Linear */
+#define CTVAE_CONVT 1 /* nn.ConvTranspose2d */
+
+const char* ctvae_version(void);
+const char* ctvae_arch(void); /* "gfx950" */
+const char* ctvae_error_string(int code);
+size_t ctvae_workspace_bytes(void); /* scratch size that is sufficient for every call below */
+
+/* y = act(conv(x, w) + bias + add)
+ * Conv2d:          vanilla_vae.py:28-29,73-74; mcq_vae.py:170-171,178-179,189-190,205-209; vq_vae.py:63-67
+ * ConvTranspose2d: vanilla_vae.py:50-55,65-70; mcq_vae.py:223-236        Linear: vanilla_vae.py:36-37,43
+ * x [B,H,W,Ci], y [B,Ho,Wo,Co]; bias/add may be NULL (add has y's layout: ResidualLayer skip, vq_vae.py:69-70). */
+int ctvae_conv_forward(int kind, const float* x, const float* w, const float* bias, const float* add, float* y, int B,
+                       int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int act, void* stream);
+
+/* dx = (dgrad(dy, w) + add) * act'(mask)      (autograd of the ops above)
+ * add / mask (saved post-activation output of the PREVIOUS layer, layout of dx) may be NULL. */
+int ctvae_conv_dgrad(int kind, const float* dy, const float* w, const float* add, const float* mask, int mask_act,
+                     float* dx, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
+                     void* stream);
+
+/* dw (+)= wgrad(x, dy);  dbias (+)= sum over pixels of dy (dbias may be NULL).  Deterministic two-pass. */
+int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float* dbias, int B, int H, int W, int Ci,
+                     int Co, int k, int stride, int pad, int out_pad, int accumulate, float* ws, size_t ws_bytes,
+                     void* stream);
+
+/* Train/eval BatchNorm2d + activation on an [R=B*H*W][C] matrix (vanilla_vae.py:30-31,56-57,71-72).
+ * training: batch statistics (biased var, eps), running stats updated with `momentum` and the unbiased
+ * variance; save_mean/save_invstd [C] are written for the backward pass. */
+int ctvae_bn_forward(const float* y, int R, int C, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, float momentum, float eps, int training, int act, float* out,
+                     float* save_mean, float* save_invstd, float* ws, size_t ws_bytes, void* stream);
+/* g_y from g_a (grad wrt the activated output `a_out`); dgamma/dbeta (+)= ... */
+int ctvae_bn_backward(const float* g_a, const float* a_out, const float* y, int R, int C, const float* gamma,
+                      const float* save_mean, const float* save_invstd, int act, float* g_y, float* dgamma,
+                      float* dbeta, int accumulate, float* ws, size_t ws_bytes, void* stream);
+
+/* layout change at the NCHW API boundary: to_nhwc=1: in [B,C,P] -> out [B,P,C]; 0: the inverse
+ * (torch.flatten on NCHW, vanilla_vae.py:85; .view(-1,512,2,2), vanilla_vae.py:102) */
+int ctvae_permute(const float* in, float* out, int B, int C, int P, int to_nhwc, void* stream);
+int ctvae_act_forward(const float* in, float* out, long n, int act, void* stream);           /* mcq_vae.py:185,216 */
+int ctvae_act_backward(const float* g_out, const float* out, float* g_in, long n, int act, void* stream);
+
+/* z = eps*exp(0.5*logvar)+mu (vanilla_vae.py:115-117); mu/logvar rows may be strided (slices of one head GEMM) */
+int ctvae_reparam_forward(const float* mu, long mu_row_stride, const float* logvar, long lv_row_stride, const float* eps,
+                          float* z, int B, int L, void* stream);
+int ctvae_reparam_backward(const float* g_z, const float* logvar, long lv_row_stride, const float* eps, float* g_mu,
+                           float* g_logvar, int B, int L, void* stream);
+
+/* out4 = {loss, mse, kld, -kld}: mse = mean((r-x)^2) (F.mse_loss, vanilla_vae.py:140, mcq_vae.py:279);
+ * kld = mean_b(-0.5*sum_d(1+lv-mu^2-e^lv)) (vanilla_vae.py:143) when mu != NULL; loss = mse + M_N*kld (+ extra[0]) */
+int ctvae_loss_forward(const float* recons, const float* x, long n, const float* mu, long mu_row_stride,
+                       const float* logvar, long lv_row_stride, int B, int L, float M_N, const float* extra, float* out4,
+                       float* ws, size_t ws_bytes, void* stream);
+int ctvae_mse_backward(const float* recons, const float* x, const float* g_loss, float* g_recons, long n, void* stream);
+int ctvae_kl_backward(const float* mu, long mu_row_stride, const float* logvar, long lv_row_stride, const float* g_loss,
+                      float* g_mu, float* g_logvar, int B, int L, float M_N, void* stream);
+
+/* Multi-codebook VQ on latents [B*HW][D]; C codebooks [K][D/C] stored back to back at `codebooks`;
+ * codebook i reads channels [i, i+D/C) (reference quirk, mcq_vae.py:104,117); inds [B,C,HW] int64.
+ * compute_inds: mcq_vae.py:26-39,100-110;  compute_latents: mcq_vae.py:41-64,112-127 */
+int ctvae_vq_inds(const float* latents, const float* codebooks, int64_t* inds, int B, int HW, int D, int K, int C,
+                  void* stream);
+int ctvae_vq_lookup(const float* latents, const float* codebooks, const int64_t* inds, float* quantized, float* vq_loss,
+                    float beta, int B, int HW, int D, int K, int C, float* ws, size_t ws_bytes, void* stream);
+/* g_latents (may be NULL) = straight-through g_q + commitment term; d_codebooks (may be NULL) (+)= embedding term */
+int ctvae_vq_backward(const float* g_quantized, const float* g_vq_loss, const float* latents, const float* codebooks,
+                      const int64_t* inds, float* g_latents, float* d_codebooks, int accumulate, float beta, int B, int HW,
+                      int D, int K, int C, void* stream);
+
+/* torch.optim.Adam step over one flat buffer (experiment.py:158-160).  state (device, 8 floats):
+ * {step, lr, beta1, beta2, eps, weight_decay, beta1^step, beta2^step}; the call advances step. */
+int ctvae_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* state, long n,
+                    float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTVAE_HIP_H */
