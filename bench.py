@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: one VanillaVAE training step (forward + loss + backward + gradient
+all-reduce (N>1) + Adam) on synthetic 64x64x3 batches, one process per GPU.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): VanillaVAE, configs/vae.yaml shapes (in_channels 3, latent_dim 128),
+per-GPU batch 256, fp32 end to end (parity target 1e-4 forces exact-f32 MFMA).  Inputs are resident in HBM
+before the timed region (4 rotating synthetic batches); forward/loss/backward (+Adam at N=1) replay as ONE
+hipGraph.  Prints one JSON line (rank 0) with the throughput, a `roofline` object for the dominant kernel
+(HIP-event timed per launch through the library's own profiler, algorithmic FLOPs from the launch geometry)
+and a `cpu_baseline` object (the CPU oracle = pure-torch port of the reference arithmetic, timed on the
+host cores of this box on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+FLOP_PER_IMG = {"VanillaVAE": 312_606_720, "MCQVAE": 4_208_984_064}   # SURVEY.md §8d convention (fwd+bwd)
+PEAK_F32_MFMA_TFLOPS = 157.3                                             # MI355X_MICROARCH.md chip table
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--model", default="VanillaVAE", choices=["VanillaVAE", "MCQVAE"])
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def build_model(name, dev, seed):
+    from ctvae_amd import filler
+    from ctvae_amd.models import vae_models
+    if name == "VanillaVAE":
+        m = vae_models[name](in_channels=3, latent_dim=128)
+    else:
+        m = vae_models[name](in_channels=3, embedding_dim=128, hidden_dims=[64, 128, 256], num_embeddings=64,
+                             img_size=64, codebooks=4, beta=0.25)
+    m.load_state_dict(filler.fill_state(filler.specs_of(m), seed + 1))
+    return m.to(dev).train()
+
+
+def cpu_baseline(model_name, seconds):
+    """Reference arithmetic (oracle port) forward+loss+backward on the host cores; BASELINE.json configs[0] (bs=64)."""
+    from ctvae_amd import filler
+    from oracle import vae_cpu as O
+    from tests import helpers as H
+    B = 64
+    threads = torch.get_num_threads()
+    if model_name == "VanillaVAE":
+        sd = filler.fill_state(H.vanilla_specs(), 1266)
+        x, eps = filler.synthetic_batch(1265, B)
+        fn = lambda: O.vanilla_step(sd, x, eps, 0.00025)
+    else:
+        sd = filler.fill_state(H.mcq_specs(H.MCQ_CFG), 1321)
+        x, _ = filler.synthetic_batch(1320, B)
+        fn = lambda: O.mcq_step(sd, x, 4, 0.25)
+    fn()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        fn()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 200:
+            break
+    return {"value": round(n * B / el, 2), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{n} steps of {model_name} bs={B} fwd+loss+bwd (oracle/vae_cpu.py, torch CPU fp32, {threads} threads, "
+                      f"{el:.1f} s)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from ctvae_amd import filler, native
+    from ctvae_amd.ddp import GradBucketAllReduce
+    from ctvae_amd.optim import FlatAdam
+    native.load()
+
+    B = args.batch
+    seed = 1265 if args.model == "VanillaVAE" else 1320
+    model = build_model(args.model, dev, seed)
+    opt = FlatAdam(model, lr=0.005 if args.model == "VanillaVAE" else 0.0005)
+    ddp = GradBucketAllReduce(model) if world > 1 else None
+    kld_w = 0.00025
+    # 4 rotating synthetic batches per rank, resident in HBM, NCHW-contiguous like a DataLoader would hand over
+    batches = [filler.synthetic_batch(seed + 1000 * rank + i, B)[0].to(dev) for i in range(4)]
+    static_x = torch.empty_like(batches[0])
+
+    def fwd_bwd():
+        model.zero_grad()
+        out = model(static_x)
+        losses = model.loss_function(*out, M_N=kld_w)
+        losses["loss"].backward()
+        return losses["loss"].detach()
+
+    def local_step():
+        l = fwd_bwd()
+        if world == 1:
+            opt.step()
+        return l
+
+    graph = None
+    if not args.no_graph:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        static_x.copy_(batches[0])
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                local_step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = local_step()
+
+    def step(i):
+        static_x.copy_(batches[i % 4], non_blocking=True)
+        if graph is not None:
+            graph.replay()
+        else:
+            local_step()
+        if world > 1:
+            ddp.all_reduce()
+            opt.step(grad_scale=ddp.grad_scale)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    ms_per_step = elapsed / args.steps * 1e3
+    value = B * world * args.steps / elapsed
+
+    roofline, kernels = None, None
+    if rank == 0 and not args.no_roofline:
+        # per-kernel HIP-event timing on the launch stream (eager launches; the graph replays the same kernels)
+        for i in range(2):
+            static_x.copy_(batches[i % 4])
+            local_step()
+        torch.cuda.synchronize()
+        native.prof_enable(True)
+        nprof = 5
+        for i in range(nprof):
+            static_x.copy_(batches[i % 4])
+            local_step()
+        torch.cuda.synchronize()
+        native.prof_enable(False)
+        rep = native.prof_report()
+        kernels = {k: {"launches_per_step": v["count"] / nprof, "ms_per_step": round(v["ms"] / nprof, 4),
+                       "avg_us": round(v["ms"] / v["count"] * 1e3, 2)} for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])}
+        name, top = max(rep.items(), key=lambda kv: kv[1]["ms"])
+        if top["flops"] > 0:
+            ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "avg_launch_us": round(top["ms"] / top["count"] * 1e3, 2),
+                        "launches_per_step": top["count"] / nprof}
+        else:
+            ach = top["bytes"] / (top["ms"] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                        "avg_launch_us": round(top["ms"] / top["count"] * 1e3, 2),
+                        "launches_per_step": top["count"] / nprof}
+        step_tflops = FLOP_PER_IMG[args.model] * (B * args.steps / elapsed) / 1e12
+        roofline["step_conv_tflops_per_gpu"] = round(step_tflops, 2)
+        roofline["step_frac_of_f32_mfma_peak"] = round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.model, args.cpu_seconds)
+
+    if rank == 0:
+        line = {
+            "metric": "images/sec/GPU fwd+bwd, 64x64x3 bs=64; recon+KL vs CPU ref",
+            "value": round(value, 1), "unit": "images/s", "per_gpu": round(value / world, 1),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.model} 64x64x3 train step fwd+loss+bwd+Adam" + ("+allreduce" if world > 1 else ""),
+                       "per_gpu_batch": B, "global_batch": B * world, "latent_dim": 128,
+                       "parallelism": f"dp{world}" if world > 1 else "single", "hipgraph": graph is not None},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        if kernels is not None:
+            line["kernels"] = kernels
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -6,12 +6,17 @@
 
 namespace ctvae {
 int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
-                   const float* mask, int mask_act, float* S, int act, hipStream_t st);
+                   const float* mask, int mask_act, float* S, int act, float* bn_part, hipStream_t st);
+int tapgemm_bn_parts(const ConvGeom& g);
 int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, float* dbias, float* ws, size_t ws_bytes,
                  int accumulate, hipStream_t st);
 int launch_bn_forward(const float* y, int R, int C, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, float momentum, float eps, int training, int act, float* out, float* save_mean,
                       float* save_invstd, float* ws, size_t ws_bytes, hipStream_t st);
+int launch_bn_finish_forward(const float* y, int R, int C, int nparts, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float momentum, float eps, int training, int act,
+                             float* out, float* save_mean, float* save_invstd, float* ws, hipStream_t st);
+size_t bn_workspace_floats(int C, int nparts);
 int launch_bn_backward(const float* ga, const float* a_out, const float* y, int R, int C, const float* gamma,
                        const float* save_mean, const float* save_invstd, int act, float* gy, float* dgamma, float* dbeta,
                        int accumulate, float* ws, size_t ws_bytes, hipStream_t st);
@@ -58,7 +63,26 @@ int ctvae_conv_forward(int kind, const float* x, const float* w, const float* bi
   if (!x || !w || !y || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
   ConvGeom g;
   if (build_geom(g, kind == CTVAE_CONV ? 0 : 1, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
-  return launch_tapgemm(g, x, w, bias, add, nullptr, 0, y, act, (hipStream_t)stream);
+  return launch_tapgemm(g, x, w, bias, add, nullptr, 0, y, act, nullptr, (hipStream_t)stream);
+}
+
+int ctvae_conv_bn_act_forward(int kind, const float* x, const float* w, const float* bias, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                              int training, int act, float* y, float* a_out, float* save_mean, float* save_invstd, int B,
+                              int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, float* ws,
+                              size_t ws_bytes, void* stream) {
+  if (!x || !w || !gamma || !beta || !y || !a_out || !ws || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
+  if (training && (!save_mean || !save_invstd)) return kErrBadArg;
+  if (!training && (!running_mean || !running_var)) return kErrBadArg;
+  if (Co % 4 != 0) return kErrBadArg;
+  ConvGeom g;
+  if (build_geom(g, kind == CTVAE_CONV ? 0 : 1, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
+  const int nparts = training ? tapgemm_bn_parts(g) : 0;
+  if (ws_bytes / sizeof(float) < bn_workspace_floats(Co, nparts)) return kErrWorkspace;
+  int rc = launch_tapgemm(g, x, w, bias, nullptr, nullptr, 0, y, ACT_NONE, training ? ws : nullptr, (hipStream_t)stream);
+  if (rc) return rc;
+  return launch_bn_finish_forward(y, g.B * g.sH * g.sW, Co, nparts, gamma, beta, running_mean, running_var, momentum, eps,
+                                  training, act, a_out, save_mean, save_invstd, ws, (hipStream_t)stream);
 }
 
 int ctvae_conv_dgrad(int kind, const float* dy, const float* w, const float* add, const float* mask, int mask_act,
@@ -67,7 +91,7 @@ int ctvae_conv_dgrad(int kind, const float* dy, const float* w, const float* add
   if (!dy || !w || !dx || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
   ConvGeom g;
   if (build_geom(g, kind == CTVAE_CONV ? 2 : 3, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
-  return launch_tapgemm(g, dy, w, nullptr, add, mask, mask_act, dx, ACT_NONE, (hipStream_t)stream);
+  return launch_tapgemm(g, dy, w, nullptr, add, mask, mask_act, dx, ACT_NONE, nullptr, (hipStream_t)stream);
 }
 
 int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float* dbias, int B, int H, int W, int Ci,

@@ -1,99 +1,139 @@
 // Train-mode BatchNorm2d + LeakyReLU on NHWC activations (vanilla_vae.py:30-31,56-57,71-72).
 // The activation tensor is a row-major [R = B*H*W][C] matrix, statistics are per column.
 //
-// forward : stats (shifted sums per block -> Chan merge)  ->  finalize (mean, invstd, scale/shift,
-//           running stats: momentum 0.1, unbiased variance)  ->  apply + LeakyReLU
+// forward : per-tile (count, mean, M2) partials come for free from the conv epilogue (tapgemm.hip) or from
+//           bn_stats_partial_kernel; bn_finalize_kernel merges them (Chan et al., parallel over partials),
+//           writes mean / invstd / scale / shift and updates the running statistics (momentum 0.1, unbiased
+//           variance); bn_apply_act_kernel streams y -> a = lrelu(y*scale+shift).
 // backward: g_bn = g_a * lrelu'(a);  dgamma = sum g_bn*xhat, dbeta = sum g_bn;
-//           g_y = gamma*invstd * (g_bn - dbeta/R - xhat*dgamma/R)
-// All of these are HBM-bound streaming kernels (roofline: bytes / 8 TB/s).
+//           g_y = gamma*invstd * (g_bn - dbeta/R - xhat*dgamma/R)   (as k1*g_bn + k2*y + k3 per channel)
+// All of these are HBM-bound streaming kernels (roofline: bytes / 8 TB/s): 16-B loads, several in flight per lane.
 #include "common.hpp"
+#include "prof.hpp"
 
 namespace ctvae {
 
-constexpr int kBnMaxBlocks = 1024;
+constexpr int kBnMaxBlocks = 2048;
 
-// ---- forward statistics -------------------------------------------------------------------------
-// part[blk][c] = (n, mean, M2) of the block's rows for column c
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float nb, float mb, float qb) {
+  if (nb > 0.f) {
+    const float nt = n + nb, d = mb - mean;
+    mean += d * (nb / nt);
+    m2 += qb + d * d * (n * nb / nt);
+    n = nt;
+  }
+}
+
+// ---- forward statistics (stand-alone form; the conv epilogue normally provides the partials) -----------
+// thread = (column quad, row lane); part[blk][c] = (n, mean, M2).  Requires (C/4) | 256.
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ y, float* __restrict__ part,
                                                                int R, int C, int rows_per_block) {
-  __shared__ float sm[3 * 256];
+  __shared__ float sm[256 * 9];
   const int tid = threadIdx.x;
-  const int cpb = C < 256 ? C : 256;  // columns per pass
-  const int rl = 256 / cpb;           // row lanes
-  const int col_l = tid % cpb, rlane = tid / cpb;
+  const int Q = C / 4;
+  const int qpp = Q < 256 ? Q : 256;   // quads per pass
+  const int rl = 256 / qpp;
+  const int ql = tid % qpp, rlane = tid / qpp;
   const int r0 = blockIdx.x * rows_per_block;
   int r1 = r0 + rows_per_block;
   if (r1 > R) r1 = R;
-  for (int c0 = 0; c0 < C; c0 += cpb) {
-    const int col = c0 + col_l;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    if (rlane < rl && col < C && r0 + rlane < r1) {
-      const float shift = y[(long)(r0 + rlane) * C + col];
-      float s1 = 0.f, s2 = 0.f;
+  for (int q0 = 0; q0 < Q; q0 += qpp) {
+    const int col = 4 * (q0 + ql);
+    float n = 0.f;
+    f32x4 mean = {0.f, 0.f, 0.f, 0.f}, m2 = {0.f, 0.f, 0.f, 0.f};
+    if (r0 + rlane < r1) {
+      const f32x4 shift = *reinterpret_cast<const f32x4*>(y + (long)(r0 + rlane) * C + col);
+      f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
       int cnt = 0;
+#pragma unroll 4
       for (int r = r0 + rlane; r < r1; r += rl) {
-        float d = y[(long)r * C + col] - shift;
-        s1 += d;
-        s2 += d * d;
+        f32x4 v = *reinterpret_cast<const f32x4*>(y + (long)r * C + col);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float d = v[k] - shift[k];
+          s1[k] += d;
+          s2[k] += d * d;
+        }
         ++cnt;
       }
       n = (float)cnt;
-      mean = shift + s1 / n;
-      m2 = s2 - s1 * s1 / n;
-      if (m2 < 0.f) m2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        mean[k] = shift[k] + s1[k] / n;
+        float q = s2[k] - s1[k] * s1[k] / n;
+        m2[k] = q > 0.f ? q : 0.f;
+      }
     }
     __syncthreads();
-    sm[tid] = n;
-    sm[256 + tid] = mean;
-    sm[512 + tid] = m2;
+    sm[tid * 9] = n;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sm[tid * 9 + 1 + k] = mean[k];
+      sm[tid * 9 + 5 + k] = m2[k];
+    }
     __syncthreads();
-    if (rlane == 0 && col < C) {
+    if (rlane == 0) {
       for (int l = 1; l < rl; ++l) {
-        float nb = sm[l * cpb + col_l], mb = sm[256 + l * cpb + col_l], qb = sm[512 + l * cpb + col_l];
-        if (nb > 0.f) {
-          float nt = n + nb, d = mb - mean;
-          mean += d * (nb / nt);
-          m2 += qb + d * d * (n * nb / nt);
-          n = nt;
+        const float* o = &sm[(l * qpp + ql) * 9];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float nn = n, mk = mean[k], qk = m2[k];
+          chan_merge(nn, mk, qk, o[0], o[1 + k], o[5 + k]);
+          mean[k] = mk;
+          m2[k] = qk;
+          if (k == 3) n = nn;
         }
       }
-      float* p = part + ((long)blockIdx.x * C + col) * 3;
-      p[0] = n; p[1] = mean; p[2] = m2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float* p = part + ((long)blockIdx.x * C + col + k) * 3;
+        p[0] = n; p[1] = mean[k]; p[2] = m2[k];
+      }
     }
   }
 }
 
-// one thread per channel merges the block partials; writes save_mean/save_invstd/scale/shift and updates running stats
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nblocks, int C,
+// block = 64 partial-lanes x 4 channels; merges `nparts` (n, mean, M2) triples per channel
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
                                                           float momentum, float eps, float* __restrict__ save_mean,
                                                           float* __restrict__ save_invstd, float* __restrict__ scale,
                                                           float* __restrict__ shift) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float sm[256 * 3];
+  const int tid = threadIdx.x;
+  const int ch = tid & 3, pl = tid >> 2;
+  const int c = blockIdx.x * 4 + ch;
   float n = 0.f, mean = 0.f, m2 = 0.f;
-  for (int b = 0; b < nblocks; ++b) {
-    const float* p = part + ((long)b * C + c) * 3;
-    float nb = p[0], mb = p[1], qb = p[2];
-    if (nb > 0.f) {
-      float nt = n + nb, d = mb - mean;
-      mean += d * (nb / nt);
-      m2 += qb + d * d * (n * nb / nt);
-      n = nt;
+  if (c < C) {
+    for (int b = pl; b < nparts; b += 64) {
+      const float* p = part + ((long)b * C + c) * 3;
+      chan_merge(n, mean, m2, p[0], p[1], p[2]);
     }
   }
-  const float var = m2 / n;
-  const float invstd = 1.0f / sqrtf(var + eps);
-  save_mean[c] = mean;
-  save_invstd[c] = invstd;
-  const float sc = gamma[c] * invstd;
-  scale[c] = sc;
-  shift[c] = beta[c] - mean * sc;
-  if (running_mean != nullptr) {
-    const float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  sm[tid * 3] = n; sm[tid * 3 + 1] = mean; sm[tid * 3 + 2] = m2;
+  __syncthreads();
+  for (int s = 32; s > 0; s >>= 1) {
+    if (pl < s) {
+      const float* o = &sm[((pl + s) * 4 + ch) * 3];
+      chan_merge(n, mean, m2, o[0], o[1], o[2]);
+      sm[tid * 3] = n; sm[tid * 3 + 1] = mean; sm[tid * 3 + 2] = m2;
+    }
+    __syncthreads();
+  }
+  if (pl == 0 && c < C) {
+    const float var = m2 / n;
+    const float invstd = 1.0f / sqrtf(var + eps);
+    save_mean[c] = mean;
+    save_invstd[c] = invstd;
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    if (running_mean != nullptr) {
+      const float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
   }
 }
 
@@ -128,70 +168,104 @@ __global__ __launch_bounds__(256) void bn_apply_act_kernel(const float* __restri
 }
 
 // ---- backward -------------------------------------------------------------------------------------
-// part[blk][c] = (sum g_bn, sum g_bn*xhat)
+// part[blk][c] = (sum g_bn, sum g_bn*xhat); thread = (column quad, row lane).  Requires (C/4) | 256.
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ ga, const float* __restrict__ a_out,
                                                              const float* __restrict__ y, const float* __restrict__ save_mean,
                                                              const float* __restrict__ save_invstd, float* __restrict__ part,
                                                              int R, int C, int rows_per_block, int act) {
-  __shared__ float sm[2 * 256];
+  __shared__ float sm[256 * 8];
   const int tid = threadIdx.x;
-  const int cpb = C < 256 ? C : 256;
-  const int rl = 256 / cpb;
-  const int col_l = tid % cpb, rlane = tid / cpb;
+  const int Q = C / 4;
+  const int qpp = Q < 256 ? Q : 256;
+  const int rl = 256 / qpp;
+  const int ql = tid % qpp, rlane = tid / qpp;
   const int r0 = blockIdx.x * rows_per_block;
   int r1 = r0 + rows_per_block;
   if (r1 > R) r1 = R;
-  for (int c0 = 0; c0 < C; c0 += cpb) {
-    const int col = c0 + col_l;
-    float s1 = 0.f, s2 = 0.f;
-    if (rlane < rl && col < C) {
-      const float mean = save_mean[col], invstd = save_invstd[col];
-      for (int r = r0 + rlane; r < r1; r += rl) {
-        const long idx = (long)r * C + col;
-        float g = ga[idx] * act_bwd_from_out(a_out[idx], act);
-        s1 += g;
-        s2 += g * ((y[idx] - mean) * invstd);
+  for (int q0 = 0; q0 < Q; q0 += qpp) {
+    const int col = 4 * (q0 + ql);
+    const f32x4 mean = *reinterpret_cast<const f32x4*>(save_mean + col);
+    const f32x4 invstd = *reinterpret_cast<const f32x4*>(save_invstd + col);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int r = r0 + rlane; r < r1; r += rl) {
+      const long idx = (long)r * C + col;
+      f32x4 g = *reinterpret_cast<const f32x4*>(ga + idx);
+      f32x4 ao = *reinterpret_cast<const f32x4*>(a_out + idx);
+      f32x4 yv = *reinterpret_cast<const f32x4*>(y + idx);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float gb = g[k] * act_bwd_from_out(ao[k], act);
+        s1[k] += gb;
+        s2[k] += gb * ((yv[k] - mean[k]) * invstd[k]);
       }
     }
     __syncthreads();
-    sm[tid] = s1;
-    sm[256 + tid] = s2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sm[tid * 8 + k] = s1[k];
+      sm[tid * 8 + 4 + k] = s2[k];
+    }
     __syncthreads();
-    if (rlane == 0 && col < C) {
+    if (rlane == 0) {
       for (int l = 1; l < rl; ++l) {
-        s1 += sm[l * cpb + col_l];
-        s2 += sm[256 + l * cpb + col_l];
+        const float* o = &sm[(l * qpp + ql) * 8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          s1[k] += o[k];
+          s2[k] += o[4 + k];
+        }
       }
-      part[((long)blockIdx.x * C + col) * 2 + 0] = s1;
-      part[((long)blockIdx.x * C + col) * 2 + 1] = s2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        part[((long)blockIdx.x * C + col + k) * 2 + 0] = s1[k];
+        part[((long)blockIdx.x * C + col + k) * 2 + 1] = s2[k];
+      }
     }
   }
 }
 
-// dgamma/dbeta (accumulate flag) and the three per-channel coefficients of g_y = k1*g_bn + k2*y + k3
+// block = 64 partial-lanes x 4 channels: dgamma/dbeta (accumulate flag) and the per-channel coefficients of
+// g_y = k1*g_bn + k2*y + k3
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int C, float R,
                                                               const float* __restrict__ gamma, const float* __restrict__ save_mean,
                                                               const float* __restrict__ save_invstd, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int accumulate,
                                                               float* __restrict__ coef /* [3][C] */) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ double sm[256 * 2];
+  const int tid = threadIdx.x;
+  const int ch = tid & 3, pl = tid >> 2;
+  const int c = blockIdx.x * 4 + ch;
   double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nblocks; ++b) {
-    s1 += (double)part[((long)b * C + c) * 2 + 0];
-    s2 += (double)part[((long)b * C + c) * 2 + 1];
+  if (c < C) {
+    for (int b = pl; b < nblocks; b += 64) {
+      s1 += (double)part[((long)b * C + c) * 2 + 0];
+      s2 += (double)part[((long)b * C + c) * 2 + 1];
+    }
   }
-  const float db = (float)s1, dg = (float)s2;
-  dgamma[c] = (accumulate ? dgamma[c] : 0.f) + dg;
-  dbeta[c] = (accumulate ? dbeta[c] : 0.f) + db;
-  const float invstd = save_invstd[c], mean = save_mean[c];
-  const float k1 = gamma[c] * invstd;
-  // g_y = k1 * (g - db/R - xhat*dg/R), xhat = (y-mean)*invstd
-  const float k2 = -k1 * dg / R * invstd;
-  const float k3 = -k1 * db / R - k2 * mean;
-  coef[c] = k1;
-  coef[C + c] = k2;
-  coef[2 * C + c] = k3;
+  sm[tid * 2] = s1; sm[tid * 2 + 1] = s2;
+  __syncthreads();
+  for (int s = 32; s > 0; s >>= 1) {
+    if (pl < s) {
+      s1 += sm[((pl + s) * 4 + ch) * 2];
+      s2 += sm[((pl + s) * 4 + ch) * 2 + 1];
+      sm[tid * 2] = s1; sm[tid * 2 + 1] = s2;
+    }
+    __syncthreads();
+  }
+  if (pl == 0 && c < C) {
+    const float db = (float)s1, dg = (float)s2;
+    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + dg;
+    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + db;
+    const float invstd = save_invstd[c], mean = save_mean[c];
+    const float k1 = gamma[c] * invstd;
+    // g_y = k1 * (g - db/R - xhat*dg/R), xhat = (y-mean)*invstd
+    const float k2 = -k1 * dg / R * invstd;
+    const float k3 = -k1 * db / R - k2 * mean;
+    coef[c] = k1;
+    coef[C + c] = k2;
+    coef[2 * C + c] = k3;
+  }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ ga, const float* __restrict__ a_out,
@@ -213,31 +287,39 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
 }
 
-static int stat_blocks(int R, int* rows_per_block) {
-  int nb = R / 64;
+static bool bn_shape_ok(int R, int C) {
+  if (C % 4 != 0 || R <= 0) return false;
+  const int Q = C / 4;
+  return Q >= 256 ? (Q % 256 == 0) : (256 % Q == 0);
+}
+
+static int stat_blocks(int R, int C, int* rows_per_block) {
+  const int Q = C / 4;
+  const int rl = Q >= 256 ? 1 : 256 / Q;
+  int nb = R / (rl * 8);             // >= 8 vector loads per lane
   if (nb < 1) nb = 1;
   if (nb > kBnMaxBlocks) nb = kBnMaxBlocks;
   *rows_per_block = ceil_div(R, nb);
   return ceil_div(R, *rows_per_block);
 }
 
-size_t bn_workspace_floats(int C) { return (size_t)kBnMaxBlocks * C * 3 + 3 * (size_t)C; }
+// workspace layout: [part: max(kBnMaxBlocks, conv tiles) * C * 3][scale C][shift C][spare C]
+size_t bn_workspace_floats(int C, int nparts) {
+  const size_t parts = nparts > kBnMaxBlocks ? (size_t)nparts : (size_t)kBnMaxBlocks;
+  return parts * C * 3 + 3 * (size_t)C;
+}
 
-int launch_bn_forward(const float* y, int R, int C, const float* gamma, const float* beta, float* running_mean,
-                      float* running_var, float momentum, float eps, int training, int act, float* out,
-                      float* save_mean, float* save_invstd, float* ws, size_t ws_bytes, hipStream_t st) {
-  if (C % 4 != 0 || R <= 0) return kErrBadArg;
-  if (ws_bytes / sizeof(float) < bn_workspace_floats(C)) return kErrWorkspace;
-  float* part = ws;
-  float* scale = ws + (size_t)kBnMaxBlocks * C * 3;
+// finalize (from `nparts` partial triples already in ws) or eval coefficients, then apply + activation
+int launch_bn_finish_forward(const float* y, int R, int C, int nparts, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float momentum, float eps, int training, int act,
+                             float* out, float* save_mean, float* save_invstd, float* ws, hipStream_t st) {
+  const size_t parts = nparts > kBnMaxBlocks ? (size_t)nparts : (size_t)kBnMaxBlocks;
+  float* scale = ws + parts * C * 3;
   float* shift = scale + C;
   if (training) {
-    int rpb;
-    const int nb = stat_blocks(R, &rpb);
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(256), 0, st, y, part, R, C, rpb);
-    CTVAE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, part, nb, C, gamma, beta,
-                       running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
+    ProfScope ps("bn_finalize_kernel", st, 0.0, 12.0 * (double)nparts * C);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, ws, nparts, C, gamma, beta, running_mean,
+                       running_var, momentum, eps, save_mean, save_invstd, scale, shift);
     CTVAE_LAUNCH_CHECK();
   } else {
     hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, C, gamma, beta, running_mean,
@@ -247,26 +329,51 @@ int launch_bn_forward(const float* y, int R, int C, const float* gamma, const fl
   const long n4 = (long)R * C / 4;
   long blocks = (n4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
+  ProfScope ps("bn_apply_act_kernel", st, 0.0, 8.0 * (double)R * C);
   hipLaunchKernelGGL(bn_apply_act_kernel, dim3((unsigned)blocks), dim3(256), 0, st, y, scale, shift, out, n4, C, act);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }
 
+int launch_bn_forward(const float* y, int R, int C, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, float momentum, float eps, int training, int act, float* out,
+                      float* save_mean, float* save_invstd, float* ws, size_t ws_bytes, hipStream_t st) {
+  if (!bn_shape_ok(R, C)) return kErrBadArg;
+  if (ws_bytes / sizeof(float) < bn_workspace_floats(C, 0)) return kErrWorkspace;
+  int nb = 0;
+  if (training) {
+    int rpb;
+    nb = stat_blocks(R, C, &rpb);
+    ProfScope ps("bn_stats_partial_kernel", st, 0.0, 4.0 * (double)R * C);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(256), 0, st, y, ws, R, C, rpb);
+    CTVAE_LAUNCH_CHECK();
+  }
+  return launch_bn_finish_forward(y, R, C, nb, gamma, beta, running_mean, running_var, momentum, eps, training, act, out,
+                                  save_mean, save_invstd, ws, st);
+}
+
 int launch_bn_backward(const float* ga, const float* a_out, const float* y, int R, int C, const float* gamma,
                        const float* save_mean, const float* save_invstd, int act, float* gy, float* dgamma,
                        float* dbeta, int accumulate, float* ws, size_t ws_bytes, hipStream_t st) {
-  if (C % 4 != 0 || R <= 0) return kErrBadArg;
-  if (ws_bytes / sizeof(float) < bn_workspace_floats(C)) return kErrWorkspace;
+  if (!bn_shape_ok(R, C)) return kErrBadArg;
+  if (ws_bytes / sizeof(float) < bn_workspace_floats(C, 0)) return kErrWorkspace;
   float* part = ws;
   float* coef = ws + (size_t)kBnMaxBlocks * C * 3;
   int rpb;
-  const int nb = stat_blocks(R, &rpb);
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb), dim3(256), 0, st, ga, a_out, y, save_mean, save_invstd, part, R, C,
-                     rpb, act);
+  const int nb = stat_blocks(R, C, &rpb);
+  {
+    ProfScope ps("bn_bwd_partial_kernel", st, 0.0, 12.0 * (double)R * C);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb), dim3(256), 0, st, ga, a_out, y, save_mean, save_invstd, part, R, C,
+                       rpb, act);
+  }
   CTVAE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, part, nb, C, (float)R, gamma,
-                     save_mean, save_invstd, dgamma, dbeta, accumulate, coef);
+  {
+    ProfScope ps("bn_bwd_finalize_kernel", st, 0.0, 8.0 * (double)nb * C);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, part, nb, C, (float)R, gamma,
+                       save_mean, save_invstd, dgamma, dbeta, accumulate, coef);
+  }
   CTVAE_LAUNCH_CHECK();
+  ProfScope ps("bn_bwd_apply_kernel", st, 0.0, 16.0 * (double)R * C);
   const long n4 = (long)R * C / 4;
   long blocks = (n4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;

@@ -4,6 +4,7 @@
 // finishing workgroup that adds the partials in double and emits the scalars.  HBM-bound:
 // algorithmic bytes = 2 * 4 * n (recons + input) + 2 * 4 * B * L.
 #include "common.hpp"
+#include "prof.hpp"
 
 namespace ctvae {
 
@@ -111,6 +112,7 @@ int launch_loss_forward(const float* r, const float* x, long n, const float* mu,
   long blocks = (n4 + 255) / 256;
   if (blocks > kLossBlocks) blocks = kLossBlocks;
   if (blocks < 1) blocks = 1;
+  ProfScope ps("mse_partial+loss_finish", st, 0.0, 8.0 * (double)n + 8.0 * (double)B * L);
   hipLaunchKernelGGL(mse_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, st, r, x, ws, n4, n);
   CTVAE_LAUNCH_CHECK();
   hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, ws, (int)blocks, 1.0 / (double)n, mu, mu_rs, lv, lv_rs,
@@ -124,6 +126,7 @@ int launch_mse_backward(const float* r, const float* x, const float* go, float* 
   long blocks = (n4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
+  ProfScope ps("mse_bwd_kernel", st, 0.0, 12.0 * (double)n);
   hipLaunchKernelGGL(mse_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, r, x, go, gr, n4, n, (float)(2.0 / (double)n));
   CTVAE_LAUNCH_CHECK();
   return 0;

@@ -2,6 +2,7 @@
 // activation backward, Gaussian reparameterisation (vanilla_vae.py:107-117) and the flat fused Adam
 // update (experiment.py:158-160).  Roofline for all of them: bytes moved / 8 TB/s.
 #include "common.hpp"
+#include "prof.hpp"
 
 namespace ctvae {
 
@@ -100,12 +101,14 @@ static inline unsigned grid_for(long n, int cap = 4096) {
 }
 
 int launch_permute(const float* in, float* out, int B, int C, int P, int to_nhwc, hipStream_t st) {
+  ProfScope ps("permute_cp_kernel", st, 0.0, 8.0 * (double)B * C * P);
   hipLaunchKernelGGL(permute_cp_kernel, dim3(grid_for((long)B * C * P)), dim3(256), 0, st, in, out, B, C, P, to_nhwc);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_act_bwd(const float* gout, const float* out, float* gin, long n, int act, hipStream_t st) {
+  ProfScope ps("act_bwd_kernel", st, 0.0, 12.0 * (double)n);
   hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, gout, out, gin, n, act);
   CTVAE_LAUNCH_CHECK();
   return 0;
@@ -132,6 +135,7 @@ int launch_reparam_bwd(const float* gz, const float* lv, long lv_rs, const float
 }
 
 int launch_adam(float* p, const float* g, float* m, float* v, float* state, long n, float grad_scale, hipStream_t st) {
+  ProfScope ps("adam_kernel", st, 0.0, 28.0 * (double)n);
   hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, st, state);
   CTVAE_LAUNCH_CHECK();
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, st, p, g, m, v, state, n, grad_scale);

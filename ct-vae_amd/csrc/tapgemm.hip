@@ -18,6 +18,7 @@
 // residual add, forward activation, or the multiplication by the previous layer's activation
 // derivative (backward).
 #include "common.hpp"
+#include "prof.hpp"
 
 namespace ctvae {
 
@@ -29,6 +30,7 @@ struct TapGemmArgs {
   const float* add;
   const float* mask;
   float* S;
+  float* bn_part;  // optional [ncls*mtiles][N][3] per-tile (count, mean, M2) of the pre-activation output
   int act;
   int mask_act;
   int Mc;      // B*Qh*Qw
@@ -321,6 +323,55 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
         }
       }
     }
+    // ---- fused BatchNorm statistics of this tile (train-mode BN follows the conv: vanilla_vae.py:28-31) ----
+    if (a.bn_part != nullptr) {
+      float cnt = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * TM + i) * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+          if (sOut[row] >= 0) { cnt += 1.f; s1 += acc[i][j][r] + bv; }
+        }
+      float mean = cnt > 0.f ? s1 / cnt : 0.f, m2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * TM + i) * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+          if (sOut[row] >= 0) { float d = (acc[i][j][r] + bv) - mean; m2 += d * d; }
+        }
+      // merge the two lane halves (Chan et al.)
+      const float ocnt = __shfl_xor(cnt, 32, 64), omean = __shfl_xor(mean, 32, 64), om2 = __shfl_xor(m2, 32, 64);
+      const float nt = cnt + ocnt;
+      if (nt > 0.f) {
+        const float d = omean - mean;
+        m2 = m2 + om2 + d * d * (cnt * ocnt / nt);
+        mean = mean + d * (ocnt / nt);
+      }
+      if (lh == 0) {  // sA is free after the main loop (last iteration ended with a barrier)
+        float* st = &sA[(wm * BN + (wn * TN + j) * 32 + li) * 3];
+        st[0] = nt; st[1] = mean; st[2] = m2;
+      }
+    }
+  }
+  if (a.bn_part != nullptr) {
+    __syncthreads();
+    if (tid < BN && n0 + tid < N) {
+      float n = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        const float nb = sA[(w * BN + tid) * 3], mb = sA[(w * BN + tid) * 3 + 1], qb = sA[(w * BN + tid) * 3 + 2];
+        if (nb > 0.f) {
+          const float nt = n + nb, d = mb - mean;
+          mean += d * (nb / nt);
+          m2 += qb + d * d * (n * nb / nt);
+          n = nt;
+        }
+      }
+      float* p = a.bn_part + ((long)(cls * a.mtiles + mt) * N + n0 + tid) * 3;
+      p[0] = n; p[1] = mean; p[2] = m2;
+    }
   }
 }
 
@@ -332,6 +383,13 @@ static int launch_cfg(const TapGemmArgs& a, bool wt, bool avec, bool bvec, hipSt
   args.mtiles = ceil_div(a.Mc, BM);
   args.ntiles = ceil_div(a.N, BN);
   dim3 grid(args.mtiles * args.ntiles, a.g.ncls), block(256);
+  char name[96];
+  snprintf(name, sizeof name, "tapgemm_kernel<%d,%d,%d,%d,%s,%s,%s>", WM, WN, TM, TN, wt ? "true" : "false",
+           avec ? "true" : "false", bvec ? "true" : "false");
+  double macs = 0;
+  for (int c = 0; c < a.g.ncls; ++c) macs += (double)a.Mc * a.N * a.g.ntaps[c] * a.g.gC;
+  const double bytes = 4.0 * ((double)a.g.B * a.g.gH * a.g.gW * a.g.gC + (double)a.g.B * a.g.sH * a.g.sW * a.g.sC);
+  ProfScope ps(name, st, 2.0 * macs, bytes);
 #define CTVAE_TG(WT_, AV_, BV_) \
   hipLaunchKernelGGL((tapgemm_kernel<WM, WN, TM, TN, WT_, AV_, BV_>), grid, block, 0, st, args)
   if constexpr (GENERIC) {  // the masked/scalar variants exist for one tile shape only
@@ -354,9 +412,23 @@ static int launch_cfg(const TapGemmArgs& a, bool wt, bool avec, bool bvec, hipSt
   return 0;
 }
 
+// rows of the bn_part array the launch will write (tile choice mirrors launch_tapgemm below)
+int tapgemm_bn_parts(const ConvGeom& g) {
+  const int Mc = g.B * g.Qh * g.Qw, N = g.sC;
+  const bool avec = (g.gC % KC) == 0;
+  const bool bvec = g.wT ? avec : ((N % 4) == 0);
+  int BM = 128;
+  if (!(N <= 32 || !avec || !bvec)) {
+    const long tiles128 = (long)ceil_div(Mc, 128) * ceil_div(N, 64) * g.ncls;
+    BM = tiles128 >= 512 ? 128 : 64;
+  }
+  return ceil_div(Mc, BM) * g.ncls;
+}
+
 int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
-                   const float* mask, int mask_act, float* S, int act, hipStream_t st) {
+                   const float* mask, int mask_act, float* S, int act, float* bn_part, hipStream_t st) {
   TapGemmArgs a{};
+  a.bn_part = bn_part;
   a.g = g;
   a.G = G; a.W = W; a.bias = bias; a.add = add; a.mask = mask; a.S = S;
   a.act = act; a.mask_act = mask_act;

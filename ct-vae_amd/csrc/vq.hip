@@ -10,6 +10,7 @@
 //  * the reference's slice quirk is reproduced: codebook i reads channels [i, i+D/C) (mcq_vae.py:104,117).
 // All HBM/L2-bound; algorithmic bytes = latents read + quantized written + indices.
 #include "common.hpp"
+#include "prof.hpp"
 
 namespace ctvae {
 
@@ -196,9 +197,10 @@ int launch_vq_inds(const float* lat, const float* cb, long long* inds, int B, in
   blocks = ceil_div(P, rpb);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(vq_inds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vq_inds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_set = true;
   }
+  ProfScope ps("vq_inds_kernel", st, 2.0 * (double)P * K * D, 4.0 * (double)P * D + 8.0 * (double)P * C);
   hipLaunchKernelGGL(vq_inds_kernel, dim3(blocks, C), dim3(256), smem, st, lat, cb, inds, P, D, K, Dc, C, HW, rpb);
   CTVAE_LAUNCH_CHECK();
   return 0;
@@ -211,6 +213,7 @@ int launch_vq_lookup(const float* lat, const float* cb, const long long* inds, f
   const int Dc = D / C, P = B * HW;
   long blocks = ((long)P * D + 255) / 256;
   if (blocks > 1024) blocks = 1024;
+  ProfScope ps("vq_lookup+loss_finish", st, 0.0, 8.0 * (double)P * D + 8.0 * (double)P * C + 4.0 * (double)K * D);
   hipLaunchKernelGGL(vq_lookup_kernel, dim3((unsigned)blocks), dim3(256), 0, st, lat, cb, inds, out, ws, P, D, K, Dc, C, HW);
   CTVAE_LAUNCH_CHECK();
   hipLaunchKernelGGL(vq_loss_finish_kernel, dim3(1), dim3(64), 0, st, ws, (int)blocks, C, 1.0 / ((double)P * Dc), beta, vq_loss);

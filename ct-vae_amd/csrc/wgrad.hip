@@ -9,6 +9,7 @@
 // v_mfma_f32_32x32x2_f32; slices are combined by a second, deterministic pass (no float atomics:
 // bitwise reproducible, and atomics would be bound at ~1.3 TB/s on gfx950).
 #include "common.hpp"
+#include "prof.hpp"
 
 namespace ctvae {
 
@@ -82,7 +83,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   constexpr int DQ = NT / 4;
   constexpr int D_V = (MC * DQ) / 256 > 0 ? (MC * DQ) / 256 : 1;
   constexpr int D_S = (MC * NT) / 256;
-  static_assert((MC * DQ) % 256 == 0 || MC * DQ == 256 / 1 || true, "");
 
   int x_dy = 0, x_dx = 0, x_c = 0;
   bool x_kok = false;
@@ -222,13 +222,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 }
 
 // dst[i] = (accumulate ? dst[i] : 0) + sum_s part[s*stride + i]
+// block = 16 split-lanes x 16 element lanes: every element's S partials are summed by 16 lanes in a fixed
+// order (lane j takes s = j, j+16, ...) and combined by a fixed shuffle tree -> deterministic, and S loads
+// are spread over lanes instead of forming one dependent chain.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ dst,
                                                               long n, int S, long stride, int accumulate) {
-  long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float v = accumulate ? dst[i] : 0.f;
-  for (int s = 0; s < S; ++s) v += part[(long)s * stride + i];
-  dst[i] = v;
+  const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long i = (long)blockIdx.x * 16 + el;
+  float v = 0.f;
+  if (i < n) {
+#pragma unroll 4
+    for (int s = sl; s < S; s += 16) v += part[(long)s * stride + i];
+  }
+  // lanes with equal `el` sit 16 apart: xor 16 and 32 inside a wave, then 4 waves through LDS
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  __shared__ float sm[4][16];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane < 16) sm[wave][lane] = v;
+  __syncthreads();
+  if (threadIdx.x < 16 && i < n) {
+    float t = ((sm[0][el] + sm[1][el]) + sm[2][el]) + sm[3][el];
+    dst[i] = (accumulate ? dst[i] : 0.f) + t;
+  }
 }
 
 size_t wgrad_workspace_floats(const ConvGeom& g, int S) {
@@ -284,6 +300,13 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
   a.ktile_start[g.ncls] = kt;
   a.ntiles = ceil_div(a.N, NT);
   dim3 grid(kt * a.ntiles, S), block(256);
+  {
+  char name[96];
+  snprintf(name, sizeof name, "wgrad_kernel<%d,%d,%s,%s>", narrow ? 4 : 2, narrow ? 1 : 2, xvec ? "true" : "false",
+           dvec ? "true" : "false");
+  const double macs = (double)a.Mc * a.N * a.rows_total;
+  const double bytes = 4.0 * ((double)g.B * g.gH * g.gW * g.gC + (double)g.B * g.sH * g.sW * g.sC);
+  ProfScope ps(name, st, 2.0 * macs, bytes);
 #define CTVAE_WG(WK_, WN_)                                                                              \
   do {                                                                                                  \
     if (xvec && dvec) hipLaunchKernelGGL((wgrad_kernel<WK_, WN_, true, true>), grid, block, 0, st, a);  \
@@ -294,13 +317,15 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
   if (narrow) CTVAE_WG(4, 1);
   else CTVAE_WG(2, 2);
 #undef CTVAE_WG
+  }
   CTVAE_LAUNCH_CHECK();
   const long n = (long)a.rows_total * a.N;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), block, 0, st, a.part, dW, n, S,
+  ProfScope ps2("reduce_partials_kernel", st, 0.0, 4.0 * (double)(S + 1) * n);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 15) / 16)), block, 0, st, a.part, dW, n, S,
                      (long)a.rows_total * a.N, accumulate);
   CTVAE_LAUNCH_CHECK();
   if (dbias) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(a.N, 256)), block, 0, st, a.pbias, dbias,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(a.N, 16)), block, 0, st, a.pbias, dbias,
                        (long)a.N, S * g.ncls, (long)a.N, accumulate);
     CTVAE_LAUNCH_CHECK();
   }

@@ -202,15 +202,18 @@ class ConvBNAct(Function):
     def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, training, spec, bn_act):
         _req_cuda(x, w, gamma)
         x = _c(x)
-        y = conv_forward_raw(x, w, b, spec, None, ACT_NONE)
-        B, H, W, C = y.shape
+        B, H, W, _ = x.shape
+        ho, wo = spec.out_hw(H, W)
+        C = spec.co
+        y = torch.empty((B, ho, wo, C), dtype=torch.float32, device=x.device)
         a = torch.empty_like(y)
         ws = native.workspace(x.device)
         save_mean = torch.empty(C, dtype=torch.float32, device=x.device)
         save_invstd = torch.empty(C, dtype=torch.float32, device=x.device)
-        native.call("ctvae_bn_forward", y.data_ptr(), B * H * W, C, gamma.data_ptr(), beta.data_ptr(),
-                    native.ptr(running_mean), native.ptr(running_var), BN_MOMENTUM, BN_EPS, 1 if training else 0, bn_act,
-                    a.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr(), ws.numel() * 4)
+        native.call("ctvae_conv_bn_act_forward", spec.kind, x.data_ptr(), w.data_ptr(), native.ptr(b), gamma.data_ptr(),
+                    beta.data_ptr(), native.ptr(running_mean), native.ptr(running_var), BN_MOMENTUM, BN_EPS,
+                    1 if training else 0, bn_act, y.data_ptr(), a.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(),
+                    B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, ws.data_ptr(), ws.numel() * 4)
         ctx.spec, ctx.bn_act, ctx.training = spec, bn_act, training
         ctx.params = (w, b, gamma, beta)
         ctx.save_for_backward(x, y, a, save_mean, save_invstd)

@@ -18,6 +18,8 @@ _fp, _vp, _i, _l, _f, _sz = _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_long, _c.c_
 # name -> argtypes (all return int unless listed in _RESTYPES)
 SIGNATURES = {
     "ctvae_conv_forward": [_i, _fp, _fp, _fp, _fp, _fp] + [_i] * 10 + [_vp],
+    "ctvae_conv_bn_act_forward": [_i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _fp, _fp, _fp, _fp] + [_i] * 9
+                                 + [_fp, _sz, _vp],
     "ctvae_conv_dgrad": [_i, _fp, _fp, _fp, _fp, _i, _fp] + [_i] * 9 + [_vp],
     "ctvae_conv_wgrad": [_i, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _sz, _vp],
     "ctvae_bn_forward": [_fp, _i, _i, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _fp, _fp, _fp, _fp, _sz, _vp],
@@ -40,6 +42,8 @@ _RESTYPES = {
     "ctvae_arch": _c.c_char_p,
     "ctvae_error_string": _c.c_char_p,
     "ctvae_workspace_bytes": _c.c_size_t,
+    "ctvae_prof_enable": None,
+    "ctvae_prof_report": _c.c_size_t,
 }
 EXPORTS = sorted(list(SIGNATURES) + list(_RESTYPES))
 
@@ -70,7 +74,8 @@ def load():
         if fn is None:
             raise RuntimeError(f"{LIB_PATH} does not export {name} (stale build?)")
         fn.restype = res
-        fn.argtypes = [_c.c_int] if name == "ctvae_error_string" else []
+        fn.argtypes = {"ctvae_error_string": [_c.c_int], "ctvae_prof_enable": [_c.c_int],
+                       "ctvae_prof_report": [_c.c_char_p, _c.c_size_t]}.get(name, [])
     if lib.ctvae_arch() != b"gfx950":
         raise RuntimeError("libctvae_hip.so was not built for gfx950")
     _lib = lib
@@ -111,3 +116,19 @@ def call(name: str, *args):
     """Launch entry point `name` on the current stream (the trailing stream argument is appended here)."""
     lib = load()
     check(getattr(lib, name)(*args, stream_ptr()), name)
+
+
+def prof_enable(on: bool):
+    load().ctvae_prof_enable(1 if on else 0)
+
+
+def prof_report() -> dict:
+    """{kernel name: dict(count, ms, flops, bytes)} since the last call (synchronises the recorded events)."""
+    lib = load()
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib.ctvae_prof_report(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, ms, fl, by = line.split("\t")
+        out[name] = dict(count=int(cnt), ms=float(ms), flops=float(fl), bytes=float(by))
+    return out

@@ -1,0 +1,53 @@
+"""Flat fused Adam (+ ExponentialLR) over a model's packed parameter buffer.
+
+Same update rule as ``torch.optim.Adam(lr, weight_decay)`` with default betas/eps, which is what the
+reference's harness builds (experiment.py:158-160); the schedule is ``ExponentialLR(gamma)`` stepped once
+per epoch (experiment.py:173-175).  One kernel launch per step for the whole model, hyper-parameters and the
+step counter live in a small device tensor so the launch is hipGraph-capturable.
+"""
+import torch
+
+from . import kernels as K
+
+
+class FlatAdam:
+    def __init__(self, model, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, params_slice=None):
+        self.model = model
+        flat = model.flat_params
+        self.slice = params_slice if params_slice is not None else slice(0, flat.numel())
+        n = flat[self.slice].numel()
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=flat.device)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=flat.device)
+        self.state = torch.tensor([0.0, lr, betas[0], betas[1], eps, weight_decay, 1.0, 1.0], dtype=torch.float32,
+                                  device=flat.device)
+        self.lr = lr
+
+    def set_lr(self, lr):
+        self.lr = lr
+        self.state[1:2].fill_(lr)
+
+    def step(self, grad_scale=1.0):
+        K.adam_step(self.model.flat_params[self.slice], self.model.flat_grads[self.slice], self.exp_avg, self.exp_avg_sq,
+                    self.state, grad_scale)
+
+    def zero_grad(self, set_to_none=False):
+        self.model.zero_grad()
+
+    def state_dict(self):
+        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "state": self.state}
+
+    def load_state_dict(self, sd):
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.state.copy_(sd["state"])
+
+
+class ExponentialLR:
+    """lr_epoch = lr0 * gamma**epoch (torch.optim.lr_scheduler.ExponentialLR), stepped once per epoch."""
+
+    def __init__(self, optimizer: FlatAdam, gamma: float):
+        self.opt, self.gamma, self.base_lr, self.epoch = optimizer, gamma, optimizer.lr, 0
+
+    def step(self):
+        self.epoch += 1
+        self.opt.set_lr(self.base_lr * self.gamma ** self.epoch)

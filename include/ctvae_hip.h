@@ -42,6 +42,15 @@ size_t ctvae_workspace_bytes(void); /* scratch size that is sufficient for every
 int ctvae_conv_forward(int kind, const float* x, const float* w, const float* bias, const float* add, float* y, int B,
                        int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int act, void* stream);
 
+/* Conv2d|ConvTranspose2d -> BatchNorm2d -> activation as one call (nn.Sequential blocks vanilla_vae.py:25-35,47-75):
+ * y = conv(x)+bias (kept for backward); the conv epilogue emits per-tile (count, mean, M2) so the batch
+ * statistics cost no extra pass over y; a_out = act(BN(y)).  Arguments as ctvae_conv_forward / ctvae_bn_forward. */
+int ctvae_conv_bn_act_forward(int kind, const float* x, const float* w, const float* bias, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                              int training, int act, float* y, float* a_out, float* save_mean, float* save_invstd, int B,
+                              int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, float* ws,
+                              size_t ws_bytes, void* stream);
+
 /* dx = (dgrad(dy, w) + add) * act'(mask)      (autograd of the ops above)
  * add / mask (saved post-activation output of the PREVIOUS layer, layout of dx) may be NULL. */
 int ctvae_conv_dgrad(int kind, const float* dy, const float* w, const float* add, const float* mask, int mask_act,
@@ -101,6 +110,13 @@ int ctvae_vq_backward(const float* g_quantized, const float* g_vq_loss, const fl
  * {step, lr, beta1, beta2, eps, weight_decay, beta1^step, beta2^step}; the call advances step. */
 int ctvae_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* state, long n,
                     float grad_scale, void* stream);
+
+/* Measurement aid (bench.py roofline leg): when enabled every launcher brackets its kernels with HIP events
+ * on the launch stream.  ctvae_prof_report synchronises them and writes one line per kernel name
+ * "name\tcount\ttotal_ms\talgorithmic_flops\talgorithmic_bytes"; returns the buffer size needed.  Must be off
+ * during hipGraph capture. */
+void ctvae_prof_enable(int on);
+size_t ctvae_prof_report(char* buf, size_t n);
 
 #ifdef __cplusplus
 }

@@ -153,7 +153,8 @@ def test_permute_roundtrip(K):
     n = K.to_nhwc(xd)
     assert torch.equal(n.cpu(), x.permute(0, 2, 3, 1).contiguous())
     assert torch.equal(K._ToNCHW.apply(n).cpu(), x)
-    assert K.to_nhwc(xd.contiguous(memory_format=torch.channels_last)).data_ptr() == xd.contiguous(memory_format=torch.channels_last).data_ptr()
+    cl = xd.contiguous(memory_format=torch.channels_last)
+    assert K.to_nhwc(cl).data_ptr() == cl.data_ptr()          # channels_last input is consumed zero-copy
 
 
 def test_adam_matches_torch(K):
