@@ -28,6 +28,8 @@ int launch_reparam_fwd(const float* mu, long mu_rs, const float* lv, long lv_rs,
 int launch_reparam_bwd(const float* gz, const float* lv, long lv_rs, const float* eps, float* gmu, float* glv, int B, int L,
                        hipStream_t st);
 int launch_adam(float* p, const float* g, float* m, float* v, float* state, long n, float grad_scale, hipStream_t st);
+int launch_gumbel_fwd(const float* p, const float* noise, float* out, float* soft, long n, hipStream_t st);
+int launch_gumbel_bwd(const float* go, const float* p, const float* soft, float* gp, long n, hipStream_t st);
 int launch_loss_forward(const float* r, const float* x, long n, const float* mu, long mu_rs, const float* lv, long lv_rs,
                         int B, int L, float M_N, const float* extra, float* out3, float* ws, size_t ws_bytes, hipStream_t st);
 int launch_mse_backward(const float* r, const float* x, const float* go, float* gr, long n, hipStream_t st);
@@ -187,6 +189,16 @@ int ctvae_vq_backward(const float* g_quantized, const float* g_vq_loss, const fl
   if (!latents || !codebooks || !inds || C <= 0) return kErrBadArg;
   return launch_vq_backward(g_quantized, g_vq_loss, latents, codebooks, (const long long*)inds, g_latents, d_codebooks,
                             accumulate, beta, B, HW, D, K, C, (hipStream_t)stream);
+}
+
+int ctvae_gumbel_st_forward(const float* p, const float* gumbel_noise, float* sample, float* soft, long n, void* stream) {
+  if (!p || !gumbel_noise || !sample || !soft || n <= 0) return kErrBadArg;
+  return launch_gumbel_fwd(p, gumbel_noise, sample, soft, n, (hipStream_t)stream);
+}
+
+int ctvae_gumbel_st_backward(const float* g_sample, const float* p, const float* soft, float* g_p, long n, void* stream) {
+  if (!g_sample || !p || !soft || !g_p || n <= 0) return kErrBadArg;
+  return launch_gumbel_bwd(g_sample, p, soft, g_p, n, (hipStream_t)stream);
 }
 
 int ctvae_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* state, long n,

@@ -93,6 +93,32 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// Straight-through Bernoulli sample through a 2-class Gumbel-softmax (tau = 1, hard) of
+// log(clamp([1-p, p], 1e-4)) (ct_mcq_vae.py:126,177-183).  noise = 2 standard Gumbel draws/element.
+__global__ __launch_bounds__(256) void gumbel_st_fwd_kernel(const float* __restrict__ p, const float* __restrict__ noise,
+                                                            float* __restrict__ out, float* __restrict__ soft, long n) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float pi = p[i];
+    const float a0 = logf(fmaxf(1.f - pi, 1e-4f)) + noise[2 * i];
+    const float a1 = logf(fmaxf(pi, 1e-4f)) + noise[2 * i + 1];
+    const float y1 = 1.f / (1.f + expf(a0 - a1));
+    const float hard = a1 > a0 ? 1.f : 0.f;      // argmax keeps the first maximum on ties
+    out[i] = (hard - y1) + y1;                   // y_hard - y_soft.detach() + y_soft
+    soft[i] = y1;
+  }
+}
+
+__global__ __launch_bounds__(256) void gumbel_st_bwd_kernel(const float* __restrict__ go, const float* __restrict__ p,
+                                                            const float* __restrict__ soft, float* __restrict__ gp, long n) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float pi = p[i], y1 = soft[i];
+    const float d = (pi > 1e-4f ? 1.f / pi : 0.f) + ((1.f - pi) > 1e-4f ? 1.f / (1.f - pi) : 0.f);
+    gp[i] = go[i] * y1 * (1.f - y1) * d;
+  }
+}
+
 static inline unsigned grid_for(long n, int cap = 4096) {
   long b = (n + 255) / 256;
   if (b > cap) b = cap;
@@ -130,6 +156,18 @@ int launch_reparam_fwd(const float* mu, long mu_rs, const float* lv, long lv_rs,
 int launch_reparam_bwd(const float* gz, const float* lv, long lv_rs, const float* eps, float* gmu, float* glv, int B, int L,
                        hipStream_t st) {
   hipLaunchKernelGGL(reparam_bwd_kernel, dim3(ceil_div(B * L, 256)), dim3(256), 0, st, gz, lv, lv_rs, eps, gmu, glv, B, L);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_gumbel_fwd(const float* p, const float* noise, float* out, float* soft, long n, hipStream_t st) {
+  hipLaunchKernelGGL(gumbel_st_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, noise, out, soft, n);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_gumbel_bwd(const float* go, const float* p, const float* soft, float* gp, long n, hipStream_t st) {
+  hipLaunchKernelGGL(gumbel_st_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, go, p, soft, gp, n);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }

@@ -345,6 +345,28 @@ class VAELoss(Function):
         return g_r, None, g_mu, g_lv, g_extra, None
 
 
+class GumbelBernoulliST(Function):
+    """Straight-through Bernoulli(p) sample via hard 2-class Gumbel-softmax (ct_mcq_vae.py:177-183); noise [...,2]."""
+
+    @staticmethod
+    def forward(ctx, p, noise):
+        _req_cuda(p, noise)
+        p, noise = _c(p), _c(noise)
+        out = torch.empty_like(p)
+        soft = torch.empty_like(p)
+        native.call("ctvae_gumbel_st_forward", p.data_ptr(), noise.data_ptr(), out.data_ptr(), soft.data_ptr(), p.numel())
+        ctx.save_for_backward(p, soft)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        p, soft = ctx.saved_tensors
+        g = _c(g)
+        gp = torch.empty_like(p)
+        native.call("ctvae_gumbel_st_backward", g.data_ptr(), p.data_ptr(), soft.data_ptr(), gp.data_ptr(), p.numel())
+        return gp, None
+
+
 # ---------------------------------------------------------------------------------------------------
 # vector quantiser
 # ---------------------------------------------------------------------------------------------------

@@ -1,0 +1,246 @@
+"""CausalTransition (reference: models/ct_mcq_vae.py:14-333) — SURVEY.md §8(f) "next #1".
+
+Status: restated from the reference text with torch device ops; the two ``GATv2Conv`` layers and
+``dense_to_sparse`` live in torch-geometric 2.2.0, which is absent here, so their arithmetic follows the
+published GATv2 algorithm and **parity is unpinned** (no reference fixture covers it).  The Gumbel
+straight-through sampler (K17) is a HIP kernel with injectable noise; everything else is torch-level.
+
+Design notes (MI355X-first rather than a PyG translation):
+* graphs are B disjoint dense graphs of 64(+1 action [+1 noise]) nodes, so GATv2 runs as *dense batched*
+  masked attention over ``[B, N, N]`` instead of scatter/gather over an edge list;
+* the pair-MLP ``Linear(2D, 800)`` over all 64x64 node pairs is evaluated as ``U_i + V_j`` with two
+  ``[B*64, D] x [D, 800]`` GEMMs (the concatenation in ct_mcq_vae.py:141-147 is linear in its halves),
+  which removes the 0.85 GMAC/sample pair GEMM the reference materialises;
+* ``state_dict`` keys mirror the reference (``graph_transitioner.module_{0,2}.*`` as PyG names them).
+"""
+import math
+from typing import List
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from .. import kernels as K
+from .types_ import Tensor
+
+
+class PositionalEncoding(nn.Module):
+    """Sinusoidal table + Dropout(0.1) (ct_mcq_vae.py:14-38)."""
+
+    def __init__(self, d_model: int, dropout: float = 0.1, max_len: int = 4096):
+        super().__init__()
+        self.dropout = nn.Dropout(p=dropout)
+        position = torch.arange(max_len).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
+        pe = torch.zeros(max_len, 1, d_model)
+        pe[:, 0, 0::2] = torch.sin(position * div_term)
+        pe[:, 0, 1::2] = torch.cos(position * div_term)
+        self.register_buffer('pe', pe)
+
+    def forward(self, x: Tensor) -> Tensor:       # x [B, S, D]
+        return self.dropout(x + self.pe[:x.size(1), 0].to(x.device).unsqueeze(0))
+
+
+class DenseGATv2(nn.Module):
+    """GATv2Conv(in, out, heads, edge_dim=1, concat=True, add_self_loops=True(fill 'mean'), negative_slope=0.2)
+    on a batch of dense weighted graphs.  adj[b, r, c] != 0 is an edge r -> c carrying attribute adj[b, r, c]."""
+
+    def __init__(self, in_channels, out_channels, heads, negative_slope=0.2):
+        super().__init__()
+        self.heads, self.out_channels, self.negative_slope = heads, out_channels, negative_slope
+        self.lin_l = nn.Linear(in_channels, heads * out_channels)
+        self.lin_r = nn.Linear(in_channels, heads * out_channels)
+        self.lin_edge = nn.Linear(1, heads * out_channels, bias=False)
+        self.att = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.bias = nn.Parameter(torch.zeros(heads * out_channels))
+        for w in (self.lin_l.weight, self.lin_r.weight, self.lin_edge.weight, self.att):
+            nn.init.xavier_uniform_(w)
+        nn.init.zeros_(self.lin_l.bias)
+        nn.init.zeros_(self.lin_r.bias)
+
+    def forward(self, x, adj):                    # x [B,N,Cin], adj [B,N,N]
+        B, N, _ = x.shape
+        H, C = self.heads, self.out_channels
+        xl = self.lin_l(x).view(B, N, H, C)       # source side
+        xr = self.lin_r(x).view(B, N, H, C)       # target side
+        eye = torch.eye(N, dtype=torch.bool, device=x.device).unsqueeze(0)
+        edge = (adj != 0) & ~eye                  # existing self loops are removed first
+        w = adj * edge
+        deg = edge.sum(1).clamp(min=1)            # incoming edges per target
+        attr = w + torch.diag_embed(w.sum(1) / deg)   # self loops carry the mean incoming attribute
+        keep = edge | eye
+        we = self.lin_edge.weight.view(H, C)
+        outs = []
+        for h in range(H):                        # head by head keeps the [B,N,N,C] score tensor small
+            m = xl[:, :, None, h, :] + xr[:, None, :, h, :] + attr.unsqueeze(-1) * we[h]
+            s = (F.leaky_relu(m, self.negative_slope) * self.att[0, h]).sum(-1)
+            alpha = torch.softmax(s.masked_fill(~keep, float('-inf')), dim=1)      # over sources r of each target c
+            outs.append(torch.einsum('brc,brk->bck', alpha, xl[:, :, h, :]))
+        return torch.stack(outs, 2).reshape(B, N, H * C) + self.bias
+
+
+class _GraphTransitioner(nn.Module):
+    """gnn.Sequential([GATv2Conv, LeakyReLU]*k + [GATv2Conv]) with PyG's child names module_{i}."""
+
+    def __init__(self, input_dim, latent_dims, heads):
+        super().__init__()
+        c, idx = input_dim, 0
+        self.order = []
+        for dim in latent_dims:
+            self.add_module(f"module_{idx}", DenseGATv2(c, dim, heads))
+            self.add_module(f"module_{idx + 1}", nn.LeakyReLU())
+            self.order += [f"module_{idx}", f"module_{idx + 1}"]
+            idx += 2
+            c = dim * heads
+        self.add_module(f"module_{idx}", DenseGATv2(c, input_dim, heads))
+        self.order.append(f"module_{idx}")
+
+    def forward(self, x, adj):
+        for name in self.order:
+            m = self._modules[name]
+            x = m(x, adj) if isinstance(m, DenseGATv2) else m(x)
+        return x
+
+
+def sample_bernoulli_st(p, noise=None):
+    """Straight-through Bernoulli sample via 2-class Gumbel-softmax(tau=1, hard=True) of log(clamp([1-p, p], 1e-4))
+    (ct_mcq_vae.py:177-183): HIP kernel, noise = two standard Gumbel draws per element (injectable)."""
+    if noise is None:
+        noise = -torch.empty(p.shape + (2,), device=p.device, dtype=p.dtype).exponential_().log()
+    return K.GumbelBernoulliST.apply(p, noise)
+
+
+class CausalTransition(nn.Module):
+
+    def __init__(self, input_dim: int, action_dim: int, latent_dims: List = None, noise: str = "off",
+                 c_alpha: float = 0.7, c_beta: float = 0.4, c_delta: float = 0.4, c_epsilon: float = 0.4,
+                 comp_adj_optim: str = "comp", **kwargs) -> None:
+        super().__init__()
+        self.input_dim, self.action_dim, self.noise = input_dim, action_dim, noise
+        self.alpha, self.beta, self.delta, self.epsilon = c_alpha, c_beta, c_delta, c_epsilon
+        self.a_dense = nn.Linear(action_dim, input_dim)
+        self.pos_encoding = PositionalEncoding(input_dim)
+        if latent_dims is None:
+            latent_dims = [800, 100]
+        self.latent_dims = latent_dims
+        self.graph_discovers = nn.ModuleList([
+            nn.Sequential(nn.Linear(2 * input_dim, latent_dims[0]), nn.LeakyReLU(), nn.Linear(latent_dims[0], 1), nn.Sigmoid())
+            for _ in range(action_dim + 1)])
+        self.mask = nn.Sequential(nn.Linear(action_dim + input_dim, input_dim), nn.Sigmoid())
+        self.nb_heads = 1 + action_dim
+        self.graph_transitioner = _GraphTransitioner(input_dim, latent_dims[1:], self.nb_heads)
+
+    # ---- pieces ----------------------------------------------------------------------------------
+    def _pair_coeffs(self, disc, x):
+        """sigmoid(w2 . lrelu(W1 [x_i ; x_j] + b1) + b2) for every ordered pair (i, j): [B,N,D] -> [B,N,N]."""
+        D = x.size(-1)
+        lin1, lin2 = disc[0], disc[2]
+        u = F.linear(x, lin1.weight[:, :D])                    # x_i half
+        v = F.linear(x, lin1.weight[:, D:], lin1.bias)         # x_j half (+ bias)
+        h = F.leaky_relu(u.unsqueeze(2) + v.unsqueeze(1))      # [B,N,N,hidden]
+        return torch.sigmoid(F.linear(h, lin2.weight, lin2.bias)).squeeze(-1)
+
+    def _compute_mask(self, one_hot_latent, action, noise=None):
+        B, S, _ = one_hot_latent.shape
+        act = action.unsqueeze(1).expand(B, S, action.size(-1)).to(torch.float32)
+        pos = self.pos_encoding(torch.zeros_like(one_hot_latent))
+        inter = self.mask(torch.cat([act, pos], dim=-1))
+        p = (one_hot_latent * inter).sum(dim=-1)               # [B,S]
+        return sample_bernoulli_st(p, noise).unsqueeze(-1)
+
+    def _compute_adj(self, latent, action, mask):
+        no_inter = self._pair_coeffs(self.graph_discovers[0], latent)
+        if mask is None:
+            return no_inter
+        ids = torch.argmax(action, dim=-1)
+        inter = torch.zeros_like(no_inter)
+        for i in set(ids.tolist()):
+            sel = torch.where(ids == i)[0]
+            inter[sel] = self._pair_coeffs(self.graph_discovers[1 + i], latent[sel])
+        return no_inter * (1 - mask) + inter * mask
+
+    def _compute_y(self, latent, action, adjacency, mask):
+        B, S, D = latent.shape
+        action_node = self.a_dense(action)
+        if self.noise == "exo":
+            latent = latent + torch.randn_like(latent)
+            supp = action_node.unsqueeze(1)
+        elif self.noise == "endo":
+            supp = torch.stack([action_node, torch.randn_like(action_node)], dim=1)
+        else:
+            supp = action_node.unsqueeze(1)
+        ns = supp.size(1)
+        nodes = torch.cat([latent, supp], 1)
+        # extra nodes: edges from every latent node to them (column of ones), none leaving (row of zeros)
+        adj = F.pad(F.pad(adjacency, (0, ns, 0, 0), value=1.0), (0, 0, 0, ns), value=0.0)
+        y = self.graph_transitioner(nodes, adj)[:, :S].view(B, S, self.nb_heads, D)
+        base = y[:, :, 0]
+        if mask is None:
+            return base.softmax(dim=-1)
+        head = (action.argmax(dim=-1) + 1).view(B, 1, 1, 1).expand(B, S, 1, D)
+        return (base * (1 - mask) + torch.gather(y, 2, head).squeeze(2) * mask).softmax(dim=-1)
+
+    # ---- modes -----------------------------------------------------------------------------------
+    def forward(self, latent: Tensor, **kwargs) -> List[Tensor]:
+        shape = latent.shape                                   # [B,D,H,W]
+        lat = latent.permute(0, 2, 3, 1).reshape(shape[0], -1, shape[1])
+        pos = self.pos_encoding(lat)
+        action = torch.zeros(lat.size(0), self.action_dim, device=lat.device)
+        adj = self._compute_adj(pos, action, None)             # mask == 0 in base mode
+        graph = sample_bernoulli_st(adj, kwargs.get("gumbel"))
+        latent_y = self._compute_y(pos, action, adj * graph, None)
+        ident = torch.eye(graph.size(-1), device=lat.device, dtype=graph.dtype).expand_as(graph)
+        y_id = self._compute_y(pos, action, ident, None)
+        ct_reg = self.alpha * (F.cross_entropy(y_id.reshape(-1, shape[1]).clamp(min=1e-4).log(),
+                                               lat.reshape(-1, shape[1]).argmax(dim=-1))
+                               + F.mse_loss(graph, ident))
+        return [latent_y.permute(0, 2, 1).reshape(shape), ct_reg, {"ct_adjacency": adj.mean(0)}]
+
+    def forward_action(self, latent: Tensor, action: Tensor, **kwargs) -> List[Tensor]:
+        shape = latent.shape
+        lat = latent.permute(0, 2, 3, 1).reshape(shape[0], -1, shape[1])
+        mask = self._compute_mask(lat, action)
+        pos = self.pos_encoding(lat)
+        adj = self._compute_adj(pos, action, mask)
+        graph = sample_bernoulli_st(adj)
+        latent_y = self._compute_y(pos, action, adj * graph, mask)
+        ct_reg = self.beta * self.adjacency_KL_loss(adj) + self.delta * self.graph_size_loss(graph) \
+            + self.epsilon * self.positive_trial_loss(adj)
+        return [latent_y.permute(0, 2, 1).reshape(shape), ct_reg,
+                {"ct_mask": mask.view(shape[:1] + shape[2:]).mean(0), "ct_adjacency": adj.mean(0)}]
+
+    def forward_transition(self, latent: Tensor, latent_y: Tensor, **kwargs) -> List[Tensor]:
+        B, A = latent.size(0), self.action_dim
+        y_inds = latent_y.permute(0, 2, 3, 1).reshape(-1, latent_y.size(1)).argmax(dim=-1)
+        dist = []
+        for i in range(A):
+            a = F.one_hot(torch.full((B,), i, device=latent.device), A).to(latent.dtype)
+            y = self.forward_action(latent, a)[0]
+            y_log = y.permute(0, 2, 3, 1).reshape(-1, latent_y.size(1)).clamp(min=1e-4).log()
+            dist.append(F.cross_entropy(y_log, y_inds, reduction='none').view(B, -1).mean(dim=-1))
+        return [F.softmin(torch.stack(dist, 1), dim=-1), torch.tensor(0.0), {}]
+
+    # ---- losses / metrics (ct_mcq_vae.py:297-333) --------------------------------------------------
+    def latent_loss(self, latent, latent_y):
+        lat = latent.permute(0, 2, 3, 1).reshape(-1, latent.size(1)).clamp(min=1e-4).log()
+        tgt = latent_y.detach().permute(0, 2, 3, 1).reshape(-1, latent_y.size(1)).argmax(dim=-1)
+        return F.cross_entropy(lat, tgt)
+
+    def adjacency_KL_loss(self, adj):
+        logc = adj.reshape(adj.size(0), -1).log_softmax(dim=-1)
+        target = torch.rand(logc.shape, device=logc.device).softmax(dim=-1)
+        return F.kl_div(logc, target, reduction="batchmean")
+
+    def graph_size_loss(self, graph):
+        return torch.linalg.matrix_norm(graph).mean()
+
+    def positive_trial_loss(self, adj):
+        return torch.linalg.vector_norm((1 - adj).prod(-1), dim=-1).mean()
+
+    def causal_accuracy(self, action_probas, action):
+        return (torch.argmax(action_probas, dim=-1) == torch.argmax(action, dim=-1)).float().mean()
+
+    def causal_undirected_accuracy(self, action_probas, action):
+        dim = action.size(-1)
+        rec = F.one_hot(torch.argmax(action_probas, dim=-1), num_classes=dim)
+        return self.causal_accuracy(rec[:, dim // 2:] + rec[:, :dim // 2], action[:, dim // 2:] + action[:, :dim // 2])

@@ -181,6 +181,19 @@ class FlatParamMixin:
                         g.copy_(p.grad)
                 p.grad = g
 
+    def flat_range(self, prefix: str) -> slice:
+        """Contiguous slice of the flat buffers that holds every parameter under sub-module `prefix`
+        (experiment.py:157 optimises only ``getattr(model, update_parameters).parameters()``)."""
+        base = self.flat_params.data_ptr()
+        spans = sorted(((p.data_ptr() - base) // 4, p.numel()) for n, p in self.named_parameters()
+                       if n.startswith(prefix + "."))
+        if not spans:
+            raise KeyError(prefix)
+        lo, hi = spans[0][0], spans[-1][0] + spans[-1][1]
+        if sum(n for _, n in spans) != hi - lo:
+            raise RuntimeError(f"parameters of '{prefix}' are not contiguous in the flat buffer")
+        return slice(lo, hi)
+
     @property
     def flat_params(self):
         if getattr(self, "_flat_params", None) is None:

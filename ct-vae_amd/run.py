@@ -1,0 +1,122 @@
+"""Entry point mirroring the reference's ``run.py`` (run.py:21-110): ``python -m ctvae_amd.run -c configs/vae.yaml``.
+
+Consumes the reference's YAML layout unchanged (model_params / data_params / exp_params / trainer_params /
+logging_params; ``model_params`` is splatted into ``vae_models[name]``), with the tolerances of SURVEY N4:
+``find_unused_parameters`` optional, ``gpus`` int or list, ``dataset_name`` defaults to a synthetic source.
+One process per GPU (launch with ``python -m torch.distributed.run``); Lightning / wandb are not required.
+Checkpoints: top-k on ``val_Reconstruction_Loss`` + ``last.ckpt`` with ``state_dict`` keys prefixed ``model.``
+so they interchange with the reference's (run.py:85-97).
+"""
+import argparse
+import json
+import os
+
+import torch
+import torch.distributed as dist
+import yaml
+
+from . import filler
+from .ddp import GradBucketAllReduce
+from .experiment import VAEXperiment
+from .models import vae_models
+
+
+class SyntheticData:
+    """Synthetic stand-in for dataset.py's VAEDataset with the reference's batch contracts: plain datasets
+    yield (X, labels); T-datasets yield (X, labels, {"action", "input_y", "mode"}) with one mode per batch."""
+
+    def __init__(self, data_params, model_params, device, rank=0, world=1, steps_per_epoch=8, seed=0):
+        self.p, self.mp, self.dev, self.rank, self.world = data_params, model_params, device, rank, world
+        self.steps, self.seed = steps_per_epoch, seed
+        name = data_params.get("dataset_name", "synthetic")
+        self.transition = name.startswith("T")
+        self.action_dim = model_params.get("action_dim", 12)
+
+    def _batches(self, bs, base_seed):
+        img = self.p.get("patch_size", 64)
+        for i in range(self.steps):
+            s = base_seed + 7919 * i + 104729 * self.rank          # each rank takes its own rows of the global batch
+            if self.transition:
+                x, y, a = filler.synthetic_pairs(s, bs, self.action_dim, img)
+                mode = ["base", "action", "causal"][i % 3]
+                opts = {"mode": [mode] * bs}
+                if mode != "base":
+                    opts.update({"action": a.to(self.dev), "input_y": y.to(self.dev)})
+                yield (x.to(self.dev), torch.zeros(bs, device=self.dev), opts)
+            else:
+                x, _ = filler.synthetic_batch(s, bs, img=img)
+                yield (x.to(self.dev), torch.zeros(bs, device=self.dev))
+
+    def train(self):
+        return self._batches(self.p["train_batch_size"], self.seed)
+
+    def val(self):
+        return self._batches(self.p["val_batch_size"], self.seed + 1_000_003)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description='MI355X runner for the ct-vae models')
+    ap.add_argument('--config', '-c', dest="filename", metavar='FILE', default='configs/vae.yaml')
+    ap.add_argument('--steps-per-epoch', type=int, default=8, help="synthetic data: batches per epoch")
+    ap.add_argument('--max-epochs', type=int, default=None)
+    args = ap.parse_args(argv)
+    with open(args.filename) as f:
+        config = yaml.safe_load(f)
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    gpus = config.get('trainer_params', {}).get('gpus', 1)
+    use_gpu = (len(gpus) if isinstance(gpus, (list, tuple)) else int(gpus)) != 0
+    if not (use_gpu and torch.cuda.is_available()):
+        raise SystemExit("ctvae_amd runs on MI355X GPUs only: the hot path has no CPU fallback (use the reference for gpus: [])")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    seed = config['exp_params'].get('manual_seed', 0)
+    torch.manual_seed(seed)                                           # seed_everything (run.py:48)
+    mp = dict(config['model_params'])
+    model = vae_models[mp['name']](**mp).to(dev)
+    ckpt_path = config['trainer_params'].get('load_weights_only') and config['trainer_params'].get('resume_from_checkpoint')
+    if ckpt_path:                                                     # weights-only restore (run.py:85-89)
+        sd = torch.load(ckpt_path, map_location=dev, weights_only=True)['state_dict']
+        model.load_state_dict({k[6:]: v for k, v in sd.items() if k.startswith("model.")}, strict=False)
+    ddp = GradBucketAllReduce(model) if world > 1 else None
+    log_dir = os.path.join(config['logging_params'].get('save_dir', 'logs/'), config['logging_params'].get('name', mp['name']))
+    os.makedirs(os.path.join(log_dir, "checkpoints"), exist_ok=True)
+    log_file = open(os.path.join(log_dir, f"metrics_rank{rank}.jsonl"), "a") if rank == 0 else None
+    exp = VAEXperiment(model, config['exp_params'], ddp=ddp, log_file=log_file)
+    data = SyntheticData(config['data_params'], mp, dev, rank, world, args.steps_per_epoch, seed)
+
+    best = []
+
+    def on_epoch_end(epoch, rec):
+        if rank != 0:
+            return
+        print(json.dumps(rec), flush=True)
+        state = {"state_dict": {"model." + k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()},
+                 "epoch": epoch}
+        torch.save(state, os.path.join(log_dir, "checkpoints", "last.ckpt"))
+        score = rec.get("val_Reconstruction_Loss")
+        if score is not None:                                         # ModelCheckpoint(save_top_k=2, monitor=val_Reconstruction_Loss)
+            path = os.path.join(log_dir, "checkpoints", f"epoch={epoch}.ckpt")
+            torch.save(state, path)
+            best.append((score, path))
+            best.sort()
+            for _, p in best[2:]:
+                if os.path.exists(p):
+                    os.remove(p)
+            del best[2:]
+
+    epochs = args.max_epochs or config['trainer_params'].get('max_epochs', 1)
+    hist = exp.fit(data.train, data.val, max_epochs=epochs, on_epoch_end=on_epoch_end)
+    if world > 1:
+        dist.destroy_process_group()
+    return hist
+
+
+if __name__ == "__main__":
+    main()

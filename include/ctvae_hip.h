@@ -106,6 +106,12 @@ int ctvae_vq_backward(const float* g_quantized, const float* g_vq_loss, const fl
                       const int64_t* inds, float* g_latents, float* d_codebooks, int accumulate, float beta, int B, int HW,
                       int D, int K, int C, void* stream);
 
+/* Straight-through Bernoulli(p) sample = F.gumbel_softmax(log(clamp([1-p,p],1e-4)), tau=1, hard=True)[...,1]
+ * (ct_mcq_vae.py:126,177-183).  gumbel_noise [n][2] standard Gumbel draws (injectable);
+ * `soft` [n] keeps the soft probability for the backward pass. */
+int ctvae_gumbel_st_forward(const float* p, const float* gumbel_noise, float* sample, float* soft, long n, void* stream);
+int ctvae_gumbel_st_backward(const float* g_sample, const float* p, const float* soft, float* g_p, long n, void* stream);
+
 /* torch.optim.Adam step over one flat buffer (experiment.py:158-160).  state (device, 8 floats):
  * {step, lr, beta1, beta2, eps, weight_decay, beta1^step, beta2^step}; the call advances step. */
 int ctvae_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* state, long n,

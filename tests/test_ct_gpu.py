@@ -1,0 +1,146 @@
+"""GPU: CTMCQVAE modes, the Gumbel straight-through kernel, the training harness (VAEXperiment + FlatAdam)
+and the YAML runner."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from ctvae_amd import filler
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda")
+
+
+def build_ct(dev, seed, **over):
+    from ctvae_amd.models import vae_models
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "ct_mcq_vae.yaml")))["model_params"]
+    cfg.update(over)
+    torch.manual_seed(seed)
+    m = vae_models["CTMCQVAE"](**cfg)
+    conv = filler.fill_state(H.mcq_specs(H.CT_CONV_CFG), seed + 1)
+    m.load_state_dict(conv, strict=False)
+    return m.to(dev).train()
+
+
+def test_gumbel_st_kernel(dev):
+    from ctvae_amd import kernels as K
+    g = torch.Generator().manual_seed(4)
+    p = torch.rand(3, 64, 64, generator=g)
+    p[0, 0, :4] = torch.tensor([0.0, 1.0, 5e-5, 1 - 5e-5])
+    noise = -torch.empty(3, 64, 64, 2).exponential_(generator=g).log()
+    pr = p.clone().requires_grad_(True)
+    logits = torch.stack([1 - pr, pr], dim=-1).clamp(min=1e-4).log()
+    y_soft = ((logits + noise) / 1.0).softmax(-1)
+    idx = y_soft.max(-1, keepdim=True)[1]
+    y_hard = torch.zeros_like(logits).scatter_(-1, idx, 1.0)
+    ref = (y_hard - y_soft.detach() + y_soft)[..., 1]
+    w = torch.randn(3, 64, 64, generator=g)
+    (ref * w).sum().backward()
+    pd = p.to(dev).requires_grad_(True)
+    out = K.GumbelBernoulliST.apply(pd, noise.to(dev))
+    (out * w.to(dev)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=1e-6)
+    np.testing.assert_allclose(pd.grad.cpu().numpy(), pr.grad.numpy(), atol=1e-4, rtol=1e-3)
+
+
+def test_ct_conv_path_matches_golden(dev, golden):
+    """skip_transition=True decodes compute_latents(latents, argmin indices): the conv/VQ/decoder path of CT must equal
+    the MCQVAE(codebooks=1, beta=0.1) golden vectors whatever the causal layer does."""
+    g = golden("ctconv_b2")
+    seed = int(g["seed"])
+    m = build_ct(dev, seed, skip_transition=True)
+    x, _ = filler.synthetic_batch(seed, 2)
+    out = m(x.to(dev), mode="base")
+    assert len(out) == 5 and out[4]["mode"] == "base"
+    np.testing.assert_allclose(out[0].detach().cpu().numpy(), g["recons"], atol=TOL, rtol=0)
+    assert abs(out[2].item() - float(g["loss.VQ_Loss"])) <= TOL
+    losses = m.loss_function(*out)
+    assert abs(losses["Reconstruction_Loss"].item() - float(g["loss.Reconstruction_Loss"])) <= TOL
+    assert set(losses) >= {"loss", "Reconstruction_Loss", "VQ_Loss", "CT_Loss", "ct_adjacency", "mode"}
+    losses["loss"].backward()
+    conv_grads = {k: p.grad for k, p in m.named_parameters() if not k.startswith("ct_layer.")}
+    for k in ("decoder.10.0.weight", "decoder.3.resblock.2.weight", "encoder.0.0.weight", "vq_layer.quantizers.0.embedding.weight"):
+        np.testing.assert_allclose(conv_grads[k].cpu().numpy(), g["grad." + k], atol=TOL, rtol=2e-3, err_msg=k)
+    ct_g = [p.grad for k, p in m.named_parameters() if k.startswith("ct_layer.graph_discovers.0")]
+    assert all(torch.isfinite(t).all() for t in ct_g) and sum(float(t.abs().sum()) for t in ct_g) > 0
+
+
+@pytest.mark.parametrize("mode", ["base", "action", "causal"])
+def test_ct_modes_run_and_backprop(dev, mode):
+    m = build_ct(dev, 11)
+    x, y, a = filler.synthetic_pairs(11, 3, 12)
+    kw = {"mode": [mode] * 3}
+    if mode != "base":
+        kw.update(input_y=y.to(dev), action=a.to(dev))
+    out = m(x.to(dev), **kw)
+    losses = m.loss_function(*out)
+    assert torch.isfinite(losses["loss"])
+    m.zero_grad()
+    losses["loss"].backward()
+    assert torch.isfinite(m.flat_grads).all()
+    sl = m.flat_range("ct_layer")
+    assert float(m.flat_grads[sl].abs().sum()) > 0
+    if mode == "causal":
+        assert out[0].shape == (3, 12) and abs(float(out[0].sum()) - 3.0) < 1e-4      # action probabilities
+    else:
+        assert out[0].shape == (3, 3, 64, 64)
+    if mode == "action":
+        assert float(out[2]) == 0.0 and out[1].data_ptr() == kw["input_y"].data_ptr()   # vq_loss forced 0, recon vs y
+
+
+def test_harness_three_adam_steps_match_reference(dev, golden):
+    """VAEXperiment.training_step + FlatAdam on one batch for 3 steps: the loss trajectory recorded from the reference's
+    modules with torch.optim.Adam (oracle/gen_golden.py) must be reproduced (H1 in SURVEY §8a)."""
+    from ctvae_amd.experiment import VAEXperiment
+    from ctvae_amd.models import vae_models
+    g = golden("vanilla_b2")
+    seed = int(g["seed"])
+    m = vae_models["VanillaVAE"](in_channels=3, latent_dim=128)
+    m.load_state_dict(filler.fill_state(H.vanilla_specs(), seed + 1))
+    m = m.to(dev).train()
+    exp = VAEXperiment(m, {"LR": float(g["lr"]), "weight_decay": 0.0, "scheduler_gamma": 0.95, "kld_weight": float(g["M_N"])})
+    x, eps = filler.synthetic_batch(seed, 2)
+    xd, ed = x.to(dev), eps.to(dev)
+    got = []
+    for step in range(3):
+        m.zero_grad()
+        out = m(xd, eps=ed)
+        l = m.loss_function(*out, M_N=exp.params["kld_weight"])
+        l["loss"].backward()
+        exp.optimizer_step()
+        got.append(l["loss"].item())
+    np.testing.assert_allclose(got, g["adam_losses"], rtol=2e-3, atol=1e-4)
+    # weights (not the BN-cancelled conv biases, whose gradient is rounding noise) follow the reference after 3 steps
+    for k, p in m.named_parameters():
+        if k.endswith(".0.bias") and not k.startswith("final_layer.3"):
+            continue
+        H.assert_cks_close(H.cks(p), g["adam3." + k], rtol=5e-3, atol=1e-3, what=k)
+    exp.scheduler.step()
+    assert abs(exp.optimizer.state[1].item() - float(g["lr"]) * 0.95) < 1e-9
+
+
+def test_runner_consumes_yaml(dev, tmp_path):
+    from ctvae_amd import run
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "mcq_vae.yaml")))
+    cfg["logging_params"]["save_dir"] = str(tmp_path)
+    cfg["data_params"]["train_batch_size"] = 8
+    cfg["data_params"]["val_batch_size"] = 8
+    p = tmp_path / "cfg.yaml"
+    p.write_text(yaml.safe_dump(cfg))
+    hist = run.main(["-c", str(p), "--steps-per-epoch", "3", "--max-epochs", "2"])
+    assert len(hist) == 2 and "val_Reconstruction_Loss" in hist[-1] and hist[-1]["train_images"] == 24
+    ck = torch.load(tmp_path / "MCQVAE" / "checkpoints" / "last.ckpt", weights_only=True)
+    assert all(k.startswith("model.") for k in ck["state_dict"])
+    assert ck["state_dict"]["model.encoder.0.0.weight"].shape == (64, 3, 4, 4)

@@ -1,0 +1,113 @@
+"""CPU: host-side logic of the drop-in boundary — state_dict keys/shapes, packed layouts, the flat buffers,
+YAML contract, synthetic batch contract."""
+import os
+
+import pytest
+import torch
+import yaml
+
+from ctvae_amd import filler
+from ctvae_amd.models import vae_models
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_vanilla_state_dict_contract():
+    m = vae_models["VanillaVAE"](in_channels=3, latent_dim=128, name="VanillaVAE")      # unknown kwargs are swallowed
+    specs = H.vanilla_specs()
+    sd = m.state_dict()
+    assert [k for k, _, _ in specs] == list(sd.keys())
+    assert all(tuple(sd[k].shape) == tuple(s) for k, s, _ in specs)
+    assert sum(p.numel() for p in m.parameters()) == 3_937_635                           # SURVEY §6 census
+    ref = filler.fill_state(specs, 3)
+    m.load_state_dict(ref)                                                                # strict
+    assert all(torch.equal(v, ref[k]) for k, v in m.state_dict().items())
+    # packed layouts
+    w = m.encoder[1]._modules["0"].weight
+    assert w.stride() == (1, 64, 3 * 32 * 64, 32 * 64)
+    wt = m.decoder[0]._modules["0"].weight
+    assert wt.shape == (512, 256, 3, 3) and wt.stride() == (256, 1, 3 * 512 * 256, 512 * 256)
+    assert m.fc_mu.weight.stride() == (1, 256) and m.fc_var.weight.data_ptr() - m.fc_mu.weight.data_ptr() == 128 * 4
+    # gradients are views of the flat gradient buffer with the same layout
+    assert all(p.grad is not None and p.grad.stride() == p.stride() for p in m.parameters())
+    m.flat_grads.fill_(1.0)
+    assert float(m.fc_var.bias.grad.sum()) == 128.0
+    m.zero_grad()
+    assert float(m.flat_grads.abs().sum()) == 0.0
+    # the reference mutates hidden_dims in place and hard-codes 512
+    hd = [32, 64, 128, 256, 512]
+    vae_models["VAE"](3, 16, hd)
+    assert hd == [512, 256, 128, 64, 32]
+    with pytest.raises(ValueError):
+        vae_models["GaussianVAE"](3, 16, [32, 64])
+
+
+@pytest.mark.parametrize("cfg", [H.MCQ_CFG, H.CT_CONV_CFG])
+def test_mcq_state_dict_contract(cfg):
+    m = vae_models["MCQVAE"](**{**cfg, "hidden_dims": list(cfg["hidden_dims"])})
+    specs = H.mcq_specs(cfg)
+    sd = m.state_dict()
+    assert [k for k, _, _ in specs] == list(sd.keys())
+    assert all(tuple(sd[k].shape) == tuple(s) for k, s, _ in specs)
+    assert sum(p.numel() for p in m.parameters()) == 10_108_163
+    m.vq_layer._codebooks()                                                               # back to back after flattening
+
+
+def test_ctmcqvae_contract():
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "ct_mcq_vae.yaml")))["model_params"]
+    m = vae_models["CTMCQVAE"](**cfg)
+    keys = list(m.state_dict().keys())
+    conv_keys = [k for k, _, _ in H.mcq_specs(H.CT_CONV_CFG)]
+    assert [k for k in keys if not k.startswith("ct_layer.")] == conv_keys
+    ct = [k for k in keys if k.startswith("ct_layer.")]
+    for want in ("ct_layer.a_dense.weight", "ct_layer.pos_encoding.pe", "ct_layer.graph_discovers.12.2.bias",
+                 "ct_layer.mask.0.weight", "ct_layer.graph_transitioner.module_0.att",
+                 "ct_layer.graph_transitioner.module_0.lin_l.weight", "ct_layer.graph_transitioner.module_0.lin_edge.weight",
+                 "ct_layer.graph_transitioner.module_2.bias"):
+        assert want in ct, want
+    sd = m.state_dict()
+    assert sd["ct_layer.graph_discovers.0.0.weight"].shape == (800, 128)                  # Linear(2*64, 800)
+    assert sd["ct_layer.graph_transitioner.module_0.lin_l.weight"].shape == (1300, 64)   # heads 13 x 100
+    assert sd["ct_layer.graph_transitioner.module_2.lin_r.weight"].shape == (832, 1300)  # heads 13 x 64
+    assert sd["ct_layer.mask.0.weight"].shape == (64, 76)
+    n_ct = sum(p.numel() for n, p in m.named_parameters() if n.startswith("ct_layer."))
+    assert abs(n_ct - 3.70e6) < 0.05e6                                                    # SURVEY A.3 (~3.70 M)
+    sl = m.flat_range("ct_layer")                                                         # update_parameters: "ct_layer"
+    assert sl.stop - sl.start == n_ct and sl.stop == m.flat_params.numel()
+    # one-hot formatting round trip (ct_mcq_vae.py:472-496)
+    inds = torch.randint(0, 64, (2, 1, 8, 8))
+    oh = m.ct_preprocess(inds, (2, 128, 8, 8))
+    assert oh.shape == (2, 64, 8, 8) and torch.equal(m.ct_postprocess(oh, (2, 128, 8, 8)), inds)
+
+
+def test_yaml_contract():
+    """Facts of the three in-scope reference configs (configs/vae.yaml, mcq_vae.yaml, ct_mcq_vae.yaml)."""
+    want = {
+        "vae.yaml": ("VanillaVAE", {"in_channels": 3, "latent_dim": 128}, {"LR": 0.005, "scheduler_gamma": 0.95, "kld_weight": 0.00025, "manual_seed": 1265}, 64),
+        "mcq_vae.yaml": ("MCQVAE", {"embedding_dim": 128, "hidden_dims": [64, 128, 256], "num_embeddings": 64, "codebooks": 4, "beta": 0.25},
+                         {"LR": 0.0005, "scheduler_gamma": 0.98, "manual_seed": 1320}, 64),
+        "ct_mcq_vae.yaml": ("CTMCQVAE", {"action_dim": 12, "codebooks": 1, "beta": 0.1, "gamma": 1.5, "c_alpha": 0.01, "c_beta": 0.4, "c_delta": 0.01, "c_epsilon": 0.1, "noise": "off"},
+                            {"LR": 0.0005, "scheduler_gamma": 0.994, "manual_seed": 1250, "update_parameters": "ct_layer", "find_unused_parameters": True}, 16),
+    }
+    for fn, (name, mp, ep, bs) in want.items():
+        cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", fn)))
+        assert set(cfg) == {"model_params", "data_params", "exp_params", "trainer_params", "logging_params"}
+        assert cfg["model_params"]["name"] == name and name in vae_models
+        assert all(cfg["model_params"][k] == v for k, v in mp.items())
+        assert all(cfg["exp_params"][k] == v for k, v in ep.items())
+        assert cfg["data_params"]["train_batch_size"] == bs and cfg["data_params"]["patch_size"] == 64
+
+
+def test_synthetic_batch_contract():
+    from ctvae_amd.run import SyntheticData
+    d = SyntheticData({"dataset_name": "TShapes3D", "train_batch_size": 4, "val_batch_size": 4, "patch_size": 64},
+                      {"action_dim": 12}, torch.device("cpu"), rank=1, world=2, steps_per_epoch=3)
+    batches = list(d.train())
+    assert [b[2]["mode"][0] for b in batches] == ["base", "action", "causal"]
+    x, labels, opts = batches[1]
+    assert x.shape == (4, 3, 64, 64) and opts["action"].shape == (4, 12) and opts["input_y"].shape == (4, 3, 64, 64)
+    assert float(opts["action"].sum()) == 4.0 and 0.0 <= float(x.min()) and float(x.max()) < 1.0
+    d0 = SyntheticData({"train_batch_size": 4, "val_batch_size": 4}, {}, torch.device("cpu"), rank=0, world=2, steps_per_epoch=1)
+    d1 = SyntheticData({"train_batch_size": 4, "val_batch_size": 4}, {}, torch.device("cpu"), rank=1, world=2, steps_per_epoch=1)
+    assert not torch.equal(next(iter(d0.train()))[0], next(iter(d1.train()))[0])           # ranks see different rows
