@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--detail", action="store_true", help="per-shape kernel table on stderr (diagnostic)")
     return ap.parse_args()
 
 
@@ -208,6 +209,18 @@ def main():
         step_tflops = FLOP_PER_IMG[args.model] * (B * args.steps / elapsed) / 1e12
         roofline["step_conv_tflops_per_gpu"] = round(step_tflops, 2)
         roofline["step_frac_of_f32_mfma_peak"] = round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)
+
+    if rank == 0 and args.detail:
+        native.prof_enable(True, detailed=True)
+        for i in range(3):
+            static_x.copy_(batches[i % 4])
+            local_step()
+        torch.cuda.synchronize()
+        native.prof_enable(False)
+        for k, v in sorted(native.prof_report().items(), key=lambda kv: -kv[1]["ms"]):
+            tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
+            print(f"{v['ms'] / 3 * 1e3:9.1f} us/step  {v['count'] // 3:3d}x  {tf:7.1f} TF/s  {v['bytes'] / max(v['ms'], 1e-9) / 1e6:8.1f} GB/s  {k}",
+                  file=sys.stderr)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -6,8 +6,9 @@
 
 namespace ctvae {
 int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
-                   const float* mask, int mask_act, float* S, int act, float* bn_part, hipStream_t st);
-int tapgemm_bn_parts(const ConvGeom& g);
+                   const float* mask, int mask_act, float* S, int act, float* bn_part, float* ws, size_t ws_floats,
+                   hipStream_t st);
+void tapgemm_plan(const ConvGeom& g, size_t ws_floats, TapGemmPlan& p);
 int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, float* dbias, float* ws, size_t ws_bytes,
                  int accumulate, hipStream_t st);
 int launch_bn_forward(const float* y, int R, int C, const float* gamma, const float* beta, float* running_mean,
@@ -61,11 +62,12 @@ const char* ctvae_error_string(int code) {
 size_t ctvae_workspace_bytes(void) { return (size_t)256 << 20; }
 
 int ctvae_conv_forward(int kind, const float* x, const float* w, const float* bias, const float* add, float* y, int B,
-                       int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int act, void* stream) {
+                       int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int act, float* ws,
+                       size_t ws_bytes, void* stream) {
   if (!x || !w || !y || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
   ConvGeom g;
   if (build_geom(g, kind == CTVAE_CONV ? 0 : 1, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
-  return launch_tapgemm(g, x, w, bias, add, nullptr, 0, y, act, nullptr, (hipStream_t)stream);
+  return launch_tapgemm(g, x, w, bias, add, nullptr, 0, y, act, nullptr, ws, ws_bytes / sizeof(float), (hipStream_t)stream);
 }
 
 int ctvae_conv_bn_act_forward(int kind, const float* x, const float* w, const float* bias, const float* gamma,
@@ -79,21 +81,33 @@ int ctvae_conv_bn_act_forward(int kind, const float* x, const float* w, const fl
   if (Co % 4 != 0) return kErrBadArg;
   ConvGeom g;
   if (build_geom(g, kind == CTVAE_CONV ? 0 : 1, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
-  const int nparts = training ? tapgemm_bn_parts(g) : 0;
-  if (ws_bytes / sizeof(float) < bn_workspace_floats(Co, nparts)) return kErrWorkspace;
-  int rc = launch_tapgemm(g, x, w, bias, nullptr, nullptr, 0, y, ACT_NONE, training ? ws : nullptr, (hipStream_t)stream);
+  const size_t wsf = ws_bytes / sizeof(float);
+  TapGemmPlan plan;
+  tapgemm_plan(g, wsf, plan);
+  const int R = g.B * g.sH * g.sW;
+  if (plan.splitk > 1 || !training) {
+    // small layer run split-K (or eval mode): conv first, then statistics from y with the stand-alone kernels
+    int rc = launch_tapgemm(g, x, w, bias, nullptr, nullptr, 0, y, ACT_NONE, nullptr, ws, wsf, (hipStream_t)stream);
+    if (rc) return rc;
+    return launch_bn_forward(y, R, Co, gamma, beta, running_mean, running_var, momentum, eps, training, act, a_out, save_mean,
+                             save_invstd, ws, ws_bytes, (hipStream_t)stream);
+  }
+  const int nparts = plan.bn_parts;
+  if (wsf < bn_workspace_floats(Co, nparts)) return kErrWorkspace;
+  int rc = launch_tapgemm(g, x, w, bias, nullptr, nullptr, 0, y, ACT_NONE, ws, nullptr, 0, (hipStream_t)stream);
   if (rc) return rc;
-  return launch_bn_finish_forward(y, g.B * g.sH * g.sW, Co, nparts, gamma, beta, running_mean, running_var, momentum, eps,
-                                  training, act, a_out, save_mean, save_invstd, ws, (hipStream_t)stream);
+  return launch_bn_finish_forward(y, R, Co, nparts, gamma, beta, running_mean, running_var, momentum, eps, training, act,
+                                  a_out, save_mean, save_invstd, ws, (hipStream_t)stream);
 }
 
 int ctvae_conv_dgrad(int kind, const float* dy, const float* w, const float* add, const float* mask, int mask_act,
-                     float* dx, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
-                     void* stream) {
+                     float* dx, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, float* ws,
+                     size_t ws_bytes, void* stream) {
   if (!dy || !w || !dx || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
   ConvGeom g;
   if (build_geom(g, kind == CTVAE_CONV ? 2 : 3, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
-  return launch_tapgemm(g, dy, w, nullptr, add, mask, mask_act, dx, ACT_NONE, nullptr, (hipStream_t)stream);
+  return launch_tapgemm(g, dy, w, nullptr, add, mask, mask_act, dx, ACT_NONE, nullptr, ws, ws_bytes / sizeof(float),
+                        (hipStream_t)stream);
 }
 
 int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float* dbias, int B, int H, int W, int Ci,

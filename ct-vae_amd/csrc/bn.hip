@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
   }
 }
 
-// block = 64 partial-lanes x 4 channels; merges `nparts` (n, mean, M2) triples per channel
+// one block (256 partial-lanes) per channel: merges `nparts` (n, mean, M2) triples with Chan's formula
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
@@ -102,26 +102,23 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* __restrict__ shift) {
   __shared__ float sm[256 * 3];
   const int tid = threadIdx.x;
-  const int ch = tid & 3, pl = tid >> 2;
-  const int c = blockIdx.x * 4 + ch;
+  const int c = blockIdx.x;
   float n = 0.f, mean = 0.f, m2 = 0.f;
-  if (c < C) {
-    for (int b = pl; b < nparts; b += 64) {
-      const float* p = part + ((long)b * C + c) * 3;
-      chan_merge(n, mean, m2, p[0], p[1], p[2]);
-    }
+  for (int b = tid; b < nparts; b += 256) {
+    const float* p = part + ((long)b * C + c) * 3;
+    chan_merge(n, mean, m2, p[0], p[1], p[2]);
   }
   sm[tid * 3] = n; sm[tid * 3 + 1] = mean; sm[tid * 3 + 2] = m2;
   __syncthreads();
-  for (int s = 32; s > 0; s >>= 1) {
-    if (pl < s) {
-      const float* o = &sm[((pl + s) * 4 + ch) * 3];
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+      const float* o = &sm[(tid + s) * 3];
       chan_merge(n, mean, m2, o[0], o[1], o[2]);
       sm[tid * 3] = n; sm[tid * 3 + 1] = mean; sm[tid * 3 + 2] = m2;
     }
     __syncthreads();
   }
-  if (pl == 0 && c < C) {
+  if (tid == 0) {
     const float var = m2 / n;
     const float invstd = 1.0f / sqrtf(var + eps);
     save_mean[c] = mean;
@@ -225,35 +222,27 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   }
 }
 
-// block = 64 partial-lanes x 4 channels: dgamma/dbeta (accumulate flag) and the per-channel coefficients of
-// g_y = k1*g_bn + k2*y + k3
+// one block per channel: dgamma/dbeta (accumulate flag) and the per-channel coefficients of g_y = k1*g_bn + k2*y + k3
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int C, float R,
                                                               const float* __restrict__ gamma, const float* __restrict__ save_mean,
                                                               const float* __restrict__ save_invstd, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int accumulate,
                                                               float* __restrict__ coef /* [3][C] */) {
-  __shared__ double sm[256 * 2];
+  __shared__ double sm[8];
   const int tid = threadIdx.x;
-  const int ch = tid & 3, pl = tid >> 2;
-  const int c = blockIdx.x * 4 + ch;
+  const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  if (c < C) {
-    for (int b = pl; b < nblocks; b += 64) {
-      s1 += (double)part[((long)b * C + c) * 2 + 0];
-      s2 += (double)part[((long)b * C + c) * 2 + 1];
-    }
+  for (int b = tid; b < nblocks; b += 256) {
+    s1 += (double)part[((long)b * C + c) * 2 + 0];
+    s2 += (double)part[((long)b * C + c) * 2 + 1];
   }
-  sm[tid * 2] = s1; sm[tid * 2 + 1] = s2;
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  if ((tid & 63) == 0) { sm[(tid >> 6) * 2] = s1; sm[(tid >> 6) * 2 + 1] = s2; }
   __syncthreads();
-  for (int s = 32; s > 0; s >>= 1) {
-    if (pl < s) {
-      s1 += sm[((pl + s) * 4 + ch) * 2];
-      s2 += sm[((pl + s) * 4 + ch) * 2 + 1];
-      sm[tid * 2] = s1; sm[tid * 2 + 1] = s2;
-    }
-    __syncthreads();
-  }
-  if (pl == 0 && c < C) {
+  if (tid == 0) {
+    s1 = (sm[0] + sm[2]) + (sm[4] + sm[6]);
+    s2 = (sm[1] + sm[3]) + (sm[5] + sm[7]);
     const float db = (float)s1, dg = (float)s2;
     dgamma[c] = (accumulate ? dgamma[c] : 0.f) + dg;
     dbeta[c] = (accumulate ? dbeta[c] : 0.f) + db;
@@ -318,7 +307,7 @@ int launch_bn_finish_forward(const float* y, int R, int C, int nparts, const flo
   float* shift = scale + C;
   if (training) {
     ProfScope ps("bn_finalize_kernel", st, 0.0, 12.0 * (double)nparts * C);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, ws, nparts, C, gamma, beta, running_mean,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, ws, nparts, C, gamma, beta, running_mean,
                        running_var, momentum, eps, save_mean, save_invstd, scale, shift);
     CTVAE_LAUNCH_CHECK();
   } else {
@@ -369,7 +358,7 @@ int launch_bn_backward(const float* ga, const float* a_out, const float* y, int 
   CTVAE_LAUNCH_CHECK();
   {
     ProfScope ps("bn_bwd_finalize_kernel", st, 0.0, 8.0 * (double)nb * C);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, part, nb, C, (float)R, gamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, part, nb, C, (float)R, gamma,
                        save_mean, save_invstd, dgamma, dbeta, accumulate, coef);
   }
   CTVAE_LAUNCH_CHECK();

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <string.h>
 
 #include "geom.hpp"
 
@@ -56,6 +58,12 @@ __device__ __forceinline__ float block_sum_256(float v, float* sm /* >=4 floats 
 }
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+struct TapGemmPlan {
+  int BM, BN, mtiles, ntiles, splitk;
+  int thin;      // 1: VALU thin-layer kernels (thin.hip) instead of the MFMA tile kernel
+  int bn_parts;  // rows of (count, mean, M2) partials a BN-statistics epilogue would write
+};
 
 #define CTVAE_LAUNCH_CHECK()                   \
   do {                                         \

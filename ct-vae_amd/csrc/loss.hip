@@ -11,7 +11,9 @@ namespace ctvae {
 constexpr int kLossBlocks = 1024;
 
 __global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ r, const float* __restrict__ x,
-                                                          float* __restrict__ part, long n4, long n) {
+                                                          float* __restrict__ part, long n4, long n,
+                                                          const float* __restrict__ mu, long mu_rs,
+                                                          const float* __restrict__ lv, long lv_rs, int B, int L) {
   __shared__ float sm[4];
   float s = 0.f;
   const long stride = (long)gridDim.x * 256;
@@ -30,39 +32,42 @@ __global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restric
       s += d * d;
     }
   }
+  float k = 0.f;          // KL terms 1 + lv - mu^2 - e^lv, spread over the same grid
+  if (mu != nullptr) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)B * L; i += stride) {
+      int b = (int)(i / L), d = (int)(i - (long)b * L);
+      float m = mu[b * mu_rs + d], l = lv[b * lv_rs + d];
+      k += 1.f + l - m * m - expf(l);
+    }
+  }
   s = block_sum_256(s, sm);
-  if (threadIdx.x == 0) part[blockIdx.x] = s;
+  k = block_sum_256(k, sm);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = s;
+    part[gridDim.x + blockIdx.x] = k;
+  }
 }
 
 // out[0] = loss = mse + M_N*kld (+ extra[0] if given), out[1] = mse, out[2] = kld, out[3] = -kld ('KLD' key, vanilla_vae.py:146)
-__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ part, int nparts, double inv_n,
-                                                          const float* __restrict__ mu, long mu_rs,
-                                                          const float* __restrict__ lv, long lv_rs, int B, int L, float M_N,
-                                                          const float* __restrict__ extra, float* __restrict__ out) {
-  __shared__ double smd[4];
-  double s = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += 256) s += (double)part[i];
-  double k = 0.0;
-  if (mu != nullptr) {
-    for (int i = threadIdx.x; i < B * L; i += 256) {
-      int b = i / L, d = i - b * L;
-      float m = mu[b * mu_rs + d], l = lv[b * lv_rs + d];
-      k += (double)(1.f + l - m * m - expf(l));
-    }
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ part, int nparts, double inv_n, int has_kl,
+                                                          int B, float M_N, const float* __restrict__ extra,
+                                                          float* __restrict__ out) {
+  __shared__ double smd[8];
+  double s = 0.0, k = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) {
+    s += (double)part[i];
+    k += (double)part[nparts + i];
   }
   s = wave_sum_d(s);
   k = wave_sum_d(k);
   const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) smd[w] = s;
+  if ((threadIdx.x & 63) == 0) { smd[w] = s; smd[4 + w] = k; }
   __syncthreads();
-  double st = smd[0] + smd[1] + smd[2] + smd[3];
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) smd[w] = k;
-  __syncthreads();
-  double kt = smd[0] + smd[1] + smd[2] + smd[3];
   if (threadIdx.x == 0) {
+    const double st = smd[0] + smd[1] + smd[2] + smd[3];
+    const double kt = smd[4] + smd[5] + smd[6] + smd[7];
     float mse = (float)(st * inv_n);
-    float kld = mu != nullptr ? (float)(-0.5 * kt / (double)B) : 0.f;
+    float kld = has_kl ? (float)(-0.5 * kt / (double)B) : 0.f;
     float loss = mse + M_N * kld;
     if (extra != nullptr) loss += extra[0];
     out[0] = loss;
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(256) void kl_bwd_kernel(const float* __restrict__ m
   glv[i] = sc * 0.5f * (expf(lv[b * lv_rs + d]) - 1.f);
 }
 
-size_t loss_workspace_floats() { return kLossBlocks; }
+size_t loss_workspace_floats() { return 2 * kLossBlocks; }
 
 int launch_loss_forward(const float* r, const float* x, long n, const float* mu, long mu_rs, const float* lv, long lv_rs,
                         int B, int L, float M_N, const float* extra, float* out4, float* ws, size_t ws_bytes,
@@ -112,11 +117,14 @@ int launch_loss_forward(const float* r, const float* x, long n, const float* mu,
   long blocks = (n4 + 255) / 256;
   if (blocks > kLossBlocks) blocks = kLossBlocks;
   if (blocks < 1) blocks = 1;
-  ProfScope ps("mse_partial+loss_finish", st, 0.0, 8.0 * (double)n + 8.0 * (double)B * L);
-  hipLaunchKernelGGL(mse_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, st, r, x, ws, n4, n);
+  {
+  ProfScope ps("mse_partial_kernel", st, 0.0, 8.0 * (double)n);
+  hipLaunchKernelGGL(mse_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, st, r, x, ws, n4, n, mu, mu_rs, lv, lv_rs, B, L);
+  }
   CTVAE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, ws, (int)blocks, 1.0 / (double)n, mu, mu_rs, lv, lv_rs,
-                     B, L, M_N, extra, out4);
+  ProfScope ps2("loss_finish_kernel", st, 0.0, 8.0 * (double)B * L);
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, ws, (int)blocks, 1.0 / (double)n, mu != nullptr ? 1 : 0,
+                     B, M_N, extra, out4);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }

@@ -20,6 +20,7 @@ struct Rec {
 static std::vector<Rec> g_recs;
 
 bool prof_enabled() { return g_enabled != 0; }
+bool prof_detailed() { return g_enabled >= 2; }
 
 ProfScope::ProfScope(const char* name, hipStream_t st, double flops, double bytes) : idx_(-1), st_(st) {
   if (!g_enabled) return;

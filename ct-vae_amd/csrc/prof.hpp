@@ -4,6 +4,7 @@
 
 namespace ctvae {
 bool prof_enabled();
+bool prof_detailed();  // level 2: kernel names carry the problem shape
 struct ProfScope {
   ProfScope(const char* name, hipStream_t st, double flops, double bytes);
   ~ProfScope();

@@ -31,6 +31,8 @@ struct TapGemmArgs {
   const float* mask;
   float* S;
   float* bn_part;  // optional [ncls*mtiles][N][3] per-tile (count, mean, M2) of the pre-activation output
+  float* part;     // split-K partial sums [splitk][B*sH*sW][N] (raw accumulators), used when splitk > 1
+  int splitk;
   int act;
   int mask_act;
   int Mc;      // B*Qh*Qw
@@ -263,11 +265,20 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
 
   const int li = lane & 31, lh = lane >> 5;
 
-  load_chunk(0);
-  store_chunk();
+  // split-K: this workgroup owns chunks [c0, c1) of the class's K range
+  int c0 = 0, c1 = nch;
+  if (a.splitk > 1) {
+    const int cps = (nch + a.splitk - 1) / a.splitk;
+    c0 = blockIdx.z * cps;
+    c1 = c0 + cps < nch ? c0 + cps : nch;
+  }
+  if (c0 < c1) {
+    load_chunk(c0);
+    store_chunk();
+  }
   __syncthreads();
-  for (int c = 0; c < nch; ++c) {
-    if (c + 1 < nch) load_chunk(c + 1);
+  for (int c = c0; c < c1; ++c) {
+    if (c + 1 < c1) load_chunk(c + 1);
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) {
       f32x4 af[TM];
@@ -294,7 +305,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
-    if (c + 1 < nch) {
+    if (c + 1 < c1) {
       store_chunk();
       __syncthreads();
     }
@@ -302,6 +313,22 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
 
   // ---- epilogue ------------------------------------------------------------------------------
   const int N = a.N;
+  if (a.splitk > 1) {  // raw partial sums; bias / activation / BN statistics happen in splitk_finish_kernel
+    float* dst = a.part + (long)blockIdx.z * ((long)g.B * g.sH * g.sW) * N;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + li;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * TM + i) * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+          const int sp = sOut[row];
+          if (sp >= 0 && col < N) dst[(long)sp * N + col] = acc[i][j][r];
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + (wn * TN + j) * 32 + li;
@@ -375,6 +402,33 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
   }
 }
 
+// S[i] = epi(sum_z part[z][i]) for the split-K path (N % 4 == 0)
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ part, int splitk, long stride,
+                                                            const float* __restrict__ bias, const float* __restrict__ add,
+                                                            const float* __restrict__ mask, int mask_act, int act,
+                                                            float* __restrict__ S, long n4, int N) {
+  const long gs = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += gs) {
+    f32x4 v = reinterpret_cast<const f32x4*>(part)[i];
+    for (int z = 1; z < splitk; ++z) {
+      f32x4 t = reinterpret_cast<const f32x4*>(part + z * stride)[i];
+      v += t;
+    }
+    const int col = (int)((i * 4) % N);
+    if (bias != nullptr) v += *reinterpret_cast<const f32x4*>(bias + col);
+    if (add != nullptr) v += reinterpret_cast<const f32x4*>(add)[i];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = act_fwd(v[k], act);
+    if (mask != nullptr) {
+      f32x4 m = reinterpret_cast<const f32x4*>(mask)[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] *= act_bwd_from_out(m[k], mask_act);
+    }
+    reinterpret_cast<f32x4*>(S)[i] = o;
+  }
+}
+
 // ---- host side --------------------------------------------------------------------------------
 template <int WM, int WN, int TM, int TN, bool GENERIC>
 static int launch_cfg(const TapGemmArgs& a, bool wt, bool avec, bool bvec, hipStream_t st) {
@@ -382,12 +436,17 @@ static int launch_cfg(const TapGemmArgs& a, bool wt, bool avec, bool bvec, hipSt
   TapGemmArgs args = a;
   args.mtiles = ceil_div(a.Mc, BM);
   args.ntiles = ceil_div(a.N, BN);
-  dim3 grid(args.mtiles * args.ntiles, a.g.ncls), block(256);
-  char name[96];
+  dim3 grid(args.mtiles * args.ntiles, a.g.ncls, a.splitk > 1 ? a.splitk : 1), block(256);
+  char name[160];
   snprintf(name, sizeof name, "tapgemm_kernel<%d,%d,%d,%d,%s,%s,%s>", WM, WN, TM, TN, wt ? "true" : "false",
            avec ? "true" : "false", bvec ? "true" : "false");
   double macs = 0;
   for (int c = 0; c < a.g.ncls; ++c) macs += (double)a.Mc * a.N * a.g.ntaps[c] * a.g.gC;
+  if (prof_detailed()) {
+    size_t l = strlen(name);
+    snprintf(name + l, sizeof name - l, " M=%dx%d N=%d C=%d taps=%d sk=%d", a.g.ncls, a.Mc, a.N, a.g.gC, a.g.ntaps[a.g.ncls - 1],
+             a.splitk);
+  }
   const double bytes = 4.0 * ((double)a.g.B * a.g.gH * a.g.gW * a.g.gC + (double)a.g.B * a.g.sH * a.g.sW * a.g.sC);
   ProfScope ps(name, st, 2.0 * macs, bytes);
 #define CTVAE_TG(WT_, AV_, BV_) \
@@ -412,21 +471,50 @@ static int launch_cfg(const TapGemmArgs& a, bool wt, bool avec, bool bvec, hipSt
   return 0;
 }
 
-// rows of the bn_part array the launch will write (tile choice mirrors launch_tapgemm below)
-int tapgemm_bn_parts(const ConvGeom& g) {
+bool thin_forward_supported(const ConvGeom& g);
+int thin_bn_parts(const ConvGeom& g);
+int launch_thin_forward(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
+                        const float* mask, int mask_act, float* S, int act, float* bn_part, hipStream_t st);
+
+// tile shape and split-K factor a launch will use (mirrored by the BN-statistics consumers)
+void tapgemm_plan(const ConvGeom& g, size_t ws_floats, TapGemmPlan& p) {
   const int Mc = g.B * g.Qh * g.Qw, N = g.sC;
+  p.thin = 0;
+  if (thin_forward_supported(g)) {
+    p.thin = 1; p.BM = p.BN = 0; p.mtiles = p.ntiles = 0; p.splitk = 1;
+    p.bn_parts = thin_bn_parts(g);
+    return;
+  }
   const bool avec = (g.gC % KC) == 0;
   const bool bvec = g.wT ? avec : ((N % 4) == 0);
-  int BM = 128;
+  p.BM = 128; p.BN = 32; p.splitk = 1;
   if (!(N <= 32 || !avec || !bvec)) {
     const long tiles128 = (long)ceil_div(Mc, 128) * ceil_div(N, 64) * g.ncls;
-    BM = tiles128 >= 512 ? 128 : 64;
+    p.BM = tiles128 >= 512 ? 128 : 64;
+    p.BN = 64;
   }
-  return ceil_div(Mc, BM) * g.ncls;
+  p.mtiles = ceil_div(Mc, p.BM);
+  p.ntiles = ceil_div(N, p.BN);
+  const long wgs = (long)p.mtiles * p.ntiles * g.ncls;
+  int nch_min = 1 << 30;
+  for (int c = 0; c < g.ncls; ++c) {
+    const int nch = avec ? g.ntaps[c] * g.gC / KC : ceil_div(g.ntaps[c] * g.gC, KC);
+    if (nch < nch_min) nch_min = nch;
+  }
+  if (avec && bvec && (N % 4) == 0 && wgs < 384 && nch_min >= 8) {
+    int sk = (int)((768 + wgs - 1) / wgs);
+    if (sk > nch_min / 4) sk = nch_min / 4;
+    if (sk > 16) sk = 16;
+    const size_t per = (size_t)g.B * g.sH * g.sW * N;
+    while (sk > 1 && per * sk > ws_floats) --sk;
+    if (sk > 1) p.splitk = sk;
+  }
+  p.bn_parts = p.mtiles * g.ncls;
 }
 
 int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
-                   const float* mask, int mask_act, float* S, int act, float* bn_part, hipStream_t st) {
+                   const float* mask, int mask_act, float* S, int act, float* bn_part, float* ws, size_t ws_floats,
+                   hipStream_t st) {
   TapGemmArgs a{};
   a.bn_part = bn_part;
   a.g = g;
@@ -438,15 +526,30 @@ int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const floa
   const bool wt = g.wT != 0;
   const bool avec = (g.gC % KC) == 0;
   const bool bvec = wt ? avec : ((a.N % 4) == 0);
-  if (!avec) {
+  if (!avec && !thin_forward_supported(g)) {
     for (int c = 0; c < g.ncls; ++c)
       if (g.ntaps[c] * g.gC > 64) return kErrBadArg;  // scalar path keeps its k-table in LDS
   }
-  // tile choice: N<=32 -> 128x32 (4x1 waves); big problems -> 128x64; small M -> 64x64
-  if (a.N <= 32 || !avec || !bvec) return launch_cfg<4, 1, 1, 1, true>(a, wt, avec, bvec, st);
-  const long tiles128 = (long)ceil_div(a.Mc, 128) * ceil_div(a.N, 64) * g.ncls;
-  if (tiles128 >= 512) return launch_cfg<2, 2, 2, 1, false>(a, wt, avec, bvec, st);
-  return launch_cfg<2, 2, 1, 1, false>(a, wt, avec, bvec, st);
+  // tile choice: N<=32 -> 128x32 (4x1 waves); big problems -> 128x64; small M -> 64x64 (+ split-K when the grid is small)
+  TapGemmPlan plan;
+  tapgemm_plan(g, ws != nullptr ? ws_floats : 0, plan);
+  if (plan.thin) return launch_thin_forward(g, G, W, bias, add, mask, mask_act, S, act, bn_part, st);
+  a.splitk = plan.splitk;
+  a.part = ws;
+  if (plan.splitk > 1 && bn_part != nullptr) return kErrBadArg;  // caller must take BN statistics from S instead
+  int rc;
+  if (plan.BN == 32) rc = launch_cfg<4, 1, 1, 1, true>(a, wt, avec, bvec, st);
+  else if (plan.BM == 128) rc = launch_cfg<2, 2, 2, 1, false>(a, wt, avec, bvec, st);
+  else rc = launch_cfg<2, 2, 1, 1, false>(a, wt, avec, bvec, st);
+  if (rc || plan.splitk <= 1) return rc;
+  const long n = (long)g.B * g.sH * g.sW * a.N, n4 = n / 4;
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  ProfScope ps("splitk_finish_kernel", st, 0.0, 4.0 * (double)(plan.splitk + 1) * n);
+  hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ws, plan.splitk, n, bias, add, mask,
+                     mask_act, act, S, n4, a.N);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
 }
 
 }  // namespace ctvae

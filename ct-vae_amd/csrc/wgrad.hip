@@ -247,6 +247,38 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
+// few slices: plain element-wise pass (float4 when n % 4 == 0)
+__global__ __launch_bounds__(256) void reduce_partials_small_kernel(const float* __restrict__ part, float* __restrict__ dst,
+                                                                    long n, int S, long stride, int accumulate) {
+  const long gs = (long)gridDim.x * 256;
+  if ((n & 3) == 0 && (stride & 3) == 0) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += gs) {
+      f32x4 v = accumulate ? reinterpret_cast<const f32x4*>(dst)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < S; ++s) v += reinterpret_cast<const f32x4*>(part + (long)s * stride)[i];
+      reinterpret_cast<f32x4*>(dst)[i] = v;
+    }
+  } else {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += gs) {
+      float v = accumulate ? dst[i] : 0.f;
+      for (int s = 0; s < S; ++s) v += part[(long)s * stride + i];
+      dst[i] = v;
+    }
+  }
+}
+
+static void launch_reduce(const float* part, float* dst, long n, int S, long stride, int accumulate, hipStream_t st) {
+  if (S <= 8) {
+    long blocks = ((n + 3) / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(reduce_partials_small_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, dst, n, S, stride, accumulate);
+  } else {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, part, dst, n, S, stride,
+                       accumulate);
+  }
+}
+
 size_t wgrad_workspace_floats(const ConvGeom& g, int S) {
   int taps_total = 0;
   for (int c = 0; c < g.ncls; ++c) taps_total += g.ntaps[c];
@@ -270,8 +302,30 @@ static int choose_splits(const ConvGeom& g, int KT, int NT, size_t ws_floats) {
   return S;
 }
 
+bool thin_wgrad_supported(const ConvGeom& g);
+size_t thin_wgrad_workspace_floats(const ConvGeom& g);
+int launch_thin_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, float** part_out, float** pbias_out,
+                      int* nparts_w, int* nparts_b, bool want_bias, hipStream_t st);
+
 int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, float* dbias, float* ws,
                  size_t ws_bytes, int accumulate, hipStream_t st) {
+  if (thin_wgrad_supported(g) && thin_wgrad_workspace_floats(g) <= ws_bytes / sizeof(float)) {
+    float *part = nullptr, *pb = nullptr;
+    int nw = 0, nb = 0;
+    int rc = launch_thin_wgrad(g, X, dY, ws, &part, &pb, &nw, &nb, dbias != nullptr, st);
+    if (rc) return rc;
+    int taps = 0;
+    for (int c = 0; c < g.ncls; ++c) taps += g.ntaps[c];
+    const long n = (long)taps * g.gC * g.sC;
+    ProfScope ps("reduce_partials_kernel", st, 0.0, 4.0 * (double)(nw + 1) * n);
+    launch_reduce(part, dW, n, nw, n, accumulate, st);
+    CTVAE_LAUNCH_CHECK();
+    if (dbias) {
+      launch_reduce(pb, dbias, (long)g.sC, nb, (long)g.sC, accumulate, st);
+      CTVAE_LAUNCH_CHECK();
+    }
+    return 0;
+  }
   WgradArgs a{};
   a.g = g;
   a.X = X; a.dY = dY;
@@ -301,10 +355,14 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
   a.ntiles = ceil_div(a.N, NT);
   dim3 grid(kt * a.ntiles, S), block(256);
   {
-  char name[96];
+  char name[160];
   snprintf(name, sizeof name, "wgrad_kernel<%d,%d,%s,%s>", narrow ? 4 : 2, narrow ? 1 : 2, xvec ? "true" : "false",
            dvec ? "true" : "false");
   const double macs = (double)a.Mc * a.N * a.rows_total;
+  if (prof_detailed()) {
+    size_t l = strlen(name);
+    snprintf(name + l, sizeof name - l, " M=%dx%d N=%d rows=%d S=%d", g.ncls, a.Mc, a.N, a.rows_total, S);
+  }
   const double bytes = 4.0 * ((double)g.B * g.gH * g.gW * g.gC + (double)g.B * g.sH * g.sW * g.sC);
   ProfScope ps(name, st, 2.0 * macs, bytes);
 #define CTVAE_WG(WK_, WN_)                                                                              \
@@ -320,13 +378,14 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
   }
   CTVAE_LAUNCH_CHECK();
   const long n = (long)a.rows_total * a.N;
-  ProfScope ps2("reduce_partials_kernel", st, 0.0, 4.0 * (double)(S + 1) * n);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 15) / 16)), block, 0, st, a.part, dW, n, S,
-                     (long)a.rows_total * a.N, accumulate);
+  char rname[96];
+  snprintf(rname, sizeof rname, "reduce_partials_kernel");
+  if (prof_detailed()) snprintf(rname, sizeof rname, "reduce_partials_kernel n=%ld S=%d", n, S);
+  ProfScope ps2(rname, st, 0.0, 4.0 * (double)(S + 1) * n);
+  launch_reduce(a.part, dW, n, S, (long)a.rows_total * a.N, accumulate, st);
   CTVAE_LAUNCH_CHECK();
   if (dbias) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(a.N, 16)), block, 0, st, a.pbias, dbias,
-                       (long)a.N, S * g.ncls, (long)a.N, accumulate);
+    launch_reduce(a.pbias, dbias, (long)a.N, S * g.ncls, (long)a.N, accumulate, st);
     CTVAE_LAUNCH_CHECK();
   }
   return 0;

@@ -68,8 +68,10 @@ def conv_forward_raw(x, w, b, spec: ConvSpec, add=None, act=None):
     B, H, W, _ = x.shape
     ho, wo = spec.out_hw(H, W)
     y = torch.empty((B, ho, wo, spec.co), dtype=torch.float32, device=x.device)
+    ws = native.workspace(x.device)
     native.call("ctvae_conv_forward", spec.kind, x.data_ptr(), w.data_ptr(), native.ptr(b), native.ptr(add), y.data_ptr(),
-                B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, spec.act if act is None else act)
+                B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, spec.act if act is None else act,
+                ws.data_ptr(), ws.numel() * 4)
     return y
 
 
@@ -77,8 +79,10 @@ def conv_dgrad_raw(dy, w, spec: ConvSpec, in_hw, add=None, mask=None, mask_act=A
     B = dy.shape[0]
     H, W = in_hw
     dx = torch.empty((B, H, W, spec.ci), dtype=torch.float32, device=dy.device)
+    ws = native.workspace(dy.device)
     native.call("ctvae_conv_dgrad", spec.kind, dy.data_ptr(), w.data_ptr(), native.ptr(add), native.ptr(mask), mask_act,
-                dx.data_ptr(), B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad)
+                dx.data_ptr(), B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad,
+                ws.data_ptr(), ws.numel() * 4)
     return dx
 
 

@@ -17,10 +17,10 @@ _fp, _vp, _i, _l, _f, _sz = _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_long, _c.c_
 
 # name -> argtypes (all return int unless listed in _RESTYPES)
 SIGNATURES = {
-    "ctvae_conv_forward": [_i, _fp, _fp, _fp, _fp, _fp] + [_i] * 10 + [_vp],
+    "ctvae_conv_forward": [_i, _fp, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _sz, _vp],
     "ctvae_conv_bn_act_forward": [_i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _fp, _fp, _fp, _fp] + [_i] * 9
                                  + [_fp, _sz, _vp],
-    "ctvae_conv_dgrad": [_i, _fp, _fp, _fp, _fp, _i, _fp] + [_i] * 9 + [_vp],
+    "ctvae_conv_dgrad": [_i, _fp, _fp, _fp, _fp, _i, _fp] + [_i] * 9 + [_fp, _sz, _vp],
     "ctvae_conv_wgrad": [_i, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _sz, _vp],
     "ctvae_bn_forward": [_fp, _i, _i, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _fp, _fp, _fp, _fp, _sz, _vp],
     "ctvae_bn_backward": [_fp, _fp, _fp, _i, _i, _fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _fp, _sz, _vp],
@@ -120,8 +120,9 @@ def call(name: str, *args):
     check(getattr(lib, name)(*args, stream_ptr()), name)
 
 
-def prof_enable(on: bool):
-    load().ctvae_prof_enable(1 if on else 0)
+def prof_enable(on, detailed: bool = False):
+    """on=False: off; on=True: per kernel symbol; detailed=True: names also carry the problem shape."""
+    load().ctvae_prof_enable((2 if detailed else 1) if on else 0)
 
 
 def prof_report() -> dict:

@@ -38,9 +38,11 @@ size_t ctvae_workspace_bytes(void); /* scratch size that is sufficient for every
 /* y = act(conv(x, w) + bias + add)
  * Conv2d:          vanilla_vae.py:28-29,73-74; mcq_vae.py:170-171,178-179,189-190,205-209; vq_vae.py:63-67
  * ConvTranspose2d: vanilla_vae.py:50-55,65-70; mcq_vae.py:223-236        Linear: vanilla_vae.py:36-37,43
- * x [B,H,W,Ci], y [B,Ho,Wo,Co]; bias/add may be NULL (add has y's layout: ResidualLayer skip, vq_vae.py:69-70). */
+ * x [B,H,W,Ci], y [B,Ho,Wo,Co]; bias/add may be NULL (add has y's layout: ResidualLayer skip, vq_vae.py:69-70).
+ * ws: scratch for the split-K partial sums of small-grid layers (may be NULL: no split-K). */
 int ctvae_conv_forward(int kind, const float* x, const float* w, const float* bias, const float* add, float* y, int B,
-                       int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int act, void* stream);
+                       int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int act, float* ws,
+                       size_t ws_bytes, void* stream);
 
 /* Conv2d|ConvTranspose2d -> BatchNorm2d -> activation as one call (nn.Sequential blocks vanilla_vae.py:25-35,47-75):
  * y = conv(x)+bias (kept for backward); the conv epilogue emits per-tile (count, mean, M2) so the batch
@@ -54,8 +56,8 @@ int ctvae_conv_bn_act_forward(int kind, const float* x, const float* w, const fl
 /* dx = (dgrad(dy, w) + add) * act'(mask)      (autograd of the ops above)
  * add / mask (saved post-activation output of the PREVIOUS layer, layout of dx) may be NULL. */
 int ctvae_conv_dgrad(int kind, const float* dy, const float* w, const float* add, const float* mask, int mask_act,
-                     float* dx, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
-                     void* stream);
+                     float* dx, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, float* ws,
+                     size_t ws_bytes, void* stream);
 
 /* dw (+)= wgrad(x, dy);  dbias (+)= sum over pixels of dy (dbias may be NULL).  Deterministic two-pass. */
 int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float* dbias, int B, int H, int W, int Ci,

@@ -122,11 +122,13 @@ def test_harness_three_adam_steps_match_reference(dev, golden):
         exp.optimizer_step()
         got.append(l["loss"].item())
     np.testing.assert_allclose(got, g["adam_losses"], rtol=2e-3, atol=1e-4)
-    # weights (not the BN-cancelled conv biases, whose gradient is rounding noise) follow the reference after 3 steps
+    # weights (not the BN-cancelled conv biases, whose gradient is rounding noise) follow the reference after 3 steps.
+    # Adam normalises every element's step to ~lr, so an element whose gradient is within rounding of zero may move by
+    # +-lr per step in either direction: allow a handful of such flips (atol = 6*lr) on top of the relative bound.
     for k, p in m.named_parameters():
         if k.endswith(".0.bias") and not k.startswith("final_layer.3"):
             continue
-        H.assert_cks_close(H.cks(p), g["adam3." + k], rtol=5e-3, atol=1e-3, what=k)
+        H.assert_cks_close(H.cks(p), g["adam3." + k], rtol=5e-3, atol=6 * float(g["lr"]), what=k)
     exp.scheduler.step()
     assert abs(exp.optimizer.state[1].item() - float(g["lr"]) * 0.95) < 1e-9
 
