@@ -18,7 +18,7 @@ int launch_bn_finish_forward(const float* y, int R, int C, int nparts, const flo
                              float* running_mean, float* running_var, float momentum, float eps, int training, int act,
                              float* out, float* save_mean, float* save_invstd, float* ws, hipStream_t st);
 size_t bn_workspace_floats(int C, int nparts);
-int launch_bn_backward(const float* ga, const float* a_out, const float* y, int R, int C, const float* gamma,
+int launch_bn_backward(const float* ga, const float* beta, const float* y, int R, int C, const float* gamma,
                        const float* save_mean, const float* save_invstd, int act, float* gy, float* dgamma, float* dbeta,
                        int accumulate, float* ws, size_t ws_bytes, hipStream_t st);
 int launch_permute(const float* in, float* out, int B, int C, int P, int to_nhwc, hipStream_t st);
@@ -129,11 +129,11 @@ int ctvae_bn_forward(const float* y, int R, int C, const float* gamma, const flo
                            save_invstd, ws, ws_bytes, (hipStream_t)stream);
 }
 
-int ctvae_bn_backward(const float* g_a, const float* a_out, const float* y, int R, int C, const float* gamma,
+int ctvae_bn_backward(const float* g_a, const float* beta, const float* y, int R, int C, const float* gamma,
                       const float* save_mean, const float* save_invstd, int act, float* g_y, float* dgamma,
                       float* dbeta, int accumulate, float* ws, size_t ws_bytes, void* stream) {
-  if (!g_a || !a_out || !y || !gamma || !save_mean || !save_invstd || !g_y || !dgamma || !dbeta || !ws) return kErrBadArg;
-  return launch_bn_backward(g_a, a_out, y, R, C, gamma, save_mean, save_invstd, act, g_y, dgamma, dbeta, accumulate, ws,
+  if (!g_a || !beta || !y || !gamma || !save_mean || !save_invstd || !g_y || !dgamma || !dbeta || !ws) return kErrBadArg;
+  return launch_bn_backward(g_a, beta, y, R, C, gamma, save_mean, save_invstd, act, g_y, dgamma, dbeta, accumulate, ws,
                             ws_bytes, (hipStream_t)stream);
 }
 

@@ -166,7 +166,10 @@ __global__ __launch_bounds__(256) void bn_apply_act_kernel(const float* __restri
 
 // ---- backward -------------------------------------------------------------------------------------
 // part[blk][c] = (sum g_bn, sum g_bn*xhat); thread = (column quad, row lane).  Requires (C/4) | 256.
-__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ ga, const float* __restrict__ a_out,
+// The activation derivative is taken from the sign of z = gamma*invstd*(y-mean)+beta (same sign as the saved
+// output a, so `a` need not be re-read: 8 instead of 12 bytes per element).
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ ga, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
                                                              const float* __restrict__ y, const float* __restrict__ save_mean,
                                                              const float* __restrict__ save_invstd, float* __restrict__ part,
                                                              int R, int C, int rows_per_block, int act) {
@@ -183,18 +186,20 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     const int col = 4 * (q0 + ql);
     const f32x4 mean = *reinterpret_cast<const f32x4*>(save_mean + col);
     const f32x4 invstd = *reinterpret_cast<const f32x4*>(save_invstd + col);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + col);
+    const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + col);
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+#pragma unroll 4
     for (int r = r0 + rlane; r < r1; r += rl) {
       const long idx = (long)r * C + col;
       f32x4 g = *reinterpret_cast<const f32x4*>(ga + idx);
-      f32x4 ao = *reinterpret_cast<const f32x4*>(a_out + idx);
       f32x4 yv = *reinterpret_cast<const f32x4*>(y + idx);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        float gb = g[k] * act_bwd_from_out(ao[k], act);
+        const float xh = (yv[k] - mean[k]) * invstd[k];
+        float gb = g[k] * act_bwd_from_out(act_fwd(gm[k] * xh + bt[k], act), act);
         s1[k] += gb;
-        s2[k] += gb * ((yv[k] - mean[k]) * invstd[k]);
+        s2[k] += gb * xh;
       }
     }
     __syncthreads();
@@ -227,7 +232,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               const float* __restrict__ gamma, const float* __restrict__ save_mean,
                                                               const float* __restrict__ save_invstd, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int accumulate,
-                                                              float* __restrict__ coef /* [3][C] */) {
+                                                              const float* __restrict__ beta,
+                                                              float* __restrict__ coef /* [5][C]: k1,k2,k3,scale,shift */) {
   __shared__ double sm[8];
   const int tid = threadIdx.x;
   const int c = blockIdx.x;
@@ -254,24 +260,28 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     coef[c] = k1;
     coef[C + c] = k2;
     coef[2 * C + c] = k3;
+    coef[3 * C + c] = k1;                       // forward scale = gamma*invstd
+    coef[4 * C + c] = beta[c] - mean * k1;      // forward shift
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ ga, const float* __restrict__ a_out,
-                                                           const float* __restrict__ y, const float* __restrict__ coef,
-                                                           float* __restrict__ gy, long n4, int C, int act) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ ga, const float* __restrict__ y,
+                                                           const float* __restrict__ coef, float* __restrict__ gy, long n4,
+                                                           int C, int act) {
   const long stride = (long)gridDim.x * 256;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     const int c = (int)((i * 4) % C);
     f32x4 g = reinterpret_cast<const f32x4*>(ga)[i];
-    f32x4 ao = reinterpret_cast<const f32x4*>(a_out)[i];
     f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
     f32x4 k1 = *reinterpret_cast<const f32x4*>(coef + c);
     f32x4 k2 = *reinterpret_cast<const f32x4*>(coef + C + c);
     f32x4 k3 = *reinterpret_cast<const f32x4*>(coef + 2 * C + c);
+    f32x4 sc = *reinterpret_cast<const f32x4*>(coef + 3 * C + c);
+    f32x4 sh = *reinterpret_cast<const f32x4*>(coef + 4 * C + c);
     f32x4 o;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = k1[k] * (g[k] * act_bwd_from_out(ao[k], act)) + k2[k] * yv[k] + k3[k];
+    for (int k = 0; k < 4; ++k)
+      o[k] = k1[k] * (g[k] * act_bwd_from_out(act_fwd(yv[k] * sc[k] + sh[k], act), act)) + k2[k] * yv[k] + k3[k];
     reinterpret_cast<f32x4*>(gy)[i] = o;
   }
 }
@@ -295,7 +305,7 @@ static int stat_blocks(int R, int C, int* rows_per_block) {
 // workspace layout: [part: max(kBnMaxBlocks, conv tiles) * C * 3][scale C][shift C][spare C]
 size_t bn_workspace_floats(int C, int nparts) {
   const size_t parts = nparts > kBnMaxBlocks ? (size_t)nparts : (size_t)kBnMaxBlocks;
-  return parts * C * 3 + 3 * (size_t)C;
+  return parts * C * 3 + 5 * (size_t)C;
 }
 
 // finalize (from `nparts` partial triples already in ws) or eval coefficients, then apply + activation
@@ -341,7 +351,7 @@ int launch_bn_forward(const float* y, int R, int C, const float* gamma, const fl
                                   save_mean, save_invstd, ws, st);
 }
 
-int launch_bn_backward(const float* ga, const float* a_out, const float* y, int R, int C, const float* gamma,
+int launch_bn_backward(const float* ga, const float* beta, const float* y, int R, int C, const float* gamma,
                        const float* save_mean, const float* save_invstd, int act, float* gy, float* dgamma,
                        float* dbeta, int accumulate, float* ws, size_t ws_bytes, hipStream_t st) {
   if (!bn_shape_ok(R, C)) return kErrBadArg;
@@ -351,22 +361,22 @@ int launch_bn_backward(const float* ga, const float* a_out, const float* y, int 
   int rpb;
   const int nb = stat_blocks(R, C, &rpb);
   {
-    ProfScope ps("bn_bwd_partial_kernel", st, 0.0, 12.0 * (double)R * C);
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb), dim3(256), 0, st, ga, a_out, y, save_mean, save_invstd, part, R, C,
-                       rpb, act);
+    ProfScope ps("bn_bwd_partial_kernel", st, 0.0, 8.0 * (double)R * C);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb), dim3(256), 0, st, ga, gamma, beta, y, save_mean, save_invstd, part, R,
+                       C, rpb, act);
   }
   CTVAE_LAUNCH_CHECK();
   {
     ProfScope ps("bn_bwd_finalize_kernel", st, 0.0, 8.0 * (double)nb * C);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, part, nb, C, (float)R, gamma,
-                       save_mean, save_invstd, dgamma, dbeta, accumulate, coef);
+                       save_mean, save_invstd, dgamma, dbeta, accumulate, beta, coef);
   }
   CTVAE_LAUNCH_CHECK();
-  ProfScope ps("bn_bwd_apply_kernel", st, 0.0, 16.0 * (double)R * C);
+  ProfScope ps("bn_bwd_apply_kernel", st, 0.0, 12.0 * (double)R * C);
   const long n4 = (long)R * C / 4;
   long blocks = (n4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ga, a_out, y, coef, gy, n4, C, act);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ga, y, coef, gy, n4, C, act);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }

@@ -17,6 +17,8 @@
 // (register prefetch) and occupancy (small accumulators) hides the rest.  Epilogue fuses bias,
 // residual add, forward activation, or the multiplication by the previous layer's activation
 // derivative (backward).
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "prof.hpp"
 
@@ -33,6 +35,8 @@ struct TapGemmArgs {
   float* bn_part;  // optional [ncls*mtiles][N][3] per-tile (count, mean, M2) of the pre-activation output
   float* part;     // split-K partial sums [splitk][B*sH*sW][N] (raw accumulators), used when splitk > 1
   int splitk;
+  int lgQw, lgQhw; // log2(Qw), log2(Qh*Qw) when both are powers of two, else -1 (generic division)
+  int ablate;      // diagnostics only (CTVAE_ABLATE): 1 skip global loads, 2 skip MFMAs, 4 skip LDS stores
   int act;
   int mask_act;
   int Mc;      // B*Qh*Qw
@@ -44,12 +48,14 @@ struct TapGemmArgs {
 constexpr int KC = 32;
 constexpr int LDK = KC + 4;  // padded K-contiguous LDS row (floats)
 
-template <int WM, int WN, int TM, int TN, bool WT, bool AVEC, bool BVEC>
+template <int WM, int WN, int TM, int TN, bool WT, bool AVEC, bool BVEC, bool DB>
 __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   static_assert(WM * WN == 4, "4 waves per workgroup");
-  __shared__ __attribute__((aligned(16))) float sA[BM * LDK];
-  __shared__ __attribute__((aligned(16))) float sB[WT ? BN * LDK : KC * BN];
+  constexpr int SA = BM * LDK, SB = WT ? BN * LDK : KC * BN;
+  constexpr int NBUF = DB ? 2 : 1;  // DB: double-buffered K chunks (small grids, 1-2 workgroups per CU); else occupancy hides latency
+  __shared__ __attribute__((aligned(16))) float sAbuf[NBUF * SA];
+  __shared__ __attribute__((aligned(16))) float sBbuf[NBUF * SB];
   __shared__ int sRowPix[BM];
   __shared__ int sRowYX[BM];
   __shared__ int sOut[BM];
@@ -72,7 +78,14 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
     int m = m0 + r;
     if (m < a.Mc) {
       int b, qy, qx;
-      decode_m(g, m, b, qy, qx);
+      if (a.lgQw >= 0) {          // power-of-two grids (every layer of the three models): shifts instead of divisions
+        b = m >> a.lgQhw;
+        const int rr = m & ((1 << a.lgQhw) - 1);
+        qy = rr >> a.lgQw;
+        qx = rr & ((1 << a.lgQw) - 1);
+      } else {
+        decode_m(g, m, b, qy, qx);
+      }
       sRowPix[r] = (b * g.gH + qy * g.is) * g.gW + qx * g.is;  // may lie outside the image; range-checked per tap
       sRowYX[r] = ((qy * g.is) << 16) | (qx * g.is);
       sOut[r] = scatter_pix(g, cls, b, qy, qx);
@@ -107,7 +120,32 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
   f32x4 rb[BVEC ? B_V : 1];
   float rbs[BVEC ? 1 : B_S];
 
+  // vector path: per-row element offset and per-row validity masks are fixed for the tile, so a chunk's address
+  // is one add and its bounds check two bit tests (all loads are issued unconditionally).  Tap offsets lie in
+  // [-3, 4] (k <= 4): bit (d+3) of the y / x byte says whether row r may read at dy = d / dx = d.
+  int a_off[AVEC ? A_V : 1];
+  unsigned a_ok[AVEC ? A_V : 1];
+  if constexpr (AVEC) {
+#pragma unroll
+    for (int j = 0; j < A_V; ++j) {
+      const int r = (tid >> 3) + 32 * j;
+      const int pix = sRowPix[r], yx = sRowYX[r];
+      unsigned m = 0;
+      if (pix >= 0) {
+        const int iy0 = yx >> 16, ix0 = yx & 0xffff;
+#pragma unroll
+        for (int d = -3; d <= 4; ++d) {
+          if ((unsigned)(iy0 + d) < (unsigned)g.gH) m |= 1u << (d + 3);
+          if ((unsigned)(ix0 + d) < (unsigned)g.gW) m |= 1u << (d + 11);
+        }
+      }
+      a_ok[j] = m;
+      a_off[j] = pix * gC + 4 * (tid & 7);
+    }
+  }
+
   auto load_chunk = [&](int c) {
+    if (a.ablate & 1) return;
     // tap for this chunk (vector path: chunk lies inside one tap)
     int t = 0, ci0 = 0;
     Tap tp{0, 0, 0};
@@ -119,18 +157,13 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
     }
     // ---- A ----
     if constexpr (AVEC) {
-      const int kq = tid & 7;
+      const int tapoff = (tp.dy * g.gW + tp.dx) * gC + ci0;   // wave-uniform
 #pragma unroll
       for (int j = 0; j < A_V; ++j) {
-        int r = (tid >> 3) + 32 * j;
-        int pix = sRowPix[r], yx = sRowYX[r];
-        int iy = (yx >> 16) + tp.dy, ix = (yx & 0xffff) + tp.dx;
-        bool ok = (pix >= 0) && ((unsigned)iy < (unsigned)g.gH) && ((unsigned)ix < (unsigned)g.gW);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) {
-          long off = (long)(pix + tp.dy * g.gW + tp.dx) * gC + ci0 + 4 * kq;
-          v = *reinterpret_cast<const f32x4*>(a.G + off);
-        }
+        const bool ok = ((a_ok[j] >> (tp.dy + 3)) & (a_ok[j] >> (tp.dx + 11)) & 1u) != 0;
+        const unsigned off = ok ? (unsigned)(a_off[j] + tapoff) : 0u;
+        f32x4 v = *reinterpret_cast<const f32x4*>(a.G + off);
+        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
         ra[j] = v;
       }
     } else {
@@ -157,19 +190,22 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
           int f = tid + 256 * j;
           int kr = f / (BN / 4), nq = f - kr * (BN / 4);
           int n = n0 + 4 * nq;
-          long row;
           bool ok = n < a.N;
           if constexpr (AVEC) {
-            row = (long)tp.wtap * g.wCi + ci0 + kr;
+            const unsigned wbase = (unsigned)((tp.wtap * g.wCi + ci0) * g.wCo);   // wave-uniform
+            const unsigned off = ok ? wbase + (unsigned)(kr * g.wCo + n) : 0u;
+            f32x4 v = *reinterpret_cast<const f32x4*>(a.W + off);
+            if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            rb[j] = v;
           } else {
             int k = c * KC + kr;
             int wt = sTab[(k & 63) * 4 + 3];
             ok = ok && (k < Ktot);
-            row = (long)wt * g.wCi + sTab[(k & 63) * 4 + 2];
+            long row = (long)wt * g.wCi + sTab[(k & 63) * 4 + 2];
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4*>(a.W + row * g.wCo + n);
+            rb[j] = v;
           }
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (ok) v = *reinterpret_cast<const f32x4*>(a.W + row * g.wCo + n);
-          rb[j] = v;
         }
       } else {
 #pragma unroll
@@ -198,8 +234,11 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
         for (int j = 0; j < B_V; ++j) {
           int nr = (tid >> 3) + 32 * j;
           int n = n0 + nr;
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (n < a.N) v = *reinterpret_cast<const f32x4*>(a.W + ((long)tp.wtap * g.wCi + n) * g.wCo + ci0 + 4 * kq);
+          const bool ok = n < a.N;
+          const unsigned wbase = (unsigned)(tp.wtap * g.wCi * g.wCo + ci0);      // wave-uniform
+          const unsigned off = ok ? wbase + (unsigned)(n * g.wCo + 4 * kq) : 0u;
+          f32x4 v = *reinterpret_cast<const f32x4*>(a.W + off);
+          if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
           rb[j] = v;
         }
       } else {
@@ -217,7 +256,10 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
     }
   };
 
-  auto store_chunk = [&]() {
+  auto store_chunk = [&](int buf) {
+    if (a.ablate & 4) return;
+    float* sA = sAbuf + buf * SA;
+    float* sB = sBbuf + buf * SB;
     if constexpr (AVEC) {
       const int kq = tid & 7;
 #pragma unroll
@@ -265,6 +307,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
 
   const int li = lane & 31, lh = lane >> 5;
 
+  if (a.ablate & 32) { if (a_ok[0] == 0x12345u && a_off[0] == 77) a.S[tid] = 1.f; return; }
   // split-K: this workgroup owns chunks [c0, c1) of the class's K range
   int c0 = 0, c1 = nch;
   if (a.splitk > 1) {
@@ -274,45 +317,71 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
   }
   if (c0 < c1) {
     load_chunk(c0);
-    store_chunk();
+    store_chunk(0);
   }
   __syncthreads();
   for (int c = c0; c < c1; ++c) {
+    const int cur = DB ? ((c - c0) & 1) : 0;
+    const float* sA = sAbuf + cur * SA;
+    const float* sB = sBbuf + cur * SB;
     if (c + 1 < c1) load_chunk(c + 1);
-#pragma unroll
-    for (int kg = 0; kg < 4; ++kg) {
-      f32x4 af[TM];
-      float bf[TN][4];
+    // fragments of k-group kg+1 are read from LDS before the MFMAs of k-group kg are issued (register double
+    // buffering), so the LDS latency hides under the 64-cycle MFMAs instead of stalling in front of them
+    f32x4 af[2][TM];
+    float bf[2][TN][4];
+    auto read_frags = [&](int kg, int slot) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        af[i] = *reinterpret_cast<const f32x4*>(&sA[((wm * TM + i) * 32 + li) * LDK + kg * 8 + 4 * lh]);
+        af[slot][i] = *reinterpret_cast<const f32x4*>(&sA[((wm * TM + i) * 32 + li) * LDK + kg * 8 + 4 * lh]);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if constexpr (WT) {
           f32x4 t4 = *reinterpret_cast<const f32x4*>(&sB[((wn * TN + j) * 32 + li) * LDK + kg * 8 + 4 * lh]);
-          bf[j][0] = t4[0]; bf[j][1] = t4[1]; bf[j][2] = t4[2]; bf[j][3] = t4[3];
+          bf[slot][j][0] = t4[0]; bf[slot][j][1] = t4[1]; bf[slot][j][2] = t4[2]; bf[slot][j][3] = t4[3];
         } else {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) bf[j][s] = sB[(kg * 8 + 4 * lh + s) * BN + (wn * TN + j) * 32 + li];
+          for (int s = 0; s < 4; ++s) bf[slot][j][s] = sB[(kg * 8 + 4 * lh + s) * BN + (wn * TN + j) * 32 + li];
         }
       }
+    };
+    read_frags(0, 0);
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+    for (int kg = 0; kg < 4; ++kg) {
+      if (kg + 1 < 4) read_frags(kg + 1, (kg + 1) & 1);
+      if (a.ablate & 2) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+            acc[i][j][0] += af[kg & 1][i][0] * bf[kg & 1][j][0] + af[kg & 1][i][1] * bf[kg & 1][j][1] +
+                            af[kg & 1][i][2] * bf[kg & 1][j][2] + af[kg & 1][i][3] * bf[kg & 1][j][3];
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kg & 1][i][s], bf[kg & 1][j][s], acc[i][j], 0, 0, 0);
+      }
     }
-    __syncthreads();
-    if (c + 1 < c1) {
-      store_chunk();
+    if constexpr (DB) {
+      // the other buffer was last read in iteration c-1, which every wave left through the barrier below
+      if (c + 1 < c1) store_chunk(cur ^ 1);
       __syncthreads();
+    } else {
+      __syncthreads();
+      if (c + 1 < c1) {
+        store_chunk(0);
+        __syncthreads();
+      }
     }
   }
 
   // ---- epilogue ------------------------------------------------------------------------------
   const int N = a.N;
+  if (a.ablate & 8) { if (acc[0][0][0] == 123.456f) a.S[tid] = 1.f; return; }
+  if (a.ablate & 16) { a.S[(long)blockIdx.x * 256 + tid] = acc[0][0][0] + acc[TM - 1][TN - 1][15]; return; }
   if (a.splitk > 1) {  // raw partial sums; bias / activation / BN statistics happen in splitk_finish_kernel
     float* dst = a.part + (long)blockIdx.z * ((long)g.B * g.sH * g.sW) * N;
 #pragma unroll
@@ -334,19 +403,29 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
     const int col = n0 + (wn * TN + j) * 32 + li;
     const bool cok = col < N;
     const float bv = (a.bias != nullptr && cok) ? a.bias[col] : 0.f;
+    const bool plain = (a.add == nullptr) && (a.mask == nullptr);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (wm * TM + i) * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
-        const int sp = sOut[row];
-        if (sp >= 0 && cok) {
-          const long idx = (long)sp * N + col;
-          float v = acc[i][j][r] + bv;
-          if (a.add != nullptr) v += a.add[idx];
-          v = act_fwd(v, a.act);
-          if (a.mask != nullptr) v *= act_bwd_from_out(a.mask[idx], a.mask_act);
-          a.S[idx] = v;
+      for (int q4 = 0; q4 < 4; ++q4) {
+        // rows 8*q4 + 4*lh + {0,1,2,3} of this 32-row tile: their scatter indices are 4 consecutive ints in LDS
+        const int row0 = (wm * TM + i) * 32 + 8 * q4 + 4 * lh;
+        const int sp4[4] = {sOut[row0], sOut[row0 + 1], sOut[row0 + 2], sOut[row0 + 3]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int sp = sp4[q];
+          if (sp >= 0 && cok) {
+            const unsigned idx = (unsigned)sp * (unsigned)N + (unsigned)col;
+            float v = acc[i][j][4 * q4 + q] + bv;
+            if (plain) {
+              v = act_fwd(v, a.act);
+            } else {
+              if (a.add != nullptr) v += a.add[idx];
+              v = act_fwd(v, a.act);
+              if (a.mask != nullptr) v *= act_bwd_from_out(a.mask[idx], a.mask_act);
+            }
+            a.S[idx] = v;
+          }
         }
       }
     }
@@ -377,7 +456,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
         mean = mean + d * (ocnt / nt);
       }
       if (lh == 0) {  // sA is free after the main loop (last iteration ended with a barrier)
-        float* st = &sA[(wm * BN + (wn * TN + j) * 32 + li) * 3];
+        float* st = &sAbuf[(wm * BN + (wn * TN + j) * 32 + li) * 3];
         st[0] = nt; st[1] = mean; st[2] = m2;
       }
     }
@@ -388,7 +467,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
       float n = 0.f, mean = 0.f, m2 = 0.f;
 #pragma unroll
       for (int w = 0; w < WM; ++w) {
-        const float nb = sA[(w * BN + tid) * 3], mb = sA[(w * BN + tid) * 3 + 1], qb = sA[(w * BN + tid) * 3 + 2];
+        const float nb = sAbuf[(w * BN + tid) * 3], mb = sAbuf[(w * BN + tid) * 3 + 1], qb = sAbuf[(w * BN + tid) * 3 + 2];
         if (nb > 0.f) {
           const float nt = n + nb, d = mb - mean;
           mean += d * (nb / nt);
@@ -431,15 +510,15 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
 
 // ---- host side --------------------------------------------------------------------------------
 template <int WM, int WN, int TM, int TN, bool GENERIC>
-static int launch_cfg(const TapGemmArgs& a, bool wt, bool avec, bool bvec, hipStream_t st) {
+static int launch_cfg(const TapGemmArgs& a, bool wt, bool avec, bool bvec, bool db, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   TapGemmArgs args = a;
   args.mtiles = ceil_div(a.Mc, BM);
   args.ntiles = ceil_div(a.N, BN);
   dim3 grid(args.mtiles * args.ntiles, a.g.ncls, a.splitk > 1 ? a.splitk : 1), block(256);
   char name[160];
-  snprintf(name, sizeof name, "tapgemm_kernel<%d,%d,%d,%d,%s,%s,%s>", WM, WN, TM, TN, wt ? "true" : "false",
-           avec ? "true" : "false", bvec ? "true" : "false");
+  snprintf(name, sizeof name, "tapgemm_kernel<%d,%d,%d,%d,%s,%s,%s,%s>", WM, WN, TM, TN, wt ? "true" : "false",
+           avec ? "true" : "false", bvec ? "true" : "false", (db && avec && bvec) ? "true" : "false");
   double macs = 0;
   for (int c = 0; c < a.g.ncls; ++c) macs += (double)a.Mc * a.N * a.g.ntaps[c] * a.g.gC;
   if (prof_detailed()) {
@@ -449,9 +528,13 @@ static int launch_cfg(const TapGemmArgs& a, bool wt, bool avec, bool bvec, hipSt
   }
   const double bytes = 4.0 * ((double)a.g.B * a.g.gH * a.g.gW * a.g.gC + (double)a.g.B * a.g.sH * a.g.sW * a.g.sC);
   ProfScope ps(name, st, 2.0 * macs, bytes);
-#define CTVAE_TG(WT_, AV_, BV_) \
-  hipLaunchKernelGGL((tapgemm_kernel<WM, WN, TM, TN, WT_, AV_, BV_>), grid, block, 0, st, args)
-  if constexpr (GENERIC) {  // the masked/scalar variants exist for one tile shape only
+#define CTVAE_TG(WT_, AV_, BV_)                                                                                  \
+  do {                                                                                                           \
+    if (db) hipLaunchKernelGGL((tapgemm_kernel<WM, WN, TM, TN, WT_, AV_, BV_, true>), grid, block, 0, st, args);  \
+    else hipLaunchKernelGGL((tapgemm_kernel<WM, WN, TM, TN, WT_, AV_, BV_, false>), grid, block, 0, st, args);    \
+  } while (0)
+  if constexpr (GENERIC) {  // the masked/scalar variants exist for one tile shape only (single-buffered)
+    if (!avec || !bvec) db = false;
     if (!wt) {
       if (avec && bvec) CTVAE_TG(false, true, true);
       else if (!avec && bvec) CTVAE_TG(false, false, true);
@@ -492,6 +575,13 @@ void tapgemm_plan(const ConvGeom& g, size_t ws_floats, TapGemmPlan& p) {
     const long tiles128 = (long)ceil_div(Mc, 128) * ceil_div(N, 64) * g.ncls;
     p.BM = tiles128 >= 512 ? 128 : 64;
     p.BN = 64;
+    // EXPERIMENT (CTVAE_BIGTILE): 4 accumulator tiles per wave
+    { const char* e = getenv("CTVAE_BIGTILE"); const int big = e ? atoi(e) : 0;
+      if (big < 0) { p.BM = 64; p.BN = 64; }
+      else if (big) {
+        if (N % 128 == 0 && (long)ceil_div(Mc, 128) * (N / 128) * g.ncls >= big) { p.BM = 128; p.BN = 128; }
+        else if (N == 64 && (long)ceil_div(Mc, 256) * g.ncls >= big) { p.BM = 256; p.BN = 64; }
+      } }
   }
   p.mtiles = ceil_div(Mc, p.BM);
   p.ntiles = ceil_div(N, p.BN);
@@ -523,6 +613,18 @@ int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const floa
   a.Mc = g.B * g.Qh * g.Qw;
   a.N = g.sC;
   if (a.Mc <= 0 || a.N <= 0) return kErrBadArg;
+  if ((long)g.B * g.sH * g.sW * g.sC >= (1L << 31) || (long)g.B * g.gH * g.gW * g.gC >= (1L << 31)) return kErrBadArg;
+  for (int c = 0; c < g.ncls; ++c)
+    for (int t = 0; t < g.ntaps[c]; ++t) {
+      const Tap& tp = g.taps[c][t];
+      if (tp.dy < -3 || tp.dy > 4 || tp.dx < -3 || tp.dx > 4) return kErrBadArg;
+    }
+  {
+    auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+    const int lw = lg2(g.Qw), lh2 = lg2(g.Qh);
+    a.lgQw = (lw >= 0 && lh2 >= 0) ? lw : -1;
+    a.lgQhw = (lw >= 0 && lh2 >= 0) ? lw + lh2 : -1;
+  }
   const bool wt = g.wT != 0;
   const bool avec = (g.gC % KC) == 0;
   const bool bvec = wt ? avec : ((a.N % 4) == 0);
@@ -536,11 +638,16 @@ int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const floa
   if (plan.thin) return launch_thin_forward(g, G, W, bias, add, mask, mask_act, S, act, bn_part, st);
   a.splitk = plan.splitk;
   a.part = ws;
+  { const char* e = getenv("CTVAE_ABLATE"); a.ablate = e ? atoi(e) : 0; }
   if (plan.splitk > 1 && bn_part != nullptr) return kErrBadArg;  // caller must take BN statistics from S instead
   int rc;
-  if (plan.BN == 32) rc = launch_cfg<4, 1, 1, 1, true>(a, wt, avec, bvec, st);
-  else if (plan.BM == 128) rc = launch_cfg<2, 2, 2, 1, false>(a, wt, avec, bvec, st);
-  else rc = launch_cfg<2, 2, 1, 1, false>(a, wt, avec, bvec, st);
+  // few workgroups per CU -> latency must be hidden inside the workgroup (double-buffered LDS); many -> by occupancy
+  const bool db = (long)plan.mtiles * plan.ntiles * g.ncls * plan.splitk <= 1024;
+  if (plan.BN == 32) rc = launch_cfg<4, 1, 1, 1, true>(a, wt, avec, bvec, db, st);
+  else if (plan.BN == 128) rc = launch_cfg<2, 2, 2, 2, false>(a, wt, avec, bvec, db, st);
+  else if (plan.BM == 256) rc = launch_cfg<4, 1, 2, 2, false>(a, wt, avec, bvec, db, st);
+  else if (plan.BM == 128) rc = launch_cfg<2, 2, 2, 1, false>(a, wt, avec, bvec, db, st);
+  else rc = launch_cfg<2, 2, 1, 1, false>(a, wt, avec, bvec, db, st);
   if (rc || plan.splitk <= 1) return rc;
   const long n = (long)g.B * g.sH * g.sW * a.N, n4 = n / 4;
   long blocks = (n4 + 255) / 256;

@@ -31,8 +31,10 @@ template <int WK, int WN, bool XVEC, bool DVEC>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   constexpr int KT = WK * 32, NT = WN * 32;
   static_assert(WK * WN == 4, "4 waves");
-  __shared__ __attribute__((aligned(16))) float sX[MC * KT];
-  __shared__ __attribute__((aligned(16))) float sD[MC * NT];
+  // single-buffered on purpose: the split-M grid is sized for ~4 workgroups per CU and occupancy hides the
+  // load latency better than a second LDS buffer (which would halve the resident workgroups)
+  __shared__ __attribute__((aligned(16))) float sXbuf[MC * KT];
+  __shared__ __attribute__((aligned(16))) float sDbuf[MC * NT];
   __shared__ int sRowPix[2][MC];
   __shared__ int sRowYX[2][MC];
   __shared__ int sRowOut[2][MC];
@@ -150,6 +152,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   };
 
   auto store_chunk = [&]() {
+    float* sX = sXbuf;
+    float* sD = sDbuf;
     if constexpr (XVEC) {
 #pragma unroll
       for (int j = 0; j < X_V; ++j) {
@@ -187,6 +191,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     store_chunk();
     __syncthreads();
     for (int c = 0; c < nch; ++c) {
+      const float* sX = sXbuf;
+      const float* sD = sDbuf;
       if (c + 1 < nch) load_chunk((c + 1) & 1);
       if (c + 2 < nch) rowinfo(c + 2, c & 1);
 #pragma unroll

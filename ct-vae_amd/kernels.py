@@ -239,7 +239,7 @@ class ConvBNAct(Function):
         if accg != accb:
             (gg if accg == 0 else gbt).zero_()
             accg = 1
-        native.call("ctvae_bn_backward", g_a.data_ptr(), a.data_ptr(), y.data_ptr(), B * H * W, C, gamma.data_ptr(),
+        native.call("ctvae_bn_backward", g_a.data_ptr(), beta.data_ptr(), y.data_ptr(), B * H * W, C, gamma.data_ptr(),
                     save_mean.data_ptr(), save_invstd.data_ptr(), ctx.bn_act, g_y.data_ptr(), gg.data_ptr(), gbt.data_ptr(),
                     accg, ws.data_ptr(), ws.numel() * 4)
         conv_wgrad_raw(x, g_y, w, b, spec)

@@ -70,8 +70,9 @@ int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float
 int ctvae_bn_forward(const float* y, int R, int C, const float* gamma, const float* beta, float* running_mean,
                      float* running_var, float momentum, float eps, int training, int act, float* out,
                      float* save_mean, float* save_invstd, float* ws, size_t ws_bytes, void* stream);
-/* g_y from g_a (grad wrt the activated output `a_out`); dgamma/dbeta (+)= ... */
-int ctvae_bn_backward(const float* g_a, const float* a_out, const float* y, int R, int C, const float* gamma,
+/* g_y from g_a (grad wrt the activated output); the activation derivative is re-derived from the sign of
+ * gamma*invstd*(y-mean)+beta, so the activated tensor is not read; dgamma/dbeta (+)= ... */
+int ctvae_bn_backward(const float* g_a, const float* beta, const float* y, int R, int C, const float* gamma,
                       const float* save_mean, const float* save_invstd, int act, float* g_y, float* dgamma,
                       float* dbeta, int accumulate, float* ws, size_t ws_bytes, void* stream);
 
