@@ -17,43 +17,19 @@
 // (register prefetch) and occupancy (small accumulators) hides the rest.  Epilogue fuses bias,
 // residual add, forward activation, or the multiplication by the previous layer's activation
 // derivative (backward).
-#include <stdlib.h>
-
-#include "common.hpp"
 #include "prof.hpp"
+#include "tapgemm.hpp"
 
 namespace ctvae {
 
-struct TapGemmArgs {
-  ConvGeom g;
-  const float* G;
-  const float* W;
-  const float* bias;
-  const float* add;
-  const float* mask;
-  float* S;
-  float* bn_part;  // optional [ncls*mtiles][N][3] per-tile (count, mean, M2) of the pre-activation output
-  float* part;     // split-K partial sums [splitk][B*sH*sW][N] (raw accumulators), used when splitk > 1
-  int splitk;
-  int lgQw, lgQhw; // log2(Qw), log2(Qh*Qw) when both are powers of two, else -1 (generic division)
-  int ablate;      // diagnostics only (CTVAE_ABLATE): 1 skip global loads, 2 skip MFMAs, 4 skip LDS stores
-  int act;
-  int mask_act;
-  int Mc;      // B*Qh*Qw
-  int N;       // sC
-  int mtiles;  // per class
-  int ntiles;
-};
-
-constexpr int KC = 32;
-constexpr int LDK = KC + 4;  // padded K-contiguous LDS row (floats)
-
-template <int WM, int WN, int TM, int TN, bool WT, bool AVEC, bool BVEC, bool DB>
-__global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
+// Masked / scalar-staging variant (any channel count): used for the 3-channel-input side of the nets.
+template <int WM, int WN, int TM, int TN, bool WT, bool AVEC, bool BVEC>
+__global__ __launch_bounds__(256) void tapgemm_masked_kernel(const TapGemmArgs a) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int SA = BM * LDK, SB = WT ? BN * LDK : KC * BN;
-  constexpr int NBUF = DB ? 2 : 1;  // DB: double-buffered K chunks (small grids, 1-2 workgroups per CU); else occupancy hides latency
+  constexpr bool DB = false;
+  constexpr int NBUF = 1;
   __shared__ __attribute__((aligned(16))) float sAbuf[NBUF * SA];
   __shared__ __attribute__((aligned(16))) float sBbuf[NBUF * SB];
   __shared__ int sRowPix[BM];
@@ -145,7 +121,6 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
   }
 
   auto load_chunk = [&](int c) {
-    if (a.ablate & 1) return;
     // tap for this chunk (vector path: chunk lies inside one tap)
     int t = 0, ci0 = 0;
     Tap tp{0, 0, 0};
@@ -257,7 +232,6 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
   };
 
   auto store_chunk = [&](int buf) {
-    if (a.ablate & 4) return;
     float* sA = sAbuf + buf * SA;
     float* sB = sBbuf + buf * SB;
     if constexpr (AVEC) {
@@ -307,7 +281,6 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
 
   const int li = lane & 31, lh = lane >> 5;
 
-  if (a.ablate & 32) { if (a_ok[0] == 0x12345u && a_off[0] == 77) a.S[tid] = 1.f; return; }
   // split-K: this workgroup owns chunks [c0, c1) of the class's K range
   int c0 = 0, c1 = nch;
   if (a.splitk > 1) {
@@ -348,14 +321,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) {
       if (kg + 1 < 4) read_frags(kg + 1, (kg + 1) & 1);
-      if (a.ablate & 2) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j][0] += af[kg & 1][i][0] * bf[kg & 1][j][0] + af[kg & 1][i][1] * bf[kg & 1][j][1] +
-                            af[kg & 1][i][2] * bf[kg & 1][j][2] + af[kg & 1][i][3] * bf[kg & 1][j][3];
-      } else {
+      {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -380,8 +346,6 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
 
   // ---- epilogue ------------------------------------------------------------------------------
   const int N = a.N;
-  if (a.ablate & 8) { if (acc[0][0][0] == 123.456f) a.S[tid] = 1.f; return; }
-  if (a.ablate & 16) { a.S[(long)blockIdx.x * 256 + tid] = acc[0][0][0] + acc[TM - 1][TN - 1][15]; return; }
   if (a.splitk > 1) {  // raw partial sums; bias / activation / BN statistics happen in splitk_finish_kernel
     float* dst = a.part + (long)blockIdx.z * ((long)g.B * g.sH * g.sW) * N;
 #pragma unroll
@@ -509,45 +473,33 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
 }
 
 // ---- host side --------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN, bool GENERIC>
-static int launch_cfg(const TapGemmArgs& a, bool wt, bool avec, bool bvec, bool db, hipStream_t st) {
-  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+// masked variants: one tile shape (128 x 32), single-buffered
+static int launch_masked(const TapGemmArgs& a, bool wt, bool avec, bool bvec, hipStream_t st) {
+  constexpr int BM = 128, BN = 32;
   TapGemmArgs args = a;
   args.mtiles = ceil_div(a.Mc, BM);
   args.ntiles = ceil_div(a.N, BN);
-  dim3 grid(args.mtiles * args.ntiles, a.g.ncls, a.splitk > 1 ? a.splitk : 1), block(256);
+  dim3 grid(args.mtiles * args.ntiles, a.g.ncls, 1), block(256);
   char name[160];
-  snprintf(name, sizeof name, "tapgemm_kernel<%d,%d,%d,%d,%s,%s,%s,%s>", WM, WN, TM, TN, wt ? "true" : "false",
-           avec ? "true" : "false", bvec ? "true" : "false", (db && avec && bvec) ? "true" : "false");
+  snprintf(name, sizeof name, "tapgemm_masked_kernel<%s,%s,%s>", wt ? "true" : "false", avec ? "true" : "false",
+           bvec ? "true" : "false");
   double macs = 0;
   for (int c = 0; c < a.g.ncls; ++c) macs += (double)a.Mc * a.N * a.g.ntaps[c] * a.g.gC;
   if (prof_detailed()) {
     size_t l = strlen(name);
-    snprintf(name + l, sizeof name - l, " M=%dx%d N=%d C=%d taps=%d sk=%d", a.g.ncls, a.Mc, a.N, a.g.gC, a.g.ntaps[a.g.ncls - 1],
-             a.splitk);
+    snprintf(name + l, sizeof name - l, " M=%dx%d N=%d C=%d taps=%d", a.g.ncls, a.Mc, a.N, a.g.gC, a.g.ntaps[a.g.ncls - 1]);
   }
   const double bytes = 4.0 * ((double)a.g.B * a.g.gH * a.g.gW * a.g.gC + (double)a.g.B * a.g.sH * a.g.sW * a.g.sC);
   ProfScope ps(name, st, 2.0 * macs, bytes);
-#define CTVAE_TG(WT_, AV_, BV_)                                                                                  \
-  do {                                                                                                           \
-    if (db) hipLaunchKernelGGL((tapgemm_kernel<WM, WN, TM, TN, WT_, AV_, BV_, true>), grid, block, 0, st, args);  \
-    else hipLaunchKernelGGL((tapgemm_kernel<WM, WN, TM, TN, WT_, AV_, BV_, false>), grid, block, 0, st, args);    \
-  } while (0)
-  if constexpr (GENERIC) {  // the masked/scalar variants exist for one tile shape only (single-buffered)
-    if (!avec || !bvec) db = false;
-    if (!wt) {
-      if (avec && bvec) CTVAE_TG(false, true, true);
-      else if (!avec && bvec) CTVAE_TG(false, false, true);
-      else if (avec && !bvec) CTVAE_TG(false, true, false);
-      else CTVAE_TG(false, false, false);
-    } else {
-      if (avec) CTVAE_TG(true, true, true);
-      else CTVAE_TG(true, false, false);
-    }
+#define CTVAE_TG(WT_, AV_, BV_) hipLaunchKernelGGL((tapgemm_masked_kernel<4, 1, 1, 1, WT_, AV_, BV_>), grid, block, 0, st, args)
+  if (!wt) {
+    if (avec && bvec) CTVAE_TG(false, true, true);
+    else if (!avec && bvec) CTVAE_TG(false, false, true);
+    else if (avec && !bvec) CTVAE_TG(false, true, false);
+    else CTVAE_TG(false, false, false);
   } else {
-    if (!avec || !bvec) return kErrBadArg;
-    if (!wt) CTVAE_TG(false, true, true);
-    else CTVAE_TG(true, true, true);
+    if (avec) CTVAE_TG(true, true, true);
+    else CTVAE_TG(true, false, false);
   }
 #undef CTVAE_TG
   CTVAE_LAUNCH_CHECK();
@@ -575,13 +527,6 @@ void tapgemm_plan(const ConvGeom& g, size_t ws_floats, TapGemmPlan& p) {
     const long tiles128 = (long)ceil_div(Mc, 128) * ceil_div(N, 64) * g.ncls;
     p.BM = tiles128 >= 512 ? 128 : 64;
     p.BN = 64;
-    // EXPERIMENT (CTVAE_BIGTILE): 4 accumulator tiles per wave
-    { const char* e = getenv("CTVAE_BIGTILE"); const int big = e ? atoi(e) : 0;
-      if (big < 0) { p.BM = 64; p.BN = 64; }
-      else if (big) {
-        if (N % 128 == 0 && (long)ceil_div(Mc, 128) * (N / 128) * g.ncls >= big) { p.BM = 128; p.BN = 128; }
-        else if (N == 64 && (long)ceil_div(Mc, 256) * g.ncls >= big) { p.BM = 256; p.BN = 64; }
-      } }
   }
   p.mtiles = ceil_div(Mc, p.BM);
   p.ntiles = ceil_div(N, p.BN);
@@ -613,7 +558,8 @@ int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const floa
   a.Mc = g.B * g.Qh * g.Qw;
   a.N = g.sC;
   if (a.Mc <= 0 || a.N <= 0) return kErrBadArg;
-  if ((long)g.B * g.sH * g.sW * g.sC >= (1L << 31) || (long)g.B * g.gH * g.gW * g.gC >= (1L << 31)) return kErrBadArg;
+  // buffer resources take 31-bit byte counts: every tensor bound here must stay below 2 GiB
+  if ((long)g.B * g.sH * g.sW * g.sC >= (1L << 29) || (long)g.B * g.gH * g.gW * g.gC >= (1L << 29)) return kErrBadArg;
   for (int c = 0; c < g.ncls; ++c)
     for (int t = 0; t < g.ntaps[c]; ++t) {
       const Tap& tp = g.taps[c][t];
@@ -638,16 +584,16 @@ int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const floa
   if (plan.thin) return launch_thin_forward(g, G, W, bias, add, mask, mask_act, S, act, bn_part, st);
   a.splitk = plan.splitk;
   a.part = ws;
-  { const char* e = getenv("CTVAE_ABLATE"); a.ablate = e ? atoi(e) : 0; }
+
   if (plan.splitk > 1 && bn_part != nullptr) return kErrBadArg;  // caller must take BN statistics from S instead
   int rc;
-  // few workgroups per CU -> latency must be hidden inside the workgroup (double-buffered LDS); many -> by occupancy
-  const bool db = (long)plan.mtiles * plan.ntiles * g.ncls * plan.splitk <= 1024;
-  if (plan.BN == 32) rc = launch_cfg<4, 1, 1, 1, true>(a, wt, avec, bvec, db, st);
-  else if (plan.BN == 128) rc = launch_cfg<2, 2, 2, 2, false>(a, wt, avec, bvec, db, st);
-  else if (plan.BM == 256) rc = launch_cfg<4, 1, 2, 2, false>(a, wt, avec, bvec, db, st);
-  else if (plan.BM == 128) rc = launch_cfg<2, 2, 2, 1, false>(a, wt, avec, bvec, db, st);
-  else rc = launch_cfg<2, 2, 1, 1, false>(a, wt, avec, bvec, db, st);
+  if (!avec || !bvec) {
+    rc = launch_masked(a, wt, avec, bvec, st);
+  } else {
+    // few workgroups per CU -> latency must be hidden inside the workgroup (double-buffered LDS); many -> by occupancy
+    const bool db = (long)plan.mtiles * plan.ntiles * g.ncls * plan.splitk <= 1024;
+    rc = launch_tapgemm_fast(a, plan, db, st);
+  }
   if (rc || plan.splitk <= 1) return rc;
   const long n = (long)g.B * g.sH * g.sW * a.N, n4 = n / 4;
   long blocks = (n4 + 255) / 256;

@@ -1,0 +1,45 @@
+// Shared declarations of the tap-GEMM kernels (tapgemm.hip: masked small-channel variant + dispatch;
+// tapgemm_fast.hip: the vector/MFMA main kernel).
+#pragma once
+#include "common.hpp"
+
+namespace ctvae {
+
+struct TapGemmArgs {
+  ConvGeom g;
+  const float* G;
+  const float* W;
+  const float* bias;
+  const float* add;
+  const float* mask;
+  float* S;
+  float* bn_part;  // optional [ncls*mtiles][N][3] per-tile (count, mean, M2) of the pre-activation output
+  float* part;     // split-K partial sums [splitk][B*sH*sW][N] (raw accumulators), used when splitk > 1
+  int splitk;
+  int lgQw, lgQhw; // log2(Qw), log2(Qh*Qw) when both are powers of two, else -1 (generic division)
+  int act;
+  int mask_act;
+  int Mc;      // B*Qh*Qw
+  int N;       // sC
+  int mtiles;  // per class
+  int ntiles;
+};
+
+constexpr int KC = 32;
+constexpr int LDK = KC + 4;  // padded K-contiguous LDS row (floats)
+
+// m -> (b, qy, qx), by shifts when the class grid is a power of two
+__device__ __forceinline__ void decode_m_fast(const TapGemmArgs& a, int m, int& b, int& qy, int& qx) {
+  if (a.lgQw >= 0) {
+    b = m >> a.lgQhw;
+    const int rr = m & ((1 << a.lgQhw) - 1);
+    qy = rr >> a.lgQw;
+    qx = rr & ((1 << a.lgQw) - 1);
+  } else {
+    decode_m(a.g, m, b, qy, qx);
+  }
+}
+
+int launch_tapgemm_fast(const TapGemmArgs& a, const TapGemmPlan& plan, bool db, hipStream_t st);
+
+}  // namespace ctvae

@@ -1,0 +1,389 @@
+// Tap-GEMM main kernel (vector path: gathered channels % 32 == 0, N % 4 == 0).  See tapgemm.hip for the op
+// list and geom.hpp for the geometry.
+//
+// Design rule measured on gfx950 (tools/mfma_probe.hip): v_mfma_f32_32x32x2_f32 runs on the SIMD's vector
+// datapath, so VALU instructions of ANY wave on that SIMD do not overlap with it -- SIMD time = MFMA time +
+// VALU time.  Hence everything around the 64-cycle MFMAs is written to issue as few VALU instructions as
+// possible:
+//   * global loads go through buffer resources: 32-bit byte offsets, the wave-uniform part of an address rides
+//     in the scalar offset, and an out-of-range offset returns 0 -> zero padding / tile edges cost one select;
+//   * per-row offsets and the separable y/x validity masks of the im2col gather are computed once per tile;
+//   * the epilogue uses 32-bit indices, drops stores by sending them out of range (no branches), and takes
+//     per-row scatter indices from arithmetic (dense scatter) or one 16-byte LDS read per 4 rows (parity classes);
+//   * fragments of the next 8-deep k-group are read from LDS before the MFMAs of the current one.
+// Workgroup = 4 waves, tile BM x BN = (WM*TM*32) x (WN*TN*32), K chunks of 32, optional LDS double buffering
+// for grids with <= 2 workgroups per CU (otherwise occupancy hides the global-load latency).
+#include <type_traits>
+
+#include "prof.hpp"
+#include "tapgemm.hpp"
+
+namespace ctvae {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOOB = 0x80000000u;  // byte offset beyond any buffer we bind (tensors are < 2 GiB)
+
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0));
+}
+__device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned voff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+template <int WM, int WN, int TM, int TN, bool WT, bool DB>
+__global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int SA = BM * LDK, SB = WT ? BN * LDK : KC * BN;
+  constexpr int NBUF = DB ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) float sAbuf[NBUF * SA];
+  __shared__ __attribute__((aligned(16))) float sBbuf[NBUF * SB];
+  __shared__ __attribute__((aligned(16))) int sOut[BM];
+
+  const ConvGeom& g = a.g;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int cls = blockIdx.y;
+  const int mt = blockIdx.x / a.ntiles, nt = blockIdx.x - mt * a.ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int ntaps = g.ntaps[cls];
+  const int gC = g.gC, N = a.N;
+  const int nch = ntaps * gC / KC;
+  const bool dense = (g.os == 1);   // scatter index == m
+
+  const __amdgpu_buffer_rsrc_t rG = make_rsrc(a.G, (long)g.B * g.gH * g.gW * gC * 4);
+  long wtaps = 0;
+  for (int c = 0; c < g.ncls; ++c) wtaps += g.ntaps[c];
+  const __amdgpu_buffer_rsrc_t rW = make_rsrc(a.W, wtaps * g.wCi * g.wCo * 4);
+
+  // ---- per-thread constants of the tile ---------------------------------------------------------------
+  constexpr int A_V = BM / 32;  // 16-B loads per thread and chunk (gathered operand)
+  constexpr int B_V = BN / 32;  // 16-B loads per thread and chunk (weights)
+  unsigned a_off[A_V], a_ok[A_V];
+#pragma unroll
+  for (int j = 0; j < A_V; ++j) {
+    const int m = m0 + (tid >> 3) + 32 * j;
+    unsigned msk = 0;
+    int pix = 0;
+    if (m < a.Mc) {
+      int b, qy, qx;
+      decode_m_fast(a, m, b, qy, qx);
+      const int iy0 = qy * g.is, ix0 = qx * g.is;
+      pix = (b * g.gH + iy0) * g.gW + ix0;
+#pragma unroll
+      for (int d = -3; d <= 4; ++d) {  // bit (d+3): dy = d allowed; bit (d+11): dx = d allowed
+        if ((unsigned)(iy0 + d) < (unsigned)g.gH) msk |= 1u << (d + 3);
+        if ((unsigned)(ix0 + d) < (unsigned)g.gW) msk |= 1u << (d + 11);
+      }
+    }
+    a_ok[j] = msk;
+    a_off[j] = (unsigned)(pix * gC + 4 * (tid & 7)) * 4u;
+  }
+  unsigned b_off[B_V];
+#pragma unroll
+  for (int j = 0; j < B_V; ++j) {
+    if constexpr (!WT) {   // Wmat[t][c][n] = W[t][c][n]: rows k, 16 B along n
+      const int f = tid + 256 * j;
+      const int kr = f / (BN / 4), nq = f - kr * (BN / 4);
+      const int n = n0 + 4 * nq;
+      b_off[j] = n < N ? (unsigned)(kr * g.wCo + n) * 4u : kOOB;
+    } else {               // Wmat[t][c][n] = W[t][n][c]: rows n, 16 B along c
+      const int n = n0 + (tid >> 3) + 32 * j;
+      b_off[j] = n < N ? (unsigned)(n * g.wCo + 4 * (tid & 7)) * 4u : kOOB;
+    }
+  }
+  if (!dense) {
+    for (int r = tid; r < BM; r += 256) {
+      const int m = m0 + r;
+      int sp = -1;
+      if (m < a.Mc) {
+        int b, qy, qx;
+        decode_m_fast(a, m, b, qy, qx);
+        sp = scatter_pix(g, cls, b, qy, qx);
+      }
+      sOut[r] = sp;
+    }
+  }
+
+  f32x4 ra[A_V], rb[B_V];
+  auto load_chunk = [&](int c) {
+    const int k0 = c * KC;
+    const int t = k0 / gC;
+    const int ci0 = k0 - t * gC;
+    const Tap tp = g.taps[cls][t];
+    const unsigned tapoff = (unsigned)(((tp.dy * g.gW + tp.dx) * gC + ci0) * 4);   // wave-uniform, may wrap (two's complement)
+    const int sy = tp.dy + 3, sx = tp.dx + 11;
+#pragma unroll
+    for (int j = 0; j < A_V; ++j) {
+      const bool ok = ((a_ok[j] >> sy) & (a_ok[j] >> sx) & 1u) != 0;
+      ra[j] = buf_load4(rG, ok ? a_off[j] + tapoff : kOOB, 0);
+    }
+    const unsigned wsoff = WT ? (unsigned)(tp.wtap * g.wCi * g.wCo + ci0) * 4u : (unsigned)((tp.wtap * g.wCi + ci0) * g.wCo) * 4u;
+#pragma unroll
+    for (int j = 0; j < B_V; ++j) rb[j] = buf_load4(rW, b_off[j], wsoff);
+  };
+  auto store_chunk = [&](int buf) {
+    float* sA = sAbuf + buf * SA;
+    float* sB = sBbuf + buf * SB;
+#pragma unroll
+    for (int j = 0; j < A_V; ++j) *reinterpret_cast<f32x4*>(&sA[((tid >> 3) + 32 * j) * LDK + 4 * (tid & 7)]) = ra[j];
+#pragma unroll
+    for (int j = 0; j < B_V; ++j) {
+      if constexpr (!WT) {
+        const int f = tid + 256 * j;
+        const int kr = f / (BN / 4), nq = f - kr * (BN / 4);
+        *reinterpret_cast<f32x4*>(&sB[kr * BN + 4 * nq]) = rb[j];
+      } else {
+        *reinterpret_cast<f32x4*>(&sB[((tid >> 3) + 32 * j) * LDK + 4 * (tid & 7)]) = rb[j];
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // split-K: this workgroup owns chunks [c0, c1) of the class's K range
+  int c0 = 0, c1 = nch;
+  if (a.splitk > 1) {
+    const int cps = (nch + a.splitk - 1) / a.splitk;
+    c0 = blockIdx.z * cps;
+    c1 = c0 + cps < nch ? c0 + cps : nch;
+  }
+  if (c0 < c1) {
+    load_chunk(c0);
+    store_chunk(0);
+  }
+  __syncthreads();
+  for (int c = c0; c < c1; ++c) {
+    const int cur = DB ? ((c - c0) & 1) : 0;
+    const float* sA = sAbuf + cur * SA;
+    const float* sB = sBbuf + cur * SB;
+    if (c + 1 < c1) load_chunk(c + 1);
+    f32x4 af[2][TM];
+    float bf[2][TN][4];
+    auto read_frags = [&](int kg, int slot) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[slot][i] = *reinterpret_cast<const f32x4*>(&sA[((wm * TM + i) * 32 + li) * LDK + kg * 8 + 4 * lh]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (WT) {
+          const f32x4 t4 = *reinterpret_cast<const f32x4*>(&sB[((wn * TN + j) * 32 + li) * LDK + kg * 8 + 4 * lh]);
+          bf[slot][j][0] = t4[0]; bf[slot][j][1] = t4[1]; bf[slot][j][2] = t4[2]; bf[slot][j][3] = t4[3];
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) bf[slot][j][s] = sB[(kg * 8 + 4 * lh + s) * BN + (wn * TN + j) * 32 + li];
+        }
+      }
+    };
+    read_frags(0, 0);
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      if (kg + 1 < 4) read_frags(kg + 1, (kg + 1) & 1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kg & 1][i][s], bf[kg & 1][j][s], acc[i][j], 0, 0, 0);
+    }
+    if constexpr (DB) {
+      // the other buffer was last read in iteration c-1, which every wave left through the barrier below
+      if (c + 1 < c1) store_chunk(cur ^ 1);
+      __syncthreads();
+    } else {
+      __syncthreads();
+      if (c + 1 < c1) {
+        store_chunk(0);
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---- epilogue -----------------------------------------------------------------------------------------
+  const long sbytes = (long)g.B * g.sH * g.sW * N * 4;
+  if (a.splitk > 1) {  // raw partial sums; bias / activation happen in splitk_finish_kernel
+    const __amdgpu_buffer_rsrc_t rP = make_rsrc(a.part + (long)blockIdx.z * (sbytes / 4), sbytes);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + li;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int row0 = (wm * TM + i) * 32 + 8 * q4 + 4 * lh;
+          int sp4[4];
+          if (dense) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sp4[q] = (m0 + row0 + q < a.Mc) ? m0 + row0 + q : -1;
+          } else {
+            const int4 t = *reinterpret_cast<const int4*>(&sOut[row0]);
+            sp4[0] = t.x; sp4[1] = t.y; sp4[2] = t.z; sp4[3] = t.w;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            buf_store1(rP, (sp4[q] >= 0 && col < N) ? ((unsigned)sp4[q] * (unsigned)N + (unsigned)col) * 4u : kOOB,
+                       acc[i][j][4 * q4 + q]);
+        }
+    }
+    return;
+  }
+
+  const __amdgpu_buffer_rsrc_t rS = make_rsrc(a.S, sbytes);
+  const __amdgpu_buffer_rsrc_t rAdd = make_rsrc(a.add, a.add != nullptr ? sbytes : 0);
+  const __amdgpu_buffer_rsrc_t rMask = make_rsrc(a.mask, a.mask != nullptr ? sbytes : 0);
+  const bool full_m = (m0 + BM <= a.Mc);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + li;
+    const bool cok = col < N;
+    const float bv = (a.bias != nullptr && cok) ? a.bias[col] : 0.f;
+    float cnt = 0.f, s1 = 0.f;     // BN statistics of this lane's column (valid rows only)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int row0 = (wm * TM + i) * 32 + 8 * q4 + 4 * lh;
+        unsigned voff[4];
+        if (dense) {
+          const unsigned base = ((unsigned)(m0 + row0) * (unsigned)N + (unsigned)col) * 4u;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const bool ok = cok && (full_m || m0 + row0 + q < a.Mc);
+            voff[q] = ok ? base + (unsigned)(q * N) * 4u : kOOB;
+          }
+        } else {
+          const int4 t = *reinterpret_cast<const int4*>(&sOut[row0]);
+          const int sp4[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            voff[q] = (cok && sp4[q] >= 0) ? ((unsigned)sp4[q] * (unsigned)N + (unsigned)col) * 4u : kOOB;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = acc[i][j][4 * q4 + q] + bv;
+          acc[i][j][4 * q4 + q] = v;                      // kept for the variance pass
+          if (a.bn_part != nullptr && voff[q] != kOOB) { cnt += 1.f; s1 += v; }
+          if (a.add != nullptr) v += buf_load1(rAdd, voff[q]);
+          if (a.act == ACT_LRELU) v = fmaxf(v, v * kLeaky);
+          else if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
+          else if (a.act == ACT_TANH) v = tanhf(v);
+          if (a.mask != nullptr) {
+            const float mk = buf_load1(rMask, voff[q]);
+            if (a.mask_act == ACT_LRELU) v = mk > 0.f ? v : v * kLeaky;
+            else if (a.mask_act == ACT_RELU) v = mk > 0.f ? v : 0.f;
+            else if (a.mask_act == ACT_TANH) v *= 1.f - mk * mk;
+          }
+          buf_store1(rS, voff[q], v);
+        }
+      }
+    }
+    // ---- fused BatchNorm statistics of this tile (train-mode BN follows the conv: vanilla_vae.py:28-31) ----
+    if (a.bn_part != nullptr) {
+      const float mean0 = cnt > 0.f ? s1 / cnt : 0.f;
+      float m2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int row0 = (wm * TM + i) * 32 + 8 * q4 + 4 * lh;
+          bool ok4[4];
+          if (dense) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ok4[q] = cok && (full_m || m0 + row0 + q < a.Mc);
+          } else {
+            const int4 t = *reinterpret_cast<const int4*>(&sOut[row0]);
+            ok4[0] = cok && t.x >= 0; ok4[1] = cok && t.y >= 0; ok4[2] = cok && t.z >= 0; ok4[3] = cok && t.w >= 0;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float d = acc[i][j][4 * q4 + q] - mean0;
+            m2 += ok4[q] ? d * d : 0.f;
+          }
+        }
+      // merge the two lane halves (Chan et al.)
+      float mean = mean0;
+      const float ocnt = __shfl_xor(cnt, 32, 64), omean = __shfl_xor(mean, 32, 64), om2 = __shfl_xor(m2, 32, 64);
+      const float ntot = cnt + ocnt;
+      if (ntot > 0.f) {
+        const float d = omean - mean;
+        m2 = m2 + om2 + d * d * (cnt * ocnt / ntot);
+        mean = mean + d * (ocnt / ntot);
+      }
+      if (lh == 0) {  // the A buffer is free after the main loop (its last iteration ended with a barrier)
+        float* st = &sAbuf[(wm * BN + (wn * TN + j) * 32 + li) * 3];
+        st[0] = ntot; st[1] = mean; st[2] = m2;
+      }
+    }
+  }
+  if (a.bn_part != nullptr) {
+    __syncthreads();
+    if (tid < BN && n0 + tid < N) {
+      float n = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        const float nb = sAbuf[(w * BN + tid) * 3], mb = sAbuf[(w * BN + tid) * 3 + 1], qb = sAbuf[(w * BN + tid) * 3 + 2];
+        if (nb > 0.f) {
+          const float nt2 = n + nb, d = mb - mean;
+          mean += d * (nb / nt2);
+          m2 += qb + d * d * (n * nb / nt2);
+          n = nt2;
+        }
+      }
+      float* p = a.bn_part + ((long)(cls * a.mtiles + mt) * N + n0 + tid) * 3;
+      p[0] = n; p[1] = mean; p[2] = m2;
+    }
+  }
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_fast_cfg(const TapGemmArgs& a, bool db, hipStream_t st) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  TapGemmArgs args = a;
+  args.mtiles = ceil_div(a.Mc, BM);
+  args.ntiles = ceil_div(a.N, BN);
+  const bool wt = a.g.wT != 0;
+  dim3 grid(args.mtiles * args.ntiles, a.g.ncls, a.splitk > 1 ? a.splitk : 1), block(256);
+  char name[160];
+  snprintf(name, sizeof name, "tapgemm_fast_kernel<%d,%d,%d,%d,%s,%s>", WM, WN, TM, TN, wt ? "true" : "false", db ? "true" : "false");
+  double macs = 0;
+  for (int c = 0; c < a.g.ncls; ++c) macs += (double)a.Mc * a.N * a.g.ntaps[c] * a.g.gC;
+  if (prof_detailed()) {
+    size_t l = strlen(name);
+    snprintf(name + l, sizeof name - l, " M=%dx%d N=%d C=%d taps=%d sk=%d", a.g.ncls, a.Mc, a.N, a.g.gC, a.g.ntaps[a.g.ncls - 1],
+             a.splitk);
+  }
+  const double bytes = 4.0 * ((double)a.g.B * a.g.gH * a.g.gW * a.g.gC + (double)a.g.B * a.g.sH * a.g.sW * a.g.sC);
+  ProfScope ps(name, st, 2.0 * macs, bytes);
+  if (!wt) {
+    if (db) hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, false, true>), grid, block, 0, st, args);
+    else hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, false, false>), grid, block, 0, st, args);
+  } else {
+    if (db) hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, true, true>), grid, block, 0, st, args);
+    else hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, true, false>), grid, block, 0, st, args);
+  }
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_tapgemm_fast(const TapGemmArgs& a, const TapGemmPlan& plan, bool db, hipStream_t st) {
+  if (plan.BN == 32) return launch_fast_cfg<4, 1, 1, 1>(a, db, st);
+  if (plan.BM == 128) return launch_fast_cfg<2, 2, 2, 1>(a, db, st);
+  return launch_fast_cfg<2, 2, 1, 1>(a, db, st);
+}
+
+}  // namespace ctvae
