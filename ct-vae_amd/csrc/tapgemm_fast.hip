@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) 
           if (a.add != nullptr) v += buf_load1(rAdd, voff[q]);
           if (a.act == ACT_LRELU) v = fmaxf(v, v * kLeaky);
           else if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
-          else if (a.act == ACT_TANH) v = tanhf(v);
+          else if (a.act == ACT_TANH) v = act_fwd(v, ACT_TANH);
           if (a.mask != nullptr) {
             const float mk = buf_load1(rMask, voff[q]);
             if (a.mask_act == ACT_LRELU) v = mk > 0.f ? v : v * kLeaky;

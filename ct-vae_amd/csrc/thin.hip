@@ -1,12 +1,17 @@
 // Thin (3-channel output) layers: the image-side convolutions whose GEMM has N <= 4
-// (vanilla_vae.py:73 final_layer.3; mcq_vae.py:233 decoder's last ConvTranspose2d, forward and wgrad;
-// the 3-channel-INPUT side keeps the masked MFMA path: broadcasting 3 values per tap through vector loads is TA-bound).  An MFMA tile would be >=90 % padding there, so these run on the VALU with the
-// wide channel dimension on the lanes (coalesced 128/256-B rows), the weights of a lane held in registers for
-// the whole launch, and the narrow operand broadcast.  They are bandwidth/issue bound: roofline = HBM bytes.
-//
-//   narrow_out : S[m][n<NO] = sum_t sum_c      G[gpix][c] * W[t][c][n]          lanes = c/4, shuffle-reduced (NO <= 4)
-//   wgrad_narrow_n : dW[t][c][n<NO] = sum_m X[gpix][c] * dY[spix][n]           lanes = c/4
-// Geometry (taps, parity classes, weight orientation) is the same ConvGeom as the MFMA path (geom.hpp).
+// (vanilla_vae.py:73 final_layer.3; mcq_vae.py:233 the decoder's last ConvTranspose2d), forward and wgrad.
+// An MFMA tile would be >=90 % padding there, so they run on the VALU -- and since they move the largest
+// activations of the nets (32x64x64 per image) they are built around the memory system:
+//   * one workgroup = one TH x TW tile of output pixels of one image (and one output-parity class); the
+//     input patch (tile + halo) x all channels is staged ONCE into LDS with coalesced 16-B loads, so every
+//     input element leaves L2 once instead of once per tap (9x for the 3x3 conv);
+//   * lanes = (pixel slot, 4-channel group): each tap is one ds_read_b128 per lane, the weights of a lane's
+//     4 channels x taps x 3 outputs stay in registers for the whole launch;
+//   * forward: shuffle-reduce over the channel groups, bias + tanh, 12 B per pixel out;
+//   * wgrad: per-lane accumulators over all the workgroup's tiles (persistent loop), then a fixed-order merge of
+//     pixel slots / waves -> one partial slab per workgroup, reduced by the caller (deterministic);
+//   * optional on-the-fly input transform a = act(x*scale[c] + shift[c]) while staging (fused BatchNorm apply).
+// The 3-channel-INPUT side keeps the masked MFMA path: broadcasting 3 values per tap through vector loads is TA-bound.
 #include "common.hpp"
 #include "prof.hpp"
 
@@ -14,193 +19,188 @@ namespace ctvae {
 
 struct ThinArgs {
   ConvGeom g;
-  const float* G;      // gathered operand (X for wgrad)
+  const float* G;       // gathered operand (layer input X)
   const float* W;
   const float* bias;
-  const float* add;
-  const float* mask;
-  const float* dY;     // wgrad only
-  float* S;            // output (partials for wgrad)
-  float* pbias;        // wgrad: bias partials [nwg][N]
-  float* bn_part;      // narrow_in: per-workgroup (count, mean, M2) [nwg][N][3]
-  int act, mask_act;
-  int Mc, N;
-  int groups_per_cls;  // pixel groups per class
+  const float* dY;      // wgrad only
+  const float* in_scale;  // optional per-channel affine + activation applied to G while staging
+  const float* in_shift;
+  float* S;             // forward output / wgrad partial slabs
+  float* pbias;         // wgrad: bias partials [nwg][NO]
+  int in_act;
+  int act;
+  int tiles_y, tiles_x;   // tiles per image and class
+  int ntiles;             // B * tiles_y * tiles_x
+  int dmin_y, dmin_x, PH, PW;
+  unsigned inv_PW;        // ceil(65536 / PW): pp / PW == (pp * inv_PW) >> 16 for pp < 900
+  int rows_total;
 };
 
-__device__ __forceinline__ float wmat(const ConvGeom& g, const float* W, int wtap, int c, int n) {
-  return g.wT ? W[((long)wtap * g.wCi + n) * g.wCo + c] : W[((long)wtap * g.wCi + c) * g.wCo + n];
-}
+constexpr unsigned kOOBt = 0x80000000u;
 
-// ---------------------------------------------------------------------------------------------------------
-// narrow_out: LP = gC/4 lanes per pixel (each lane 4 channels), PPW = 64/LP pixels per wave step.
-template <int LP, int NO, int TMAX>
-__global__ __launch_bounds__(256) void thin_narrow_out_kernel(const ThinArgs a) {
-  constexpr int PPW = 64 / LP;
+// TH x TW tile, LP = gC/4 lanes per pixel.  LDS patch: [PH*PW][gC + 4] floats.
+template <int LP, int NO, int TMAX, int TH, int TW, bool WGRAD>
+__global__ __launch_bounds__(256) void thin_tile_kernel(const ThinArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int GC = LP * 4, LDP = GC + 4, PPW = 64 / LP, NPIX = TH * TW;
+  constexpr int ITERS = NPIX / (4 * PPW);
+  static_assert(NPIX % (4 * PPW) == 0, "tile must be a multiple of the pixels one pass covers");
+  float* sP = smem;                                  // patch
+  float* sDY = smem + a.PH * a.PW * LDP;             // wgrad: dY of the tile [NPIX][4]
   const ConvGeom& g = a.g;
   const int cls = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cq = lane % LP, slot = lane / LP;
   const int ntaps = g.ntaps[cls];
 
-  float w[TMAX][4][NO];
-  int tdy[TMAX], tdx[TMAX];
+  float w[WGRAD ? 1 : TMAX][4][NO];
+  float acc_w[WGRAD ? TMAX : 1][4][NO];
+  int tofs[TMAX];                                    // LDS float offset of tap t relative to the pixel's patch origin
 #pragma unroll
   for (int t = 0; t < TMAX; ++t) {
     const bool tk = t < ntaps;
     const Tap tp = g.taps[cls][tk ? t : 0];
-    tdy[t] = tp.dy;
-    tdx[t] = tp.dx;
+    tofs[t] = ((tp.dy - a.dmin_y) * a.PW + (tp.dx - a.dmin_x)) * LDP;
+    if constexpr (!WGRAD) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int n = 0; n < NO; ++n) w[t][j][n] = tk ? wmat(g, a.W, tp.wtap, 4 * cq + j, n) : 0.f;
-  }
-
-  const int wave_global = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
-  const int ngroups = (a.Mc + PPW - 1) / PPW;
-  for (int grp = wave_global; grp < ngroups; grp += nwaves) {
-    const int m = grp * PPW + slot;
-    float acc[NO];
+        for (int n = 0; n < NO; ++n) w[t][j][n] = tk ? a.W[((long)tp.wtap * g.wCi + 4 * cq + j) * g.wCo + n] : 0.f;
+    } else {
 #pragma unroll
-    for (int n = 0; n < NO; ++n) acc[n] = 0.f;
-    int b = 0, qy = 0, qx = 0;
-    const bool mok = m < a.Mc;
-    if (mok) {
-      decode_m(g, m, b, qy, qx);
-      const int iy0 = qy * g.is, ix0 = qx * g.is;
-      const long base = ((long)b * g.gH) * g.gW;
-      // all tap loads are issued unconditionally (clamped address, zeroed afterwards) so they overlap
-      f32x4 xv[TMAX];
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int t = 0; t < TMAX; ++t) {
-        const int iy = iy0 + tdy[t], ix = ix0 + tdx[t];
-        const bool ok = (t < ntaps) && (unsigned)iy < (unsigned)g.gH && (unsigned)ix < (unsigned)g.gW;
-        const long off = ok ? (base + (long)iy * g.gW + ix) * g.gC : 0;
-        f32x4 x = *reinterpret_cast<const f32x4*>(a.G + off + 4 * cq);
-        if (!ok) x = f32x4{0.f, 0.f, 0.f, 0.f};
-        xv[t] = x;
-      }
-#pragma unroll
-      for (int t = 0; t < TMAX; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int n = 0; n < NO; ++n) acc[n] += xv[t][j] * w[t][j][n];
-    }
-#pragma unroll
-    for (int o = LP / 2; o > 0; o >>= 1)
-#pragma unroll
-      for (int n = 0; n < NO; ++n) acc[n] += __shfl_xor(acc[n], o, 64);
-    if (mok && cq == 0) {
-      const long idx0 = (long)scatter_pix(g, cls, b, qy, qx) * NO;
-#pragma unroll
-      for (int n = 0; n < NO; ++n) {
-        float v = acc[n] + (a.bias != nullptr ? a.bias[n] : 0.f);
-        if (a.add != nullptr) v += a.add[idx0 + n];
-        v = act_fwd(v, a.act);
-        if (a.mask != nullptr) v *= act_bwd_from_out(a.mask[idx0 + n], a.mask_act);
-        a.S[idx0 + n] = v;
-      }
+        for (int n = 0; n < NO; ++n) acc_w[t][j][n] = 0.f;
     }
   }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// wgrad, narrow dY (NO <= 4 channels), wide X: lanes = channel quad of X.
-template <int LP, int NO, int TMAX>
-__global__ __launch_bounds__(256) void thin_wgrad_narrow_n_kernel(const ThinArgs a, int rows_total) {
-  constexpr int PPW = 64 / LP;
-  const ConvGeom& g = a.g;
-  const int cls = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cq = lane % LP, slot = lane / LP;
-  const int ntaps = g.ntaps[cls];
-  int tdy[TMAX], tdx[TMAX];
-#pragma unroll
-  for (int t = 0; t < TMAX; ++t) {
-    const Tap tp = g.taps[cls][t < ntaps ? t : 0];
-    tdy[t] = tp.dy;
-    tdx[t] = tp.dx;
-  }
-  float acc[TMAX][4][NO];
-#pragma unroll
-  for (int t = 0; t < TMAX; ++t)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int n = 0; n < NO; ++n) acc[t][j][n] = 0.f;
   float bsum[NO];
 #pragma unroll
   for (int n = 0; n < NO; ++n) bsum[n] = 0.f;
+  float bias_r[NO];
+#pragma unroll
+  for (int n = 0; n < NO; ++n) bias_r[n] = (!WGRAD && a.bias != nullptr) ? a.bias[n] : 0.f;
 
-  const int wave_global = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
-  const int ngroups = (a.Mc + PPW - 1) / PPW;
-  for (int grp = wave_global; grp < ngroups; grp += nwaves) {
-    const int m = grp * PPW + slot;
-    if (m < a.Mc) {
-      int b, qy, qx;
-      decode_m(g, m, b, qy, qx);
-      const float* dyp = a.dY + (long)scatter_pix(g, cls, b, qy, qx) * NO;
-      float dy[NO];
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.G), 0, (int)((long)g.B * g.gH * g.gW * GC * 4), 0x00020000);
+  const bool xform = a.in_scale != nullptr;
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int b = tile / (a.tiles_y * a.tiles_x);
+    const int tr = tile - b * (a.tiles_y * a.tiles_x);
+    const int qy0 = (tr / a.tiles_x) * TH, qx0 = (tr % a.tiles_x) * TW;
+    const int iy_lo = qy0 * g.is + a.dmin_y, ix_lo = qx0 * g.is + a.dmin_x;
+    __syncthreads();                                 // previous tile fully consumed
+    // ---- stage the input patch (and dY) ---------------------------------------------------------------
+    const int nvec = a.PH * a.PW * LP;
+    for (int e = tid; e < nvec; e += 256) {
+      const int pp = e / LP, c4 = e - pp * LP;
+      const int py = (int)(((unsigned)pp * a.inv_PW) >> 16), px = pp - py * a.PW;   // no integer division in the hot loop
+      const int iy = iy_lo + py, ix = ix_lo + px;
+      const bool ok = (unsigned)iy < (unsigned)g.gH && (unsigned)ix < (unsigned)g.gW;
+      const unsigned off = ok ? (unsigned)(((b * g.gH + iy) * g.gW + ix) * GC + 4 * c4) * 4u : kOOBt;
+      f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, (int)off, 0, 0));
+      if (xform) {
+        const f32x4 tsc = *reinterpret_cast<const f32x4*>(a.in_scale + 4 * c4);
+        const f32x4 tsh = *reinterpret_cast<const f32x4*>(a.in_shift + 4 * c4);
 #pragma unroll
-      for (int n = 0; n < NO; ++n) {
-        dy[n] = dyp[n];
-        bsum[n] += dy[n];
+        for (int k = 0; k < 4; ++k) v[k] = ok ? act_fwd(v[k] * tsc[k] + tsh[k], a.in_act) : 0.f;   // padding stays 0
       }
-      const int iy0 = qy * g.is, ix0 = qx * g.is;
-      const long base = ((long)b * g.gH) * g.gW;
-      f32x4 xv[TMAX];
-#pragma unroll
-      for (int t = 0; t < TMAX; ++t) {
-        const int iy = iy0 + tdy[t], ix = ix0 + tdx[t];
-        const bool ok = (t < ntaps) && (unsigned)iy < (unsigned)g.gH && (unsigned)ix < (unsigned)g.gW;
-        const long off = ok ? (base + (long)iy * g.gW + ix) * g.gC : 0;
-        f32x4 x = *reinterpret_cast<const f32x4*>(a.G + off + 4 * cq);
-        if (!ok) x = f32x4{0.f, 0.f, 0.f, 0.f};
-        xv[t] = x;
-      }
-#pragma unroll
-      for (int t = 0; t < TMAX; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int n = 0; n < NO; ++n) acc[t][j][n] += xv[t][j] * dy[n];
+      *reinterpret_cast<f32x4*>(&sP[pp * LDP + 4 * c4]) = v;
     }
-  }
-  // merge the PPW pixel slots (lanes cq + LP*s), then the waves
-  __shared__ float sm[4][TMAX * 4 * NO][LP];
+    if constexpr (WGRAD) {
+      for (int e = tid; e < NPIX; e += 256) {
+        const int ly = e / TW, lx = e - ly * TW;
+        const int qy = qy0 + ly, qx = qx0 + lx;
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+        if (qy < g.Qh && qx < g.Qw) {
+          const float* p = a.dY + (long)scatter_pix(g, cls, b, qy, qx) * NO;
 #pragma unroll
-  for (int t = 0; t < TMAX; ++t)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int n = 0; n < NO; ++n) {
-        float v = acc[t][j][n];
-#pragma unroll
-        for (int o = LP; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-        if (slot == 0) sm[wave][(t * 4 + j) * NO + n][cq] = v;
+          for (int n = 0; n < NO; ++n) d[n] = p[n];
+        }
+        *reinterpret_cast<f32x4*>(&sDY[e * 4]) = d;
       }
-  __syncthreads();
-  for (int e = tid; e < TMAX * 4 * NO * LP; e += 256) {
-    const int r = e / LP, q = e % LP;
-    const int t = r / (4 * NO), j = (r / NO) % 4, n = r % NO;
-    if (t < ntaps) {
-      const float v = ((sm[0][r][q] + sm[1][r][q]) + sm[2][r][q]) + sm[3][r][q];
-      const int wrow = g.taps[cls][t].wtap * g.gC + 4 * q + j;
-      a.S[((long)blockIdx.x * rows_total + wrow) * NO + n] = v;
-    }
-  }
-  if (a.pbias != nullptr) {
-    __shared__ float sb[4][NO];
-#pragma unroll
-    for (int n = 0; n < NO; ++n) {
-      float v = (cq == 0) ? bsum[n] : 0.f;   // every lane of a pixel slot saw the same dY: count it once
-      v = wave_sum(v);
-      if (lane == 0) sb[wave][n] = v;
     }
     __syncthreads();
-    if (tid < NO) a.pbias[((long)blockIdx.x * g.ncls + cls) * NO + tid] = ((sb[0][tid] + sb[1][tid]) + sb[2][tid]) + sb[3][tid];
+    // ---- compute ---------------------------------------------------------------------------------------
+#pragma unroll 1
+    for (int it = 0; it < ITERS; ++it) {
+      const int p = it * (4 * PPW) + wave * PPW + slot;
+      const int ly = p / TW, lx = p - ly * TW;
+      const float* base = sP + ((ly * g.is) * a.PW + lx * g.is) * LDP + 4 * cq;
+      f32x4 xv[TMAX];
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t) xv[t] = (t < ntaps) ? *reinterpret_cast<const f32x4*>(base + tofs[t]) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (!WGRAD) {
+        float acc[NO];
+#pragma unroll
+        for (int n = 0; n < NO; ++n) acc[n] = 0.f;
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int n = 0; n < NO; ++n) acc[n] += xv[t][j] * w[t][j][n];
+#pragma unroll
+        for (int o = LP / 2; o > 0; o >>= 1)
+#pragma unroll
+          for (int n = 0; n < NO; ++n) acc[n] += __shfl_xor(acc[n], o, 64);
+        // after the butterfly every lane of the slot holds the sums: lane cq < NO finishes output channel cq
+        const int qy = qy0 + ly, qx = qx0 + lx;
+        float mine = acc[0] + bias_r[0];
+#pragma unroll
+        for (int n = 1; n < NO; ++n) mine = (cq == n) ? acc[n] + bias_r[n] : mine;
+        mine = act_fwd(mine, a.act);
+        if (cq < NO && qy < g.Qh && qx < g.Qw) a.S[(long)scatter_pix(g, cls, b, qy, qx) * NO + cq] = mine;
+      } else {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(&sDY[p * 4]);
+#pragma unroll
+        for (int n = 0; n < NO; ++n) bsum[n] += d[n];
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int n = 0; n < NO; ++n) acc_w[t][j][n] += xv[t][j] * d[n];
+      }
+    }
+  }
+
+  if constexpr (WGRAD) {
+    // merge the PPW pixel slots (lanes cq + LP*s) by shuffles, then the 4 waves through LDS, in a fixed order
+    __syncthreads();
+    float* sm = smem;                                  // [4][TMAX*4*NO][LP]
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int n = 0; n < NO; ++n) {
+          float v = acc_w[t][j][n];
+#pragma unroll
+          for (int o = LP; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+          if (slot == 0) sm[(wave * (TMAX * 4 * NO) + (t * 4 + j) * NO + n) * LP + cq] = v;
+        }
+    float bs[NO];
+#pragma unroll
+    for (int n = 0; n < NO; ++n) bs[n] = wave_sum(cq == 0 ? bsum[n] : 0.f);   // every lane of a slot saw the same dY
+    __syncthreads();
+    for (int e = tid; e < TMAX * 4 * NO * LP; e += 256) {
+      const int r = e / LP, q = e - r * LP;
+      const int t = r / (4 * NO), j = (r / NO) % 4, n = r % NO;
+      if (t < ntaps) {
+        constexpr int R = TMAX * 4 * NO;
+        const float v = ((sm[(0 * R + r) * LP + q] + sm[(1 * R + r) * LP + q]) + sm[(2 * R + r) * LP + q]) + sm[(3 * R + r) * LP + q];
+        const int wrow = g.taps[cls][t].wtap * GC + 4 * q + j;
+        a.S[((long)blockIdx.x * a.rows_total + wrow) * NO + n] = v;
+      }
+    }
+    if (a.pbias != nullptr) {
+      __syncthreads();
+      if (lane == 0)
+#pragma unroll
+        for (int n = 0; n < NO; ++n) sm[wave * NO + n] = bs[n];
+      __syncthreads();
+      if (tid < NO) a.pbias[((long)blockIdx.x * g.ncls + cls) * NO + tid] = ((sm[tid] + sm[NO + tid]) + sm[2 * NO + tid]) + sm[3 * NO + tid];
+    }
   }
 }
 
@@ -211,88 +211,102 @@ static int max_taps(const ConvGeom& g) {
   return m;
 }
 
-bool thin_forward_supported(const ConvGeom& g) {
-  const int N = g.sC, T = max_taps(g);
-  if (N == 3 && (g.gC == 32 || g.gC == 64) && T <= 9 && g.wT == 0) return true;        // narrow_out (forward only)
-  return false;
+static bool thin_shape_ok(const ConvGeom& g) {
+  if (g.wT != 0 || g.sC != 3) return false;
+  if (!(g.gC == 32 || g.gC == 64)) return false;
+  const int TH = 8, TW = g.gC == 32 ? 32 : 16;
+  if (g.Qh % TH != 0 || g.Qw % TW != 0) return false;
+  return max_taps(g) <= 9;
 }
 
-int thin_bn_parts(const ConvGeom& g) { return 0; }
+bool thin_forward_supported(const ConvGeom& g) { return thin_shape_ok(g); }
+bool thin_wgrad_supported(const ConvGeom& g) { return thin_shape_ok(g); }
+int thin_bn_parts(const ConvGeom&) { return 0; }
 
-int launch_thin_forward(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
-                        const float* mask, int mask_act, float* S, int act, float* bn_part, hipStream_t st) {
-  ThinArgs a{};
-  a.g = g; a.G = G; a.W = W; a.bias = bias; a.add = add; a.mask = mask; a.S = S; a.bn_part = bn_part;
-  a.act = act; a.mask_act = mask_act;
-  a.Mc = g.B * g.Qh * g.Qw;
-  a.N = g.sC;
-  const int T = max_taps(g);
-  dim3 grid(1024, g.ncls), block(256);
-  const double macs = (double)a.Mc * a.N * g.gC * [&] { int s = 0; for (int c = 0; c < g.ncls; ++c) s += g.ntaps[c]; return s; }();
-  const double bytes = 4.0 * ((double)g.B * g.gH * g.gW * g.gC + (double)g.B * g.sH * g.sW * g.sC);
-  {
-    if (bn_part != nullptr) return kErrBadArg;
-    ProfScope ps("thin_narrow_out_kernel", st, 2.0 * macs, bytes);
-    if (g.gC == 32) {
-      if (T <= 4) hipLaunchKernelGGL((thin_narrow_out_kernel<8, 3, 4>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((thin_narrow_out_kernel<8, 3, 9>), grid, block, 0, st, a);
-    } else {
-      if (T <= 4) hipLaunchKernelGGL((thin_narrow_out_kernel<16, 3, 4>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((thin_narrow_out_kernel<16, 3, 9>), grid, block, 0, st, a);
-    }
-  }
-  CTVAE_LAUNCH_CHECK();
-  return 0;
-}
-
-bool thin_wgrad_supported(const ConvGeom& g) {
-  const int N = g.sC, T = max_taps(g);
-  if (g.wT != 0) return false;
-  if (N == 3 && (g.gC == 32 || g.gC == 64) && T <= 9) return true;
-  return false;
-}
-
-constexpr int kThinWgradWgs = 256;
+constexpr int kThinWgs = 768;   // persistent workgroups per class (wgrad partial slabs): 3 per CU hide the LDS/VALU latency
 
 size_t thin_wgrad_workspace_floats(const ConvGeom& g) {
   int taps = 0;
   for (int c = 0; c < g.ncls; ++c) taps += g.ntaps[c];
-  return (size_t)kThinWgradWgs * ((size_t)taps * g.gC * g.sC + (size_t)g.ncls * g.sC);
+  return (size_t)kThinWgs * ((size_t)taps * g.gC * g.sC + (size_t)g.ncls * g.sC);
 }
 
-// writes partials [kThinWgradWgs][rows_total*N] (+ bias partials) into ws; the caller reduces them
+template <bool WGRAD>
+static int launch_thin(ThinArgs& a, int nwg, hipStream_t st, const char* pname) {
+  const ConvGeom& g = a.g;
+  const int TH = 8, TW = g.gC == 32 ? 32 : 16;
+  int dmin_y = 1 << 20, dmax_y = -(1 << 20), dmin_x = 1 << 20, dmax_x = -(1 << 20);
+  for (int c = 0; c < g.ncls; ++c)
+    for (int t = 0; t < g.ntaps[c]; ++t) {
+      const Tap& tp = g.taps[c][t];
+      dmin_y = tp.dy < dmin_y ? tp.dy : dmin_y; dmax_y = tp.dy > dmax_y ? tp.dy : dmax_y;
+      dmin_x = tp.dx < dmin_x ? tp.dx : dmin_x; dmax_x = tp.dx > dmax_x ? tp.dx : dmax_x;
+    }
+  a.dmin_y = dmin_y; a.dmin_x = dmin_x;
+  a.PH = (TH - 1) * g.is + (dmax_y - dmin_y) + 1;
+  a.PW = (TW - 1) * g.is + (dmax_x - dmin_x) + 1;
+  if (a.PH * a.PW >= 900) return kErrBadArg;
+  a.inv_PW = (65536u + a.PW - 1) / a.PW;
+  a.tiles_y = g.Qh / TH; a.tiles_x = g.Qw / TW;
+  a.ntiles = g.B * a.tiles_y * a.tiles_x;
+  int taps = 0;
+  for (int c = 0; c < g.ncls; ++c) taps += g.ntaps[c];
+  a.rows_total = taps * g.gC;
+  const int T = max_taps(g);
+  const int LDP = g.gC + 4;
+  size_t smem = (size_t)a.PH * a.PW * LDP * 4 + (WGRAD ? (size_t)TH * TW * 16 : 0);
+  const size_t merge = WGRAD ? (size_t)4 * (T <= 4 ? 4 : 9) * 4 * 3 * (g.gC / 4) * 4 : 0;
+  if (merge > smem) smem = merge;
+  if (smem > 160 * 1024) return kErrBadArg;
+  dim3 grid(nwg < a.ntiles ? nwg : a.ntiles, g.ncls), block(256);
+  const double macs = (double)g.B * g.Qh * g.Qw * g.sC * g.gC * taps;
+  const double bytes = 4.0 * ((double)g.B * g.gH * g.gW * g.gC + (double)g.B * g.sH * g.sW * g.sC);
+  ProfScope ps(pname, st, 2.0 * macs, bytes);
+#define CTVAE_THIN(LP_, TM_, TW_)                                                                                     \
+  do {                                                                                                                \
+    auto kern = thin_tile_kernel<LP_, 3, TM_, 8, TW_, WGRAD>;                                                         \
+    if (smem > 64 * 1024)                                                                                             \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL(kern, grid, block, smem, st, a);                                                               \
+  } while (0)
+  if (g.gC == 32) {
+    if (T <= 4) CTVAE_THIN(8, 4, 32);
+    else CTVAE_THIN(8, 9, 32);
+  } else {
+    if (T <= 4) CTVAE_THIN(16, 4, 16);
+    else CTVAE_THIN(16, 9, 16);
+  }
+#undef CTVAE_THIN
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_thin_forward(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
+                        const float* mask, int mask_act, float* S, int act, float* bn_part, hipStream_t st) {
+  if (add != nullptr || mask != nullptr || bn_part != nullptr) return kErrBadArg;
+  ThinArgs a{};
+  a.g = g; a.G = G; a.W = W; a.bias = bias; a.S = S; a.act = act;
+  return launch_thin<false>(a, 2048, st, "thin_tile_kernel<fwd>");
+}
+
+// writes partials [nwg][rows_total*N] (+ bias partials) into ws; the caller reduces them
 int launch_thin_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, float** part_out, float** pbias_out,
                       int* nparts_w, int* nparts_b, bool want_bias, hipStream_t st) {
   ThinArgs a{};
   a.g = g; a.G = X; a.dY = dY;
-  a.Mc = g.B * g.Qh * g.Qw;
-  a.N = g.sC;
   int taps = 0;
   for (int c = 0; c < g.ncls; ++c) taps += g.ntaps[c];
   const int rows_total = taps * g.gC;
+  const int ntiles = g.B * (g.Qh / 8) * (g.Qw / (g.gC == 32 ? 32 : 16));
+  const int nwg = ntiles < kThinWgs ? ntiles : kThinWgs;
   a.S = ws;
-  a.pbias = want_bias ? ws + (size_t)kThinWgradWgs * rows_total * a.N : nullptr;
-  // every (workgroup, class) writes only its own class's rows: zero-fill is not needed because the reduce
-  // below sums rows over workgroups and each row belongs to exactly one class -> all rows are written by all wgs
-  const int T = max_taps(g);
-  dim3 grid(kThinWgradWgs, g.ncls), block(256);
-  const double macs = (double)a.Mc * a.N * rows_total;
-  const double bytes = 4.0 * ((double)g.B * g.gH * g.gW * g.gC + (double)g.B * g.sH * g.sW * g.sC);
-  {
-    ProfScope ps("thin_wgrad_narrow_n_kernel", st, 2.0 * macs, bytes);
-    if (g.gC == 32) {
-      if (T <= 4) hipLaunchKernelGGL((thin_wgrad_narrow_n_kernel<8, 3, 4>), grid, block, 0, st, a, rows_total);
-      else hipLaunchKernelGGL((thin_wgrad_narrow_n_kernel<8, 3, 9>), grid, block, 0, st, a, rows_total);
-    } else {
-      if (T <= 4) hipLaunchKernelGGL((thin_wgrad_narrow_n_kernel<16, 3, 4>), grid, block, 0, st, a, rows_total);
-      else hipLaunchKernelGGL((thin_wgrad_narrow_n_kernel<16, 3, 9>), grid, block, 0, st, a, rows_total);
-    }
-  }
-  CTVAE_LAUNCH_CHECK();
+  a.pbias = want_bias ? ws + (size_t)nwg * rows_total * g.sC : nullptr;
+  int rc = launch_thin<true>(a, nwg, st, "thin_tile_kernel<wgrad>");
+  if (rc) return rc;
   *part_out = a.S;
   *pbias_out = a.pbias;
-  *nparts_w = kThinWgradWgs;
-  *nparts_b = kThinWgradWgs * g.ncls;
+  *nparts_w = nwg;
+  *nparts_b = nwg * g.ncls;
   return 0;
 }
 
