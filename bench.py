@@ -65,7 +65,9 @@ def cpu_baseline(model_name, seconds):
     from oracle import vae_cpu as O
     from tests import helpers as H
     B = 64
-    threads = torch.get_num_threads()
+    # a one-GPU box grants ~16 host cores to the job; more torch threads than that only oversubscribes
+    threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    torch.set_num_threads(threads)
     if model_name == "VanillaVAE":
         sd = filler.fill_state(H.vanilla_specs(), 1266)
         x, eps = filler.synthetic_batch(1265, B)
