@@ -13,10 +13,10 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
                  int accumulate, hipStream_t st);
 int launch_bn_forward(const float* y, int R, int C, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, float momentum, float eps, int training, int act, float* out, float* save_mean,
-                      float* save_invstd, float* ws, size_t ws_bytes, hipStream_t st);
+                      float* save_invstd, float* ws, size_t ws_bytes, long long* nbt, hipStream_t st);
 int launch_bn_finish_forward(const float* y, int R, int C, int nparts, const float* gamma, const float* beta,
                              float* running_mean, float* running_var, float momentum, float eps, int training, int act,
-                             float* out, float* save_mean, float* save_invstd, float* ws, hipStream_t st);
+                             float* out, float* save_mean, float* save_invstd, float* ws, long long* nbt, hipStream_t st);
 size_t bn_workspace_floats(int C, int nparts);
 int launch_bn_backward(const float* ga, const float* beta, const float* y, int R, int C, const float* gamma,
                        const float* save_mean, const float* save_invstd, int act, float* gy, float* dgamma, float* dbeta,
@@ -72,9 +72,10 @@ int ctvae_conv_forward(int kind, const float* x, const float* w, const float* bi
 
 int ctvae_conv_bn_act_forward(int kind, const float* x, const float* w, const float* bias, const float* gamma,
                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                              int training, int act, float* y, float* a_out, float* save_mean, float* save_invstd, int B,
-                              int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, float* ws,
-                              size_t ws_bytes, void* stream) {
+                              int training, int act, float* y, float* a_out, float* save_mean, float* save_invstd,
+                              int64_t* num_batches_tracked, int B, int H, int W, int Ci, int Co, int k, int stride, int pad,
+                              int out_pad, float* ws, size_t ws_bytes, void* stream) {
+  long long* nbt = (long long*)num_batches_tracked;
   if (!x || !w || !gamma || !beta || !y || !a_out || !ws || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
   if (training && (!save_mean || !save_invstd)) return kErrBadArg;
   if (!training && (!running_mean || !running_var)) return kErrBadArg;
@@ -90,14 +91,14 @@ int ctvae_conv_bn_act_forward(int kind, const float* x, const float* w, const fl
     int rc = launch_tapgemm(g, x, w, bias, nullptr, nullptr, 0, y, ACT_NONE, nullptr, ws, wsf, (hipStream_t)stream);
     if (rc) return rc;
     return launch_bn_forward(y, R, Co, gamma, beta, running_mean, running_var, momentum, eps, training, act, a_out, save_mean,
-                             save_invstd, ws, ws_bytes, (hipStream_t)stream);
+                             save_invstd, ws, ws_bytes, nbt, (hipStream_t)stream);
   }
   const int nparts = plan.bn_parts;
   if (wsf < bn_workspace_floats(Co, nparts)) return kErrWorkspace;
   int rc = launch_tapgemm(g, x, w, bias, nullptr, nullptr, 0, y, ACT_NONE, ws, nullptr, 0, (hipStream_t)stream);
   if (rc) return rc;
   return launch_bn_finish_forward(y, R, Co, nparts, gamma, beta, running_mean, running_var, momentum, eps, training, act,
-                                  a_out, save_mean, save_invstd, ws, (hipStream_t)stream);
+                                  a_out, save_mean, save_invstd, ws, nbt, (hipStream_t)stream);
 }
 
 int ctvae_conv_dgrad(int kind, const float* dy, const float* w, const float* add, const float* mask, int mask_act,
@@ -121,12 +122,13 @@ int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float
 
 int ctvae_bn_forward(const float* y, int R, int C, const float* gamma, const float* beta, float* running_mean,
                      float* running_var, float momentum, float eps, int training, int act, float* out,
-                     float* save_mean, float* save_invstd, float* ws, size_t ws_bytes, void* stream) {
+                     float* save_mean, float* save_invstd, int64_t* num_batches_tracked, float* ws, size_t ws_bytes,
+                     void* stream) {
   if (!y || !gamma || !beta || !out || !ws) return kErrBadArg;
   if (training && (!save_mean || !save_invstd)) return kErrBadArg;
   if (!training && (!running_mean || !running_var)) return kErrBadArg;
   return launch_bn_forward(y, R, C, gamma, beta, running_mean, running_var, momentum, eps, training, act, out, save_mean,
-                           save_invstd, ws, ws_bytes, (hipStream_t)stream);
+                           save_invstd, ws, ws_bytes, (long long*)num_batches_tracked, (hipStream_t)stream);
 }
 
 int ctvae_bn_backward(const float* g_a, const float* beta, const float* y, int R, int C, const float* gamma,

@@ -99,10 +99,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
                                                           float momentum, float eps, float* __restrict__ save_mean,
                                                           float* __restrict__ save_invstd, float* __restrict__ scale,
-                                                          float* __restrict__ shift) {
+                                                          float* __restrict__ shift, long long* __restrict__ num_batches_tracked) {
   __shared__ float sm[256 * 3];
   const int tid = threadIdx.x;
   const int c = blockIdx.x;
+  if (c == 0 && tid == 0 && num_batches_tracked != nullptr) num_batches_tracked[0] += 1;   // nn.BatchNorm2d bookkeeping
   float n = 0.f, mean = 0.f, m2 = 0.f;
   for (int b = tid; b < nparts; b += 256) {
     const float* p = part + ((long)b * C + c) * 3;
@@ -311,14 +312,14 @@ size_t bn_workspace_floats(int C, int nparts) {
 // finalize (from `nparts` partial triples already in ws) or eval coefficients, then apply + activation
 int launch_bn_finish_forward(const float* y, int R, int C, int nparts, const float* gamma, const float* beta,
                              float* running_mean, float* running_var, float momentum, float eps, int training, int act,
-                             float* out, float* save_mean, float* save_invstd, float* ws, hipStream_t st) {
+                             float* out, float* save_mean, float* save_invstd, float* ws, long long* nbt, hipStream_t st) {
   const size_t parts = nparts > kBnMaxBlocks ? (size_t)nparts : (size_t)kBnMaxBlocks;
   float* scale = ws + parts * C * 3;
   float* shift = scale + C;
   if (training) {
     ProfScope ps("bn_finalize_kernel", st, 0.0, 12.0 * (double)nparts * C);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, ws, nparts, C, gamma, beta, running_mean,
-                       running_var, momentum, eps, save_mean, save_invstd, scale, shift);
+                       running_var, momentum, eps, save_mean, save_invstd, scale, shift, nbt);
     CTVAE_LAUNCH_CHECK();
   } else {
     hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, C, gamma, beta, running_mean,
@@ -336,7 +337,7 @@ int launch_bn_finish_forward(const float* y, int R, int C, int nparts, const flo
 
 int launch_bn_forward(const float* y, int R, int C, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, float momentum, float eps, int training, int act, float* out,
-                      float* save_mean, float* save_invstd, float* ws, size_t ws_bytes, hipStream_t st) {
+                      float* save_mean, float* save_invstd, float* ws, size_t ws_bytes, long long* nbt, hipStream_t st) {
   if (!bn_shape_ok(R, C)) return kErrBadArg;
   if (ws_bytes / sizeof(float) < bn_workspace_floats(C, 0)) return kErrWorkspace;
   int nb = 0;
@@ -348,7 +349,7 @@ int launch_bn_forward(const float* y, int R, int C, const float* gamma, const fl
     CTVAE_LAUNCH_CHECK();
   }
   return launch_bn_finish_forward(y, R, C, nb, gamma, beta, running_mean, running_var, momentum, eps, training, act, out,
-                                  save_mean, save_invstd, ws, st);
+                                  save_mean, save_invstd, ws, nbt, st);
 }
 
 int launch_bn_backward(const float* ga, const float* beta, const float* y, int R, int C, const float* gamma,

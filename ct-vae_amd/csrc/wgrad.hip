@@ -438,6 +438,38 @@ __global__ __launch_bounds__(256) void reduce_partials_small_kernel(const float*
   }
 }
 
+// two reductions (weights and bias) in ONE launch: blocks [0, nb1) do job 1, the rest job 2
+struct ReduceJob { const float* part; float* dst; long n; int S; long stride; };
+__global__ __launch_bounds__(256) void reduce_partials2_kernel(ReduceJob j1, ReduceJob j2, int nb1, int accumulate) {
+  const bool second = (int)blockIdx.x >= nb1;
+  const ReduceJob j = second ? j2 : j1;
+  const int blk = second ? blockIdx.x - nb1 : blockIdx.x;
+  const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long i = (long)blk * 16 + el;
+  float v = 0.f;
+  if (i < j.n) {
+#pragma unroll 4
+    for (int s = sl; s < j.S; s += 16) v += j.part[(long)s * j.stride + i];
+  }
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  __shared__ float sm[4][16];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane < 16) sm[wave][lane] = v;
+  __syncthreads();
+  if (threadIdx.x < 16 && i < j.n) {
+    float t = ((sm[0][el] + sm[1][el]) + sm[2][el]) + sm[3][el];
+    j.dst[i] = (accumulate ? j.dst[i] : 0.f) + t;
+  }
+}
+
+static void launch_reduce2(const float* p1, float* d1, long n1, int S1, long st1, const float* p2, float* d2, long n2, int S2,
+                           long st2, int accumulate, hipStream_t st) {
+  ReduceJob j1{p1, d1, n1, S1, st1}, j2{p2, d2, n2, S2, st2};
+  const int nb1 = (int)((n1 + 15) / 16), nb2 = (int)((n2 + 15) / 16);
+  hipLaunchKernelGGL(reduce_partials2_kernel, dim3(nb1 + nb2), dim3(256), 0, st, j1, j2, nb1, accumulate);
+}
+
 static void launch_reduce(const float* part, float* dst, long n, int S, long stride, int accumulate, hipStream_t st) {
   if (S <= 8) {
     long blocks = ((n + 3) / 4 + 255) / 256;
@@ -489,12 +521,9 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
     for (int c = 0; c < g.ncls; ++c) taps += g.ntaps[c];
     const long n = (long)taps * g.gC * g.sC;
     ProfScope ps("reduce_partials_kernel", st, 0.0, 4.0 * (double)(nw + 1) * n);
-    launch_reduce(part, dW, n, nw, n, accumulate, st);
+    if (dbias) launch_reduce2(part, dW, n, nw, n, pb, dbias, (long)g.sC, nb, (long)g.sC, accumulate, st);
+    else launch_reduce(part, dW, n, nw, n, accumulate, st);
     CTVAE_LAUNCH_CHECK();
-    if (dbias) {
-      launch_reduce(pb, dbias, (long)g.sC, nb, (long)g.sC, accumulate, st);
-      CTVAE_LAUNCH_CHECK();
-    }
     return 0;
   }
   WgradArgs a{};
@@ -560,12 +589,9 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
   snprintf(rname, sizeof rname, "reduce_partials_kernel");
   if (prof_detailed()) snprintf(rname, sizeof rname, "reduce_partials_kernel n=%ld S=%d", n, S);
   ProfScope ps2(rname, st, 0.0, 4.0 * (double)(S + 1) * n);
-  launch_reduce(a.part, dW, n, S, (long)a.rows_total * a.N, accumulate, st);
+  if (dbias) launch_reduce2(a.part, dW, n, S, (long)a.rows_total * a.N, a.pbias, dbias, (long)a.N, S * g.ncls, (long)a.N, accumulate, st);
+  else launch_reduce(a.part, dW, n, S, (long)a.rows_total * a.N, accumulate, st);
   CTVAE_LAUNCH_CHECK();
-  if (dbias) {
-    launch_reduce(a.pbias, dbias, (long)a.N, S * g.ncls, (long)a.N, accumulate, st);
-    CTVAE_LAUNCH_CHECK();
-  }
   return 0;
 }
 

@@ -103,6 +103,32 @@ def conv_wgrad_raw(x, dy, w_param, b_param, spec: ConvSpec):
                 B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, acc, ws.data_ptr(), ws.numel() * 4)
 
 
+_side_streams = {}
+
+
+def wgrad_dgrad_concurrent(x, g, w_param, b_param, spec, need_dgrad):
+    """wgrad and dgrad of one layer are independent (both only read g): wgrad goes to a side HIP stream so the two
+    kernels share the chip instead of running back to back (each alone leaves CUs waiting on its own load latency).
+    Fork/join with stream waits only -> capturable into the step's hipGraph."""
+    g_x = None
+    if not need_dgrad:
+        conv_wgrad_raw(x, g, w_param, b_param, spec)
+        return None
+    cur = torch.cuda.current_stream()
+    key = (x.device.index, cur.cuda_stream)
+    side = _side_streams.get(key)
+    if side is None:
+        side = _side_streams[key] = torch.cuda.Stream(device=x.device)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        conv_wgrad_raw(x, g, w_param, b_param, spec)
+    g_x = conv_dgrad_raw(g, w_param, spec, (x.shape[1], x.shape[2]))
+    cur.wait_stream(side)
+    x.record_stream(side)
+    g.record_stream(side)
+    return g_x
+
+
 def act_backward_raw(g_out, out, act):
     if act == ACT_NONE:
         return g_out
@@ -191,10 +217,7 @@ class ConvAct(Function):
         x, y = ctx.saved_tensors
         g_y = _c(g_y)
         g_pre = act_backward_raw(g_y, y, spec.act) if spec.act != ACT_NONE else g_y
-        conv_wgrad_raw(x, g_pre, ctx.w, ctx.b, spec)
-        g_x = None
-        if ctx.needs_input_grad[0]:
-            g_x = conv_dgrad_raw(g_pre, ctx.w, spec, (x.shape[1], x.shape[2]))
+        g_x = wgrad_dgrad_concurrent(x, g_pre, ctx.w, ctx.b, spec, ctx.needs_input_grad[0])
         g_add = g_pre if (ctx.has_add and ctx.needs_input_grad[3]) else None
         return g_x, None, None, g_add, None
 
@@ -203,7 +226,7 @@ class ConvBNAct(Function):
     """a = act(BatchNorm2d(conv(x, w) + b)) with train-mode batch statistics (vanilla_vae.py:25-35,47-75)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, training, spec, bn_act):
+    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, training, spec, bn_act, num_batches_tracked=None):
         _req_cuda(x, w, gamma)
         x = _c(x)
         B, H, W, _ = x.shape
@@ -217,7 +240,7 @@ class ConvBNAct(Function):
         native.call("ctvae_conv_bn_act_forward", spec.kind, x.data_ptr(), w.data_ptr(), native.ptr(b), gamma.data_ptr(),
                     beta.data_ptr(), native.ptr(running_mean), native.ptr(running_var), BN_MOMENTUM, BN_EPS,
                     1 if training else 0, bn_act, y.data_ptr(), a.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(),
-                    B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, ws.data_ptr(), ws.numel() * 4)
+                    native.ptr(num_batches_tracked) if training else None, B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, ws.data_ptr(), ws.numel() * 4)
         ctx.spec, ctx.bn_act, ctx.training = spec, bn_act, training
         ctx.params = (w, b, gamma, beta)
         ctx.save_for_backward(x, y, a, save_mean, save_invstd)
@@ -242,11 +265,8 @@ class ConvBNAct(Function):
         native.call("ctvae_bn_backward", g_a.data_ptr(), beta.data_ptr(), y.data_ptr(), B * H * W, C, gamma.data_ptr(),
                     save_mean.data_ptr(), save_invstd.data_ptr(), ctx.bn_act, g_y.data_ptr(), gg.data_ptr(), gbt.data_ptr(),
                     accg, ws.data_ptr(), ws.numel() * 4)
-        conv_wgrad_raw(x, g_y, w, b, spec)
-        g_x = None
-        if ctx.needs_input_grad[0]:
-            g_x = conv_dgrad_raw(g_y, w, spec, (x.shape[1], x.shape[2]))
-        return (g_x,) + (None,) * 9
+        g_x = wgrad_dgrad_concurrent(x, g_y, w, b, spec, ctx.needs_input_grad[0])
+        return (g_x,) + (None,) * 10
 
 
 class ActFn(Function):
@@ -276,6 +296,24 @@ def _rows(t):
     if t.dim() != 2 or t.stride(1) != 1:
         t = t.contiguous()
     return t, t.stride(0)
+
+
+class SplitHeads(Function):
+    """[B,2L] fused fc_mu|fc_var output -> (mu, log_var) views; backward gathers both gradients with one
+    kernel instead of two zero-fills, two strided copies and an add."""
+
+    @staticmethod
+    def forward(ctx, heads, L):
+        ctx.L = L
+        return heads[:, :L], heads[:, L:]
+
+    @staticmethod
+    def backward(ctx, g_mu, g_lv):
+        if g_mu is None:
+            g_mu = torch.zeros_like(g_lv)
+        if g_lv is None:
+            g_lv = torch.zeros_like(g_mu)
+        return torch.cat([g_mu, g_lv], dim=1), None
 
 
 class Reparameterize(Function):

@@ -10,11 +10,9 @@ from .packing import PackedBN, PackedConv
 
 def conv_bn_leaky(x, conv, bn, spec, training):
     """Conv (+bias) -> train/eval BatchNorm2d -> LeakyReLU on the holders `conv` / `bn`."""
-    a = K.ConvBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                          training, spec, K.ACT_LRELU)
-    if training:
-        bn.num_batches_tracked += 1
-    return a
+    # num_batches_tracked is advanced by the finalize kernel (no separate launch)
+    return K.ConvBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                             training, spec, K.ACT_LRELU, bn.num_batches_tracked)
 
 
 class ConvBNLeaky(nn.Module):

@@ -94,8 +94,8 @@ class VanillaVAE(BaseVAE):
         B = h.shape[0]
         flat = K._ToNCHW.apply(h).view(B, 1, 1, -1)                      # torch.flatten(start_dim=1) on NCHW
         heads = K.ConvAct.apply(flat, self.fc_mu.weight, self.fc_mu.bias, None, self._head_spec).view(B, -1)
-        L = self.latent_dim
-        return [heads[:, :L], heads[:, L:]]
+        mu, log_var = K.SplitHeads.apply(heads, self.latent_dim)
+        return [mu, log_var]
 
     def decode(self, z: Tensor) -> Tensor:
         """[B,L] -> [B,3,64,64] (vanilla_vae.py:94-105)."""

@@ -49,9 +49,9 @@ int ctvae_conv_forward(int kind, const float* x, const float* w, const float* bi
  * statistics cost no extra pass over y; a_out = act(BN(y)).  Arguments as ctvae_conv_forward / ctvae_bn_forward. */
 int ctvae_conv_bn_act_forward(int kind, const float* x, const float* w, const float* bias, const float* gamma,
                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                              int training, int act, float* y, float* a_out, float* save_mean, float* save_invstd, int B,
-                              int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, float* ws,
-                              size_t ws_bytes, void* stream);
+                              int training, int act, float* y, float* a_out, float* save_mean, float* save_invstd,
+                              int64_t* num_batches_tracked, int B, int H, int W, int Ci, int Co, int k, int stride, int pad,
+                              int out_pad, float* ws, size_t ws_bytes, void* stream);
 
 /* dx = (dgrad(dy, w) + add) * act'(mask)      (autograd of the ops above)
  * add / mask (saved post-activation output of the PREVIOUS layer, layout of dx) may be NULL. */
@@ -66,10 +66,12 @@ int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float
 
 /* Train/eval BatchNorm2d + activation on an [R=B*H*W][C] matrix (vanilla_vae.py:30-31,56-57,71-72).
  * training: batch statistics (biased var, eps), running stats updated with `momentum` and the unbiased
- * variance; save_mean/save_invstd [C] are written for the backward pass. */
+ * variance; save_mean/save_invstd [C] are written for the backward pass; num_batches_tracked (may be NULL) is
+ * incremented on the device (nn.BatchNorm2d bookkeeping without an extra launch). */
 int ctvae_bn_forward(const float* y, int R, int C, const float* gamma, const float* beta, float* running_mean,
                      float* running_var, float momentum, float eps, int training, int act, float* out,
-                     float* save_mean, float* save_invstd, float* ws, size_t ws_bytes, void* stream);
+                     float* save_mean, float* save_invstd, int64_t* num_batches_tracked, float* ws, size_t ws_bytes,
+                     void* stream);
 /* g_y from g_a (grad wrt the activated output); the activation derivative is re-derived from the sign of
  * gamma*invstd*(y-mean)+beta, so the activated tensor is not read; dgamma/dbeta (+)= ... */
 int ctvae_bn_backward(const float* g_a, const float* beta, const float* y, int R, int C, const float* gamma,

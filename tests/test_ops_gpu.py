@@ -107,10 +107,12 @@ def test_conv_bn_lrelu(K, C, R_shape):
     wp = as_param(pack(w.detach(), False).to(dev), False)
     bp, gp, btp = (torch.nn.Parameter(t.detach().to(dev)) for t in (b, gamma, beta))
     rmd, rvd = rm.to(dev), rv.to(dev)
-    out = K.ConvBNAct.apply(xd, wp, bp, gp, btp, rmd, rvd, True, spec, K.ACT_LRELU)
+    nbt = torch.zeros((), dtype=torch.long, device=dev)
+    out = K.ConvBNAct.apply(xd, wp, bp, gp, btp, rmd, rvd, True, spec, K.ACT_LRELU, nbt)
     out.backward(ga.permute(0, 2, 3, 1).contiguous().to(dev))
     torch.cuda.synchronize()
     np.testing.assert_allclose(out.detach().cpu().permute(0, 3, 1, 2).numpy(), a.detach().numpy(), atol=TOL, rtol=1e-4)
+    assert int(nbt.item()) == 1
     np.testing.assert_allclose(rmd.cpu().numpy(), rm_ref.numpy(), atol=1e-5, rtol=1e-5)
     np.testing.assert_allclose(rvd.cpu().numpy(), rv_ref.numpy(), atol=1e-5, rtol=1e-4)
     np.testing.assert_allclose(xd.grad.cpu().permute(0, 3, 1, 2).numpy(), x.grad.numpy(), atol=TOL, rtol=1e-3)
