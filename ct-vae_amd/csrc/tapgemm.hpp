@@ -40,6 +40,6 @@ __device__ __forceinline__ void decode_m_fast(const TapGemmArgs& a, int m, int& 
   }
 }
 
-int launch_tapgemm_fast(const TapGemmArgs& a, const TapGemmPlan& plan, bool db, hipStream_t st);
+int launch_tapgemm_fast(const TapGemmArgs& a, const TapGemmPlan& plan, int pf, hipStream_t st);
 
 }  // namespace ctvae

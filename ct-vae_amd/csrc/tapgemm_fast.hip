@@ -36,8 +36,22 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long 
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 
-template <int WM, int WN, int TM, int TN, bool WT, bool DB>
+#ifdef CTVAE_PHASE_TIMING
+// diagnostic build only (tools/phase_probe.py): per-workgroup timestamps of the kernel phases, 100 MHz clock
+__device__ unsigned long long g_phase[8 * 8192];
+#define PHASE(i) do { if (threadIdx.x == 0 && blockIdx.z == 0) g_phase[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 8 + (i)] = wall_clock64(); } while (0)
+extern "C" int ctvae_debug_phase_read(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), (size_t)n * 8);
+}
+#else
+#define PHASE(i) do {} while (0)
+#endif
+
+template <int WM, int WN, int TM, int TN, bool WT, int PF>
 __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) {
+  constexpr bool DB = PF >= 1;      // PF: 0 single LDS buffer, 1 double buffer, 2 double buffer + loads two chunks ahead,
+                                    //     3 double buffer, explicitly software-pipelined (see the main loop)
+  constexpr int NSET = PF == 2 ? 2 : 1;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int SA = BM * LDK, SB = WT ? BN * LDK : KC * BN;
@@ -46,6 +60,7 @@ __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) 
   __shared__ __attribute__((aligned(16))) float sBbuf[NBUF * SB];
   __shared__ __attribute__((aligned(16))) int sOut[BM];
 
+  PHASE(0);
   const ConvGeom& g = a.g;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -113,8 +128,9 @@ __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) 
     }
   }
 
-  f32x4 ra[A_V], rb[B_V];
-  auto load_chunk = [&](int c) {
+  f32x4 ra[NSET][A_V], rb[NSET][B_V];
+  auto load_chunk = [&](int c, auto set_c) {
+    constexpr int set = decltype(set_c)::value;
     const int k0 = c * KC;
     const int t = k0 / gC;
     const int ci0 = k0 - t * gC;
@@ -124,25 +140,26 @@ __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) 
 #pragma unroll
     for (int j = 0; j < A_V; ++j) {
       const bool ok = ((a_ok[j] >> sy) & (a_ok[j] >> sx) & 1u) != 0;
-      ra[j] = buf_load4(rG, ok ? a_off[j] + tapoff : kOOB, 0);
+      ra[set][j] = buf_load4(rG, ok ? a_off[j] + tapoff : kOOB, 0);
     }
     const unsigned wsoff = WT ? (unsigned)(tp.wtap * g.wCi * g.wCo + ci0) * 4u : (unsigned)((tp.wtap * g.wCi + ci0) * g.wCo) * 4u;
 #pragma unroll
-    for (int j = 0; j < B_V; ++j) rb[j] = buf_load4(rW, b_off[j], wsoff);
+    for (int j = 0; j < B_V; ++j) rb[set][j] = buf_load4(rW, b_off[j], wsoff);
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf, auto set_c) {
+    constexpr int set = decltype(set_c)::value;
     float* sA = sAbuf + buf * SA;
     float* sB = sBbuf + buf * SB;
 #pragma unroll
-    for (int j = 0; j < A_V; ++j) *reinterpret_cast<f32x4*>(&sA[((tid >> 3) + 32 * j) * LDK + 4 * (tid & 7)]) = ra[j];
+    for (int j = 0; j < A_V; ++j) *reinterpret_cast<f32x4*>(&sA[((tid >> 3) + 32 * j) * LDK + 4 * (tid & 7)]) = ra[set][j];
 #pragma unroll
     for (int j = 0; j < B_V; ++j) {
       if constexpr (!WT) {
         const int f = tid + 256 * j;
         const int kr = f / (BN / 4), nq = f - kr * (BN / 4);
-        *reinterpret_cast<f32x4*>(&sB[kr * BN + 4 * nq]) = rb[j];
+        *reinterpret_cast<f32x4*>(&sB[kr * BN + 4 * nq]) = rb[set][j];
       } else {
-        *reinterpret_cast<f32x4*>(&sB[((tid >> 3) + 32 * j) * LDK + 4 * (tid & 7)]) = rb[j];
+        *reinterpret_cast<f32x4*>(&sB[((tid >> 3) + 32 * j) * LDK + 4 * (tid & 7)]) = rb[set][j];
       }
     }
   };
@@ -162,16 +179,11 @@ __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) 
     c0 = blockIdx.z * cps;
     c1 = c0 + cps < nch ? c0 + cps : nch;
   }
-  if (c0 < c1) {
-    load_chunk(c0);
-    store_chunk(0);
-  }
-  __syncthreads();
-  for (int c = c0; c < c1; ++c) {
-    const int cur = DB ? ((c - c0) & 1) : 0;
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, NSET - 1>;
+  auto compute_chunk = [&](int cur) {
     const float* sA = sAbuf + cur * SA;
     const float* sB = sBbuf + cur * SB;
-    if (c + 1 < c1) load_chunk(c + 1);
     f32x4 af[2][TM];
     float bf[2][TN][4];
     auto read_frags = [&](int kg, int slot) {
@@ -201,20 +213,155 @@ __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) 
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kg & 1][i][s], bf[kg & 1][j][s], acc[i][j], 0, 0, 0);
     }
-    if constexpr (DB) {
-      // the other buffer was last read in iteration c-1, which every wave left through the barrier below
-      if (c + 1 < c1) store_chunk(cur ^ 1);
+  };
+
+  if constexpr (PF == 3) {
+    // ---- software-pipelined loop: one barrier per chunk, no exposed latency ---------------------------------
+    // iteration c:  A) chunk c+1 registers -> other LDS buffer, global loads of chunk c+2, LDS reads of k-groups
+    //                  2,3 of chunk c, MFMAs of k-groups 0,1 (fragments read during the previous iteration)
+    //               B) barrier: chunk c+1 is complete in LDS, nobody reads this buffer's k-groups any more
+    //               C) LDS reads of k-groups 0,1 of chunk c+1, MFMAs of k-groups 2,3 of chunk c
+    // sched_barrier keeps the compiler from sinking the reads next to their uses (it otherwise serialises
+    // read -> wait -> MFMA and leaves the matrix pipe idle for an LDS latency 6x per chunk).
+    // Tap constants live in lanes (lane t = tap t) and are fetched with v_readlane: no scalar loads, hence no
+    // lgkmcnt(0) drains, and no integer division in the loop.
+    unsigned tv_off = 0, tv_sh = 0, tv_w = 0;
+    if (lane < ntaps) {
+      const Tap tp = g.taps[cls][lane];
+      tv_off = (unsigned)(((tp.dy * g.gW + tp.dx) * gC) * 4);
+      tv_sh = (unsigned)(tp.dy + 3) | ((unsigned)(tp.dx + 11) << 8);
+      tv_w = WT ? (unsigned)(tp.wtap * g.wCi * g.wCo) * 4u : (unsigned)(tp.wtap * g.wCi * g.wCo) * 4u;
+    }
+    int lt = (c0 * KC) / gC, lci = c0 * KC - lt * gC;    // tap / channel offset of the next chunk to load
+    auto load_next = [&]() {
+      const unsigned tapoff = (unsigned)__builtin_amdgcn_readlane((int)tv_off, lt) + (unsigned)lci * 4u;
+      const unsigned sh = (unsigned)__builtin_amdgcn_readlane((int)tv_sh, lt);
+      const unsigned wsoff = (unsigned)__builtin_amdgcn_readlane((int)tv_w, lt) + (WT ? (unsigned)lci * 4u : (unsigned)(lci * g.wCo) * 4u);
+      const unsigned sy = sh & 0xff, sx = sh >> 8;
+#pragma unroll
+      for (int j = 0; j < A_V; ++j) {
+        const bool ok = ((a_ok[j] >> sy) & (a_ok[j] >> sx) & 1u) != 0;
+        ra[0][j] = buf_load4(rG, ok ? a_off[j] + tapoff : kOOB, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < B_V; ++j) rb[0][j] = buf_load4(rW, b_off[j], wsoff);
+      lci += KC;
+      if (lci == gC) { lci = 0; ++lt; }
+    };
+    f32x4 af[4][TM];
+    float bf[4][TN][4];
+    auto read_kg = [&](int buf, auto kg_c) {
+      constexpr int kg = decltype(kg_c)::value;
+      const float* sA = sAbuf + buf * SA;
+      const float* sB = sBbuf + buf * SB;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[kg][i] = *reinterpret_cast<const f32x4*>(&sA[((wm * TM + i) * 32 + li) * LDK + kg * 8 + 4 * lh]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (WT) {
+          const f32x4 t4 = *reinterpret_cast<const f32x4*>(&sB[((wn * TN + j) * 32 + li) * LDK + kg * 8 + 4 * lh]);
+          bf[kg][j][0] = t4[0]; bf[kg][j][1] = t4[1]; bf[kg][j][2] = t4[2]; bf[kg][j][3] = t4[3];
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bf[kg][j][q] = sB[(kg * 8 + 4 * lh + q) * BN + (wn * TN + j) * 32 + li];
+        }
+      }
+    };
+    auto mfma_kg = [&](auto kg_c) {
+      constexpr int kg = decltype(kg_c)::value;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kg][i][q], bf[kg][j][q], acc[i][j], 0, 0, 0);
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    using K3 = std::integral_constant<int, 3>;
+    PHASE(1);
+    if (c0 < c1) {
+      load_next();
+      store_chunk(0, S0{});
+    }
+    __syncthreads();
+    PHASE(2);
+    if (c0 < c1) {
+      read_kg(0, K0{});
+      read_kg(0, K1{});
+      if (c0 + 1 < c1) load_next();
+    }
+    for (int c = c0; c < c1; ++c) {
+      const int cur = (c - c0) & 1;
+      const bool more = c + 1 < c1;
+      if (more) store_chunk(cur ^ 1, S0{});
+      if (c + 2 < c1) load_next();
+      read_kg(cur, K2{});
+      read_kg(cur, K3{});
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_kg(K0{});
+      mfma_kg(K1{});
+      __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
-    } else {
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+        read_kg(cur ^ 1, K0{});
+        read_kg(cur ^ 1, K1{});
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_kg(K2{});
+      mfma_kg(K3{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+  if (c0 < c1) {
+    load_chunk(c0, S0{});
+    store_chunk(0, S0{});
+    if constexpr (PF >= 2) {
+      if (c0 + 1 < c1) load_chunk(c0 + 1, S1{});
+    }
+  }
+  __syncthreads();
+  if constexpr (PF >= 2) {
+    // chunk c sits in LDS buffer (c-c0)&1; register set (c-c0)&1 is free again once chunk c was stored, and
+    // takes chunk c+2 while chunk c+1 (other set) is still in flight: two chunk-times of load latency hidden.
+    for (int c = c0; c < c1; c += 2) {
+      if (c + 2 < c1) load_chunk(c + 2, S0{});
+      compute_chunk(0);
+      if (c + 1 < c1) store_chunk(1, S1{});
       __syncthreads();
       if (c + 1 < c1) {
-        store_chunk(0);
+        if (c + 3 < c1) load_chunk(c + 3, S1{});
+        compute_chunk(1);
+        if (c + 2 < c1) store_chunk(0, S0{});
         __syncthreads();
       }
     }
+  } else {
+    for (int c = c0; c < c1; ++c) {
+      const int cur = DB ? ((c - c0) & 1) : 0;
+      if (c + 1 < c1) load_chunk(c + 1, S0{});
+      compute_chunk(cur);
+      if constexpr (DB) {
+        // the other buffer was last read in iteration c-1, which every wave left through the barrier below
+        if (c + 1 < c1) store_chunk(cur ^ 1, S0{});
+        __syncthreads();
+      } else {
+        __syncthreads();
+        if (c + 1 < c1) {
+          store_chunk(0, S0{});
+          __syncthreads();
+        }
+      }
+    }
   }
+  }   // PF != 3
 
   // ---- epilogue -----------------------------------------------------------------------------------------
+  PHASE(3);
   const long sbytes = (long)g.B * g.sH * g.sW * N * 4;
   if (a.splitk > 1) {  // raw partial sums; bias / activation happen in splitk_finish_kernel
     const __amdgpu_buffer_rsrc_t rP = make_rsrc(a.part + (long)blockIdx.z * (sbytes / 4), sbytes);
@@ -348,10 +495,15 @@ __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) 
       p[0] = n; p[1] = mean; p[2] = m2;
     }
   }
+#ifdef CTVAE_PHASE_TIMING
+  PHASE(4);
+  __builtin_amdgcn_s_waitcnt(0);   // all counters zero: the stores have retired
+  PHASE(5);
+#endif
 }
 
 template <int WM, int WN, int TM, int TN>
-static int launch_fast_cfg(const TapGemmArgs& a, bool db, hipStream_t st) {
+static int launch_fast_cfg(const TapGemmArgs& a, int pf, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   TapGemmArgs args = a;
   args.mtiles = ceil_div(a.Mc, BM);
@@ -359,7 +511,7 @@ static int launch_fast_cfg(const TapGemmArgs& a, bool db, hipStream_t st) {
   const bool wt = a.g.wT != 0;
   dim3 grid(args.mtiles * args.ntiles, a.g.ncls, a.splitk > 1 ? a.splitk : 1), block(256);
   char name[160];
-  snprintf(name, sizeof name, "tapgemm_fast_kernel<%d,%d,%d,%d,%s,%s>", WM, WN, TM, TN, wt ? "true" : "false", db ? "true" : "false");
+  snprintf(name, sizeof name, "tapgemm_fast_kernel<%d,%d,%d,%d,%s,%d>", WM, WN, TM, TN, wt ? "true" : "false", pf);
   double macs = 0;
   for (int c = 0; c < a.g.ncls; ++c) macs += (double)a.Mc * a.N * a.g.ntaps[c] * a.g.gC;
   if (prof_detailed()) {
@@ -370,20 +522,24 @@ static int launch_fast_cfg(const TapGemmArgs& a, bool db, hipStream_t st) {
   const double bytes = 4.0 * ((double)a.g.B * a.g.gH * a.g.gW * a.g.gC + (double)a.g.B * a.g.sH * a.g.sW * a.g.sC);
   ProfScope ps(name, st, 2.0 * macs, bytes);
   if (!wt) {
-    if (db) hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, false, true>), grid, block, 0, st, args);
-    else hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, false, false>), grid, block, 0, st, args);
+    if (pf == 3) hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, false, 3>), grid, block, 0, st, args);
+    else if (pf == 2) hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, false, 2>), grid, block, 0, st, args);
+    else if (pf == 1) hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, false, 1>), grid, block, 0, st, args);
+    else hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, false, 0>), grid, block, 0, st, args);
   } else {
-    if (db) hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, true, true>), grid, block, 0, st, args);
-    else hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, true, false>), grid, block, 0, st, args);
+    if (pf == 3) hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, true, 3>), grid, block, 0, st, args);
+    else if (pf == 2) hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, true, 2>), grid, block, 0, st, args);
+    else if (pf == 1) hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, true, 1>), grid, block, 0, st, args);
+    else hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, true, 0>), grid, block, 0, st, args);
   }
   CTVAE_LAUNCH_CHECK();
   return 0;
 }
 
-int launch_tapgemm_fast(const TapGemmArgs& a, const TapGemmPlan& plan, bool db, hipStream_t st) {
-  if (plan.BN == 32) return launch_fast_cfg<4, 1, 1, 1>(a, db, st);
-  if (plan.BM == 128) return launch_fast_cfg<2, 2, 2, 1>(a, db, st);
-  return launch_fast_cfg<2, 2, 1, 1>(a, db, st);
+int launch_tapgemm_fast(const TapGemmArgs& a, const TapGemmPlan& plan, int pf, hipStream_t st) {
+  if (plan.BN == 32) return launch_fast_cfg<4, 1, 1, 1>(a, pf, st);
+  if (plan.BM == 128) return launch_fast_cfg<2, 2, 2, 1>(a, pf, st);
+  return launch_fast_cfg<2, 2, 1, 1>(a, pf, st);
 }
 
 }  // namespace ctvae

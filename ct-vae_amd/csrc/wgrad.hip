@@ -392,94 +392,99 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradArgs a, int 
   if (do_bias && n0 + tid < N) a.pbias[(long)(split * g.ncls + cls) * N + n0 + tid] = bsum;
 }
 
-// dst[i] = (accumulate ? dst[i] : 0) + sum_s part[s*stride + i]
-// block = 16 split-lanes x 16 element lanes: every element's S partials are summed by 16 lanes in a fixed
-// order (lane j takes s = j, j+16, ...) and combined by a fixed shuffle tree -> deterministic, and S loads
-// are spread over lanes instead of forming one dependent chain.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ dst,
-                                                              long n, int S, long stride, int accumulate) {
+// dst[i] = (accumulate ? dst[i] : 0) + sum_s part[s*stride + i], for up to two jobs (weights, bias) in ONE launch:
+// blocks [0, nb1) serve job 1, the rest job 2.  Two block shapes, both deterministic (fixed summation order):
+//  * few slices (S <= 8): one thread per float4 / float, a plain pass over the slices;
+//  * many slices: 16 split-lanes x 16 element-lanes; lane j sums s = j, j+16, ... , then a fixed shuffle tree
+//    and a 4-wave LDS combine.  With VEC the element lane covers a float4 (64 elements per block).
+struct ReduceJob {
+  const float* part;
+  float* dst;
+  long n;
+  int S;
+  long stride;
+  int small;   // block shape
+  int vec;     // float4 lanes (n % 4 == 0 and stride % 4 == 0)
+};
+
+template <typename T>
+__device__ __forceinline__ T rzero();
+template <>
+__device__ __forceinline__ float rzero<float>() { return 0.f; }
+template <>
+__device__ __forceinline__ f32x4 rzero<f32x4>() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+template <typename T>
+__device__ __forceinline__ void reduce_small(const ReduceJob& j, int blk, int accumulate) {
+  const long n = j.n / (long)(sizeof(T) / 4), i = (long)blk * 256 + threadIdx.x;
+  if (i >= n) return;
+  T v = accumulate ? reinterpret_cast<const T*>(j.dst)[i] : rzero<T>();
+  for (int s = 0; s < j.S; ++s) v += reinterpret_cast<const T*>(j.part + (long)s * j.stride)[i];
+  reinterpret_cast<T*>(j.dst)[i] = v;
+}
+
+template <typename T>
+__device__ __forceinline__ void reduce_split(const ReduceJob& j, int blk, int accumulate, T (*sm)[16]) {
   const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const long i = (long)blockIdx.x * 16 + el;
-  float v = 0.f;
+  const long n = j.n / (long)(sizeof(T) / 4), i = (long)blk * 16 + el;
+  T v = rzero<T>();
   if (i < n) {
 #pragma unroll 4
-    for (int s = sl; s < S; s += 16) v += part[(long)s * stride + i];
+    for (int s = sl; s < j.S; s += 16) v += reinterpret_cast<const T*>(j.part + (long)s * j.stride)[i];
   }
   // lanes with equal `el` sit 16 apart: xor 16 and 32 inside a wave, then 4 waves through LDS
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  __shared__ float sm[4][16];
+  if constexpr (sizeof(T) == 4) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] += __shfl_xor(v[k], 16, 64);
+      v[k] += __shfl_xor(v[k], 32, 64);
+    }
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane < 16) sm[wave][lane] = v;
   __syncthreads();
   if (threadIdx.x < 16 && i < n) {
-    float t = ((sm[0][el] + sm[1][el]) + sm[2][el]) + sm[3][el];
-    dst[i] = (accumulate ? dst[i] : 0.f) + t;
+    T t = ((sm[0][el] + sm[1][el]) + sm[2][el]) + sm[3][el];
+    T* d = reinterpret_cast<T*>(j.dst) + i;
+    *d = accumulate ? (*d + t) : t;
   }
 }
 
-// few slices: plain element-wise pass (float4 when n % 4 == 0)
-__global__ __launch_bounds__(256) void reduce_partials_small_kernel(const float* __restrict__ part, float* __restrict__ dst,
-                                                                    long n, int S, long stride, int accumulate) {
-  const long gs = (long)gridDim.x * 256;
-  if ((n & 3) == 0 && (stride & 3) == 0) {
-    const long n4 = n >> 2;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += gs) {
-      f32x4 v = accumulate ? reinterpret_cast<const f32x4*>(dst)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int s = 0; s < S; ++s) v += reinterpret_cast<const f32x4*>(part + (long)s * stride)[i];
-      reinterpret_cast<f32x4*>(dst)[i] = v;
-    }
-  } else {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += gs) {
-      float v = accumulate ? dst[i] : 0.f;
-      for (int s = 0; s < S; ++s) v += part[(long)s * stride + i];
-      dst[i] = v;
-    }
-  }
-}
-
-// two reductions (weights and bias) in ONE launch: blocks [0, nb1) do job 1, the rest job 2
-struct ReduceJob { const float* part; float* dst; long n; int S; long stride; };
-__global__ __launch_bounds__(256) void reduce_partials2_kernel(ReduceJob j1, ReduceJob j2, int nb1, int accumulate) {
+__global__ __launch_bounds__(256) void reduce_partials_kernel(ReduceJob j1, ReduceJob j2, int nb1, int accumulate) {
+  __shared__ f32x4 sm[4][16];
   const bool second = (int)blockIdx.x >= nb1;
   const ReduceJob j = second ? j2 : j1;
   const int blk = second ? blockIdx.x - nb1 : blockIdx.x;
-  const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const long i = (long)blk * 16 + el;
-  float v = 0.f;
-  if (i < j.n) {
-#pragma unroll 4
-    for (int s = sl; s < j.S; s += 16) v += j.part[(long)s * j.stride + i];
+  if (j.small) {
+    if (j.vec) reduce_small<f32x4>(j, blk, accumulate);
+    else reduce_small<float>(j, blk, accumulate);
+  } else {
+    if (j.vec) reduce_split<f32x4>(j, blk, accumulate, sm);
+    else reduce_split<float>(j, blk, accumulate, reinterpret_cast<float(*)[16]>(sm));
   }
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  __shared__ float sm[4][16];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane < 16) sm[wave][lane] = v;
-  __syncthreads();
-  if (threadIdx.x < 16 && i < j.n) {
-    float t = ((sm[0][el] + sm[1][el]) + sm[2][el]) + sm[3][el];
-    j.dst[i] = (accumulate ? j.dst[i] : 0.f) + t;
-  }
+}
+
+static int reduce_job_blocks(ReduceJob& j) {
+  if (j.n <= 0 || j.S <= 0) return 0;
+  j.vec = ((j.n & 3) == 0 && (j.stride & 3) == 0 && (((uintptr_t)j.part | (uintptr_t)j.dst) & 15) == 0) ? 1 : 0;
+  j.small = j.S <= 8 ? 1 : 0;
+  const long items = j.vec ? j.n / 4 : j.n;
+  return (int)(j.small ? (items + 255) / 256 : (items + 15) / 16);
 }
 
 static void launch_reduce2(const float* p1, float* d1, long n1, int S1, long st1, const float* p2, float* d2, long n2, int S2,
                            long st2, int accumulate, hipStream_t st) {
-  ReduceJob j1{p1, d1, n1, S1, st1}, j2{p2, d2, n2, S2, st2};
-  const int nb1 = (int)((n1 + 15) / 16), nb2 = (int)((n2 + 15) / 16);
-  hipLaunchKernelGGL(reduce_partials2_kernel, dim3(nb1 + nb2), dim3(256), 0, st, j1, j2, nb1, accumulate);
+  ReduceJob j1{p1, d1, n1, S1, st1, 0, 0}, j2{p2, d2, n2, S2, st2, 0, 0};
+  const int nb1 = reduce_job_blocks(j1), nb2 = reduce_job_blocks(j2);
+  if (nb1 + nb2 == 0) return;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(nb1 + nb2), dim3(256), 0, st, j1, j2, nb1, accumulate);
 }
 
 static void launch_reduce(const float* part, float* dst, long n, int S, long stride, int accumulate, hipStream_t st) {
-  if (S <= 8) {
-    long blocks = ((n + 3) / 4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(reduce_partials_small_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, dst, n, S, stride, accumulate);
-  } else {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, part, dst, n, S, stride,
-                       accumulate);
-  }
+  launch_reduce2(part, dst, n, S, stride, nullptr, nullptr, 0, 0, 0, accumulate, st);
 }
 
 size_t wgrad_workspace_floats(const ConvGeom& g, int S) {

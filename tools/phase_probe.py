@@ -1,0 +1,41 @@
+"""Where does a tap-GEMM launch spend its time?  Needs the diagnostic build:
+    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DCTVAE_PHASE_TIMING -shared ct-vae_amd/csrc/*.hip -o /tmp/libctvae_timing.so
+Prints, per configuration, the mean over workgroups of each phase (us) and the launch span."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from ctvae_amd import native
+native.LIB_PATH = os.environ.get("CTVAE_TIMING_LIB", "/tmp/libctvae_timing.so")
+from ctvae_amd import kernels as K
+
+lib = native.load()
+lib.ctvae_debug_phase_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
+dev = torch.device("cuda")
+B, Co = 256, 128
+for H, ci, k in [(8, 32, 1), (8, 64, 3), (8, 256, 3), (16, 64, 3)]:
+    spec = K.ConvSpec(K.CONV, ci, Co, k, 1, k // 2, 0, K.ACT_LRELU)
+    x = torch.randn(B, H, H, ci, device=dev)
+    w = torch.randn(k, k, ci, Co, device=dev) * 0.05
+    b = torch.randn(Co, device=dev)
+    for _ in range(3):
+        K.conv_forward_raw(x, w, b, spec)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    K.conv_forward_raw(x, w, b, spec)
+    e1.record()
+    torch.cuda.synchronize()
+    nwg = (B * H * H // 64) * (Co // 64)
+    nwg = min(nwg, 8192)
+    buf = np.zeros(8192 * 8, dtype=np.uint64)
+    lib.ctvae_debug_phase_read(buf.ctypes.data, buf.size)
+    t = buf.reshape(8192, 8)[:nwg, :6].astype(np.int64)
+    t0 = t[:, 0].min()
+    rel = (t - t0) / 100.0
+    names = ["entry", "prologue done", "first chunk in LDS", "main loop done", "stores issued", "stores retired"]
+    print(f"H={H} Ci={ci} k={k} chunks={k * k * ci // 32} WGs={nwg}  event-timed launch {e0.elapsed_time(e1) * 1e3:.1f} us, "
+          f"span first entry -> last retire {rel[:, 5].max():.1f} us")
+    for i, n in enumerate(names):
+        d = rel[:, i] - (rel[:, i - 1] if i else 0)
+        print(f"    {n:20s} at mean {rel[:, i].mean():7.2f} (min {rel[:, i].min():6.2f} max {rel[:, i].max():6.2f})   phase mean {d.mean():6.2f} us")
