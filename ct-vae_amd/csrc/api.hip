@@ -7,7 +7,8 @@
 namespace ctvae {
 int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
                    const float* mask, int mask_act, float* S, int act, float* bn_part, float* ws, size_t ws_floats,
-                   hipStream_t st);
+                   hipStream_t st, const BnBwdFuse* bnb = nullptr);
+int tapgemm_bnb_rows(const ConvGeom& g, size_t ws_floats);
 void tapgemm_plan(const ConvGeom& g, size_t ws_floats, TapGemmPlan& p);
 int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, float* dbias, float* ws, size_t ws_bytes,
                  int accumulate, hipStream_t st);
@@ -20,7 +21,7 @@ int launch_bn_finish_forward(const float* y, int R, int C, int nparts, const flo
 size_t bn_workspace_floats(int C, int nparts);
 int launch_bn_backward(const float* ga, const float* beta, const float* y, int R, int C, const float* gamma,
                        const float* save_mean, const float* save_invstd, int act, float* gy, float* dgamma, float* dbeta,
-                       int accumulate, float* ws, size_t ws_bytes, hipStream_t st);
+                       int accumulate, float* ws, size_t ws_bytes, const float* part_in, int part_rows, hipStream_t st);
 int launch_permute(const float* in, float* out, int B, int C, int P, int to_nhwc, hipStream_t st);
 int launch_act_bwd(const float* gout, const float* out, float* gin, long n, int act, hipStream_t st);
 int launch_act_fwd(const float* in, float* out, long n, int act, hipStream_t st);
@@ -111,6 +112,30 @@ int ctvae_conv_dgrad(int kind, const float* dy, const float* w, const float* add
                         (hipStream_t)stream);
 }
 
+int ctvae_conv_dgrad_bn_rows(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
+                             size_t ws_bytes) {
+  if (kind != CTVAE_CONV && kind != CTVAE_CONVT) return 0;
+  ConvGeom g;
+  if (build_geom(g, kind == CTVAE_CONV ? 2 : 3, B, H, W, Ci, Co, k, stride, pad, out_pad)) return 0;
+  return tapgemm_bnb_rows(g, ws_bytes / sizeof(float));
+}
+
+int ctvae_conv_dgrad_bn(int kind, const float* dy, const float* w, const float* add, const float* mask, int mask_act,
+                        float* dx, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
+                        const float* bn_y, const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
+                        const float* bn_beta, int bn_act, float* bn_part, int bn_part_rows, float* ws, size_t ws_bytes,
+                        void* stream) {
+  if (!dy || !w || !dx || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
+  if (!bn_y || !bn_mean || !bn_invstd || !bn_gamma || !bn_beta || !bn_part) return kErrBadArg;
+  ConvGeom g;
+  if (build_geom(g, kind == CTVAE_CONV ? 2 : 3, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
+  const int rows = tapgemm_bnb_rows(g, ws_bytes / sizeof(float));
+  if (rows <= 0 || rows != bn_part_rows) return kErrBadArg;
+  const BnBwdFuse f{bn_y, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_act, bn_part};
+  return launch_tapgemm(g, dy, w, nullptr, add, mask, mask_act, dx, ACT_NONE, nullptr, ws, ws_bytes / sizeof(float),
+                        (hipStream_t)stream, &f);
+}
+
 int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float* dbias, int B, int H, int W, int Ci,
                      int Co, int k, int stride, int pad, int out_pad, int accumulate, float* ws, size_t ws_bytes,
                      void* stream) {
@@ -133,10 +158,12 @@ int ctvae_bn_forward(const float* y, int R, int C, const float* gamma, const flo
 
 int ctvae_bn_backward(const float* g_a, const float* beta, const float* y, int R, int C, const float* gamma,
                       const float* save_mean, const float* save_invstd, int act, float* g_y, float* dgamma,
-                      float* dbeta, int accumulate, float* ws, size_t ws_bytes, void* stream) {
+                      float* dbeta, int accumulate, const float* part_in, int part_rows, float* ws, size_t ws_bytes,
+                      void* stream) {
   if (!g_a || !beta || !y || !gamma || !save_mean || !save_invstd || !g_y || !dgamma || !dbeta || !ws) return kErrBadArg;
+  if ((part_in != nullptr) != (part_rows > 0)) return kErrBadArg;
   return launch_bn_backward(g_a, beta, y, R, C, gamma, save_mean, save_invstd, act, g_y, dgamma, dbeta, accumulate, ws,
-                            ws_bytes, (hipStream_t)stream);
+                            ws_bytes, part_in, part_rows, (hipStream_t)stream);
 }
 
 int ctvae_permute(const float* in, float* out, int B, int C, int P, int to_nhwc, void* stream) {

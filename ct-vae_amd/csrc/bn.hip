@@ -354,16 +354,20 @@ int launch_bn_forward(const float* y, int R, int C, const float* gamma, const fl
 
 int launch_bn_backward(const float* ga, const float* beta, const float* y, int R, int C, const float* gamma,
                        const float* save_mean, const float* save_invstd, int act, float* gy, float* dgamma,
-                       float* dbeta, int accumulate, float* ws, size_t ws_bytes, hipStream_t st) {
+                       float* dbeta, int accumulate, float* ws, size_t ws_bytes, const float* part_in, int part_rows,
+                       hipStream_t st) {
   if (!bn_shape_ok(R, C)) return kErrBadArg;
   if (ws_bytes / sizeof(float) < bn_workspace_floats(C, 0)) return kErrWorkspace;
-  float* part = ws;
+  const float* part = ws;
   float* coef = ws + (size_t)kBnMaxBlocks * C * 3;
   int rpb;
-  const int nb = stat_blocks(R, C, &rpb);
-  {
+  int nb = stat_blocks(R, C, &rpb);
+  if (part_in != nullptr && part_rows > 0) {   // sums already emitted per tile by the dgrad that produced ga
+    part = part_in;
+    nb = part_rows;
+  } else {
     ProfScope ps("bn_bwd_partial_kernel", st, 0.0, 8.0 * (double)R * C);
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb), dim3(256), 0, st, ga, gamma, beta, y, save_mean, save_invstd, part, R,
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb), dim3(256), 0, st, ga, gamma, beta, y, save_mean, save_invstd, ws, R,
                        C, rpb, act);
   }
   CTVAE_LAUNCH_CHECK();

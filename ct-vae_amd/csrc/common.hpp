@@ -59,6 +59,17 @@ __device__ __forceinline__ float block_sum_256(float v, float* sm /* >=4 floats 
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// BatchNorm(+activation) layer whose output gradient a dgrad launch produces (fused backward sums)
+struct BnBwdFuse {
+  const float* y;
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+  int act;
+  float* part;   // [rows][C][2], rows = tapgemm_bnb_rows()
+};
+
 struct TapGemmPlan {
   int BM, BN, mtiles, ntiles, splitk;
   int thin;      // 1: VALU thin-layer kernels (thin.hip) instead of the MFMA tile kernel

@@ -391,8 +391,38 @@ __global__ __launch_bounds__(256) void tapgemm_masked_kernel(const TapGemmArgs a
               if (a.mask != nullptr) v *= act_bwd_from_out(a.mask[idx], a.mask_act);
             }
             a.S[idx] = v;
+            if (a.bnb_part != nullptr) acc[i][j][4 * q4 + q] = v;   // the stored gradient, for the BN-backward sums
           }
         }
+      }
+    }
+    // ---- fused BatchNorm-backward sums (see TapGemmArgs::bnb_*) ----
+    if (a.bnb_part != nullptr) {
+      const float bmean = cok ? a.bnb_mean[col] : 0.f, binv = cok ? a.bnb_invstd[col] : 0.f;
+      const float bgm = cok ? a.bnb_gamma[col] : 0.f, bbt = cok ? a.bnb_beta[col] : 0.f;
+      float s1b = 0.f, s2b = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float yv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int sp = sOut[(wm * TM + i) * 32 + 8 * (r >> 2) + 4 * lh + (r & 3)];
+          yv[r] = (sp >= 0 && cok) ? a.bnb_y[(unsigned)sp * (unsigned)N + (unsigned)col] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int sp = sOut[(wm * TM + i) * 32 + 8 * (r >> 2) + 4 * lh + (r & 3)];
+          const float xh = (yv[r] - bmean) * binv;
+          const float gp = (sp >= 0 && cok) ? acc[i][j][r] * act_bwd_from_out(act_fwd(bgm * xh + bbt, a.bnb_act), a.bnb_act) : 0.f;
+          s1b += gp;
+          s2b += gp * xh;
+        }
+      }
+      s1b += __shfl_xor(s1b, 32, 64);
+      s2b += __shfl_xor(s2b, 32, 64);
+      if (lh == 0) {
+        float* st = &sAbuf[(wm * BN + (wn * TN + j) * 32 + li) * 2];
+        st[0] = s1b; st[1] = s2b;
       }
     }
     // ---- fused BatchNorm statistics of this tile (train-mode BN follows the conv: vanilla_vae.py:28-31) ----
@@ -443,6 +473,19 @@ __global__ __launch_bounds__(256) void tapgemm_masked_kernel(const TapGemmArgs a
       }
       float* p = a.bn_part + ((long)(cls * a.mtiles + mt) * N + n0 + tid) * 3;
       p[0] = n; p[1] = mean; p[2] = m2;
+    }
+  }
+  if (a.bnb_part != nullptr) {
+    __syncthreads();
+    if (tid < BN && n0 + tid < N) {
+      float s1b = 0.f, s2b = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        s1b += sAbuf[(w * BN + tid) * 2];
+        s2b += sAbuf[(w * BN + tid) * 2 + 1];
+      }
+      float* p = a.bnb_part + ((long)(cls * a.mtiles + mt) * N + n0 + tid) * 2;
+      p[0] = s1b; p[1] = s2b;
     }
   }
 }
@@ -549,11 +592,24 @@ void tapgemm_plan(const ConvGeom& g, size_t ws_floats, TapGemmPlan& p) {
   p.bn_parts = p.mtiles * g.ncls;
 }
 
+// rows of the fused BN-backward partial table a dgrad launch of this geometry writes (0: this configuration cannot
+// fuse -- split-K keeps its epilogue in splitk_finish_kernel, the thin path has none)
+int tapgemm_bnb_rows(const ConvGeom& g, size_t ws_floats) {
+  TapGemmPlan plan;
+  tapgemm_plan(g, ws_floats, plan);
+  if (plan.thin || plan.splitk > 1) return 0;
+  return plan.bn_parts;
+}
+
 int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
                    const float* mask, int mask_act, float* S, int act, float* bn_part, float* ws, size_t ws_floats,
-                   hipStream_t st) {
+                   hipStream_t st, const BnBwdFuse* bnb) {
   TapGemmArgs a{};
   a.bn_part = bn_part;
+  if (bnb != nullptr && bnb->part != nullptr) {
+    a.bnb_y = bnb->y; a.bnb_mean = bnb->mean; a.bnb_invstd = bnb->invstd; a.bnb_gamma = bnb->gamma; a.bnb_beta = bnb->beta;
+    a.bnb_act = bnb->act; a.bnb_part = bnb->part;
+  }
   a.g = g;
   a.G = G; a.W = W; a.bias = bias; a.add = add; a.mask = mask; a.S = S;
   a.act = act; a.mask_act = mask_act;
@@ -583,6 +639,7 @@ int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const floa
   // tile choice: N<=32 -> 128x32 (4x1 waves); big problems -> 128x64; small M -> 64x64 (+ split-K when the grid is small)
   TapGemmPlan plan;
   tapgemm_plan(g, ws != nullptr ? ws_floats : 0, plan);
+  if (a.bnb_part != nullptr && (plan.thin || plan.splitk > 1)) return kErrBadArg;   // see tapgemm_bnb_rows()
   if (plan.thin) return launch_thin_forward(g, G, W, bias, add, mask, mask_act, S, act, bn_part, st);
   a.splitk = plan.splitk;
   a.part = ws;

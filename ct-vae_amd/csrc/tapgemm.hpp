@@ -14,6 +14,16 @@ struct TapGemmArgs {
   const float* mask;
   float* S;
   float* bn_part;  // optional [ncls*mtiles][N][3] per-tile (count, mean, M2) of the pre-activation output
+  // optional: S is the gradient w.r.t. the OUTPUT a = act(BN(y)) of a BatchNorm layer -> the epilogue also emits that
+  // layer's backward sums per tile, bnb_part[ncls*mtiles][N][2] = (sum g', sum g'*xhat), g' = S*act'(gamma*xhat+beta),
+  // xhat = (y-mean)*invstd: the separate pass over (g_a, y) of bn.hip:bn_bwd_partial_kernel is not needed then
+  const float* bnb_y;
+  const float* bnb_mean;
+  const float* bnb_invstd;
+  const float* bnb_gamma;
+  const float* bnb_beta;
+  float* bnb_part;
+  int bnb_act;
   float* part;     // split-K partial sums [splitk][B*sH*sW][N] (raw accumulators), used when splitk > 1
   int splitk;
   int lgQw, lgQhw; // log2(Qw), log2(Qh*Qw) when both are powers of two, else -1 (generic division)

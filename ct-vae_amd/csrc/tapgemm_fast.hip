@@ -393,6 +393,8 @@ __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) 
   const __amdgpu_buffer_rsrc_t rS = make_rsrc(a.S, sbytes);
   const __amdgpu_buffer_rsrc_t rAdd = make_rsrc(a.add, a.add != nullptr ? sbytes : 0);
   const __amdgpu_buffer_rsrc_t rMask = make_rsrc(a.mask, a.mask != nullptr ? sbytes : 0);
+  const bool bnb = a.bnb_part != nullptr;
+  const __amdgpu_buffer_rsrc_t rY = make_rsrc(a.bnb_y, bnb ? sbytes : 0);
   const bool full_m = (m0 + BM <= a.Mc);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -436,7 +438,54 @@ __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) 
             else if (a.mask_act == ACT_TANH) v *= 1.f - mk * mk;
           }
           buf_store1(rS, voff[q], v);
+          if (bnb) acc[i][j][4 * q4 + q] = v;            // the stored gradient, for the BN-backward sums below
         }
+      }
+    }
+    // ---- fused BatchNorm-backward sums: S is d/d(act(BN(y))) of the producing layer -------------------------
+    if (bnb) {
+      float yv[TM][16];
+      bool okv[TM][16];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int row0 = (wm * TM + i) * 32 + 8 * q4 + 4 * lh;
+          unsigned voff[4];
+          if (dense) {
+            const unsigned base = ((unsigned)(m0 + row0) * (unsigned)N + (unsigned)col) * 4u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) voff[q] = (cok && (full_m || m0 + row0 + q < a.Mc)) ? base + (unsigned)(q * N) * 4u : kOOB;
+          } else {
+            const int4 t = *reinterpret_cast<const int4*>(&sOut[row0]);
+            const int sp4[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              voff[q] = (cok && sp4[q] >= 0) ? ((unsigned)sp4[q] * (unsigned)N + (unsigned)col) * 4u : kOOB;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            yv[i][4 * q4 + q] = buf_load1(rY, voff[q]);
+            okv[i][4 * q4 + q] = voff[q] != kOOB;
+          }
+        }
+      const float bmean = cok ? a.bnb_mean[col] : 0.f, binv = cok ? a.bnb_invstd[col] : 0.f;
+      const float bgm = cok ? a.bnb_gamma[col] : 0.f, bbt = cok ? a.bnb_beta[col] : 0.f;
+      float s1b = 0.f, s2b = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float xh = (yv[i][r] - bmean) * binv;
+          const float gp = okv[i][r] ? acc[i][j][r] * act_bwd_from_out(act_fwd(bgm * xh + bbt, a.bnb_act), a.bnb_act) : 0.f;
+          s1b += gp;
+          s2b += gp * xh;
+        }
+      s1b += __shfl_xor(s1b, 32, 64);
+      s2b += __shfl_xor(s2b, 32, 64);
+      if (lh == 0) {  // the A buffer is free after the main loop
+        float* st = &sAbuf[(wm * BN + (wn * TN + j) * 32 + li) * 2];
+        st[0] = s1b; st[1] = s2b;
       }
     }
     // ---- fused BatchNorm statistics of this tile (train-mode BN follows the conv: vanilla_vae.py:28-31) ----
@@ -493,6 +542,19 @@ __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) 
       }
       float* p = a.bn_part + ((long)(cls * a.mtiles + mt) * N + n0 + tid) * 3;
       p[0] = n; p[1] = mean; p[2] = m2;
+    }
+  }
+  if (bnb) {
+    __syncthreads();
+    if (tid < BN && n0 + tid < N) {
+      float s1b = 0.f, s2b = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {   // fixed order -> deterministic
+        s1b += sAbuf[(w * BN + tid) * 2];
+        s2b += sAbuf[(w * BN + tid) * 2 + 1];
+      }
+      float* p = a.bnb_part + ((long)(cls * a.mtiles + mt) * N + n0 + tid) * 2;
+      p[0] = s1b; p[1] = s2b;
     }
   }
 #ifdef CTVAE_PHASE_TIMING

@@ -88,6 +88,74 @@ def conv_dgrad_raw(dy, w, spec: ConvSpec, in_hw, add=None, mask=None, mask_act=A
     return dx
 
 
+class BNLink:
+    """Hand-over between a train-mode ConvBNAct layer and the layer that consumes its output ``a``.
+
+    The consumer's data-gradient kernel produces g_a; given the BatchNorm's y/mean/invstd/gamma/beta it also emits the
+    per-tile backward sums (ctvae_conv_dgrad_bn), which the BatchNorm's own backward then takes instead of running a
+    separate pass over (g_a, y).  The sums are only used when the gradient tensor that arrives is exactly the one the
+    dgrad wrote (same storage pointer, same version counter): if autograd summed several contributions, or anything
+    modified it in place, the BatchNorm falls back to its own pass."""
+    __slots__ = ("y", "mean", "invstd", "gamma", "beta", "act", "part", "rows", "g_ptr", "g_ver", "g_shape")
+
+    def __init__(self, y, mean, invstd, gamma, beta, act):
+        self.y, self.mean, self.invstd, self.gamma, self.beta, self.act = y, mean, invstd, gamma, beta, act
+        self.part = None
+        self.rows = 0
+        self.g_ptr = self.g_ver = self.g_shape = None
+
+    def publish(self, g, part, rows):
+        self.part, self.rows = part, rows
+        self.g_ptr, self.g_ver, self.g_shape = g.data_ptr(), g._version, tuple(g.shape)
+
+    def take(self, g):
+        """(part, rows) when ``g`` is the tensor the sums were computed for, else (None, 0).  One use only."""
+        part, rows = self.part, self.rows
+        self.part, self.rows = None, 0
+        if part is None or g.data_ptr() != self.g_ptr or g._version != self.g_ver or tuple(g.shape) != self.g_shape:
+            return None, 0
+        return part, rows
+
+
+_last_link = None     # set by ConvBNAct.forward, picked up by the caller of .apply (models/blocks.py) right after
+
+
+def pop_bn_link():
+    global _last_link
+    link, _last_link = _last_link, None
+    return link
+
+
+def link_of(x):
+    """BNLink of a tensor that is the untouched, contiguous output of a train-mode ConvBNAct (else None)."""
+    link = getattr(x, "_ctvae_bn_link", None)
+    return link if (link is not None and x.is_contiguous()) else None
+
+
+_bn_rows_cache = {}
+
+
+def conv_dgrad_bn_raw(dy, w, spec: ConvSpec, in_hw, link: BNLink):
+    """dgrad + fused BatchNorm-backward sums of the layer that produced this layer's input; None if not fusable."""
+    B = dy.shape[0]
+    H, W = in_hw
+    ws = native.workspace(dy.device)
+    key = (spec.kind, B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, ws.numel())
+    rows = _bn_rows_cache.get(key)
+    if rows is None:
+        rows = _bn_rows_cache[key] = native.load().ctvae_conv_dgrad_bn_rows(*key[:-1], ws.numel() * 4)
+    if rows <= 0 or tuple(link.y.shape) != (B, H, W, spec.ci):
+        return None
+    dx = torch.empty((B, H, W, spec.ci), dtype=torch.float32, device=dy.device)
+    part = torch.empty(rows * spec.ci * 2, dtype=torch.float32, device=dy.device)
+    native.call("ctvae_conv_dgrad_bn", spec.kind, dy.data_ptr(), w.data_ptr(), None, None, ACT_NONE, dx.data_ptr(),
+                B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, link.y.data_ptr(),
+                link.mean.data_ptr(), link.invstd.data_ptr(), link.gamma.data_ptr(), link.beta.data_ptr(), link.act,
+                part.data_ptr(), rows, ws.data_ptr(), ws.numel() * 4)
+    link.publish(dx, part, rows)
+    return dx
+
+
 def conv_wgrad_raw(x, dy, w_param, b_param, spec: ConvSpec):
     B, H, W, _ = x.shape
     ws = native.workspace(x.device)
@@ -105,13 +173,19 @@ def conv_wgrad_raw(x, dy, w_param, b_param, spec: ConvSpec):
                 B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, acc, ws.data_ptr(), ws.numel() * 4)
 
 
-def wgrad_then_dgrad(x, g, w_param, b_param, spec, need_dgrad):
+def wgrad_then_dgrad(x, g, w_param, b_param, spec, need_dgrad, link=None):
     """Weight gradient (accumulated straight into ``.grad``) and data gradient of one layer, on the launch stream.
     Measured on MI355X: putting the wgrad kernels on a second HIP stream (joined right after dgrad, or once at the
     end of backward) is SLOWER than back-to-back launches (2.43 vs 2.32 ms/step) -- each GEMM launch already covers
     every CU, and the fork/join edges cost more than the overlap of prologue/epilogue phases returns."""
     conv_wgrad_raw(x, g, w_param, b_param, spec)
-    return conv_dgrad_raw(g, w_param, spec, (x.shape[1], x.shape[2])) if need_dgrad else None
+    if not need_dgrad:
+        return None
+    if link is not None:
+        dx = conv_dgrad_bn_raw(g, w_param, spec, (x.shape[1], x.shape[2]), link)
+        if dx is not None:
+            return dx
+    return conv_dgrad_raw(g, w_param, spec, (x.shape[1], x.shape[2]))
 
 
 def act_backward_raw(g_out, out, act):
@@ -187,6 +261,7 @@ class ConvAct(Function):
     @staticmethod
     def forward(ctx, x, w, b, add, spec):
         _req_cuda(x, w)
+        ctx.link_in = link_of(x)
         x = _c(x)
         add_c = _c(add) if add is not None else None
         y = conv_forward_raw(x, w, b, spec, add_c)
@@ -202,7 +277,7 @@ class ConvAct(Function):
         x, y = ctx.saved_tensors
         g_y = _c(g_y)
         g_pre = act_backward_raw(g_y, y, spec.act) if spec.act != ACT_NONE else g_y
-        g_x = wgrad_then_dgrad(x, g_pre, ctx.w, ctx.b, spec, ctx.needs_input_grad[0])
+        g_x = wgrad_then_dgrad(x, g_pre, ctx.w, ctx.b, spec, ctx.needs_input_grad[0], ctx.link_in)
         g_add = g_pre if (ctx.has_add and ctx.needs_input_grad[3]) else None
         return g_x, None, None, g_add, None
 
@@ -212,7 +287,9 @@ class ConvBNAct(Function):
 
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, training, spec, bn_act, num_batches_tracked=None):
+        global _last_link
         _req_cuda(x, w, gamma)
+        ctx.link_in = link_of(x)
         x = _c(x)
         B, H, W, _ = x.shape
         ho, wo = spec.out_hw(H, W)
@@ -229,6 +306,7 @@ class ConvBNAct(Function):
         ctx.spec, ctx.bn_act, ctx.training = spec, bn_act, training
         ctx.params = (w, b, gamma, beta)
         ctx.save_for_backward(x, y, a, save_mean, save_invstd)
+        ctx.link_out = _last_link = BNLink(y, save_mean, save_invstd, gamma, beta, bn_act) if training else None
         return a
 
     @staticmethod
@@ -247,10 +325,11 @@ class ConvBNAct(Function):
         if accg != accb:
             (gg if accg == 0 else gbt).zero_()
             accg = 1
+        part, rows = ctx.link_out.take(g_a) if ctx.link_out is not None else (None, 0)
         native.call("ctvae_bn_backward", g_a.data_ptr(), beta.data_ptr(), y.data_ptr(), B * H * W, C, gamma.data_ptr(),
                     save_mean.data_ptr(), save_invstd.data_ptr(), ctx.bn_act, g_y.data_ptr(), gg.data_ptr(), gbt.data_ptr(),
-                    accg, ws.data_ptr(), ws.numel() * 4)
-        g_x = wgrad_then_dgrad(x, g_y, w, b, spec, ctx.needs_input_grad[0])
+                    accg, native.ptr(part), rows, ws.data_ptr(), ws.numel() * 4)
+        g_x = wgrad_then_dgrad(x, g_y, w, b, spec, ctx.needs_input_grad[0], ctx.link_in)
         return (g_x,) + (None,) * 10
 
 

@@ -11,8 +11,12 @@ from .packing import PackedBN, PackedConv
 def conv_bn_leaky(x, conv, bn, spec, training):
     """Conv (+bias) -> train/eval BatchNorm2d -> LeakyReLU on the holders `conv` / `bn`."""
     # num_batches_tracked is advanced by the finalize kernel (no separate launch)
-    return K.ConvBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                             training, spec, K.ACT_LRELU, bn.num_batches_tracked)
+    a = K.ConvBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                          training, spec, K.ACT_LRELU, bn.num_batches_tracked)
+    link = K.pop_bn_link()
+    if link is not None:
+        a._ctvae_bn_link = link     # lets the consumer's dgrad emit this BatchNorm's backward sums (kernels.BNLink)
+    return a
 
 
 class ConvBNLeaky(nn.Module):

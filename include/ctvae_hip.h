@@ -59,6 +59,20 @@ int ctvae_conv_dgrad(int kind, const float* dy, const float* w, const float* add
                      float* dx, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, float* ws,
                      size_t ws_bytes, void* stream);
 
+/* ctvae_conv_dgrad whose result dx is the gradient w.r.t. a = act(BN(y)), the output of a train-mode BatchNorm2d
+ * (+activation) that fed this layer (autograd of vanilla_vae.py:28-31 chained into the next block).  The epilogue
+ * also emits, per output tile, that BatchNorm's backward sums (sum g', sum g'*xhat; g' = dx*act'(gamma*xhat+beta),
+ * xhat = (y-mean)*invstd) into bn_part [bn_part_rows][Ci][2], which ctvae_bn_backward takes as part_in: one pass
+ * over (g_a, y) less.  bn_part_rows must equal ctvae_conv_dgrad_bn_rows() of the same geometry and workspace; that
+ * function returns 0 when the launch configuration cannot fuse (split-K), then use ctvae_conv_dgrad. */
+int ctvae_conv_dgrad_bn_rows(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
+                             size_t ws_bytes);
+int ctvae_conv_dgrad_bn(int kind, const float* dy, const float* w, const float* add, const float* mask, int mask_act,
+                        float* dx, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
+                        const float* bn_y, const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
+                        const float* bn_beta, int bn_act, float* bn_part, int bn_part_rows, float* ws, size_t ws_bytes,
+                        void* stream);
+
 /* dw (+)= wgrad(x, dy);  dbias (+)= sum over pixels of dy (dbias may be NULL).  Deterministic two-pass. */
 int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float* dbias, int B, int H, int W, int Ci,
                      int Co, int k, int stride, int pad, int out_pad, int accumulate, float* ws, size_t ws_bytes,
@@ -73,10 +87,12 @@ int ctvae_bn_forward(const float* y, int R, int C, const float* gamma, const flo
                      float* save_mean, float* save_invstd, int64_t* num_batches_tracked, float* ws, size_t ws_bytes,
                      void* stream);
 /* g_y from g_a (grad wrt the activated output); the activation derivative is re-derived from the sign of
- * gamma*invstd*(y-mean)+beta, so the activated tensor is not read; dgamma/dbeta (+)= ... */
+ * gamma*invstd*(y-mean)+beta, so the activated tensor is not read; dgamma/dbeta (+)= ...
+ * part_in/part_rows: the per-tile sums a ctvae_conv_dgrad_bn launch emitted for this g_a (NULL/0: computed here). */
 int ctvae_bn_backward(const float* g_a, const float* beta, const float* y, int R, int C, const float* gamma,
                       const float* save_mean, const float* save_invstd, int act, float* g_y, float* dgamma,
-                      float* dbeta, int accumulate, float* ws, size_t ws_bytes, void* stream);
+                      float* dbeta, int accumulate, const float* part_in, int part_rows, float* ws, size_t ws_bytes,
+                      void* stream);
 
 /* layout change at the NCHW API boundary: to_nhwc=1: in [B,C,P] -> out [B,P,C]; 0: the inverse
  * (torch.flatten on NCHW, vanilla_vae.py:85; .view(-1,512,2,2), vanilla_vae.py:102) */

@@ -176,3 +176,91 @@ def test_adam_matches_torch(K):
     torch.cuda.synchronize()
     np.testing.assert_allclose(pd.cpu().numpy(), ref.detach().numpy(), atol=2e-6, rtol=1e-5)
     assert state[0].item() == 4.0
+
+
+@pytest.mark.parametrize("transposed,B,H", [(False, 32, 32), (True, 128, 16), (False, 4, 16), (True, 3, 8)])
+def test_bn_backward_sums_fused_into_dgrad(K, transposed, B, H):
+    """Two chained ConvBNAct blocks: the second block's dgrad emits the first BatchNorm's backward sums
+    (ctvae_conv_dgrad_bn).  All gradients against torch autograd, and the fused path must really have run."""
+    from ctvae_amd import native
+    from ctvae_amd.models import blocks
+    g = torch.Generator().manual_seed(31 + B)
+    C0, C1, C2 = 32, 64, 32
+    x = torch.randn(B, C0, H, H, generator=g).requires_grad_(True)
+    mk = lambda ci, co: (torch.randn((ci, co, 3, 3) if transposed else (co, ci, 3, 3), generator=g) / (ci * 9) ** 0.5).requires_grad_(True)
+    w1, w2 = mk(C0, C1), mk(C1, C2)
+    b1, b2 = torch.randn(C1, generator=g).requires_grad_(True), torch.randn(C2, generator=g).requires_grad_(True)
+    gm1, bt1 = (torch.rand(C1, generator=g) + 0.5).requires_grad_(True), (torch.rand(C1, generator=g) - 0.5).requires_grad_(True)
+    gm2, bt2 = (torch.rand(C2, generator=g) + 0.5).requires_grad_(True), (torch.rand(C2, generator=g) - 0.5).requires_grad_(True)
+
+    def conv(t, w, b):
+        return F.conv_transpose2d(t, w, b, stride=2, padding=1, output_padding=1) if transposed else F.conv2d(t, w, b, stride=1, padding=1)
+
+    def bn(t, gm, bt):
+        C = t.shape[1]
+        return F.leaky_relu(F.batch_norm(t, torch.zeros(C), torch.ones(C), gm, bt, True, 0.1, 1e-5), 0.01)
+
+    out = bn(conv(bn(conv(x, w1, b1), gm1, bt1), w2, b2), gm2, bt2)
+    go = torch.randn(out.shape, generator=g)
+    out.backward(go)
+
+    dev = torch.device("cuda")
+    kind = K.CONVT if transposed else K.CONV
+    s, op = (2, 1) if transposed else (1, 0)
+    sp1 = K.ConvSpec(kind, C0, C1, 3, s, 1, op, K.ACT_NONE)
+    sp2 = K.ConvSpec(kind, C1, C2, 3, s, 1, op, K.ACT_NONE)
+
+    class Holder:
+        pass
+
+    def mkconv(w, b):
+        h = Holder()
+        h.weight, h.bias = as_param(pack(w.detach(), transposed).to(dev), transposed), torch.nn.Parameter(b.detach().to(dev))
+        return h
+
+    def mkbn(gm, bt):
+        h = Holder()
+        C = gm.numel()
+        h.weight, h.bias = torch.nn.Parameter(gm.detach().to(dev)), torch.nn.Parameter(bt.detach().to(dev))
+        h.running_mean, h.running_var = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        h.num_batches_tracked = torch.zeros((), dtype=torch.long, device=dev)
+        return h
+
+    def run(fused):
+        c1, c2, n1, n2 = mkconv(w1, b1), mkconv(w2, b2), mkbn(gm1, bt1), mkbn(gm2, bt2)
+        xd = x.detach().permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+        a1 = blocks.conv_bn_leaky(xd, c1, n1, sp1, True)
+        assert hasattr(a1, "_ctvae_bn_link")
+        if not fused:
+            del a1._ctvae_bn_link
+        a2 = blocks.conv_bn_leaky(a1, c2, n2, sp2, True)
+        native.prof_enable(True)
+        a2.backward(go.permute(0, 2, 3, 1).contiguous().to(dev))
+        torch.cuda.synchronize()
+        native.prof_enable(False)
+        rep = native.prof_report()
+        return xd.grad, c1, c2, n1, n2, rep
+
+    gx_f, c1, c2, n1, n2, rep_f = run(True)
+    gx_u, *_rest, rep_u = run(False)
+    ws = native.workspace(dev)
+    Hin = H * 2 if transposed else H          # input size of the second block
+    rows = native.load().ctvae_conv_dgrad_bn_rows(kind, B, Hin, Hin, C1, C2, 3, s, 1, op, ws.numel() * 4)
+    if B >= 32:
+        assert rows > 0, "this shape is expected to take the fused path"
+    assert rep_u["bn_bwd_partial_kernel"]["count"] == 2
+    assert rep_f["bn_bwd_partial_kernel"]["count"] == (1 if rows > 0 else 2), "fused BN-backward sums not used as planned"
+    ref = x.grad.permute(0, 2, 3, 1).numpy()
+    sc = max(1.0, float(np.abs(ref).max()))
+    # fused vs separate pass: same signs of the LeakyReLU arguments on both sides -> strict
+    np.testing.assert_allclose(gx_f.cpu().numpy(), gx_u.cpu().numpy(), atol=TOL * sc, rtol=1e-3)
+    # vs torch CPU: a pre-activation within rounding of 0 may take the other LeakyReLU slope (x100 on that element's
+    # gradient, spread over its 3x3 neighbourhood by the dgrad) -> allow a vanishing fraction of outliers
+    bad = np.abs(gx_f.cpu().numpy() - ref) > 2 * TOL * sc + 1e-3 * np.abs(ref)
+    assert bad.mean() < 5e-4, f"{bad.sum()} of {bad.size} elements differ"
+    # parameter gradients sum over up to 5e5 pixels, so one flipped slope moves them visibly: relative L2 error
+    for got, want in ((n1.weight.grad, gm1.grad), (n1.bias.grad, bt1.grad), (n2.weight.grad, gm2.grad), (n2.bias.grad, bt2.grad),
+                      (c1.weight.grad, w1.grad), (c2.weight.grad, w2.grad)):
+        err = float((got.cpu() - want).norm() / want.norm())
+        assert err < 2e-3, err
+    # (conv biases in front of train-mode BN have an analytically zero gradient -- pure summation noise, not compared)
