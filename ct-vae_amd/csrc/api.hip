@@ -7,17 +7,21 @@
 namespace ctvae {
 int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
                    const float* mask, int mask_act, float* S, int act, float* bn_part, float* ws, size_t ws_floats,
-                   hipStream_t st, const BnBwdFuse* bnb = nullptr);
+                   hipStream_t st, const BnBwdFuse* bnb = nullptr, const InXform* xf = nullptr);
+bool thin_forward_supported(const ConvGeom& g);
+bool thin_wgrad_supported(const ConvGeom& g);
 int tapgemm_bnb_rows(const ConvGeom& g, size_t ws_floats);
 void tapgemm_plan(const ConvGeom& g, size_t ws_floats, TapGemmPlan& p);
 int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, float* dbias, float* ws, size_t ws_bytes,
-                 int accumulate, hipStream_t st);
+                 int accumulate, hipStream_t st, const InXform* xf = nullptr);
 int launch_bn_forward(const float* y, int R, int C, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, float momentum, float eps, int training, int act, float* out, float* save_mean,
-                      float* save_invstd, float* ws, size_t ws_bytes, long long* nbt, hipStream_t st);
+                      float* save_invstd, float* ws, size_t ws_bytes, long long* nbt, hipStream_t st,
+                      float* coef_out = nullptr);
 int launch_bn_finish_forward(const float* y, int R, int C, int nparts, const float* gamma, const float* beta,
                              float* running_mean, float* running_var, float momentum, float eps, int training, int act,
-                             float* out, float* save_mean, float* save_invstd, float* ws, long long* nbt, hipStream_t st);
+                             float* out, float* save_mean, float* save_invstd, float* ws, long long* nbt, hipStream_t st,
+                             float* coef_out = nullptr);
 size_t bn_workspace_floats(int C, int nparts);
 int launch_bn_backward(const float* ga, const float* beta, const float* y, int R, int C, const float* gamma,
                        const float* save_mean, const float* save_invstd, int act, float* gy, float* dgamma, float* dbeta,
@@ -63,21 +67,33 @@ const char* ctvae_error_string(int code) {
 size_t ctvae_workspace_bytes(void) { return (size_t)256 << 20; }
 
 int ctvae_conv_forward(int kind, const float* x, const float* w, const float* bias, const float* add, float* y, int B,
-                       int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int act, float* ws,
-                       size_t ws_bytes, void* stream) {
+                       int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int act, const float* in_scale,
+                       const float* in_shift, int in_act, float* ws, size_t ws_bytes, void* stream) {
   if (!x || !w || !y || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
+  if ((in_scale != nullptr) != (in_shift != nullptr)) return kErrBadArg;
   ConvGeom g;
   if (build_geom(g, kind == CTVAE_CONV ? 0 : 1, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
-  return launch_tapgemm(g, x, w, bias, add, nullptr, 0, y, act, nullptr, ws, ws_bytes / sizeof(float), (hipStream_t)stream);
+  const InXform xf{in_scale, in_shift, in_act};
+  return launch_tapgemm(g, x, w, bias, add, nullptr, 0, y, act, nullptr, ws, ws_bytes / sizeof(float), (hipStream_t)stream,
+                        nullptr, &xf);
+}
+
+int ctvae_conv_input_transform_supported(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad,
+                                         int out_pad) {
+  if (kind != CTVAE_CONV && kind != CTVAE_CONVT) return 0;
+  ConvGeom g;
+  if (build_geom(g, kind == CTVAE_CONV ? 0 : 1, B, H, W, Ci, Co, k, stride, pad, out_pad)) return 0;
+  return (thin_forward_supported(g) && thin_wgrad_supported(g)) ? 1 : 0;
 }
 
 int ctvae_conv_bn_act_forward(int kind, const float* x, const float* w, const float* bias, const float* gamma,
                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                               int training, int act, float* y, float* a_out, float* save_mean, float* save_invstd,
-                              int64_t* num_batches_tracked, int B, int H, int W, int Ci, int Co, int k, int stride, int pad,
-                              int out_pad, float* ws, size_t ws_bytes, void* stream) {
+                              float* scale_shift_out, int64_t* num_batches_tracked, int B, int H, int W, int Ci, int Co, int k,
+                              int stride, int pad, int out_pad, float* ws, size_t ws_bytes, void* stream) {
   long long* nbt = (long long*)num_batches_tracked;
-  if (!x || !w || !gamma || !beta || !y || !a_out || !ws || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
+  if (!x || !w || !gamma || !beta || !y || !ws || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
+  if (!a_out && !scale_shift_out) return kErrBadArg;   // either materialise a or hand out the coefficients
   if (training && (!save_mean || !save_invstd)) return kErrBadArg;
   if (!training && (!running_mean || !running_var)) return kErrBadArg;
   if (Co % 4 != 0) return kErrBadArg;
@@ -92,14 +108,14 @@ int ctvae_conv_bn_act_forward(int kind, const float* x, const float* w, const fl
     int rc = launch_tapgemm(g, x, w, bias, nullptr, nullptr, 0, y, ACT_NONE, nullptr, ws, wsf, (hipStream_t)stream);
     if (rc) return rc;
     return launch_bn_forward(y, R, Co, gamma, beta, running_mean, running_var, momentum, eps, training, act, a_out, save_mean,
-                             save_invstd, ws, ws_bytes, nbt, (hipStream_t)stream);
+                             save_invstd, ws, ws_bytes, nbt, (hipStream_t)stream, scale_shift_out);
   }
   const int nparts = plan.bn_parts;
   if (wsf < bn_workspace_floats(Co, nparts)) return kErrWorkspace;
   int rc = launch_tapgemm(g, x, w, bias, nullptr, nullptr, 0, y, ACT_NONE, ws, nullptr, 0, (hipStream_t)stream);
   if (rc) return rc;
   return launch_bn_finish_forward(y, R, Co, nparts, gamma, beta, running_mean, running_var, momentum, eps, training, act,
-                                  a_out, save_mean, save_invstd, ws, nbt, (hipStream_t)stream);
+                                  a_out, save_mean, save_invstd, ws, nbt, (hipStream_t)stream, scale_shift_out);
 }
 
 int ctvae_conv_dgrad(int kind, const float* dy, const float* w, const float* add, const float* mask, int mask_act,
@@ -137,12 +153,14 @@ int ctvae_conv_dgrad_bn(int kind, const float* dy, const float* w, const float* 
 }
 
 int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float* dbias, int B, int H, int W, int Ci,
-                     int Co, int k, int stride, int pad, int out_pad, int accumulate, float* ws, size_t ws_bytes,
-                     void* stream) {
+                     int Co, int k, int stride, int pad, int out_pad, int accumulate, const float* in_scale,
+                     const float* in_shift, int in_act, float* ws, size_t ws_bytes, void* stream) {
   if (!x || !dy || !dw || !ws || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
+  if ((in_scale != nullptr) != (in_shift != nullptr)) return kErrBadArg;
   ConvGeom g;
   if (build_geom(g, kind == CTVAE_CONV ? 0 : 1, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
-  return launch_wgrad(g, x, dy, dw, dbias, ws, ws_bytes, accumulate, (hipStream_t)stream);
+  const InXform xf{in_scale, in_shift, in_act};
+  return launch_wgrad(g, x, dy, dw, dbias, ws, ws_bytes, accumulate, (hipStream_t)stream, &xf);
 }
 
 int ctvae_bn_forward(const float* y, int R, int C, const float* gamma, const float* beta, float* running_mean,

@@ -312,9 +312,10 @@ size_t bn_workspace_floats(int C, int nparts) {
 // finalize (from `nparts` partial triples already in ws) or eval coefficients, then apply + activation
 int launch_bn_finish_forward(const float* y, int R, int C, int nparts, const float* gamma, const float* beta,
                              float* running_mean, float* running_var, float momentum, float eps, int training, int act,
-                             float* out, float* save_mean, float* save_invstd, float* ws, long long* nbt, hipStream_t st) {
+                             float* out, float* save_mean, float* save_invstd, float* ws, long long* nbt, hipStream_t st,
+                             float* coef_out) {
   const size_t parts = nparts > kBnMaxBlocks ? (size_t)nparts : (size_t)kBnMaxBlocks;
-  float* scale = ws + parts * C * 3;
+  float* scale = coef_out != nullptr ? coef_out : ws + parts * C * 3;   // coef_out [2][C]: kept by the caller (lazy apply)
   float* shift = scale + C;
   if (training) {
     ProfScope ps("bn_finalize_kernel", st, 0.0, 12.0 * (double)nparts * C);
@@ -326,6 +327,7 @@ int launch_bn_finish_forward(const float* y, int R, int C, int nparts, const flo
                        running_var, eps, scale, shift);
     CTVAE_LAUNCH_CHECK();
   }
+  if (out == nullptr) return 0;   // the consumer applies scale/shift + activation while loading y
   const long n4 = (long)R * C / 4;
   long blocks = (n4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
@@ -337,7 +339,8 @@ int launch_bn_finish_forward(const float* y, int R, int C, int nparts, const flo
 
 int launch_bn_forward(const float* y, int R, int C, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, float momentum, float eps, int training, int act, float* out,
-                      float* save_mean, float* save_invstd, float* ws, size_t ws_bytes, long long* nbt, hipStream_t st) {
+                      float* save_mean, float* save_invstd, float* ws, size_t ws_bytes, long long* nbt, hipStream_t st,
+                      float* coef_out) {
   if (!bn_shape_ok(R, C)) return kErrBadArg;
   if (ws_bytes / sizeof(float) < bn_workspace_floats(C, 0)) return kErrWorkspace;
   int nb = 0;
@@ -349,7 +352,7 @@ int launch_bn_forward(const float* y, int R, int C, const float* gamma, const fl
     CTVAE_LAUNCH_CHECK();
   }
   return launch_bn_finish_forward(y, R, C, nb, gamma, beta, running_mean, running_var, momentum, eps, training, act, out,
-                                  save_mean, save_invstd, ws, nbt, st);
+                                  save_mean, save_invstd, ws, nbt, st, coef_out);
 }
 
 int launch_bn_backward(const float* ga, const float* beta, const float* y, int R, int C, const float* gamma,

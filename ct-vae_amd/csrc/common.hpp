@@ -59,6 +59,14 @@ __device__ __forceinline__ float block_sum_256(float v, float* sm /* >=4 floats 
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Lazy BatchNorm apply: the operand a kernel gathers is x' = act(x*scale[c] + shift[c]) of the tensor it is given
+// (padding stays 0).  Only the thin (3-output-channel) kernels implement it: they stage every input element once.
+struct InXform {
+  const float* scale;
+  const float* shift;
+  int act;
+};
+
 // BatchNorm(+activation) layer whose output gradient a dgrad launch produces (fused backward sums)
 struct BnBwdFuse {
   const float* y;

@@ -554,7 +554,8 @@ static int launch_masked(const TapGemmArgs& a, bool wt, bool avec, bool bvec, hi
 bool thin_forward_supported(const ConvGeom& g);
 int thin_bn_parts(const ConvGeom& g);
 int launch_thin_forward(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
-                        const float* mask, int mask_act, float* S, int act, float* bn_part, hipStream_t st);
+                        const float* mask, int mask_act, float* S, int act, float* bn_part, hipStream_t st,
+                        const InXform* xf);
 
 // tile shape and split-K factor a launch will use (mirrored by the BN-statistics consumers)
 void tapgemm_plan(const ConvGeom& g, size_t ws_floats, TapGemmPlan& p) {
@@ -603,7 +604,7 @@ int tapgemm_bnb_rows(const ConvGeom& g, size_t ws_floats) {
 
 int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
                    const float* mask, int mask_act, float* S, int act, float* bn_part, float* ws, size_t ws_floats,
-                   hipStream_t st, const BnBwdFuse* bnb) {
+                   hipStream_t st, const BnBwdFuse* bnb, const InXform* xf) {
   TapGemmArgs a{};
   a.bn_part = bn_part;
   if (bnb != nullptr && bnb->part != nullptr) {
@@ -640,7 +641,8 @@ int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const floa
   TapGemmPlan plan;
   tapgemm_plan(g, ws != nullptr ? ws_floats : 0, plan);
   if (a.bnb_part != nullptr && (plan.thin || plan.splitk > 1)) return kErrBadArg;   // see tapgemm_bnb_rows()
-  if (plan.thin) return launch_thin_forward(g, G, W, bias, add, mask, mask_act, S, act, bn_part, st);
+  if (xf != nullptr && xf->scale != nullptr && !plan.thin) return kErrBadArg;   // only the thin kernels transform on load
+  if (plan.thin) return launch_thin_forward(g, G, W, bias, add, mask, mask_act, S, act, bn_part, st, xf);
   a.splitk = plan.splitk;
   a.part = ws;
 

@@ -282,18 +282,21 @@ static int launch_thin(ThinArgs& a, int nwg, hipStream_t st, const char* pname) 
 }
 
 int launch_thin_forward(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
-                        const float* mask, int mask_act, float* S, int act, float* bn_part, hipStream_t st) {
+                        const float* mask, int mask_act, float* S, int act, float* bn_part, hipStream_t st,
+                        const InXform* xf) {
   if (add != nullptr || mask != nullptr || bn_part != nullptr) return kErrBadArg;
   ThinArgs a{};
   a.g = g; a.G = G; a.W = W; a.bias = bias; a.S = S; a.act = act;
+  if (xf != nullptr && xf->scale != nullptr) { a.in_scale = xf->scale; a.in_shift = xf->shift; a.in_act = xf->act; }
   return launch_thin<false>(a, 2048, st, "thin_tile_kernel<fwd>");
 }
 
 // writes partials [nwg][rows_total*N] (+ bias partials) into ws; the caller reduces them
 int launch_thin_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, float** part_out, float** pbias_out,
-                      int* nparts_w, int* nparts_b, bool want_bias, hipStream_t st) {
+                      int* nparts_w, int* nparts_b, bool want_bias, hipStream_t st, const InXform* xf) {
   ThinArgs a{};
   a.g = g; a.G = X; a.dY = dY;
+  if (xf != nullptr && xf->scale != nullptr) { a.in_scale = xf->scale; a.in_shift = xf->shift; a.in_act = xf->act; }
   int taps = 0;
   for (int c = 0; c < g.ncls; ++c) taps += g.ntaps[c];
   const int rows_total = taps * g.gC;

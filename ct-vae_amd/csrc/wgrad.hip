@@ -513,14 +513,16 @@ static int choose_splits(const ConvGeom& g, int KT, int NT, size_t ws_floats) {
 bool thin_wgrad_supported(const ConvGeom& g);
 size_t thin_wgrad_workspace_floats(const ConvGeom& g);
 int launch_thin_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, float** part_out, float** pbias_out,
-                      int* nparts_w, int* nparts_b, bool want_bias, hipStream_t st);
+                      int* nparts_w, int* nparts_b, bool want_bias, hipStream_t st, const InXform* xf);
 
 int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, float* dbias, float* ws,
-                 size_t ws_bytes, int accumulate, hipStream_t st) {
-  if (thin_wgrad_supported(g) && thin_wgrad_workspace_floats(g) <= ws_bytes / sizeof(float)) {
+                 size_t ws_bytes, int accumulate, hipStream_t st, const InXform* xf) {
+  const bool thin = thin_wgrad_supported(g) && thin_wgrad_workspace_floats(g) <= ws_bytes / sizeof(float);
+  if (xf != nullptr && xf->scale != nullptr && !thin) return kErrBadArg;   // only the thin kernels transform on load
+  if (thin) {
     float *part = nullptr, *pb = nullptr;
     int nw = 0, nb = 0;
-    int rc = launch_thin_wgrad(g, X, dY, ws, &part, &pb, &nw, &nb, dbias != nullptr, st);
+    int rc = launch_thin_wgrad(g, X, dY, ws, &part, &pb, &nw, &nb, dbias != nullptr, st, xf);
     if (rc) return rc;
     int taps = 0;
     for (int c = 0; c < g.ncls; ++c) taps += g.ntaps[c];

@@ -66,14 +66,17 @@ def grad_target(p):
 # ---------------------------------------------------------------------------------------------------
 # low level launch helpers (no autograd)
 # ---------------------------------------------------------------------------------------------------
-def conv_forward_raw(x, w, b, spec: ConvSpec, add=None, act=None):
+def conv_forward_raw(x, w, b, spec: ConvSpec, add=None, act=None, in_coef=None, in_act=ACT_NONE):
+    """in_coef [2][Ci]: read act_in(x*scale+shift) instead of x (lazy BatchNorm apply, image-side layers only)."""
     B, H, W, _ = x.shape
     ho, wo = spec.out_hw(H, W)
     y = torch.empty((B, ho, wo, spec.co), dtype=torch.float32, device=x.device)
     ws = native.workspace(x.device)
+    sc = in_coef.data_ptr() if in_coef is not None else None
+    sh = in_coef.data_ptr() + 4 * spec.ci if in_coef is not None else None
     native.call("ctvae_conv_forward", spec.kind, x.data_ptr(), w.data_ptr(), native.ptr(b), native.ptr(add), y.data_ptr(),
                 B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, spec.act if act is None else act,
-                ws.data_ptr(), ws.numel() * 4)
+                sc, sh, in_act, ws.data_ptr(), ws.numel() * 4)
     return y
 
 
@@ -156,7 +159,7 @@ def conv_dgrad_bn_raw(dy, w, spec: ConvSpec, in_hw, link: BNLink):
     return dx
 
 
-def conv_wgrad_raw(x, dy, w_param, b_param, spec: ConvSpec):
+def conv_wgrad_raw(x, dy, w_param, b_param, spec: ConvSpec, in_coef=None, in_act=ACT_NONE):
     B, H, W, _ = x.shape
     ws = native.workspace(x.device)
     gw, acc = grad_target(w_param)
@@ -169,8 +172,11 @@ def conv_wgrad_raw(x, dy, w_param, b_param, spec: ConvSpec):
             else:
                 gb.zero_()
             acc = 1
+    sc = in_coef.data_ptr() if in_coef is not None else None
+    sh = in_coef.data_ptr() + 4 * spec.ci if in_coef is not None else None
     native.call("ctvae_conv_wgrad", spec.kind, x.data_ptr(), dy.data_ptr(), gw.data_ptr(), native.ptr(gb),
-                B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, acc, ws.data_ptr(), ws.numel() * 4)
+                B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, acc, sc, sh, in_act,
+                ws.data_ptr(), ws.numel() * 4)
 
 
 def wgrad_then_dgrad(x, g, w_param, b_param, spec, need_dgrad, link=None):
@@ -302,7 +308,7 @@ class ConvBNAct(Function):
         native.call("ctvae_conv_bn_act_forward", spec.kind, x.data_ptr(), w.data_ptr(), native.ptr(b), gamma.data_ptr(),
                     beta.data_ptr(), native.ptr(running_mean), native.ptr(running_var), BN_MOMENTUM, BN_EPS,
                     1 if training else 0, bn_act, y.data_ptr(), a.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(),
-                    native.ptr(num_batches_tracked) if training else None, B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, ws.data_ptr(), ws.numel() * 4)
+                    None, native.ptr(num_batches_tracked) if training else None, B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, ws.data_ptr(), ws.numel() * 4)
         ctx.spec, ctx.bn_act, ctx.training = spec, bn_act, training
         ctx.params = (w, b, gamma, beta)
         ctx.save_for_backward(x, y, a, save_mean, save_invstd)
@@ -331,6 +337,80 @@ class ConvBNAct(Function):
                     accg, native.ptr(part), rows, ws.data_ptr(), ws.numel() * 4)
         g_x = wgrad_then_dgrad(x, g_y, w, b, spec, ctx.needs_input_grad[0], ctx.link_in)
         return (g_x,) + (None,) * 10
+
+
+_xform_ok_cache = {}
+
+
+def input_transform_supported(spec: ConvSpec, B, H, W) -> bool:
+    """Can this layer apply the previous block's BatchNorm + activation while loading (ctvae_conv_forward in_scale)?"""
+    key = (spec.kind, B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad)
+    ok = _xform_ok_cache.get(key)
+    if ok is None:
+        ok = _xform_ok_cache[key] = bool(native.load().ctvae_conv_input_transform_supported(*key))
+    return ok
+
+
+class ConvBNActConvAct(Function):
+    """r = act2(conv2(act(BN(conv1(x))))) for an image-side conv2 (3 output channels): the reference's final_layer
+    nn.Sequential(ConvTranspose2d, BatchNorm2d, LeakyReLU, Conv2d, Tanh) (vanilla_vae.py:64-75) as ONE autograd node.
+
+    The BatchNorm output is never written: conv1 leaves y and the per-channel affine, conv2's forward and weight
+    gradient apply affine + LeakyReLU while staging their input tiles, conv2's data gradient emits the BatchNorm's
+    backward sums.  On the 64x64x32 activations of this block that removes two full passes over 134 MB per step."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, gamma, beta, running_mean, running_var, num_batches_tracked, w2, b2, training, spec1, spec2, bn_act):
+        _req_cuda(x, w1, w2, gamma)
+        ctx.link_in = link_of(x)
+        x = _c(x)
+        B, H, W, _ = x.shape
+        ho, wo = spec1.out_hw(H, W)
+        C = spec1.co
+        y1 = torch.empty((B, ho, wo, C), dtype=torch.float32, device=x.device)
+        coef = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+        save_mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        save_invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = native.workspace(x.device)
+        native.call("ctvae_conv_bn_act_forward", spec1.kind, x.data_ptr(), w1.data_ptr(), native.ptr(b1), gamma.data_ptr(),
+                    beta.data_ptr(), native.ptr(running_mean), native.ptr(running_var), BN_MOMENTUM, BN_EPS,
+                    1 if training else 0, bn_act, y1.data_ptr(), None, save_mean.data_ptr(), save_invstd.data_ptr(),
+                    coef.data_ptr(), native.ptr(num_batches_tracked) if training else None, B, H, W, spec1.ci, spec1.co,
+                    spec1.k, spec1.stride, spec1.pad, spec1.out_pad, ws.data_ptr(), ws.numel() * 4)
+        r = conv_forward_raw(y1, w2, b2, spec2, in_coef=coef, in_act=bn_act)
+        ctx.specs, ctx.bn_act, ctx.training = (spec1, spec2), bn_act, training
+        ctx.params = (w1, b1, gamma, beta, w2, b2)
+        ctx.save_for_backward(x, y1, r, coef, save_mean, save_invstd)
+        return r
+
+    @staticmethod
+    def backward(ctx, g_r):
+        if not ctx.training:
+            raise RuntimeError("backward through eval-mode BatchNorm is not supported on the HIP path")
+        spec1, spec2 = ctx.specs
+        w1, b1, gamma, beta, w2, b2 = ctx.params
+        x, y1, r, coef, save_mean, save_invstd = ctx.saved_tensors
+        g_r = _c(g_r)
+        g_pre = act_backward_raw(g_r, r, spec2.act) if spec2.act != ACT_NONE else g_r
+        conv_wgrad_raw(y1, g_pre, w2, b2, spec2, in_coef=coef, in_act=ctx.bn_act)
+        B, H, W, C = y1.shape
+        link = BNLink(y1, save_mean, save_invstd, gamma, beta, ctx.bn_act)
+        g_a = conv_dgrad_bn_raw(g_pre, w2, spec2, (H, W), link)
+        if g_a is None:
+            g_a = conv_dgrad_raw(g_pre, w2, spec2, (H, W))
+        part, rows = link.take(g_a)
+        ws = native.workspace(x.device)
+        g_y = torch.empty_like(y1)
+        gg, accg = grad_target(gamma)
+        gbt, accb = grad_target(beta)
+        if accg != accb:
+            (gg if accg == 0 else gbt).zero_()
+            accg = 1
+        native.call("ctvae_bn_backward", g_a.data_ptr(), beta.data_ptr(), y1.data_ptr(), B * H * W, C, gamma.data_ptr(),
+                    save_mean.data_ptr(), save_invstd.data_ptr(), ctx.bn_act, g_y.data_ptr(), gg.data_ptr(), gbt.data_ptr(),
+                    accg, native.ptr(part), rows, ws.data_ptr(), ws.numel() * 4)
+        g_x = wgrad_then_dgrad(x, g_y, w1, b1, spec1, ctx.needs_input_grad[0], ctx.link_in)
+        return (g_x,) + (None,) * 13
 
 
 class ActFn(Function):

@@ -33,8 +33,15 @@ class _FinalLayer(nn.Module):
         self.spec_out = K.ConvSpec(K.CONV, c, out_channels, 3, 1, 1, 0, K.ACT_TANH)
 
     def forward(self, x):
-        h = conv_bn_leaky(x, self._modules["0"], self._modules["1"], self.spec_up, self.training)
-        conv = self._modules["3"]
+        up, bn, conv = self._modules["0"], self._modules["1"], self._modules["3"]
+        B, H, W, _ = x.shape
+        ho, wo = self.spec_up.out_hw(H, W)
+        if K.input_transform_supported(self.spec_out, B, ho, wo):
+            # one node: the BatchNorm+LeakyReLU output is applied on load by the 3-channel conv, never stored
+            return K.ConvBNActConvAct.apply(x, up.weight, up.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                            bn.num_batches_tracked, conv.weight, conv.bias, self.training,
+                                            self.spec_up, self.spec_out, K.ACT_LRELU)
+        h = conv_bn_leaky(x, up, bn, self.spec_up, self.training)
         return K.ConvAct.apply(h, conv.weight, conv.bias, None, self.spec_out)
 
 

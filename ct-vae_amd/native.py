@@ -17,11 +17,11 @@ _fp, _vp, _i, _l, _f, _sz = _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_long, _c.c_
 
 # name -> argtypes (all return int unless listed in _RESTYPES)
 SIGNATURES = {
-    "ctvae_conv_forward": [_i, _fp, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _sz, _vp],
-    "ctvae_conv_bn_act_forward": [_i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _fp, _fp, _fp, _fp, _fp] + [_i] * 9
+    "ctvae_conv_forward": [_i, _fp, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _fp, _i, _fp, _sz, _vp],
+    "ctvae_conv_bn_act_forward": [_i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp] + [_i] * 9
                                  + [_fp, _sz, _vp],
     "ctvae_conv_dgrad": [_i, _fp, _fp, _fp, _fp, _i, _fp] + [_i] * 9 + [_fp, _sz, _vp],
-    "ctvae_conv_wgrad": [_i, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _sz, _vp],
+    "ctvae_conv_wgrad": [_i, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _fp, _i, _fp, _sz, _vp],
     "ctvae_bn_forward": [_fp, _i, _i, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _fp, _fp, _fp, _fp, _fp, _sz, _vp],
     "ctvae_bn_backward": [_fp, _fp, _fp, _i, _i, _fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _fp, _i, _fp, _sz, _vp],
     "ctvae_conv_dgrad_bn": [_i, _fp, _fp, _fp, _fp, _i, _fp] + [_i] * 9 + [_fp, _fp, _fp, _fp, _fp, _i, _fp, _i, _fp, _sz, _vp],
@@ -48,6 +48,7 @@ _RESTYPES = {
     "ctvae_prof_enable": None,
     "ctvae_prof_report": _c.c_size_t,
     "ctvae_conv_dgrad_bn_rows": _c.c_int,
+    "ctvae_conv_input_transform_supported": _c.c_int,
 }
 EXPORTS = sorted(list(SIGNATURES) + list(_RESTYPES))
 
@@ -80,7 +81,8 @@ def load():
         fn.restype = res
         fn.argtypes = {"ctvae_error_string": [_c.c_int], "ctvae_prof_enable": [_c.c_int],
                        "ctvae_prof_report": [_c.c_char_p, _c.c_size_t],
-                       "ctvae_conv_dgrad_bn_rows": [_c.c_int] * 10 + [_c.c_size_t]}.get(name, [])
+                       "ctvae_conv_dgrad_bn_rows": [_c.c_int] * 10 + [_c.c_size_t],
+                       "ctvae_conv_input_transform_supported": [_c.c_int] * 10}.get(name, [])
     if lib.ctvae_arch() != b"gfx950":
         raise RuntimeError("libctvae_hip.so was not built for gfx950")
     _lib = lib

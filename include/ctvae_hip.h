@@ -39,19 +39,27 @@ size_t ctvae_workspace_bytes(void); /* scratch size that is sufficient for every
  * Conv2d:          vanilla_vae.py:28-29,73-74; mcq_vae.py:170-171,178-179,189-190,205-209; vq_vae.py:63-67
  * ConvTranspose2d: vanilla_vae.py:50-55,65-70; mcq_vae.py:223-236        Linear: vanilla_vae.py:36-37,43
  * x [B,H,W,Ci], y [B,Ho,Wo,Co]; bias/add may be NULL (add has y's layout: ResidualLayer skip, vq_vae.py:69-70).
- * ws: scratch for the split-K partial sums of small-grid layers (may be NULL: no split-K). */
+ * ws: scratch for the split-K partial sums of small-grid layers (may be NULL: no split-K).
+ * in_scale/in_shift [Ci] (both or neither; NULL = plain x): the layer reads x' = act_in(x*scale[c] + shift[c]) instead
+ * of x, i.e. the BatchNorm2d + LeakyReLU in front of it (vanilla_vae.py:71-74) is applied while loading and its
+ * output never touches memory.  Only where ctvae_conv_input_transform_supported() says 1 (the 3-output-channel
+ * image-side layers); kErrBadArg otherwise. */
 int ctvae_conv_forward(int kind, const float* x, const float* w, const float* bias, const float* add, float* y, int B,
-                       int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int act, float* ws,
-                       size_t ws_bytes, void* stream);
+                       int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int act, const float* in_scale,
+                       const float* in_shift, int in_act, float* ws, size_t ws_bytes, void* stream);
+int ctvae_conv_input_transform_supported(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad,
+                                         int out_pad);
 
 /* Conv2d|ConvTranspose2d -> BatchNorm2d -> activation as one call (nn.Sequential blocks vanilla_vae.py:25-35,47-75):
  * y = conv(x)+bias (kept for backward); the conv epilogue emits per-tile (count, mean, M2) so the batch
- * statistics cost no extra pass over y; a_out = act(BN(y)).  Arguments as ctvae_conv_forward / ctvae_bn_forward. */
+ * statistics cost no extra pass over y; a_out = act(BN(y)).  Arguments as ctvae_conv_forward / ctvae_bn_forward.
+ * scale_shift_out [2][Co] (may be NULL): receives the per-channel affine a = act(y*scale + shift); with a_out == NULL
+ * the apply pass is skipped altogether and the consumer applies it on load (ctvae_conv_forward in_scale/in_shift). */
 int ctvae_conv_bn_act_forward(int kind, const float* x, const float* w, const float* bias, const float* gamma,
                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                               int training, int act, float* y, float* a_out, float* save_mean, float* save_invstd,
-                              int64_t* num_batches_tracked, int B, int H, int W, int Ci, int Co, int k, int stride, int pad,
-                              int out_pad, float* ws, size_t ws_bytes, void* stream);
+                              float* scale_shift_out, int64_t* num_batches_tracked, int B, int H, int W, int Ci, int Co, int k,
+                              int stride, int pad, int out_pad, float* ws, size_t ws_bytes, void* stream);
 
 /* dx = (dgrad(dy, w) + add) * act'(mask)      (autograd of the ops above)
  * add / mask (saved post-activation output of the PREVIOUS layer, layout of dx) may be NULL. */
@@ -74,9 +82,10 @@ int ctvae_conv_dgrad_bn(int kind, const float* dy, const float* w, const float* 
                         void* stream);
 
 /* dw (+)= wgrad(x, dy);  dbias (+)= sum over pixels of dy (dbias may be NULL).  Deterministic two-pass. */
+/* in_scale/in_shift/in_act: as ctvae_conv_forward (x is then the raw BatchNorm input y of the previous block). */
 int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float* dbias, int B, int H, int W, int Ci,
-                     int Co, int k, int stride, int pad, int out_pad, int accumulate, float* ws, size_t ws_bytes,
-                     void* stream);
+                     int Co, int k, int stride, int pad, int out_pad, int accumulate, const float* in_scale,
+                     const float* in_shift, int in_act, float* ws, size_t ws_bytes, void* stream);
 
 /* Train/eval BatchNorm2d + activation on an [R=B*H*W][C] matrix (vanilla_vae.py:30-31,56-57,71-72).
  * training: batch statistics (biased var, eps), running stats updated with `momentum` and the unbiased
