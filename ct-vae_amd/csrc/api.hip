@@ -11,6 +11,7 @@ int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const floa
 bool thin_forward_supported(const ConvGeom& g);
 bool thin_wgrad_supported(const ConvGeom& g);
 int tapgemm_bnb_rows(const ConvGeom& g, size_t ws_floats);
+bool img_dgrad_supported(const ConvGeom& g);
 void tapgemm_plan(const ConvGeom& g, size_t ws_floats, TapGemmPlan& p);
 int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, float* dbias, float* ws, size_t ws_bytes,
                  int accumulate, hipStream_t st, const InXform* xf = nullptr);
@@ -147,6 +148,7 @@ int ctvae_conv_dgrad_bn(int kind, const float* dy, const float* w, const float* 
   if (build_geom(g, kind == CTVAE_CONV ? 2 : 3, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
   const int rows = tapgemm_bnb_rows(g, ws_bytes / sizeof(float));
   if (rows <= 0 || rows != bn_part_rows) return kErrBadArg;
+  if (img_dgrad_supported(g) && (add != nullptr || mask != nullptr)) return kErrBadArg;   // image kernel has no add/mask
   const BnBwdFuse f{bn_y, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_act, bn_part};
   return launch_tapgemm(g, dy, w, nullptr, add, mask, mask_act, dx, ACT_NONE, nullptr, ws, ws_bytes / sizeof(float),
                         (hipStream_t)stream, &f);

@@ -1,0 +1,500 @@
+// Image-side 3x3 convolution between a 32-channel feature map and the 3-channel picture (vanilla_vae.py:73-74,
+// `nn.Conv2d(hidden_dims[-1], out_channels=3, kernel_size=3, padding=1)` + Tanh), forward, weight gradient and data
+// gradient, on the f32 matrix cores.
+//
+// With N = 3 an im2col GEMM tile would be 90 % padding.  These kernels turn the problem round so that the taps become
+// the GEMM's N (or K) dimension and the spatial gather happens inside LDS:
+//
+//   forward   Z[p'][(t,co)] = sum_ci a[p'][ci] * W[t][ci][co]        one 32-wide MFMA tile: M = pixels, K = 32, N = 27
+//             r[p][co]      = tanh(bias + sum_t Z[p + off_t][(t,co)])  9-point gather of the LDS-resident Z
+//   wgrad     dW[t][ci][co] = sum_p' a[p'][ci] * g[p' - off_t][co]    M = ci (32), N = (t,co) (27), K = pixels: one
+//                                                                     32x32 accumulator per wave for the whole launch
+//   dgrad     ga[p][ci]     = sum_(t,co) g[p + off_t][co] * W[t][ci][co]   M = pixels, K = 27, N = ci (32)
+//
+// One workgroup = one 8 x 32 pixel tile of one image at a time (persistent loop over tiles, next tile's global loads
+// in flight while the current one computes).  The 32-channel operand is staged ONCE per tile (tile + 1-pixel halo) with
+// 16-B coalesced loads; the optional per-channel affine + LeakyReLU of the BatchNorm in front of the layer is applied
+// there (lazy BatchNorm apply: the normalised activation never exists in HBM).  The data gradient also emits the
+// BatchNorm's backward sums per workgroup (see TapGemmArgs::bnb_*), reading y with the same 128-B-per-pixel pattern
+// it writes ga with.  All reductions run in a fixed order: bit-reproducible.
+#include "common.hpp"
+#include "prof.hpp"
+
+namespace ctvae {
+
+namespace {
+
+constexpr int TH = 8, TW = 32, PH = 10, PW = 34, NP = PH * PW /*340*/, NPP = 352 /*11 x 32*/;
+constexpr int LDA = 36;          // floats per staged pixel row (32 + 4: ds_read_b128 of 8 rows hits 32 distinct banks)
+constexpr int LDZ = 33;          // floats per Z row (odd: pixel-per-lane reads are conflict-free)
+constexpr int GH = 12, GW = 36;  // zero-ringed gradient grid of the wgrad kernel (tile + 2)
+constexpr int C = 32, NO = 3, NT = 9, NJ = 27;
+constexpr unsigned kOOBi = 0x80000000u;
+
+struct ImgArgs {
+  const float* X;      // [B,H,W,32]
+  const float* Wt;     // [9][32][3]
+  const float* bias;
+  const float* dY;     // [B,H,W,3]
+  const float* scale;  // lazy BatchNorm apply on X (may be null)
+  const float* shift;
+  float* out;
+  float* pbias;
+  const float* bn_y;   // dgrad: fused BatchNorm-backward sums (may be null)
+  const float* bn_mean;
+  const float* bn_invstd;
+  const float* bn_gamma;
+  const float* bn_beta;
+  float* bn_part;
+  int bn_act, in_act, act;
+  int B, H, W, tiles_y, tiles_x, ntiles;
+  int tdy[NT], tdx[NT], twt[NT];
+};
+
+__device__ __forceinline__ f32x4 ld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ float ld1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ void st1(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)off, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p, long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+struct TileXY {
+  int b, y0, x0;
+};
+__device__ __forceinline__ TileXY tile_xy(const ImgArgs& a, int tile) {
+  const int per = a.tiles_y * a.tiles_x;
+  const int b = tile / per, r = tile - b * per;
+  const int ty = r / a.tiles_x;
+  return TileXY{b, ty * TH, (r - ty * a.tiles_x) * TW};
+}
+
+// ---- staging of the 32-channel patch (tile + halo): 340 pixels x 8 float4, 11 per thread -------------------------
+constexpr int NLD = (NP * 8 + 255) / 256;   // 11
+
+struct Patch {
+  f32x4 v[NLD];
+  unsigned ok;   // bit j: load j is inside the image
+};
+
+__device__ __forceinline__ void patch_load(const ImgArgs& a, __amdgpu_buffer_rsrc_t rX, const TileXY& t, Patch& p) {
+  unsigned okm = 0;
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const int e = threadIdx.x + 256 * j;
+    const int pp = e >> 3, c4 = e & 7;
+    const int py = (pp * 241) >> 13, px = pp - py * PW;   // pp / 34 for pp < 352
+    const int iy = t.y0 - 1 + py, ix = t.x0 - 1 + px;
+    const bool ok = e < NP * 8 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    p.v[j] = ld4(rX, ok ? (unsigned)(((t.b * a.H + iy) * a.W + ix) * C + 4 * c4) * 4u : kOOBi);
+    okm |= (ok ? 1u : 0u) << j;
+  }
+  p.ok = okm;
+}
+
+__device__ __forceinline__ void patch_store(const ImgArgs& a, const Patch& p, float* sA) {
+  const bool xform = a.scale != nullptr;
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (xform) {   // the thread's channel quad is the same for all its loads (256 % 8 == 0)
+    sc = *reinterpret_cast<const f32x4*>(a.scale + 4 * (threadIdx.x & 7));
+    sh = *reinterpret_cast<const f32x4*>(a.shift + 4 * (threadIdx.x & 7));
+  }
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const int e = threadIdx.x + 256 * j;
+    if (e < NP * 8) {
+      f32x4 v = p.v[j];
+      if (xform) {
+        const bool ok = (p.ok >> j) & 1u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = ok ? act_fwd(v[k] * sc[k] + sh[k], a.in_act) : 0.f;   // zero padding stays zero
+      }
+      *reinterpret_cast<f32x4*>(&sA[(e >> 3) * LDA + 4 * (e & 7)]) = v;
+    }
+  }
+}
+
+// weight matrix column of lane j = 3*t + co for rows ci (forward/wgrad) -- tap table lookups without private arrays
+__device__ __forceinline__ int tap_wt(const ImgArgs& a, int t) {
+  int w = 0;
+#pragma unroll
+  for (int k = 0; k < NT; ++k) w = (t == k) ? a.twt[k] : w;
+  return w;
+}
+__device__ __forceinline__ int tap_dy(const ImgArgs& a, int t) {
+  int w = 0;
+#pragma unroll
+  for (int k = 0; k < NT; ++k) w = (t == k) ? a.tdy[k] : w;
+  return w;
+}
+__device__ __forceinline__ int tap_dx(const ImgArgs& a, int t) {
+  int w = 0;
+#pragma unroll
+  for (int k = 0; k < NT; ++k) w = (t == k) ? a.tdx[k] : w;
+  return w;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 3) void img_fwd_kernel(const ImgArgs a) {
+  __shared__ __attribute__((aligned(16))) float sA[NPP * LDA];   // patch; reused for Z [340][33]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rX = rsrc(a.X, (long)a.B * a.H * a.W * C * 4);
+  const __amdgpu_buffer_rsrc_t rO = rsrc(a.out, (long)a.B * a.H * a.W * NO * 4);
+
+  // B operand, resident for the whole launch: breg[kg*4+q] = W'[ci = kg*8 + 4*lh + q][j = li]
+  float breg[16];
+  {
+    const int t = li / 3, co = li - 3 * t;
+    const int wt = tap_wt(a, t);
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const int ci = (kk >> 2) * 8 + 4 * lh + (kk & 3);
+      breg[kk] = li < NJ ? a.Wt[(wt * C + ci) * NO + co] : 0.f;
+    }
+  }
+  float bias_r[NO];
+#pragma unroll
+  for (int n = 0; n < NO; ++n) bias_r[n] = a.bias != nullptr ? a.bias[n] : 0.f;
+  int zoff[NT];   // Z row offset of tap t relative to the output pixel's own patch row
+#pragma unroll
+  for (int t = 0; t < NT; ++t) zoff[t] = (a.tdy[t] * PW + a.tdx[t]) * LDZ + 3 * t;
+  for (int e = tid; e < (NPP - NP) * LDA; e += 256) sA[NP * LDA + e] = 0.f;   // MFMA rows beyond the patch
+
+  Patch pt;
+  int tile = blockIdx.x;
+  TileXY cur = tile_xy(a, tile < a.ntiles ? tile : 0);
+  if (tile < a.ntiles) patch_load(a, rX, cur, pt);
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    patch_store(a, pt, sA);
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    const TileXY nxt = tile_xy(a, next < a.ntiles ? next : 0);
+    if (next < a.ntiles) patch_load(a, rX, nxt, pt);   // in flight during the MFMA / gather phases
+
+    // ---- Z = patch x W' : wave w takes the 32-row blocks w, w+4, w+8 ----
+    f32x16 acc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int mt = wave + 4 * i;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+      if (mt < NPP / 32) {
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+          const f32x4 af = *reinterpret_cast<const f32x4*>(&sA[(mt * 32 + li) * LDA + kg * 8 + 4 * lh]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], breg[kg * 4 + q], acc[i], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();   // every wave is done reading the patch: its memory becomes Z
+    float* sZ = sA;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int mt = wave + 4 * i;
+      if (mt < NPP / 32 && li < NJ) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = mt * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+          if (row < NP) sZ[row * LDZ + li] = acc[i][r];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- gather: one thread per output pixel ----
+    {
+      const int ly = tid >> 5, lx = tid & 31;
+      const float* z = sZ + ((ly + 1) * PW + lx + 1) * LDZ;
+      float o[NO];
+#pragma unroll
+      for (int n = 0; n < NO; ++n) o[n] = bias_r[n];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int n = 0; n < NO; ++n) o[n] += z[zoff[t] + n];
+      const unsigned off = (unsigned)(((cur.b * a.H + cur.y0 + ly) * a.W + cur.x0 + lx) * NO) * 4u;
+#pragma unroll
+      for (int n = 0; n < NO; ++n) st1(rO, off + 4u * n, act_fwd(o[n], a.act));
+    }
+    __syncthreads();   // Z consumed before the next patch lands
+    cur = nxt;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// partial dW slab per workgroup: out[blockIdx.x][wtap*32 + ci][co]; bias partial pbias[blockIdx.x][co]
+__global__ __launch_bounds__(256) void img_wgrad_kernel(const ImgArgs a) {
+  __shared__ __attribute__((aligned(16))) float sA[NPP * LDA];
+  __shared__ __attribute__((aligned(16))) float sG[GH * GW * 4];   // cell (gy,gx) <-> tile pixel (gy-2, gx-2); ring = 0
+  __shared__ float sB[4 * NO];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rX = rsrc(a.X, (long)a.B * a.H * a.W * C * 4);
+  const __amdgpu_buffer_rsrc_t rG = rsrc(a.dY, (long)a.B * a.H * a.W * NO * 4);
+
+  for (int e = tid; e < GH * GW * 4; e += 256) sG[e] = 0.f;
+  // lane j = li = 3t + co reads g[p' - off_t][co]: patch pixel (py,px) <-> grid cell (py + 1 - dy_t, px + 1 - dx_t)
+  const int t_l = li / 3, co_l = li - 3 * t_l;
+  const bool jvalid = li < NJ;
+  const int gbase = ((1 - tap_dy(a, t_l)) * GW + (1 - tap_dx(a, t_l)) + lh) * 4 + co_l;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bs[NO] = {0.f, 0.f, 0.f};
+
+  Patch pt;
+  float gv[NO];
+  const int ly = tid >> 5, lx = tid & 31;
+  auto g_load = [&](const TileXY& t) {
+    const unsigned off = (unsigned)(((t.b * a.H + t.y0 + ly) * a.W + t.x0 + lx) * NO) * 4u;
+#pragma unroll
+    for (int n = 0; n < NO; ++n) gv[n] = ld1(rG, off + 4u * n);
+  };
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) {
+    const TileXY c0 = tile_xy(a, tile);
+    patch_load(a, rX, c0, pt);
+    g_load(c0);
+  }
+  __syncthreads();   // sG ring zeroed
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    patch_store(a, pt, sA);
+    {
+      float* cell = &sG[((ly + 2) * GW + lx + 2) * 4];
+#pragma unroll
+      for (int n = 0; n < NO; ++n) {
+        cell[n] = gv[n];
+        bs[n] += gv[n];
+      }
+    }
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    if (next < a.ntiles) {
+      const TileXY nxt = tile_xy(a, next);
+      patch_load(a, rX, nxt, pt);
+      g_load(nxt);
+    }
+    // K loop over the 340 patch pixels, two per MFMA (lh picks the odd one); the 170 steps are dealt to the 4 waves
+#pragma unroll 2
+    for (int i = wave; i < PH * (PW / 2); i += 4) {
+      const int py = (i * 241) >> 12, j = i - py * (PW / 2);   // i / 17
+      const float av = sA[(py * PW + 2 * j + lh) * LDA + li];
+      float g = sG[gbase + (py * GW + 2 * j) * 4];
+      g = jvalid ? g : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, g, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // ---- merge the 4 waves in a fixed order ----
+  float* sR = sA;   // [4][32][32]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sR[(wave * 32 + 8 * (r >> 2) + 4 * lh + (r & 3)) * 32 + li] = acc[r];
+  float bw[NO];
+#pragma unroll
+  for (int n = 0; n < NO; ++n) bw[n] = wave_sum(bs[n]);
+  if (lane == 0)
+#pragma unroll
+    for (int n = 0; n < NO; ++n) sB[wave * NO + n] = bw[n];
+  __syncthreads();
+  for (int e = tid; e < C * NJ; e += 256) {
+    const int ci = e / NJ, j = e - ci * NJ;
+    const float v = ((sR[(0 * 32 + ci) * 32 + j] + sR[(1 * 32 + ci) * 32 + j]) + sR[(2 * 32 + ci) * 32 + j]) + sR[(3 * 32 + ci) * 32 + j];
+    const int t = j / 3, co = j - 3 * t;
+    a.out[((long)blockIdx.x * (NT * C) + tap_wt(a, t) * C + ci) * NO + co] = v;
+  }
+  if (a.pbias != nullptr && tid < NO) a.pbias[(long)blockIdx.x * NO + tid] = ((sB[tid] + sB[NO + tid]) + sB[2 * NO + tid]) + sB[3 * NO + tid];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ga [B,H,W,32] from g [B,H,W,3]; optional BatchNorm-backward sums bn_part[blockIdx.x][32][2]
+__global__ __launch_bounds__(256, 4) void img_dgrad_kernel(const ImgArgs a) {
+  __shared__ __attribute__((aligned(16))) float sG[NP * 4];
+  __shared__ float sS[4 * C * 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rG = rsrc(a.dY, (long)a.B * a.H * a.W * NO * 4);
+  const long obytes = (long)a.B * a.H * a.W * C * 4;
+  const __amdgpu_buffer_rsrc_t rO = rsrc(a.out, obytes);
+  const bool bn = a.bn_part != nullptr;
+  const __amdgpu_buffer_rsrc_t rY = rsrc(a.bn_y, bn ? obytes : 0);
+
+  // k = 2s + lh = 3t + co: A element = g[p + off_t][co] (LDS offset koff), B element = W[t][ci = li][co]
+  int koff[14];
+  float bw[14];
+#pragma unroll
+  for (int s = 0; s < 14; ++s) {
+    const int k0 = 2 * s, k1 = 2 * s + 1;
+    const int t0 = k0 / 3, c0 = k0 % 3, t1 = (k1 < NJ ? k1 : 0) / 3, c1 = (k1 < NJ ? k1 : 0) % 3;
+    const int o0 = (a.tdy[t0] * PW + a.tdx[t0]) * 4 + c0, o1 = (a.tdy[t1] * PW + a.tdx[t1]) * 4 + c1;
+    const float w0 = a.Wt[(a.twt[t0] * C + li) * NO + c0];
+    const float w1 = k1 < NJ ? a.Wt[(a.twt[t1] * C + li) * NO + c1] : 0.f;
+    koff[s] = lh ? (k1 < NJ ? o1 : 0) : o0;
+    bw[s] = lh ? w1 : w0;
+  }
+  const float bmean = bn ? a.bn_mean[li] : 0.f, binv = bn ? a.bn_invstd[li] : 0.f;
+  const float bgm = bn ? a.bn_gamma[li] : 0.f, bbt = bn ? a.bn_beta[li] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+
+  // gradient patch: 340 pixels x 3 floats, threads 0..339 (+ second pass for 84 more) stage one pixel each
+  float gq[2][NO];
+  auto g_load = [&](const TileXY& t) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pp = tid + 256 * j;
+      const int py = (pp * 241) >> 13, px = pp - py * PW;
+      const int iy = t.y0 - 1 + py, ix = t.x0 - 1 + px;
+      const bool ok = pp < NP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      const unsigned off = ok ? (unsigned)(((t.b * a.H + iy) * a.W + ix) * NO) * 4u : kOOBi;
+#pragma unroll
+      for (int n = 0; n < NO; ++n) gq[j][n] = ld1(rG, ok ? off + 4u * n : kOOBi);
+    }
+  };
+  int tile = blockIdx.x;
+  TileXY cur = tile_xy(a, tile < a.ntiles ? tile : 0);
+  if (tile < a.ntiles) g_load(cur);
+  for (; tile < a.ntiles; tile += gridDim.x) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pp = tid + 256 * j;
+      if (pp < NP)
+#pragma unroll
+        for (int n = 0; n < NO; ++n) sG[pp * 4 + n] = gq[j][n];
+    }
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    const TileXY nxt = tile_xy(a, next < a.ntiles ? next : 0);
+    if (next < a.ntiles) g_load(nxt);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ly = wave + 4 * i;   // tile row = one 32-pixel MFMA block
+      const unsigned rowoff = (unsigned)(((cur.b * a.H + cur.y0 + ly) * a.W + cur.x0) * C + li) * 4u;
+      float yv[16];
+      if (bn) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yv[r] = ld1(rY, rowoff + (unsigned)((8 * (r >> 2) + 4 * lh + (r & 3)) * C) * 4u);
+      }
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* gp = &sG[((ly + 1) * PW + li + 1) * 4];
+#pragma unroll
+      for (int s = 0; s < 14; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gp[koff[s]], bw[s], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st1(rO, rowoff + (unsigned)((8 * (r >> 2) + 4 * lh + (r & 3)) * C) * 4u, acc[r]);
+      if (bn) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float xh = (yv[r] - bmean) * binv;
+          const float g1 = acc[r] * act_bwd_from_out(act_fwd(bgm * xh + bbt, a.bn_act), a.bn_act);
+          s1 += g1;
+          s2 += g1 * xh;
+        }
+      }
+    }
+    __syncthreads();
+    cur = nxt;
+  }
+  if (bn) {
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (lh == 0) {
+      sS[(wave * C + li) * 2] = s1;
+      sS[(wave * C + li) * 2 + 1] = s2;
+    }
+    __syncthreads();
+    if (tid < C * 2) {
+      const float v = ((sS[tid] + sS[C * 2 + tid]) + sS[2 * C * 2 + tid]) + sS[3 * C * 2 + tid];
+      a.bn_part[(long)blockIdx.x * C * 2 + tid] = v;
+    }
+  }
+}
+
+bool taps_ok(const ConvGeom& g) {
+  if (g.ncls != 1 || g.is != 1 || g.os != 1 || g.ntaps[0] != NT) return false;
+  if (g.gH != g.sH || g.gW != g.sW || g.sH % TH != 0 || g.sW % TW != 0) return false;
+  for (int t = 0; t < NT; ++t) {
+    const Tap& tp = g.taps[0][t];
+    if (tp.dy < -1 || tp.dy > 1 || tp.dx < -1 || tp.dx > 1 || tp.wtap < 0 || tp.wtap >= NT) return false;
+  }
+  return (long)g.B * g.sH * g.sW * C < (1L << 29);
+}
+
+void fill(ImgArgs& a, const ConvGeom& g) {
+  a.B = g.B; a.H = g.sH; a.W = g.sW;
+  a.tiles_y = g.sH / TH; a.tiles_x = g.sW / TW;
+  a.ntiles = g.B * a.tiles_y * a.tiles_x;
+  for (int t = 0; t < NT; ++t) {
+    a.tdy[t] = g.taps[0][t].dy; a.tdx[t] = g.taps[0][t].dx; a.twt[t] = g.taps[0][t].wtap;
+  }
+}
+
+}  // namespace
+
+// forward / wgrad geometry (build_geom kind 0): 32 -> 3 channels
+bool img_conv_supported(const ConvGeom& g) { return g.wT == 0 && g.gC == C && g.sC == NO && g.wCi == C && g.wCo == NO && taps_ok(g); }
+// dgrad geometry (kind 2): gathers the 3-channel gradient, scatters 32 channels
+bool img_dgrad_supported(const ConvGeom& g) { return g.wT == 1 && g.gC == NO && g.sC == C && g.wCi == C && g.wCo == NO && taps_ok(g); }
+
+constexpr int kImgFwdWgs = 768, kImgWgradWgs = 512, kImgDgradWgs = 1024;
+
+int img_wgrad_parts(const ConvGeom& g) {
+  const int nt = g.B * (g.sH / TH) * (g.sW / TW);
+  return nt < kImgWgradWgs ? nt : kImgWgradWgs;
+}
+int img_dgrad_rows(const ConvGeom& g) {
+  const int nt = g.B * (g.sH / TH) * (g.sW / TW);
+  return nt < kImgDgradWgs ? nt : kImgDgradWgs;
+}
+
+int launch_img_forward(const ConvGeom& g, const float* X, const float* W, const float* bias, float* S, int act,
+                       const InXform* xf, hipStream_t st) {
+  ImgArgs a{};
+  fill(a, g);
+  a.X = X; a.Wt = W; a.bias = bias; a.out = S; a.act = act;
+  if (xf != nullptr && xf->scale != nullptr) { a.scale = xf->scale; a.shift = xf->shift; a.in_act = xf->act; }
+  const int nwg = a.ntiles < kImgFwdWgs ? a.ntiles : kImgFwdWgs;
+  ProfScope ps("img_fwd_kernel", st, 2.0 * a.ntiles * TH * TW * NT * C * NO, 4.0 * a.ntiles * TH * TW * (C + NO));
+  hipLaunchKernelGGL(img_fwd_kernel, dim3(nwg), dim3(256), 0, st, a);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+// partial slabs [parts][9*32][3] (+ bias partials [parts][3]) into ws; the caller reduces them
+int launch_img_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, float** part_out, float** pbias_out,
+                     int* nparts, bool want_bias, const InXform* xf, hipStream_t st) {
+  ImgArgs a{};
+  fill(a, g);
+  a.X = X; a.dY = dY;
+  if (xf != nullptr && xf->scale != nullptr) { a.scale = xf->scale; a.shift = xf->shift; a.in_act = xf->act; }
+  const int nwg = img_wgrad_parts(g);
+  a.out = ws;
+  a.pbias = want_bias ? ws + (size_t)nwg * NT * C * NO : nullptr;
+  ProfScope ps("img_wgrad_kernel", st, 2.0 * a.ntiles * TH * TW * NT * C * NO, 4.0 * a.ntiles * TH * TW * (C + NO));
+  hipLaunchKernelGGL(img_wgrad_kernel, dim3(nwg), dim3(256), 0, st, a);
+  CTVAE_LAUNCH_CHECK();
+  *part_out = a.out;
+  *pbias_out = a.pbias;
+  *nparts = nwg;
+  return 0;
+}
+
+int launch_img_dgrad(const ConvGeom& g, const float* dY, const float* W, float* dX, const BnBwdFuse* bnb, hipStream_t st) {
+  ImgArgs a{};
+  fill(a, g);
+  a.dY = dY; a.Wt = W; a.out = dX;
+  if (bnb != nullptr && bnb->part != nullptr) {
+    a.bn_y = bnb->y; a.bn_mean = bnb->mean; a.bn_invstd = bnb->invstd; a.bn_gamma = bnb->gamma; a.bn_beta = bnb->beta;
+    a.bn_act = bnb->act; a.bn_part = bnb->part;
+  }
+  const int nwg = img_dgrad_rows(g);
+  ProfScope ps("img_dgrad_kernel", st, 2.0 * a.ntiles * TH * TW * NT * C * NO,
+               4.0 * a.ntiles * TH * TW * (C * (a.bn_part != nullptr ? 2 : 1) + NO));
+  hipLaunchKernelGGL(img_dgrad_kernel, dim3(nwg), dim3(256), 0, st, a);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace ctvae

@@ -593,9 +593,14 @@ void tapgemm_plan(const ConvGeom& g, size_t ws_floats, TapGemmPlan& p) {
   p.bn_parts = p.mtiles * g.ncls;
 }
 
+bool img_dgrad_supported(const ConvGeom& g);
+int img_dgrad_rows(const ConvGeom& g);
+int launch_img_dgrad(const ConvGeom& g, const float* dY, const float* W, float* dX, const BnBwdFuse* bnb, hipStream_t st);
+
 // rows of the fused BN-backward partial table a dgrad launch of this geometry writes (0: this configuration cannot
 // fuse -- split-K keeps its epilogue in splitk_finish_kernel, the thin path has none)
 int tapgemm_bnb_rows(const ConvGeom& g, size_t ws_floats) {
+  if (img_dgrad_supported(g)) return img_dgrad_rows(g);
   TapGemmPlan plan;
   tapgemm_plan(g, ws_floats, plan);
   if (plan.thin || plan.splitk > 1) return 0;
@@ -605,6 +610,10 @@ int tapgemm_bnb_rows(const ConvGeom& g, size_t ws_floats) {
 int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
                    const float* mask, int mask_act, float* S, int act, float* bn_part, float* ws, size_t ws_floats,
                    hipStream_t st, const BnBwdFuse* bnb, const InXform* xf) {
+  // data gradient of the 3x3 image-side conv (3 gathered channels): dedicated kernel, see image.hip
+  if (img_dgrad_supported(g) && bias == nullptr && add == nullptr && mask == nullptr && act == ACT_NONE && bn_part == nullptr &&
+      (xf == nullptr || xf->scale == nullptr))
+    return launch_img_dgrad(g, G, W, S, bnb, st);
   TapGemmArgs a{};
   a.bn_part = bn_part;
   if (bnb != nullptr && bnb->part != nullptr) {

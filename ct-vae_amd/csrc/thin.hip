@@ -281,10 +281,17 @@ static int launch_thin(ThinArgs& a, int nwg, hipStream_t st, const char* pname) 
   return 0;
 }
 
+bool img_conv_supported(const ConvGeom& g);
+int launch_img_forward(const ConvGeom& g, const float* X, const float* W, const float* bias, float* S, int act,
+                       const InXform* xf, hipStream_t st);
+int launch_img_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, float** part_out, float** pbias_out,
+                     int* nparts, bool want_bias, const InXform* xf, hipStream_t st);
+
 int launch_thin_forward(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
                         const float* mask, int mask_act, float* S, int act, float* bn_part, hipStream_t st,
                         const InXform* xf) {
   if (add != nullptr || mask != nullptr || bn_part != nullptr) return kErrBadArg;
+  if (img_conv_supported(g)) return launch_img_forward(g, G, W, bias, S, act, xf, st);   // 3x3 s1, 32 -> 3: MFMA form (image.hip)
   ThinArgs a{};
   a.g = g; a.G = G; a.W = W; a.bias = bias; a.S = S; a.act = act;
   if (xf != nullptr && xf->scale != nullptr) { a.in_scale = xf->scale; a.in_shift = xf->shift; a.in_act = xf->act; }
@@ -294,6 +301,13 @@ int launch_thin_forward(const ConvGeom& g, const float* G, const float* W, const
 // writes partials [nwg][rows_total*N] (+ bias partials) into ws; the caller reduces them
 int launch_thin_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, float** part_out, float** pbias_out,
                       int* nparts_w, int* nparts_b, bool want_bias, hipStream_t st, const InXform* xf) {
+  if (img_conv_supported(g)) {
+    int np = 0;
+    const int rc = launch_img_wgrad(g, X, dY, ws, part_out, pbias_out, &np, want_bias, xf, st);
+    *nparts_w = np;
+    *nparts_b = np;
+    return rc;
+  }
   ThinArgs a{};
   a.g = g; a.G = X; a.dY = dY;
   if (xf != nullptr && xf->scale != nullptr) { a.in_scale = xf->scale; a.in_shift = xf->shift; a.in_act = xf->act; }
