@@ -105,9 +105,19 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   const int c = blockIdx.x;
   if (c == 0 && tid == 0 && num_batches_tracked != nullptr) num_batches_tracked[0] += 1;   // nn.BatchNorm2d bookkeeping
   float n = 0.f, mean = 0.f, m2 = 0.f;
-  for (int b = tid; b < nparts; b += 256) {
-    const float* p = part + ((long)b * C + c) * 3;
-    chan_merge(n, mean, m2, p[0], p[1], p[2]);
+  // 8 rows per step: the loads go out together, only the (division-carrying) merges are serial
+  for (int b0 = tid; b0 < nparts; b0 += 256 * 8) {
+    float pn[8], pm[8], pq[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = b0 + 256 * u;
+      const float* p = part + ((long)(b < nparts ? b : b0) * C + c) * 3;
+      pn[u] = b < nparts ? p[0] : 0.f;
+      pm[u] = p[1];
+      pq[u] = p[2];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) chan_merge(n, mean, m2, pn[u], pm[u], pq[u]);
   }
   sm[tid * 3] = n; sm[tid * 3 + 1] = mean; sm[tid * 3 + 2] = m2;
   __syncthreads();
@@ -239,6 +249,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   const int tid = threadIdx.x;
   const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
   for (int b = tid; b < nblocks; b += 256) {
     s1 += (double)part[((long)b * C + c) * 2 + 0];
     s2 += (double)part[((long)b * C + c) * 2 + 1];

@@ -74,6 +74,20 @@ __device__ __forceinline__ TileXY tile_xy(const ImgArgs& a, int tile) {
   return TileXY{b, ty * TH, (r - ty * a.tiles_x) * TW};
 }
 
+__device__ __forceinline__ TileXY tile_xy_hw(int tiles_y, int tiles_x, int tile) {
+  const int per = tiles_y * tiles_x;
+  const int b = tile / per, r = tile - b * per;
+  const int ty = r / tiles_x;
+  return TileXY{b, ty * TH, (r - ty * tiles_x) * TW};
+}
+// table[t] for a lane-varying t without a private-memory array
+__device__ __forceinline__ int tap_dy9(const int* tab, int t) {
+  int w = 0;
+#pragma unroll
+  for (int k = 0; k < NT; ++k) w = (t == k) ? tab[k] : w;
+  return w;
+}
+
 // ---- staging of the 32-channel patch (tile + halo): 340 pixels x 8 float4, 11 per thread -------------------------
 constexpr int NLD = (NP * 8 + 255) / 256;   // 11
 
@@ -412,6 +426,217 @@ __global__ __launch_bounds__(256, 4) void img_dgrad_kernel(const ImgArgs a) {
   }
 }
 
+// =====================================================================================================================
+// Picture-side stride-2 convolution 3 -> 32 channels (vanilla_vae.py:28-29, encoder.0: Conv2d(3, 32, 3, stride 2, pad 1)).
+// Same idea with the roles swapped: K = (tap, input channel) = 27, N = 32 output channels, the 3-channel patch
+// (17 x 65 pixels for an 8 x 32 output tile) lives in LDS and the MFMA A operand is read from it with per-k offsets.
+constexpr int EPH = 2 * TH + 1, EPW = 2 * TW + 1, ENP = EPH * EPW;   // 17 x 65 = 1105
+constexpr int ENLD = (ENP + 255) / 256;                               // 5 pixels per thread
+
+struct EncArgs {
+  const float* X;     // [B,2H,2W,3]
+  const float* Wt;    // [9][3][32]
+  const float* bias;
+  const float* dY;    // wgrad: [B,H,W,32]
+  float* out;         // fwd: y [B,H,W,32]; wgrad: slabs [nwg][27][32]
+  float* pbias;       // wgrad: [nwg][32]
+  float* bn_part;     // fwd: [nwg][32][3] (count, mean, M2) of y, may be null
+  int act;
+  int B, H, W, tiles_y, tiles_x, ntiles;   // H, W: OUTPUT size
+  int tdy[NT], tdx[NT], twt[NT];
+};
+
+struct EncPatch {
+  float v[ENLD][NO];
+};
+
+__device__ __forceinline__ void enc_patch_load(const EncArgs& a, __amdgpu_buffer_rsrc_t rX, const TileXY& t, EncPatch& p) {
+  const int IH = 2 * a.H, IW = 2 * a.W;
+#pragma unroll
+  for (int j = 0; j < ENLD; ++j) {
+    const int pp = threadIdx.x + 256 * j;
+    const int py = (pp * 1009) >> 16, px = pp - py * EPW;   // pp / 65 for pp < 1280
+    const int iy = 2 * t.y0 - 1 + py, ix = 2 * t.x0 - 1 + px;
+    const bool ok = pp < ENP && (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+    const unsigned off = (unsigned)(((t.b * IH + iy) * IW + ix) * NO) * 4u;
+#pragma unroll
+    for (int n = 0; n < NO; ++n) p.v[j][n] = ld1(rX, ok ? off + 4u * n : kOOBi);
+  }
+}
+__device__ __forceinline__ void enc_patch_store(const EncPatch& p, float* sX) {
+#pragma unroll
+  for (int j = 0; j < ENLD; ++j) {
+    const int pp = threadIdx.x + 256 * j;
+    if (pp < ENP)
+#pragma unroll
+      for (int n = 0; n < NO; ++n) sX[pp * 4 + n] = p.v[j][n];
+  }
+}
+
+__global__ __launch_bounds__(256, 4) void img_enc_fwd_kernel(const EncArgs a) {
+  __shared__ __attribute__((aligned(16))) float sX[ENP * 4];
+  __shared__ float sS[4 * C * 3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rX = rsrc(a.X, (long)a.B * a.H * a.W * 4 * NO * 4);
+  const __amdgpu_buffer_rsrc_t rO = rsrc(a.out, (long)a.B * a.H * a.W * C * 4);
+  // k = 2s + lh = 3t + ci: A element = x[2q + off_t][ci] (LDS offset koff), B element = W[t][ci][co = li]
+  int koff[14];
+  float bw[14];
+#pragma unroll
+  for (int s = 0; s < 14; ++s) {
+    const int k0 = 2 * s, k1 = 2 * s + 1;
+    const int t0 = k0 / 3, c0 = k0 % 3, t1 = (k1 < NJ ? k1 : 0) / 3, c1 = (k1 < NJ ? k1 : 0) % 3;
+    const int o0 = (a.tdy[t0] * EPW + a.tdx[t0]) * 4 + c0, o1 = (a.tdy[t1] * EPW + a.tdx[t1]) * 4 + c1;
+    const float w0 = a.Wt[(a.twt[t0] * NO + c0) * C + li];
+    const float w1 = k1 < NJ ? a.Wt[(a.twt[t1] * NO + c1) * C + li] : 0.f;
+    koff[s] = lh ? (k1 < NJ ? o1 : 0) : o0;
+    bw[s] = lh ? w1 : w0;
+  }
+  const float bv = a.bias != nullptr ? a.bias[li] : 0.f;
+  float sn = 0.f, smean = 0.f, sm2 = 0.f;   // running (count, mean, M2) of this lane's channel
+
+  EncPatch pt;
+  int tile = blockIdx.x;
+  TileXY cur = tile_xy_hw(a.tiles_y, a.tiles_x, tile < a.ntiles ? tile : 0);
+  if (tile < a.ntiles) enc_patch_load(a, rX, cur, pt);
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    enc_patch_store(pt, sX);
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    const TileXY nxt = tile_xy_hw(a.tiles_y, a.tiles_x, next < a.ntiles ? next : 0);
+    if (next < a.ntiles) enc_patch_load(a, rX, nxt, pt);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ly = wave + 4 * i;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* xp = &sX[((2 * ly + 1) * EPW + 2 * li + 1) * 4];
+#pragma unroll
+      for (int s = 0; s < 14; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xp[koff[s]], bw[s], acc, 0, 0, 0);
+      const unsigned rowoff = (unsigned)(((cur.b * a.H + cur.y0 + ly) * a.W + cur.x0) * C + li) * 4u;
+      float m1 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[r] += bv;
+        m1 += acc[r];
+        st1(rO, rowoff + (unsigned)((8 * (r >> 2) + 4 * lh + (r & 3)) * C) * 4u, act_fwd(acc[r], a.act));
+      }
+      if (a.bn_part != nullptr) {   // Chan merge of this block's 16 values into the lane's running statistics
+        m1 *= (1.f / 16.f);
+        float q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) q += (acc[r] - m1) * (acc[r] - m1);
+        const float nt = sn + 16.f, d = m1 - smean;
+        smean += d * (16.f / nt);
+        sm2 += q + d * d * (sn * 16.f / nt);
+        sn = nt;
+      }
+    }
+    __syncthreads();
+    cur = nxt;
+  }
+  if (a.bn_part != nullptr) {
+    {   // the two lane halves hold the same channel
+      const float on = __shfl_xor(sn, 32, 64), om = __shfl_xor(smean, 32, 64), oq = __shfl_xor(sm2, 32, 64);
+      const float nt = sn + on;
+      if (nt > 0.f) {
+        const float d = om - smean;
+        sm2 = sm2 + oq + d * d * (sn * on / nt);
+        smean = smean + d * (on / nt);
+      }
+      sn = nt;
+    }
+    if (lh == 0) {
+      float* st = &sS[(wave * C + li) * 3];
+      st[0] = sn; st[1] = smean; st[2] = sm2;
+    }
+    __syncthreads();
+    if (tid < C) {
+      float n = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float nb = sS[(w * C + tid) * 3], mb = sS[(w * C + tid) * 3 + 1], qb = sS[(w * C + tid) * 3 + 2];
+        if (nb > 0.f) {
+          const float nt = n + nb, d = mb - mean;
+          mean += d * (nb / nt);
+          m2 += qb + d * d * (n * nb / nt);
+          n = nt;
+        }
+      }
+      float* p = a.bn_part + ((long)blockIdx.x * C + tid) * 3;
+      p[0] = n; p[1] = mean; p[2] = m2;
+    }
+  }
+}
+
+// dW[t][ci][co] = sum_q x[2q + off_t][ci] * dy[q][co]: M = co, N = (t,ci), K = output pixels.  dy goes from global memory
+// straight into the MFMA A operand (128 B per pixel), x comes from the LDS patch.
+__global__ __launch_bounds__(256, 4) void img_enc_wgrad_kernel(const EncArgs a) {
+  __shared__ __attribute__((aligned(16))) float sX[ENP * 4];
+  __shared__ __attribute__((aligned(16))) float sR[4 * 32 * 32];
+  __shared__ float sB[4 * C];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rX = rsrc(a.X, (long)a.B * a.H * a.W * 4 * NO * 4);
+  const __amdgpu_buffer_rsrc_t rG = rsrc(a.dY, (long)a.B * a.H * a.W * C * 4);
+  // lane j = li = 3t + ci reads x[2q + off_t][ci]
+  const int t_l = li / 3, ci_l = li - 3 * t_l;
+  const bool jvalid = li < NJ;
+  const int xbase = ((tap_dy9(a.tdy, t_l) + 1) * EPW + tap_dy9(a.tdx, t_l) + 1 + 2 * lh) * 4 + ci_l;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
+
+  EncPatch pt;
+  float dv[2][16];   // this wave's dy operand: rows ly = wave, wave + 4; 16 pixel pairs each
+  auto dy_load = [&](const TileXY& t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned rowoff = (unsigned)(((t.b * a.H + t.y0 + wave + 4 * i) * a.W + t.x0) * C + li) * 4u;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) dv[i][j] = ld1(rG, rowoff + (unsigned)((2 * j + lh) * C) * 4u);
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) {
+    const TileXY c0 = tile_xy_hw(a.tiles_y, a.tiles_x, tile);
+    enc_patch_load(a, rX, c0, pt);
+  }
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    const TileXY cur = tile_xy_hw(a.tiles_y, a.tiles_x, tile);
+    enc_patch_store(pt, sX);
+    dy_load(cur);
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    if (next < a.ntiles) enc_patch_load(a, rX, tile_xy_hw(a.tiles_y, a.tiles_x, next), pt);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ly = wave + 4 * i;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float xv = sX[xbase + ((2 * ly) * EPW + 4 * j) * 4];
+        xv = jvalid ? xv : 0.f;
+        bsum += dv[i][j];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[i][j], xv, acc, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sR[(wave * 32 + 8 * (r >> 2) + 4 * lh + (r & 3)) * 32 + li] = acc[r];
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (lh == 0) sB[wave * C + li] = bsum;
+  __syncthreads();
+  for (int e = tid; e < NJ * C; e += 256) {
+    const int j = e / C, co = e - j * C;
+    const float v = ((sR[(0 * 32 + co) * 32 + j] + sR[(1 * 32 + co) * 32 + j]) + sR[(2 * 32 + co) * 32 + j]) + sR[(3 * 32 + co) * 32 + j];
+    const int t = j / 3, ci = j - 3 * t;
+    a.out[((long)blockIdx.x * NJ + tap_dy9(a.twt, t) * NO + ci) * C + co] = v;
+  }
+  if (a.pbias != nullptr && tid < C) a.pbias[(long)blockIdx.x * C + tid] = ((sB[tid] + sB[C + tid]) + sB[2 * C + tid]) + sB[3 * C + tid];
+}
+
 bool taps_ok(const ConvGeom& g) {
   if (g.ncls != 1 || g.is != 1 || g.os != 1 || g.ntaps[0] != NT) return false;
   if (g.gH != g.sH || g.gW != g.sW || g.sH % TH != 0 || g.sW % TW != 0) return false;
@@ -437,6 +662,62 @@ void fill(ImgArgs& a, const ConvGeom& g) {
 bool img_conv_supported(const ConvGeom& g) { return g.wT == 0 && g.gC == C && g.sC == NO && g.wCi == C && g.wCo == NO && taps_ok(g); }
 // dgrad geometry (kind 2): gathers the 3-channel gradient, scatters 32 channels
 bool img_dgrad_supported(const ConvGeom& g) { return g.wT == 1 && g.gC == NO && g.sC == C && g.wCi == C && g.wCo == NO && taps_ok(g); }
+
+// encoder.0 geometry (kind 0, stride 2): gathers 3 channels with is = 2, scatters 32
+bool img_enc_supported(const ConvGeom& g) {
+  if (g.wT != 0 || g.gC != NO || g.sC != C || g.wCi != NO || g.wCo != C) return false;
+  if (g.ncls != 1 || g.is != 2 || g.os != 1 || g.ntaps[0] != NT) return false;
+  if (g.gH != 2 * g.sH || g.gW != 2 * g.sW || g.sH % TH != 0 || g.sW % TW != 0) return false;
+  for (int t = 0; t < NT; ++t) {
+    const Tap& tp = g.taps[0][t];
+    if (tp.dy < -1 || tp.dy > 1 || tp.dx < -1 || tp.dx > 1 || tp.wtap < 0 || tp.wtap >= NT) return false;
+  }
+  return (long)g.B * g.sH * g.sW * C < (1L << 29);
+}
+
+constexpr int kImgEncWgs = 1024;
+int img_enc_rows(const ConvGeom& g) {
+  const int nt = g.B * (g.sH / TH) * (g.sW / TW);
+  return nt < kImgEncWgs ? nt : kImgEncWgs;
+}
+
+static void fill_enc(EncArgs& a, const ConvGeom& g) {
+  a.B = g.B; a.H = g.sH; a.W = g.sW;
+  a.tiles_y = g.sH / TH; a.tiles_x = g.sW / TW;
+  a.ntiles = g.B * a.tiles_y * a.tiles_x;
+  for (int t = 0; t < NT; ++t) {
+    a.tdy[t] = g.taps[0][t].dy; a.tdx[t] = g.taps[0][t].dx; a.twt[t] = g.taps[0][t].wtap;
+  }
+}
+
+int launch_img_enc_forward(const ConvGeom& g, const float* X, const float* W, const float* bias, float* S, int act,
+                           float* bn_part, hipStream_t st) {
+  EncArgs a{};
+  fill_enc(a, g);
+  a.X = X; a.Wt = W; a.bias = bias; a.out = S; a.act = act; a.bn_part = bn_part;
+  ProfScope ps("img_enc_fwd_kernel", st, 2.0 * a.ntiles * TH * TW * NT * C * NO, 4.0 * a.ntiles * TH * TW * (C + 4 * NO));
+  hipLaunchKernelGGL(img_enc_fwd_kernel, dim3(img_enc_rows(g)), dim3(256), 0, st, a);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+// partial slabs [parts][27][32] (+ bias partials [parts][32]) into ws; the caller reduces them
+int launch_img_enc_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, float** part_out, float** pbias_out,
+                         int* nparts, bool want_bias, hipStream_t st) {
+  EncArgs a{};
+  fill_enc(a, g);
+  a.X = X; a.dY = dY;
+  const int nwg = a.ntiles < 512 ? a.ntiles : 512;
+  a.out = ws;
+  a.pbias = want_bias ? ws + (size_t)nwg * NJ * C : nullptr;
+  ProfScope ps("img_enc_wgrad_kernel", st, 2.0 * a.ntiles * TH * TW * NT * C * NO, 4.0 * a.ntiles * TH * TW * (C + 4 * NO));
+  hipLaunchKernelGGL(img_enc_wgrad_kernel, dim3(nwg), dim3(256), 0, st, a);
+  CTVAE_LAUNCH_CHECK();
+  *part_out = a.out;
+  *pbias_out = a.pbias;
+  *nparts = nwg;
+  return 0;
+}
 
 constexpr int kImgFwdWgs = 768, kImgWgradWgs = 512, kImgDgradWgs = 1024;
 

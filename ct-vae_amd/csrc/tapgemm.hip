@@ -551,6 +551,10 @@ static int launch_masked(const TapGemmArgs& a, bool wt, bool avec, bool bvec, hi
   return 0;
 }
 
+bool img_enc_supported(const ConvGeom& g);
+int img_enc_rows(const ConvGeom& g);
+int launch_img_enc_forward(const ConvGeom& g, const float* X, const float* W, const float* bias, float* S, int act,
+                           float* bn_part, hipStream_t st);
 bool thin_forward_supported(const ConvGeom& g);
 int thin_bn_parts(const ConvGeom& g);
 int launch_thin_forward(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
@@ -561,6 +565,11 @@ int launch_thin_forward(const ConvGeom& g, const float* G, const float* W, const
 void tapgemm_plan(const ConvGeom& g, size_t ws_floats, TapGemmPlan& p) {
   const int Mc = g.B * g.Qh * g.Qw, N = g.sC;
   p.thin = 0;
+  if (img_enc_supported(g)) {   // picture-side stride-2 conv: dedicated kernel, one statistics row per workgroup
+    p.BM = p.BN = 0; p.mtiles = p.ntiles = 0; p.splitk = 1;
+    p.bn_parts = img_enc_rows(g);
+    return;
+  }
   if (thin_forward_supported(g)) {
     p.thin = 1; p.BM = p.BN = 0; p.mtiles = p.ntiles = 0; p.splitk = 1;
     p.bn_parts = thin_bn_parts(g);
@@ -614,6 +623,9 @@ int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const floa
   if (img_dgrad_supported(g) && bias == nullptr && add == nullptr && mask == nullptr && act == ACT_NONE && bn_part == nullptr &&
       (xf == nullptr || xf->scale == nullptr))
     return launch_img_dgrad(g, G, W, S, bnb, st);
+  if (img_enc_supported(g) && add == nullptr && mask == nullptr && (bnb == nullptr || bnb->part == nullptr) &&
+      (xf == nullptr || xf->scale == nullptr))
+    return launch_img_enc_forward(g, G, W, bias, S, act, bn_part, st);
   TapGemmArgs a{};
   a.bn_part = bn_part;
   if (bnb != nullptr && bnb->part != nullptr) {

@@ -515,8 +515,24 @@ size_t thin_wgrad_workspace_floats(const ConvGeom& g);
 int launch_thin_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, float** part_out, float** pbias_out,
                       int* nparts_w, int* nparts_b, bool want_bias, hipStream_t st, const InXform* xf);
 
+bool img_enc_supported(const ConvGeom& g);
+int launch_img_enc_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, float** part_out, float** pbias_out,
+                         int* nparts, bool want_bias, hipStream_t st);
+
 int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, float* dbias, float* ws,
                  size_t ws_bytes, int accumulate, hipStream_t st, const InXform* xf) {
+  if (img_enc_supported(g) && (xf == nullptr || xf->scale == nullptr) && ws_bytes / sizeof(float) >= (size_t)512 * (27 * 32 + 32)) {
+    float *part = nullptr, *pb = nullptr;
+    int np = 0;
+    int rc = launch_img_enc_wgrad(g, X, dY, ws, &part, &pb, &np, dbias != nullptr, st);
+    if (rc) return rc;
+    const long n = 27L * 32;
+    ProfScope ps("reduce_partials_kernel", st, 0.0, 4.0 * (double)(np + 1) * n);
+    if (dbias) launch_reduce2(part, dW, n, np, n, pb, dbias, 32L, np, 32L, accumulate, st);
+    else launch_reduce(part, dW, n, np, n, accumulate, st);
+    CTVAE_LAUNCH_CHECK();
+    return 0;
+  }
   const bool thin = thin_wgrad_supported(g) && thin_wgrad_workspace_floats(g) <= ws_bytes / sizeof(float);
   if (xf != nullptr && xf->scale != nullptr && !thin) return kErrBadArg;   // only the thin kernels transform on load
   if (thin) {
