@@ -551,6 +551,10 @@ static int launch_masked(const TapGemmArgs& a, bool wt, bool avec, bool bvec, hi
   return 0;
 }
 
+bool upconv_supported(const ConvGeom& g);
+int upconv_rows(const ConvGeom& g);
+int launch_upconv_forward(const ConvGeom& g, const float* X, const float* W, const float* bias, float* S, int act,
+                          float* bn_part, hipStream_t st);
 bool img_enc_supported(const ConvGeom& g);
 int img_enc_rows(const ConvGeom& g);
 int launch_img_enc_forward(const ConvGeom& g, const float* X, const float* W, const float* bias, float* S, int act,
@@ -568,6 +572,11 @@ void tapgemm_plan(const ConvGeom& g, size_t ws_floats, TapGemmPlan& p) {
   if (img_enc_supported(g)) {   // picture-side stride-2 conv: dedicated kernel, one statistics row per workgroup
     p.BM = p.BN = 0; p.mtiles = p.ntiles = 0; p.splitk = 1;
     p.bn_parts = img_enc_rows(g);
+    return;
+  }
+  if (upconv_supported(g)) {    // 32 -> 32 transposed conv on the big decoder activations: persistent LDS-tile kernel
+    p.BM = p.BN = 0; p.mtiles = p.ntiles = 0; p.splitk = 1;
+    p.bn_parts = upconv_rows(g);
     return;
   }
   if (thin_forward_supported(g)) {
@@ -626,6 +635,9 @@ int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const floa
   if (img_enc_supported(g) && add == nullptr && mask == nullptr && (bnb == nullptr || bnb->part == nullptr) &&
       (xf == nullptr || xf->scale == nullptr))
     return launch_img_enc_forward(g, G, W, bias, S, act, bn_part, st);
+  if (upconv_supported(g) && add == nullptr && mask == nullptr && (bnb == nullptr || bnb->part == nullptr) &&
+      (xf == nullptr || xf->scale == nullptr))
+    return launch_upconv_forward(g, G, W, bias, S, act, bn_part, st);
   TapGemmArgs a{};
   a.bn_part = bn_part;
   if (bnb != nullptr && bnb->part != nullptr) {

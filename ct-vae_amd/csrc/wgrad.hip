@@ -515,12 +515,28 @@ size_t thin_wgrad_workspace_floats(const ConvGeom& g);
 int launch_thin_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, float** part_out, float** pbias_out,
                       int* nparts_w, int* nparts_b, bool want_bias, hipStream_t st, const InXform* xf);
 
+bool upconv_wgrad_supported(const ConvGeom& g);
+int launch_upconv_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, float** part_out, float** pbias_out,
+                        int* nparts, bool want_bias, hipStream_t st);
 bool img_enc_supported(const ConvGeom& g);
 int launch_img_enc_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, float** part_out, float** pbias_out,
                          int* nparts, bool want_bias, hipStream_t st);
 
 int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, float* dbias, float* ws,
                  size_t ws_bytes, int accumulate, hipStream_t st, const InXform* xf) {
+  if (upconv_wgrad_supported(g) && (xf == nullptr || xf->scale == nullptr) &&
+      ws_bytes / sizeof(float) >= (size_t)512 * (9 * 32 * 32 + 32)) {
+    float *part = nullptr, *pb = nullptr;
+    int np = 0;
+    int rc = launch_upconv_wgrad(g, X, dY, ws, &part, &pb, &np, dbias != nullptr, st);
+    if (rc) return rc;
+    const long n = 9L * 32 * 32;
+    ProfScope ps("reduce_partials_kernel", st, 0.0, 4.0 * (double)(np + 1) * n);
+    if (dbias) launch_reduce2(part, dW, n, np, n, pb, dbias, 32L, np, 32L, accumulate, st);
+    else launch_reduce(part, dW, n, np, n, accumulate, st);
+    CTVAE_LAUNCH_CHECK();
+    return 0;
+  }
   if (img_enc_supported(g) && (xf == nullptr || xf->scale == nullptr) && ws_bytes / sizeof(float) >= (size_t)512 * (27 * 32 + 32)) {
     float *part = nullptr, *pb = nullptr;
     int np = 0;
