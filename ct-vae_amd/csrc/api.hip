@@ -14,7 +14,7 @@ int tapgemm_bnb_rows(const ConvGeom& g, size_t ws_floats);
 bool img_dgrad_supported(const ConvGeom& g);
 void tapgemm_plan(const ConvGeom& g, size_t ws_floats, TapGemmPlan& p);
 int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, float* dbias, float* ws, size_t ws_bytes,
-                 int accumulate, hipStream_t st, const InXform* xf = nullptr);
+                 int accumulate, hipStream_t st, const InXform* xf = nullptr, const DyXform* dyx = nullptr);
 int launch_bn_forward(const float* y, int R, int C, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, float momentum, float eps, int training, int act, float* out, float* save_mean,
                       float* save_invstd, float* ws, size_t ws_bytes, long long* nbt, hipStream_t st,
@@ -26,7 +26,9 @@ int launch_bn_finish_forward(const float* y, int R, int C, int nparts, const flo
 size_t bn_workspace_floats(int C, int nparts);
 int launch_bn_backward(const float* ga, const float* beta, const float* y, int R, int C, const float* gamma,
                        const float* save_mean, const float* save_invstd, int act, float* gy, float* dgamma, float* dbeta,
-                       int accumulate, float* ws, size_t ws_bytes, const float* part_in, int part_rows, hipStream_t st);
+                       int accumulate, float* ws, size_t ws_bytes, const float* part_in, int part_rows, hipStream_t st,
+                       float* coef_out = nullptr);
+bool upconv_wgrad_supported(const ConvGeom& g);
 int launch_permute(const float* in, float* out, int B, int C, int P, int to_nhwc, hipStream_t st);
 int launch_act_bwd(const float* gout, const float* out, float* gin, long n, int act, hipStream_t st);
 int launch_act_fwd(const float* in, float* out, long n, int act, hipStream_t st);
@@ -156,13 +158,23 @@ int ctvae_conv_dgrad_bn(int kind, const float* dy, const float* w, const float* 
 
 int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float* dbias, int B, int H, int W, int Ci,
                      int Co, int k, int stride, int pad, int out_pad, int accumulate, const float* in_scale,
-                     const float* in_shift, int in_act, float* ws, size_t ws_bytes, void* stream) {
+                     const float* in_shift, int in_act, const float* dy_bn_y, const float* dy_bn_coef, int dy_bn_act,
+                     float* gy_out, float* ws, size_t ws_bytes, void* stream) {
   if (!x || !dy || !dw || !ws || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
   if ((in_scale != nullptr) != (in_shift != nullptr)) return kErrBadArg;
+  if ((dy_bn_y != nullptr) != (dy_bn_coef != nullptr) || (dy_bn_y != nullptr) != (gy_out != nullptr)) return kErrBadArg;
   ConvGeom g;
   if (build_geom(g, kind == CTVAE_CONV ? 0 : 1, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
   const InXform xf{in_scale, in_shift, in_act};
-  return launch_wgrad(g, x, dy, dw, dbias, ws, ws_bytes, accumulate, (hipStream_t)stream, &xf);
+  const DyXform dyx{dy_bn_y, dy_bn_coef, gy_out, dy_bn_act};
+  return launch_wgrad(g, x, dy, dw, dbias, ws, ws_bytes, accumulate, (hipStream_t)stream, &xf, &dyx);
+}
+
+int ctvae_conv_wgrad_bn_apply_supported(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad) {
+  if (kind != CTVAE_CONV && kind != CTVAE_CONVT) return 0;
+  ConvGeom g;
+  if (build_geom(g, kind == CTVAE_CONV ? 0 : 1, B, H, W, Ci, Co, k, stride, pad, out_pad)) return 0;
+  return upconv_wgrad_supported(g) ? 1 : 0;
 }
 
 int ctvae_bn_forward(const float* y, int R, int C, const float* gamma, const float* beta, float* running_mean,
@@ -178,12 +190,13 @@ int ctvae_bn_forward(const float* y, int R, int C, const float* gamma, const flo
 
 int ctvae_bn_backward(const float* g_a, const float* beta, const float* y, int R, int C, const float* gamma,
                       const float* save_mean, const float* save_invstd, int act, float* g_y, float* dgamma,
-                      float* dbeta, int accumulate, const float* part_in, int part_rows, float* ws, size_t ws_bytes,
-                      void* stream) {
-  if (!g_a || !beta || !y || !gamma || !save_mean || !save_invstd || !g_y || !dgamma || !dbeta || !ws) return kErrBadArg;
+                      float* dbeta, int accumulate, const float* part_in, int part_rows, float* coef_out, float* ws,
+                      size_t ws_bytes, void* stream) {
+  if (!g_a || !beta || !y || !gamma || !save_mean || !save_invstd || !dgamma || !dbeta || !ws) return kErrBadArg;
+  if (!g_y && !coef_out) return kErrBadArg;   // either apply here or hand the coefficients to the consumer
   if ((part_in != nullptr) != (part_rows > 0)) return kErrBadArg;
   return launch_bn_backward(g_a, beta, y, R, C, gamma, save_mean, save_invstd, act, g_y, dgamma, dbeta, accumulate, ws,
-                            ws_bytes, part_in, part_rows, (hipStream_t)stream);
+                            ws_bytes, part_in, part_rows, (hipStream_t)stream, coef_out);
 }
 
 int ctvae_permute(const float* in, float* out, int B, int C, int P, int to_nhwc, void* stream) {

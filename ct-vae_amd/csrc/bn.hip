@@ -369,11 +369,11 @@ int launch_bn_forward(const float* y, int R, int C, const float* gamma, const fl
 int launch_bn_backward(const float* ga, const float* beta, const float* y, int R, int C, const float* gamma,
                        const float* save_mean, const float* save_invstd, int act, float* gy, float* dgamma,
                        float* dbeta, int accumulate, float* ws, size_t ws_bytes, const float* part_in, int part_rows,
-                       hipStream_t st) {
+                       hipStream_t st, float* coef_out) {
   if (!bn_shape_ok(R, C)) return kErrBadArg;
   if (ws_bytes / sizeof(float) < bn_workspace_floats(C, 0)) return kErrWorkspace;
   const float* part = ws;
-  float* coef = ws + (size_t)kBnMaxBlocks * C * 3;
+  float* coef = coef_out != nullptr ? coef_out : ws + (size_t)kBnMaxBlocks * C * 3;   // [5][C]
   int rpb;
   int nb = stat_blocks(R, C, &rpb);
   if (part_in != nullptr && part_rows > 0) {   // sums already emitted per tile by the dgrad that produced ga
@@ -391,6 +391,7 @@ int launch_bn_backward(const float* ga, const float* beta, const float* y, int R
                        save_mean, save_invstd, dgamma, dbeta, accumulate, beta, coef);
   }
   CTVAE_LAUNCH_CHECK();
+  if (gy == nullptr) return 0;   // the consumer (weight-gradient kernel) applies the coefficients on load
   ProfScope ps("bn_bwd_apply_kernel", st, 0.0, 12.0 * (double)R * C);
   const long n4 = (long)R * C / 4;
   long blocks = (n4 + 255) / 256;

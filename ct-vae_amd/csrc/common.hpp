@@ -67,6 +67,16 @@ struct InXform {
   int act;
 };
 
+// Lazy BatchNorm-backward apply: a weight-gradient kernel is handed g_a (gradient w.r.t. the BatchNorm+activation
+// output) instead of g_y and forms g_y = k1*g_a*act'(y*scale+shift) + k2*y + k3 itself while loading, also writing it
+// to gy_out for the data-gradient kernel that follows.  coef = [5][C]: k1, k2, k3, scale, shift (bn_bwd_finalize_kernel).
+struct DyXform {
+  const float* y;
+  const float* coef;
+  float* gy_out;
+  int act;
+};
+
 // BatchNorm(+activation) layer whose output gradient a dgrad launch produces (fused backward sums)
 struct BnBwdFuse {
   const float* y;

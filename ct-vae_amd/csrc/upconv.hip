@@ -34,6 +34,10 @@ struct UpArgs {
   float* out;         // forward: y [B,2H,2W,32]; wgrad: slabs [nwg][9][32][32]
   float* pbias;       // wgrad: [nwg][32]
   float* bn_part;     // forward: [nwg][32][3], may be null
+  const float* dy_y;  // wgrad: dY is g_a; g_y = k1*g_a*act'(y*scale+shift) + k2*y + k3 is formed on load and written to gy_out
+  const float* dy_coef;
+  float* gy_out;
+  int dy_act;
   int act;
   int B, H, W, tiles_y, tiles_x, ntiles;
   int ntaps[NCLS], cpy[NCLS], cpx[NCLS];
@@ -208,6 +212,7 @@ struct ClsInfo {
   static constexpr int first = CLS == 0 ? 0 : (CLS == 1 ? 1 : (CLS == 2 ? 3 : 5));
 };
 
+template <bool FUSED>
 __global__ __launch_bounds__(256, 2) void up_wgrad_kernel(const UpArgs a) {
   __shared__ __attribute__((aligned(16))) float sA[NP * LDA];   // 42.8 KB
   __shared__ __attribute__((aligned(16))) float sR[4 * C * C];  // 16 KB: cross-wave merge, one tap at a time
@@ -215,7 +220,13 @@ __global__ __launch_bounds__(256, 2) void up_wgrad_kernel(const UpArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const __amdgpu_buffer_rsrc_t rX = rsrc(a.X, (long)a.B * a.H * a.W * C * 4);
   const int OH = 2 * a.H, OW = 2 * a.W;
-  const __amdgpu_buffer_rsrc_t rG = rsrc(a.dY, (long)a.B * OH * OW * C * 4);
+  const long obytes = (long)a.B * OH * OW * C * 4;
+  const __amdgpu_buffer_rsrc_t rG = rsrc(a.dY, obytes);
+  const __amdgpu_buffer_rsrc_t rYb = rsrc(a.dy_y, FUSED ? obytes : 0);
+  const __amdgpu_buffer_rsrc_t rGY = rsrc(a.gy_out, FUSED ? obytes : 0);
+  const float k1 = FUSED ? a.dy_coef[li] : 0.f, k2 = FUSED ? a.dy_coef[C + li] : 0.f, k3 = FUSED ? a.dy_coef[2 * C + li] : 0.f;
+  const float ksc = FUSED ? a.dy_coef[3 * C + li] : 0.f, ksh = FUSED ? a.dy_coef[4 * C + li] : 0.f;
+  const float nslope = a.dy_act == ACT_LRELU ? kLeaky : (a.dy_act == ACT_RELU ? 0.f : 1.f);   // host admits only these
 
   f32x16 acc[NT];
 #pragma unroll
@@ -226,46 +237,102 @@ __global__ __launch_bounds__(256, 2) void up_wgrad_kernel(const UpArgs a) {
 
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const TileXY cur = tile_xy(a, tile);
-    {   // no cross-tile prefetch here: the nine accumulators need the registers; the CU's second workgroup covers the wait
-      Patch pt;
-      patch_load(a, rX, cur, pt);
-      patch_store(pt, sA);
+    // no cross-tile prefetch here: the nine accumulators need the registers (the CU's second workgroup covers the
+    // wait); the patch goes through in two rounds of 5 float4 per thread for the same reason
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x4 v[NLD / 2];
+#pragma unroll
+      for (int j = 0; j < NLD / 2; ++j) {
+        const int e = tid + 256 * (j + h * (NLD / 2));
+        const int pp = e >> 3, c4 = e & 7;
+        const int py = (pp * 1986) >> 16, px = pp - py * PW;
+        const int iy = cur.y0 + py, ix = cur.x0 + px;
+        const bool ok = e < NP * 8 && iy < a.H && ix < a.W;
+        v[j] = ld4(rX, ok ? (unsigned)(((cur.b * a.H + iy) * a.W + ix) * C + 4 * c4) * 4u : kOOBu);
+      }
+#pragma unroll
+      for (int j = 0; j < NLD / 2; ++j) {
+        const int e = tid + 256 * (j + h * (NLD / 2));
+        if (e < NP * 8) *reinterpret_cast<f32x4*>(&sA[(e >> 3) * LDA + 4 * (e & 7)]) = v[j];
+      }
     }
     __syncthreads();
 
-    float dv[2][16];
-    auto dy_load = [&](int ly, int c, float* d) {
-      const unsigned rowoff = (unsigned)((((cur.b * OH + 2 * (cur.y0 + ly) + a.cpy[c]) * OW + 2 * cur.x0 + a.cpx[c]) * C + li)) * 4u;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) d[j] = ld1(rG, rowoff + (unsigned)((2 * j + lh) * 2 * C) * 4u);
+    // one step = (row, class, half row): 8 pixel pairs.  Its dy (and y) loads are issued one step ahead.
+    float dv[2][8], yv[FUSED ? 2 : 1][FUSED ? 8 : 1];
+    auto step_off = [&](int ly, int c, int h) {
+      return (unsigned)((((cur.b * OH + 2 * (cur.y0 + ly) + a.cpy[c]) * OW + 2 * cur.x0 + a.cpx[c] + 2 * (16 * h + lh)) * C + li)) * 4u;
     };
-    auto run_class = [&](int ly, auto cls_c, const float* d) {
+    auto dy_load = [&](unsigned off, auto slot_c) {
+      constexpr int slot = decltype(slot_c)::value;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dv[slot][j] = ld1(rG, off + (unsigned)(4 * j * C) * 4u);
+      if constexpr (FUSED) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) yv[slot][j] = ld1(rYb, off + (unsigned)(4 * j * C) * 4u);
+      }
+    };
+    auto run_step = [&](int ly, auto cls_c, int h, unsigned off, auto slot_c) {
       constexpr int CLS = decltype(cls_c)::value;
+      constexpr int slot = decltype(slot_c)::value;
       using CI = ClsInfo<CLS>;
       int xo[CI::ntaps];
 #pragma unroll
-      for (int t = 0; t < CI::ntaps; ++t) xo[t] = ((ly + a.tdy[CLS][t]) * PW + lh + a.tdx[CLS][t]) * LDA + li;
+      for (int t = 0; t < CI::ntaps; ++t) xo[t] = ((ly + a.tdy[CLS][t]) * PW + 16 * h + lh + a.tdx[CLS][t]) * LDA + li;
+      // x operands are fetched one pixel pair ahead; sched_barrier keeps the compiler from hoisting all 32 LDS
+      // reads of the step (live ranges would push the nine accumulators out of the register file)
+      float xa[CI::ntaps], xb[CI::ntaps];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        bsum += d[j];
+      for (int t = 0; t < CI::ntaps; ++t) xa[t] = sA[xo[t]];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j + 1 < 8) {
+#pragma unroll
+          for (int t = 0; t < CI::ntaps; ++t) xb[t] = sA[xo[t] + 2 * (j + 1) * LDA];
+        }
+        float d = dv[slot][j];
+        if constexpr (FUSED) {   // BatchNorm-backward apply on load; g_y goes out for the data-gradient kernel
+          const float yy = yv[slot][j];
+          const float g1 = (yy * ksc + ksh) > 0.f ? d : d * nslope;   // LeakyReLU / ReLU / identity derivative
+          d = k1 * g1 + k2 * yy + k3;
+          st1(rGY, off + (unsigned)(4 * j * C) * 4u, d);
+        }
+        bsum += d;
 #pragma unroll
         for (int t = 0; t < CI::ntaps; ++t)
-          acc[CI::first + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[xo[t] + 2 * j * LDA], d[j], acc[CI::first + t], 0, 0, 0);
+          acc[CI::first + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[t], d, acc[CI::first + t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < CI::ntaps; ++t) xa[t] = xb[t];
+        __builtin_amdgcn_sched_barrier(0);
       }
     };
-    // 8 (row, class) steps per wave; the next step's dy is in flight while the current one multiplies
-    dy_load(wave, 0, dv[0]);
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    unsigned o_cur = step_off(wave, 0, 0), o_nxt;
+    dy_load(o_cur, S0{});
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int ly = wave + 4 * i;
-      dy_load(ly, 1, dv[1]);
-      run_class(ly, std::integral_constant<int, 0>{}, dv[0]);
-      dy_load(ly, 2, dv[0]);
-      run_class(ly, std::integral_constant<int, 1>{}, dv[1]);
-      dy_load(ly, 3, dv[1]);
-      run_class(ly, std::integral_constant<int, 2>{}, dv[0]);
-      if (i == 0) dy_load(wave + 4, 0, dv[0]);
-      run_class(ly, std::integral_constant<int, 3>{}, dv[1]);
+      // 8 steps of this row: (c0,h0) (c0,h1) (c1,h0) ... (c3,h1); even steps use slot 0, odd steps slot 1
+      o_nxt = step_off(ly, 0, 1); dy_load(o_nxt, S1{});
+      run_step(ly, std::integral_constant<int, 0>{}, 0, o_cur, S0{});
+      o_cur = o_nxt; o_nxt = step_off(ly, 1, 0); dy_load(o_nxt, S0{});
+      run_step(ly, std::integral_constant<int, 0>{}, 1, o_cur, S1{});
+      o_cur = o_nxt; o_nxt = step_off(ly, 1, 1); dy_load(o_nxt, S1{});
+      run_step(ly, std::integral_constant<int, 1>{}, 0, o_cur, S0{});
+      o_cur = o_nxt; o_nxt = step_off(ly, 2, 0); dy_load(o_nxt, S0{});
+      run_step(ly, std::integral_constant<int, 1>{}, 1, o_cur, S1{});
+      o_cur = o_nxt; o_nxt = step_off(ly, 2, 1); dy_load(o_nxt, S1{});
+      run_step(ly, std::integral_constant<int, 2>{}, 0, o_cur, S0{});
+      o_cur = o_nxt; o_nxt = step_off(ly, 3, 0); dy_load(o_nxt, S0{});
+      run_step(ly, std::integral_constant<int, 2>{}, 1, o_cur, S1{});
+      o_cur = o_nxt; o_nxt = step_off(ly, 3, 1); dy_load(o_nxt, S1{});
+      run_step(ly, std::integral_constant<int, 3>{}, 0, o_cur, S0{});
+      o_cur = o_nxt;
+      if (i == 0) { o_nxt = step_off(wave + 4, 0, 0); dy_load(o_nxt, S0{}); }
+      run_step(ly, std::integral_constant<int, 3>{}, 1, o_cur, S1{});
+      o_cur = o_nxt;
     }
     __syncthreads();
   }
@@ -358,15 +425,18 @@ int launch_upconv_forward(const ConvGeom& g, const float* X, const float* W, con
 
 // partial slabs [parts][9][32][32] (+ bias partials [parts][32]) into ws; the caller reduces them
 int launch_upconv_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, float** part_out, float** pbias_out,
-                        int* nparts, bool want_bias, hipStream_t st) {
+                        int* nparts, bool want_bias, hipStream_t st, const DyXform* dyx) {
   UpArgs a{};
   fill(a, g);
   a.X = X; a.dY = dY;
+  if (dyx != nullptr && dyx->y != nullptr && dyx->act != ACT_NONE && dyx->act != ACT_RELU && dyx->act != ACT_LRELU) return kErrBadArg;
+  if (dyx != nullptr && dyx->y != nullptr) { a.dy_y = dyx->y; a.dy_coef = dyx->coef; a.gy_out = dyx->gy_out; a.dy_act = dyx->act; }
   const int nwg = upconv_rows(g);
   a.out = ws;
   a.pbias = want_bias ? ws + (size_t)nwg * NT * C * C : nullptr;
   ProfScope ps("up_wgrad_kernel", st, 2.0 * a.ntiles * TH * TW * NT * C * C, 4.0 * a.ntiles * TH * TW * C * 5.0);
-  hipLaunchKernelGGL(up_wgrad_kernel, dim3(nwg), dim3(256), 0, st, a);
+  if (a.dy_y != nullptr) hipLaunchKernelGGL(up_wgrad_kernel<true>, dim3(nwg), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(up_wgrad_kernel<false>, dim3(nwg), dim3(256), 0, st, a);
   CTVAE_LAUNCH_CHECK();
   *part_out = a.out;
   *pbias_out = a.pbias;

@@ -517,18 +517,20 @@ int launch_thin_wgrad(const ConvGeom& g, const float* X, const float* dY, float*
 
 bool upconv_wgrad_supported(const ConvGeom& g);
 int launch_upconv_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, float** part_out, float** pbias_out,
-                        int* nparts, bool want_bias, hipStream_t st);
+                        int* nparts, bool want_bias, hipStream_t st, const DyXform* dyx);
 bool img_enc_supported(const ConvGeom& g);
 int launch_img_enc_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, float** part_out, float** pbias_out,
                          int* nparts, bool want_bias, hipStream_t st);
 
 int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, float* dbias, float* ws,
-                 size_t ws_bytes, int accumulate, hipStream_t st, const InXform* xf) {
-  if (upconv_wgrad_supported(g) && (xf == nullptr || xf->scale == nullptr) &&
-      ws_bytes / sizeof(float) >= (size_t)512 * (9 * 32 * 32 + 32)) {
+                 size_t ws_bytes, int accumulate, hipStream_t st, const InXform* xf, const DyXform* dyx) {
+  const bool up = upconv_wgrad_supported(g) && (xf == nullptr || xf->scale == nullptr) &&
+                  ws_bytes / sizeof(float) >= (size_t)512 * (9 * 32 * 32 + 32);
+  if (dyx != nullptr && dyx->y != nullptr && !up) return kErrBadArg;   // only the transposed-conv kernel applies BN-backward on load
+  if (up) {
     float *part = nullptr, *pb = nullptr;
     int np = 0;
-    int rc = launch_upconv_wgrad(g, X, dY, ws, &part, &pb, &np, dbias != nullptr, st);
+    int rc = launch_upconv_wgrad(g, X, dY, ws, &part, &pb, &np, dbias != nullptr, st, dyx);
     if (rc) return rc;
     const long n = 9L * 32 * 32;
     ProfScope ps("reduce_partials_kernel", st, 0.0, 4.0 * (double)(np + 1) * n);

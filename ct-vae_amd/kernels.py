@@ -159,7 +159,9 @@ def conv_dgrad_bn_raw(dy, w, spec: ConvSpec, in_hw, link: BNLink):
     return dx
 
 
-def conv_wgrad_raw(x, dy, w_param, b_param, spec: ConvSpec, in_coef=None, in_act=ACT_NONE):
+def conv_wgrad_raw(x, dy, w_param, b_param, spec: ConvSpec, in_coef=None, in_act=ACT_NONE, dy_bn=None):
+    """dy_bn = (y, coef[5][Co], act, gy_out): dy is g_a of the BatchNorm behind this layer; g_y is formed on load and
+    written to gy_out (ctvae_conv_wgrad dy_bn_*)."""
     B, H, W, _ = x.shape
     ws = native.workspace(x.device)
     gw, acc = grad_target(w_param)
@@ -174,9 +176,10 @@ def conv_wgrad_raw(x, dy, w_param, b_param, spec: ConvSpec, in_coef=None, in_act
             acc = 1
     sc = in_coef.data_ptr() if in_coef is not None else None
     sh = in_coef.data_ptr() + 4 * spec.ci if in_coef is not None else None
+    by, bc, bact, bgy = (dy_bn[0].data_ptr(), dy_bn[1].data_ptr(), dy_bn[2], dy_bn[3].data_ptr()) if dy_bn is not None else (None, None, 0, None)
     native.call("ctvae_conv_wgrad", spec.kind, x.data_ptr(), dy.data_ptr(), gw.data_ptr(), native.ptr(gb),
                 B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, acc, sc, sh, in_act,
-                ws.data_ptr(), ws.numel() * 4)
+                by, bc, bact, bgy, ws.data_ptr(), ws.numel() * 4)
 
 
 def wgrad_then_dgrad(x, g, w_param, b_param, spec, need_dgrad, link=None):
@@ -334,7 +337,7 @@ class ConvBNAct(Function):
         part, rows = ctx.link_out.take(g_a) if ctx.link_out is not None else (None, 0)
         native.call("ctvae_bn_backward", g_a.data_ptr(), beta.data_ptr(), y.data_ptr(), B * H * W, C, gamma.data_ptr(),
                     save_mean.data_ptr(), save_invstd.data_ptr(), ctx.bn_act, g_y.data_ptr(), gg.data_ptr(), gbt.data_ptr(),
-                    accg, native.ptr(part), rows, ws.data_ptr(), ws.numel() * 4)
+                    accg, native.ptr(part), rows, None, ws.data_ptr(), ws.numel() * 4)
         g_x = wgrad_then_dgrad(x, g_y, w, b, spec, ctx.needs_input_grad[0], ctx.link_in)
         return (g_x,) + (None,) * 10
 
@@ -348,6 +351,18 @@ def input_transform_supported(spec: ConvSpec, B, H, W) -> bool:
     ok = _xform_ok_cache.get(key)
     if ok is None:
         ok = _xform_ok_cache[key] = bool(native.load().ctvae_conv_input_transform_supported(*key))
+    return ok
+
+
+_wgrad_bn_ok_cache = {}
+
+
+def wgrad_bn_apply_supported(spec: ConvSpec, B, H, W) -> bool:
+    """Can this layer's weight-gradient kernel apply the BatchNorm backward on load (ctvae_conv_wgrad dy_bn_*)?"""
+    key = (spec.kind, B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad)
+    ok = _wgrad_bn_ok_cache.get(key)
+    if ok is None:
+        ok = _wgrad_bn_ok_cache[key] = bool(native.load().ctvae_conv_wgrad_bn_apply_supported(*key))
     return ok
 
 
@@ -406,10 +421,21 @@ class ConvBNActConvAct(Function):
         if accg != accb:
             (gg if accg == 0 else gbt).zero_()
             accg = 1
+        lazy = wgrad_bn_apply_supported(spec1, x.shape[0], x.shape[1], x.shape[2])
+        bcoef = torch.empty(5 * C, dtype=torch.float32, device=x.device) if lazy else None
         native.call("ctvae_bn_backward", g_a.data_ptr(), beta.data_ptr(), y1.data_ptr(), B * H * W, C, gamma.data_ptr(),
-                    save_mean.data_ptr(), save_invstd.data_ptr(), ctx.bn_act, g_y.data_ptr(), gg.data_ptr(), gbt.data_ptr(),
-                    accg, native.ptr(part), rows, ws.data_ptr(), ws.numel() * 4)
-        g_x = wgrad_then_dgrad(x, g_y, w1, b1, spec1, ctx.needs_input_grad[0], ctx.link_in)
+                    save_mean.data_ptr(), save_invstd.data_ptr(), ctx.bn_act, None if lazy else g_y.data_ptr(), gg.data_ptr(),
+                    gbt.data_ptr(), accg, native.ptr(part), rows, native.ptr(bcoef), ws.data_ptr(), ws.numel() * 4)
+        if lazy:
+            # the weight-gradient kernel turns g_a into g_y on load and leaves g_y behind for the data gradient
+            conv_wgrad_raw(x, g_a, w1, b1, spec1, dy_bn=(y1, bcoef, ctx.bn_act, g_y))
+            g_x = None
+            if ctx.needs_input_grad[0]:
+                g_x = None if ctx.link_in is None else conv_dgrad_bn_raw(g_y, w1, spec1, (x.shape[1], x.shape[2]), ctx.link_in)
+                if g_x is None:
+                    g_x = conv_dgrad_raw(g_y, w1, spec1, (x.shape[1], x.shape[2]))
+        else:
+            g_x = wgrad_then_dgrad(x, g_y, w1, b1, spec1, ctx.needs_input_grad[0], ctx.link_in)
         return (g_x,) + (None,) * 13
 
 

@@ -21,9 +21,9 @@ SIGNATURES = {
     "ctvae_conv_bn_act_forward": [_i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp] + [_i] * 9
                                  + [_fp, _sz, _vp],
     "ctvae_conv_dgrad": [_i, _fp, _fp, _fp, _fp, _i, _fp] + [_i] * 9 + [_fp, _sz, _vp],
-    "ctvae_conv_wgrad": [_i, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _fp, _i, _fp, _sz, _vp],
+    "ctvae_conv_wgrad": [_i, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _sz, _vp],
     "ctvae_bn_forward": [_fp, _i, _i, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _fp, _fp, _fp, _fp, _fp, _sz, _vp],
-    "ctvae_bn_backward": [_fp, _fp, _fp, _i, _i, _fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _fp, _i, _fp, _sz, _vp],
+    "ctvae_bn_backward": [_fp, _fp, _fp, _i, _i, _fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _fp, _i, _fp, _fp, _sz, _vp],
     "ctvae_conv_dgrad_bn": [_i, _fp, _fp, _fp, _fp, _i, _fp] + [_i] * 9 + [_fp, _fp, _fp, _fp, _fp, _i, _fp, _i, _fp, _sz, _vp],
     "ctvae_permute": [_fp, _fp, _i, _i, _i, _i, _vp],
     "ctvae_act_forward": [_fp, _fp, _l, _i, _vp],
@@ -49,6 +49,7 @@ _RESTYPES = {
     "ctvae_prof_report": _c.c_size_t,
     "ctvae_conv_dgrad_bn_rows": _c.c_int,
     "ctvae_conv_input_transform_supported": _c.c_int,
+    "ctvae_conv_wgrad_bn_apply_supported": _c.c_int,
 }
 EXPORTS = sorted(list(SIGNATURES) + list(_RESTYPES))
 
@@ -82,7 +83,8 @@ def load():
         fn.argtypes = {"ctvae_error_string": [_c.c_int], "ctvae_prof_enable": [_c.c_int],
                        "ctvae_prof_report": [_c.c_char_p, _c.c_size_t],
                        "ctvae_conv_dgrad_bn_rows": [_c.c_int] * 10 + [_c.c_size_t],
-                       "ctvae_conv_input_transform_supported": [_c.c_int] * 10}.get(name, [])
+                       "ctvae_conv_input_transform_supported": [_c.c_int] * 10,
+                       "ctvae_conv_wgrad_bn_apply_supported": [_c.c_int] * 10}.get(name, [])
     if lib.ctvae_arch() != b"gfx950":
         raise RuntimeError("libctvae_hip.so was not built for gfx950")
     _lib = lib

@@ -85,7 +85,15 @@ int ctvae_conv_dgrad_bn(int kind, const float* dy, const float* w, const float* 
 /* in_scale/in_shift/in_act: as ctvae_conv_forward (x is then the raw BatchNorm input y of the previous block). */
 int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float* dbias, int B, int H, int W, int Ci,
                      int Co, int k, int stride, int pad, int out_pad, int accumulate, const float* in_scale,
-                     const float* in_shift, int in_act, float* ws, size_t ws_bytes, void* stream);
+                     const float* in_shift, int in_act, const float* dy_bn_y, const float* dy_bn_coef, int dy_bn_act,
+                     float* gy_out, float* ws, size_t ws_bytes, void* stream);
+/* dy_bn_y / dy_bn_coef / gy_out (all or none): `dy` is then g_a, the gradient w.r.t. the output of the BatchNorm +
+ * activation that follows this layer; the kernel forms g_y = k1*g_a*act'(y*scale+shift) + k2*y + k3 while loading
+ * (coef = [5][Co]: k1,k2,k3,scale,shift as written by ctvae_bn_backward coef_out), uses it for dw/dbias and writes it to
+ * gy_out for the ctvae_conv_dgrad call that follows: the separate BatchNorm-backward apply pass disappears.
+ * Only where ctvae_conv_wgrad_bn_apply_supported() says 1 (the 32->32 transposed conv of the final block). */
+int ctvae_conv_wgrad_bn_apply_supported(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad,
+                                        int out_pad);
 
 /* Train/eval BatchNorm2d + activation on an [R=B*H*W][C] matrix (vanilla_vae.py:30-31,56-57,71-72).
  * training: batch statistics (biased var, eps), running stats updated with `momentum` and the unbiased
@@ -97,11 +105,13 @@ int ctvae_bn_forward(const float* y, int R, int C, const float* gamma, const flo
                      void* stream);
 /* g_y from g_a (grad wrt the activated output); the activation derivative is re-derived from the sign of
  * gamma*invstd*(y-mean)+beta, so the activated tensor is not read; dgamma/dbeta (+)= ...
- * part_in/part_rows: the per-tile sums a ctvae_conv_dgrad_bn launch emitted for this g_a (NULL/0: computed here). */
+ * part_in/part_rows: the per-tile sums a ctvae_conv_dgrad_bn launch emitted for this g_a (NULL/0: computed here).
+ * coef_out [5][C] (may be NULL): k1,k2,k3,scale,shift of g_y = k1*g_a*act'(y*scale+shift) + k2*y + k3; with
+ * g_y == NULL the apply pass is left to ctvae_conv_wgrad (dy_bn_*). */
 int ctvae_bn_backward(const float* g_a, const float* beta, const float* y, int R, int C, const float* gamma,
                       const float* save_mean, const float* save_invstd, int act, float* g_y, float* dgamma,
-                      float* dbeta, int accumulate, const float* part_in, int part_rows, float* ws, size_t ws_bytes,
-                      void* stream);
+                      float* dbeta, int accumulate, const float* part_in, int part_rows, float* coef_out, float* ws,
+                      size_t ws_bytes, void* stream);
 
 /* layout change at the NCHW API boundary: to_nhwc=1: in [B,C,P] -> out [B,P,C]; 0: the inverse
  * (torch.flatten on NCHW, vanilla_vae.py:85; .view(-1,512,2,2), vanilla_vae.py:102) */
