@@ -47,6 +47,25 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(kernel_name):
+    """HBM-side bytes per launch of `kernel_name` from the newest committed PMC summary (profiles/*_pmc_traffic.json,
+    written by tools/pmc_summary.py from two separate `rocprofv3 --pmc` passes of this same command) or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None, None
+    want = kernel_name.replace(" ", "")
+    for k, v in d.get("kernels", {}).items():
+        if k.replace(" ", "") == want:
+            return v["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def build_model(name, dev, seed):
     from ctvae_amd import filler
     from ctvae_amd.models import vae_models
@@ -208,6 +227,10 @@ def main():
                         "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
                         "avg_launch_us": round(top["ms"] / top["count"] * 1e3, 2),
                         "launches_per_step": top["count"] / nprof}
+        if args.model == "VanillaVAE" and B == 256:   # the PMC passes were taken on this workload
+            roofline["traffic"], src = pmc_traffic(name)
+            if src:
+                roofline["traffic_source"] = src + " (bytes per launch; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"
         step_tflops = FLOP_PER_IMG[args.model] * (B * args.steps / elapsed) / 1e12
         roofline["step_conv_tflops_per_gpu"] = round(step_tflops, 2)
         roofline["step_frac_of_f32_mfma_peak"] = round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)

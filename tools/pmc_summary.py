@@ -1,0 +1,31 @@
+"""Per-kernel HBM-side traffic from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot share a pass on
+gfx950: TCC has 4 slots, they cost 3 + 2).  Usage:
+    python tools/pmc_summary.py <dir with FETCH pass> <dir with WRITE pass> <steps profiled> > profiles/rNN_pmc_traffic.json
+Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes: the counters are in KB; on gfx950
+FETCH_SIZE reports half of the bytes of coalesced streaming reads (128-B requests tallied at 64 B) -> doubled;
+WRITE_SIZE is taken as is."""
+import collections, csv, glob, json, os, sys
+
+
+def load(d):
+    f = glob.glob(os.path.join(d, "*counter_collection.csv"))[0]
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("ctvae::", "")
+        agg[name][0] += 1
+        agg[name][1] += float(r["Counter_Value"])
+    return agg
+
+
+fd, wd, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+F, W = load(fd), load(wd)
+out = {}
+for k in sorted(F, key=lambda k: -(2 * F[k][1] + W.get(k, [0, 0])[1])):
+    n = F[k][0]
+    fetch_raw = F[k][1] * 1024.0 / n
+    write = W.get(k, [1, 0.0])[1] * 1024.0 / max(W.get(k, [1, 0.0])[0], 1)
+    out[k] = {"launches_per_step": round(n / steps, 2), "fetch_bytes_raw_per_launch": round(fetch_raw),
+              "fetch_bytes_corrected_per_launch": round(2 * fetch_raw), "write_bytes_per_launch": round(write),
+              "hbm_bytes_per_launch": round(2 * fetch_raw + write)}
+json.dump({"note": "FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE as reported; separate --pmc passes, eager launches",
+           "steps": steps, "kernels": out}, sys.stdout, indent=1)
