@@ -40,6 +40,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--model", default="VanillaVAE", choices=["VanillaVAE", "MCQVAE"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N>1: one backward graph, then the all-reduce (default: backward cut at the latent, the "
+                         "decoder-side buckets are exchanged while the encoder's backward runs)")
+    ap.add_argument("--split-backward", action="store_true", help="use the two-stage backward even at N=1 (diagnostic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -152,22 +156,65 @@ def main():
             opt.step()
         return l
 
-    graph = None
+    # N>1: the backward pass is cut at the latent (ddp.SplitBackward): the decoder-side gradient range is all-reduced
+    # on the communication stream while the encoder's backward (second graph) runs
+    split = None
+    if args.model == "VanillaVAE" and ((world > 1 and not args.no_overlap) or args.split_backward):
+        from ctvae_amd.ddp import SplitBackward
+        split = SplitBackward(model)
+
+    def stage1():
+        model.zero_grad()
+        return split.stage1(static_x, M_N=kld_w)["loss"].detach()
+
+    graph = graph2 = None
     if not args.no_graph:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         static_x.copy_(batches[0])
         with torch.cuda.stream(s):
             for _ in range(3):
-                local_step()
+                if split is not None:
+                    stage1()
+                    split.stage2()
+                    if world == 1:
+                        opt.step()
+                else:
+                    local_step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_loss = local_step()
+        if split is not None:
+            with torch.cuda.graph(graph):
+                static_loss = stage1()
+            graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph2, pool=graph.pool()):
+                split.stage2()
+                if world == 1:
+                    opt.step()
+        else:
+            with torch.cuda.graph(graph):
+                static_loss = local_step()
 
     def step(i):
         static_x.copy_(batches[i % 4], non_blocking=True)
+        if split is not None:
+            if graph is not None:
+                graph.replay()
+            else:
+                stage1()
+            works = ddp.all_reduce_range(split.split, split.total) if world > 1 else []
+            if graph2 is not None:
+                graph2.replay()
+            else:
+                split.stage2()
+                if world == 1:
+                    opt.step()
+            if world > 1:
+                works += ddp.all_reduce_range(0, split.split)
+                ddp.wait(works)
+                opt.step(grad_scale=ddp.grad_scale)
+            return
         if graph is not None:
             graph.replay()
         else:
@@ -259,7 +306,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.model} 64x64x3 train step fwd+loss+bwd+Adam" + ("+allreduce" if world > 1 else ""),
                        "per_gpu_batch": B, "global_batch": B * world, "latent_dim": 128,
-                       "parallelism": f"dp{world}" if world > 1 else "single", "hipgraph": graph is not None},
+                       "parallelism": f"dp{world}" if world > 1 else "single", "hipgraph": graph is not None,
+                       "allreduce_overlap": bool(split is not None and world > 1)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if kernels is not None:

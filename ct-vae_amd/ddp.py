@@ -59,6 +59,25 @@ class GradBucketAllReduce:
             self.wait(works)
         return works
 
+    def all_reduce_range(self, lo, hi):
+        """Asynchronous SUM all-reduce of flat_grads[lo:hi] (bucketed) on the communication stream, ordered behind
+        everything issued so far on the current stream.  Returns the work handles for wait()."""
+        if self.world == 1 or hi <= lo:
+            return []
+        g = self.model.flat_grads
+        parts, off = [], lo
+        while off < hi:
+            e = min(hi, off + self.bucket_elems)
+            parts.append(g[off:e])
+            off = e
+        if g.is_cuda:
+            if self.comm_stream is None:
+                self.comm_stream = torch.cuda.Stream(device=g.device)
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                return [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.pg, async_op=True) for b in parts]
+        return [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.pg, async_op=True) for b in parts]
+
     def wait(self, works):
         for w in works:
             w.wait()
@@ -78,3 +97,50 @@ class GradBucketAllReduce:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
         t /= self.world
         return {k: t[i] for i, k in enumerate(keys)}
+
+
+class SplitBackward:
+    """VanillaVAE training step cut at the latent z, so that the decoder-side gradient buckets travel over xGMI while
+    the encoder's backward still runs (DDP's bucket/backward overlap, SURVEY.md §8e, without autograd hooks: parameter
+    gradients are written by the wgrad kernels, not by AccumulateGrad nodes).
+
+        stage1: encode -> reparameterize -> decode(z as a fresh leaf) -> loss; backward restricted to {z, decoder params}
+        stage2: backward of (loss via mu/log_var, z with the gradient stage1 left on the leaf) restricted to encoder params
+
+    Both stages are hipGraph-capturable; the flat gradient buffer is laid out in registration order, so the two sides
+    are the contiguous ranges [0, split) and [split, n)."""
+
+    DECODER_SIDE = ("decoder_input", "decoder", "final_layer")
+
+    def __init__(self, model):
+        self.model = model
+        names = [n for n, _ in model.named_parameters()]
+        dec = lambda n: n.split(".")[0] in self.DECODER_SIDE
+        self.dec_params = [p for n, p in model.named_parameters() if dec(n)]
+        self.enc_params = [p for n, p in model.named_parameters() if not dec(n)]
+        if not self.dec_params or not self.enc_params or not hasattr(model, "reparameterize"):
+            raise ValueError("SplitBackward needs a VanillaVAE-like model (encode / reparameterize / decode)")
+        base = model.flat_params.data_ptr()
+        lo = min((p.data_ptr() - base) // 4 for p in self.dec_params)
+        hi_enc = max((p.data_ptr() - base) // 4 + p.numel() for p in self.enc_params)
+        if hi_enc > lo:
+            raise ValueError("encoder- and decoder-side parameters are not two contiguous ranges of the flat buffer")
+        self.split = int(lo)
+        self.total = model.flat_params.numel()
+        self._loss = self._z = self._z_leaf = None
+        del names
+
+    def stage1(self, x, eps=None, **loss_kwargs):
+        m = self.model
+        mu, log_var = m.encode(x)
+        z = m.reparameterize(mu, log_var, eps)
+        z_leaf = z.detach().requires_grad_(True)
+        recon = m.decode(z_leaf)
+        losses = m.loss_function(recon, x, mu, log_var, **loss_kwargs)
+        loss = losses["loss"]
+        torch.autograd.backward([loss], inputs=[z_leaf] + self.dec_params, retain_graph=True)
+        self._loss, self._z, self._z_leaf = loss, z, z_leaf
+        return losses
+
+    def stage2(self):
+        torch.autograd.backward([self._loss, self._z], [None, self._z_leaf.grad], inputs=self.enc_params)

@@ -41,6 +41,16 @@ def _worker(rank, world, port, q):
         assert torch.equal(m.flat_grads, 3 * ramp)
         assert float(m.fc_mu.bias.grad[0]) == float(3 * ramp[(m.fc_mu.bias.grad.data_ptr() - m.flat_grads.data_ptr()) // 4])
         assert ddp.grad_scale == 0.5
+        # range exchange (the overlap path of bench.py: decoder-side range first, encoder-side range later)
+        from ctvae_amd.ddp import SplitBackward
+        sb = SplitBackward(m)
+        assert sb.split == m.flat_range("decoder_input").start and 0 < sb.split < sb.total
+        m.flat_grads.copy_((rank + 1) * ramp)
+        ddp.wait(ddp.all_reduce_range(sb.split, sb.total))
+        assert torch.equal(m.flat_grads[sb.split:], 3 * ramp[sb.split:])
+        assert torch.equal(m.flat_grads[:sb.split], (rank + 1) * ramp[:sb.split]), "range exchange touched the other side"
+        ddp.wait(ddp.all_reduce_range(0, sb.split))
+        assert torch.equal(m.flat_grads, 3 * ramp)
         red = ddp.reduce_scalars({"loss": torch.tensor(float(rank)), "KLD": torch.tensor(2.0 * rank)})
         assert abs(float(red["loss"]) - 0.5) < 1e-7 and abs(float(red["KLD"]) - 1.0) < 1e-7
         q.put((rank, "ok"))
