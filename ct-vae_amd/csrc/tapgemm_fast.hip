@@ -584,14 +584,11 @@ static int launch_fast_cfg(const TapGemmArgs& a, int pf, hipStream_t st) {
   const double bytes = 4.0 * ((double)a.g.B * a.g.gH * a.g.gW * a.g.gC + (double)a.g.B * a.g.sH * a.g.sW * a.g.sC);
   ProfScope ps(name, st, 2.0 * macs, bytes);
   if (!wt) {
+    // PF 1 / 2 (plain double buffer, two-chunk register prefetch) were measured and lost to 3: not instantiated
     if (pf == 3) hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, false, 3>), grid, block, 0, st, args);
-    else if (pf == 2) hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, false, 2>), grid, block, 0, st, args);
-    else if (pf == 1) hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, false, 1>), grid, block, 0, st, args);
     else hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, false, 0>), grid, block, 0, st, args);
   } else {
     if (pf == 3) hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, true, 3>), grid, block, 0, st, args);
-    else if (pf == 2) hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, true, 2>), grid, block, 0, st, args);
-    else if (pf == 1) hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, true, 1>), grid, block, 0, st, args);
     else hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, true, 0>), grid, block, 0, st, args);
   }
   CTVAE_LAUNCH_CHECK();
