@@ -52,6 +52,12 @@ void ctvae_prof_enable(int on) {
   g_enabled = on;
 }
 
+// Calibration: n event pairs with nothing between them, logged as "(empty event pair)".  What such a pair measures
+// is the cost the pair adds around every timed launch; bench.py subtracts it from the per-kernel averages.
+void ctvae_prof_calibrate(void* stream, int n) {
+  for (int i = 0; i < n; ++i) { ProfScope ps("(empty event pair)", (hipStream_t)stream, 0.0, 0.0); }
+}
+
 // Synchronises the recorded events, aggregates per kernel name and clears the log.  Writes lines
 // "name\tcount\ttotal_ms\ttotal_flops\ttotal_bytes\n" into buf (truncated to n bytes); returns bytes needed.
 size_t ctvae_prof_report(char* buf, size_t n) {

@@ -46,6 +46,7 @@ _RESTYPES = {
     "ctvae_error_string": _c.c_char_p,
     "ctvae_workspace_bytes": _c.c_size_t,
     "ctvae_prof_enable": None,
+    "ctvae_prof_calibrate": None,
     "ctvae_prof_report": _c.c_size_t,
     "ctvae_conv_dgrad_bn_rows": _c.c_int,
     "ctvae_conv_input_transform_supported": _c.c_int,
@@ -81,6 +82,7 @@ def load():
             raise RuntimeError(f"{LIB_PATH} does not export {name} (stale build?)")
         fn.restype = res
         fn.argtypes = {"ctvae_error_string": [_c.c_int], "ctvae_prof_enable": [_c.c_int],
+                       "ctvae_prof_calibrate": [_c.c_void_p, _c.c_int],
                        "ctvae_prof_report": [_c.c_char_p, _c.c_size_t],
                        "ctvae_conv_dgrad_bn_rows": [_c.c_int] * 10 + [_c.c_size_t],
                        "ctvae_conv_input_transform_supported": [_c.c_int] * 10,
@@ -130,6 +132,11 @@ def call(name: str, *args):
 def prof_enable(on, detailed: bool = False):
     """on=False: off; on=True: per kernel symbol; detailed=True: names also carry the problem shape."""
     load().ctvae_prof_enable((2 if detailed else 1) if on else 0)
+
+
+def prof_calibrate(n: int = 64):
+    """Log n empty event pairs on the current stream (key "(empty event pair)" of the next prof_report())."""
+    load().ctvae_prof_calibrate(stream_ptr(), n)
 
 
 def prof_report() -> dict:

@@ -162,6 +162,7 @@ int ctvae_adam_step(float* params, const float* grads, float* exp_avg, float* ex
  * "name\tcount\ttotal_ms\talgorithmic_flops\talgorithmic_bytes"; returns the buffer size needed.  Must be off
  * during hipGraph capture. */
 void ctvae_prof_enable(int on);
+void ctvae_prof_calibrate(void* stream, int n); /* n empty event pairs, reported as "(empty event pair)" */
 size_t ctvae_prof_report(char* buf, size_t n);
 
 #ifdef __cplusplus
