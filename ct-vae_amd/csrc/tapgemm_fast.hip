@@ -67,7 +67,15 @@ __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) 
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
   const int cls = blockIdx.y;
-  const int mt = blockIdx.x / a.ntiles, nt = blockIdx.x - mt * a.ntiles;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so the n-tiles of one
+  // m-tile (same gathered pixels) would land in 8 different L2s.  Remap so that each XCD walks a contiguous range of
+  // the (m-tile, n-tile) space; the remainder (grid.x % 8) keeps its place.
+  int tile = blockIdx.x;
+  {
+    const int per = gridDim.x >> 3;
+    if (tile < per * 8) tile = (tile & 7) * per + (tile >> 3);
+  }
+  const int mt = tile / a.ntiles, nt = tile - mt * a.ntiles;
   const int m0 = mt * BM, n0 = nt * BN;
   const int ntaps = g.ntaps[cls];
   const int gC = g.gC, N = a.N;

@@ -43,8 +43,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
-  const int split = blockIdx.y;
-  const int ktg = blockIdx.x / a.ntiles, nt = blockIdx.x - ktg * a.ntiles;
+  // XCD-aware order (see wgrad_fast_kernel): the output tiles of one pixel slice share one L2
+  int split = blockIdx.y, xtile = blockIdx.x;
+  {
+    const int T = gridDim.x, L = blockIdx.y * T + blockIdx.x, full = (gridDim.y >> 3) * 8 * T;
+    if (L < full) {
+      const int grp = L / (8 * T), r = L - grp * 8 * T;
+      split = grp * 8 + (r & 7);
+      xtile = r >> 3;
+    }
+  }
+  const int ktg = xtile / a.ntiles, nt = xtile - ktg * a.ntiles;
   int cls = 0;
 #pragma unroll
   for (int c = 1; c < kMaxCls; ++c)
@@ -249,8 +258,19 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradArgs a, int 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
-  const int split = blockIdx.y;
-  const int ktg = blockIdx.x / a.ntiles, nt = blockIdx.x - ktg * a.ntiles;
+  // XCD-aware order: every output tile of one pixel slice reads the same X / dY rows, and workgroups are dealt
+  // round-robin to the 8 XCDs (one L2 each) in linear order -> give each group of 8 slices one XCD per slice, so a
+  // slice's rows are filled into ONE L2 instead of eight.  The last (gridDim.y % 8) slices keep the plain order.
+  int split = blockIdx.y, xtile = blockIdx.x;
+  {
+    const int T = gridDim.x, L = blockIdx.y * T + blockIdx.x, full = (gridDim.y >> 3) * 8 * T;
+    if (L < full) {
+      const int grp = L / (8 * T), r = L - grp * 8 * T;
+      split = grp * 8 + (r & 7);
+      xtile = r >> 3;
+    }
+  }
+  const int ktg = xtile / a.ntiles, nt = xtile - ktg * a.ntiles;
   int cls = 0;
 #pragma unroll
   for (int c = 1; c < kMaxCls; ++c)
