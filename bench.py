@@ -27,7 +27,8 @@ if ROOT not in sys.path:
 import torch
 import torch.distributed as dist
 
-FLOP_PER_IMG = {"VanillaVAE": 312_606_720, "MCQVAE": 4_208_984_064}   # SURVEY.md §8d convention (fwd+bwd)
+FLOP_PER_IMG = {"VanillaVAE": 312_606_720, "MCQVAE": 4_208_984_064,    # SURVEY.md §8d convention (fwd+bwd)
+                "CTMCQVAE": 4_932_501_504}                             # action-mode pair, conv path only
 PEAK_F32_MFMA_TFLOPS = 157.3                                             # MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
 
@@ -38,7 +39,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
-    ap.add_argument("--model", default="VanillaVAE", choices=["VanillaVAE", "MCQVAE"])
+    ap.add_argument("--model", default="VanillaVAE", choices=["VanillaVAE", "MCQVAE", "CTMCQVAE"],
+                    help="CTMCQVAE: ct_mcq_vae.yaml shapes, action-mode pairs (x, y, one-hot action), eager launches "
+                         "(the causal-transition layer has data-dependent host control flow)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N>1: one backward graph, then the all-reduce (default: backward cut at the latent, the "
@@ -75,6 +78,14 @@ def build_model(name, dev, seed):
     from ctvae_amd.models import vae_models
     if name == "VanillaVAE":
         m = vae_models[name](in_channels=3, latent_dim=128)
+    elif name == "CTMCQVAE":
+        import yaml
+        cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "ct_mcq_vae.yaml")))["model_params"]
+        torch.manual_seed(seed)
+        m = vae_models[name](**cfg)
+        from tests import helpers as H
+        m.load_state_dict(filler.fill_state(H.mcq_specs(H.CT_CONV_CFG), seed + 1), strict=False)
+        return m.to(dev).train()
     else:
         m = vae_models[name](in_channels=3, embedding_dim=128, hidden_dims=[64, 128, 256], num_embeddings=64,
                              img_size=64, codebooks=4, beta=0.25)
@@ -134,7 +145,9 @@ def main():
     native.load()
 
     B = args.batch
-    seed = 1265 if args.model == "VanillaVAE" else 1320
+    seed = {"VanillaVAE": 1265, "MCQVAE": 1320, "CTMCQVAE": 1250}[args.model]
+    if args.model == "CTMCQVAE":
+        args.no_graph = True
     model = build_model(args.model, dev, seed)
     opt = FlatAdam(model, lr=0.005 if args.model == "VanillaVAE" else 0.0005)
     ddp = GradBucketAllReduce(model) if world > 1 else None
@@ -142,10 +155,14 @@ def main():
     # 4 rotating synthetic batches per rank, resident in HBM, NCHW-contiguous like a DataLoader would hand over
     batches = [filler.synthetic_batch(seed + 1000 * rank + i, B)[0].to(dev) for i in range(4)]
     static_x = torch.empty_like(batches[0])
+    ct_kw = None
+    if args.model == "CTMCQVAE":
+        _, y, act = filler.synthetic_pairs(seed + 1000 * rank, B, 12)
+        ct_kw = {"mode": ["action"] * B, "input_y": y.to(dev), "action": act.to(dev)}
 
     def fwd_bwd():
         model.zero_grad()
-        out = model(static_x)
+        out = model(static_x, **ct_kw) if ct_kw is not None else model(static_x)
         losses = model.loss_function(*out, M_N=kld_w)
         losses["loss"].backward()
         return losses["loss"].detach()

@@ -30,6 +30,10 @@ int launch_bn_backward(const float* ga, const float* beta, const float* y, int R
                        float* coef_out = nullptr);
 bool upconv_wgrad_supported(const ConvGeom& g);
 int launch_permute(const float* in, float* out, int B, int C, int P, int to_nhwc, hipStream_t st);
+int launch_pair_mlp_forward(const float* u, const float* v, const float* w2, const float* b2, float* out, int B, int N, int H,
+                            float slope, hipStream_t st);
+int launch_pair_mlp_backward(const float* u, const float* v, const float* w2, const float* out, const float* g_out, float* dU,
+                             float* dV, float* dw2_part, float* db2_part, int B, int N, int H, float slope, hipStream_t st);
 int launch_act_bwd(const float* gout, const float* out, float* gin, long n, int act, hipStream_t st);
 int launch_act_fwd(const float* in, float* out, long n, int act, hipStream_t st);
 int launch_reparam_fwd(const float* mu, long mu_rs, const float* lv, long lv_rs, const float* eps, float* z, int B, int L,
@@ -197,6 +201,18 @@ int ctvae_bn_backward(const float* g_a, const float* beta, const float* y, int R
   if ((part_in != nullptr) != (part_rows > 0)) return kErrBadArg;
   return launch_bn_backward(g_a, beta, y, R, C, gamma, save_mean, save_invstd, act, g_y, dgamma, dbeta, accumulate, ws,
                             ws_bytes, part_in, part_rows, (hipStream_t)stream, coef_out);
+}
+
+int ctvae_pair_mlp_forward(const float* u, const float* v, const float* w2, const float* b2, float* out, int B, int N, int H,
+                           float slope, void* stream) {
+  if (!u || !v || !w2 || !out) return kErrBadArg;
+  return launch_pair_mlp_forward(u, v, w2, b2, out, B, N, H, slope, (hipStream_t)stream);
+}
+
+int ctvae_pair_mlp_backward(const float* u, const float* v, const float* w2, const float* out, const float* g_out, float* d_u,
+                            float* d_v, float* d_w2_part, float* d_b2_part, int B, int N, int H, float slope, void* stream) {
+  if (!u || !v || !w2 || !out || !g_out || !d_u || !d_v || !d_w2_part || !d_b2_part) return kErrBadArg;
+  return launch_pair_mlp_backward(u, v, w2, out, g_out, d_u, d_v, d_w2_part, d_b2_part, B, N, H, slope, (hipStream_t)stream);
 }
 
 int ctvae_permute(const float* in, float* out, int B, int C, int P, int to_nhwc, void* stream) {

@@ -1,0 +1,146 @@
+// Pairwise edge scorer of the causal-transition layer (ct_mcq_vae.py:86-95,147-151: `graph_discovers[k]` =
+// Linear(2D, H) -> LeakyReLU -> Linear(H, 1) -> Sigmoid evaluated on EVERY ordered pair of the N latent nodes).
+//
+// The first Linear is separable, W1 [x_i ; x_j] = W1a x_i + W1b x_j, so the host computes u = x W1a^T and
+// v = x W1b^T + b1 ([B,N,H] each, two small GEMMs) and this file does the part that would otherwise materialise a
+// [B,N,N,H] tensor (13 MB per sample at N = 64, H = 800) several times per step:
+//
+//     out[b,i,j] = sigmoid(b2 + sum_h w2[h] * lrelu(u[b,i,h] + v[b,j,h]))
+//
+// forward : thread = one (i,j) pair, the h-sum runs inside the thread; v chunks are staged transposed in LDS.
+// backward: thread = one h, a workgroup owns (b, 256 h's) and walks all (i,j) pairs, so that
+//           dU[b,i,h] and dV[b,j,h] are each produced by exactly ONE thread (no atomics, bit-reproducible);
+//           dw2 / db2 leave as per-sample partials reduced by the caller.
+// Both are VALU kernels (≈7 instructions per (pair, h)); nothing of size N*N*H ever touches memory.
+#include "common.hpp"
+#include "prof.hpp"
+
+namespace ctvae {
+
+namespace {
+
+constexpr int HC = 32;    // h chunk of the forward kernel
+constexpr int JT = 64;    // j lanes per workgroup
+constexpr int IT = 4;     // i rows per workgroup
+constexpr int NMAX = 64;  // backward keeps u[i], dU[i] of one h in registers
+
+__global__ __launch_bounds__(256) void pair_mlp_fwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                          const float* __restrict__ w2, const float* __restrict__ b2,
+                                                          float* __restrict__ out, int N, int H, float slope) {
+  __shared__ float sV[HC][JT + 1];
+  __shared__ float sU[IT][HC];
+  __shared__ float sW[HC];
+  const int tid = threadIdx.x, j_l = tid & (JT - 1), i_l = tid / JT;
+  const int b = blockIdx.y, i = blockIdx.x * IT + i_l;
+  const float* ub = u + (long)b * N * H;
+  const float* vb = v + (long)b * N * H;
+  const float bias = b2 != nullptr ? b2[0] : 0.f;
+  for (int j0 = 0; j0 < N; j0 += JT) {
+    float acc = 0.f;
+    for (int h0 = 0; h0 < H; h0 += HC) {
+      __syncthreads();
+      // stage v[b, j0:j0+64, h0:h0+32] transposed (reads coalesced along h), u rows and w2
+      for (int e = tid; e < JT * HC; e += 256) {
+        const int jj = e / HC, hh = e - jj * HC;
+        const int j = j0 + jj, h = h0 + hh;
+        sV[hh][jj] = (j < N && h < H) ? vb[(long)j * H + h] : 0.f;
+      }
+      if (tid < IT * HC) {
+        const int ii = tid / HC, hh = tid - ii * HC;
+        const int gi = blockIdx.x * IT + ii, h = h0 + hh;
+        sU[ii][hh] = (gi < N && h < H) ? ub[(long)gi * H + h] : 0.f;
+      }
+      if (tid < HC) sW[tid] = (h0 + tid < H) ? w2[h0 + tid] : 0.f;   // zero weight masks the h tail
+      __syncthreads();
+#pragma unroll
+      for (int hh = 0; hh < HC; ++hh) {
+        const float t = sU[i_l][hh] + sV[hh][j_l];
+        acc += sW[hh] * fmaxf(t, t * slope);
+      }
+    }
+    const int j = j0 + j_l;
+    if (i < N && j < N) out[((long)b * N + i) * N + j] = 1.f / (1.f + __expf(-(acc + bias)));
+  }
+}
+
+// grid (ceil(H/256), B).  dw2_part [B][H], dgs_part [B][gridDim.x] (sum of g*s*(1-s), identical for every h block)
+__global__ __launch_bounds__(256) void pair_mlp_bwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                          const float* __restrict__ w2, const float* __restrict__ out,
+                                                          const float* __restrict__ g_out, float* __restrict__ dU,
+                                                          float* __restrict__ dV, float* __restrict__ dw2_part,
+                                                          float* __restrict__ db2_part, int N, int H, float slope) {
+  __shared__ __attribute__((aligned(16))) float sG[NMAX][NMAX];   // [j][i] = g * s * (1 - s)
+  __shared__ float sRed[4];
+  const int tid = threadIdx.x, b = blockIdx.y, h = blockIdx.x * 256 + tid;
+  const bool hok = h < H;
+  const long bo = (long)b * N * H;
+  float gsum = 0.f;
+  for (int e = tid; e < NMAX * NMAX; e += 256) {
+    const int i = e / NMAX, j = e - i * NMAX;   // coalesced along j
+    float gs = 0.f;
+    if (i < N && j < N) {
+      const float s = out[((long)b * N + i) * N + j];
+      gs = g_out[((long)b * N + i) * N + j] * s * (1.f - s);
+    }
+    sG[j][i] = gs;
+    gsum += gs;
+  }
+  gsum = block_sum_256(gsum, sRed);   // contains the barrier that publishes sG
+  if (tid == 0 && blockIdx.x == 0) db2_part[b] = gsum;
+
+  float ur[NMAX], du[NMAX];
+#pragma unroll
+  for (int i = 0; i < NMAX; ++i) {
+    ur[i] = (hok && i < N) ? u[bo + (long)i * H + h] : 0.f;
+    du[i] = 0.f;
+  }
+  const float wh = hok ? w2[h] : 0.f;
+  float dw = 0.f;
+  for (int j = 0; j < N; ++j) {
+    const float vj = hok ? v[bo + (long)j * H + h] : 0.f;
+    float dvj = 0.f;
+#pragma unroll
+    for (int i4 = 0; i4 < NMAX; i4 += 4) {
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(&sG[j][i4]);   // same address in every lane: broadcast
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float t = ur[i4 + q] + vj;
+        const float sl = t > 0.f ? 1.f : slope;
+        const float gd = g4[q] * sl;
+        du[i4 + q] += gd;
+        dvj += gd;
+        dw += gd * t;                 // g * lrelu(t) = g * sl * t
+      }
+    }
+    if (hok) dV[bo + (long)j * H + h] = wh * dvj;
+  }
+  if (hok) {
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i)
+      if (i < N) dU[bo + (long)i * H + h] = wh * du[i];
+    dw2_part[(long)b * H + h] = dw;
+  }
+}
+
+}  // namespace
+
+int launch_pair_mlp_forward(const float* u, const float* v, const float* w2, const float* b2, float* out, int B, int N, int H,
+                            float slope, hipStream_t st) {
+  if (B <= 0 || N <= 0 || H <= 0) return kErrBadArg;
+  ProfScope ps("pair_mlp_fwd_kernel", st, 3.0 * B * (double)N * N * H, 4.0 * B * (2.0 * N * H + (double)N * N));
+  hipLaunchKernelGGL(pair_mlp_fwd_kernel, dim3((N + IT - 1) / IT, B), dim3(256), 0, st, u, v, w2, b2, out, N, H, slope);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_pair_mlp_backward(const float* u, const float* v, const float* w2, const float* out, const float* g_out, float* dU,
+                             float* dV, float* dw2_part, float* db2_part, int B, int N, int H, float slope, hipStream_t st) {
+  if (B <= 0 || N <= 0 || H <= 0 || N > NMAX) return kErrBadArg;
+  ProfScope ps("pair_mlp_bwd_kernel", st, 7.0 * B * (double)N * N * H, 4.0 * B * (4.0 * N * H + 2.0 * N * N));
+  hipLaunchKernelGGL(pair_mlp_bwd_kernel, dim3((H + 255) / 256, B), dim3(256), 0, st, u, v, w2, out, g_out, dU, dV, dw2_part,
+                     db2_part, N, H, slope);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace ctvae

@@ -557,6 +557,37 @@ class VAELoss(Function):
         return g_r, None, g_mu, g_lv, g_extra, None
 
 
+class PairMLP(Function):
+    """out[b,i,j] = sigmoid(b2 + sum_h w2[h] * leaky_relu(u[b,i,h] + v[b,j,h])): the all-pairs tail of
+    ``CausalTransition.graph_discovers[k]`` (ct_mcq_vae.py:86-95,147-151) without the [B,N,N,H] intermediates."""
+
+    SLOPE = 0.01   # nn.LeakyReLU() default
+
+    @staticmethod
+    def forward(ctx, u, v, w2, b2):
+        _req_cuda(u, v, w2)
+        u, v, w2 = _c(u), _c(v), _c(w2.reshape(-1))
+        B, N, H = u.shape
+        out = torch.empty((B, N, N), dtype=torch.float32, device=u.device)
+        native.call("ctvae_pair_mlp_forward", u.data_ptr(), v.data_ptr(), w2.data_ptr(), native.ptr(b2), out.data_ptr(),
+                    B, N, H, PairMLP.SLOPE)
+        ctx.save_for_backward(u, v, w2, out)
+        ctx.w2_shape = None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        u, v, w2, out = ctx.saved_tensors
+        B, N, H = u.shape
+        g = _c(g)
+        du, dv = torch.empty_like(u), torch.empty_like(v)
+        dw2p = torch.empty((B, H), dtype=torch.float32, device=u.device)
+        db2p = torch.empty(B, dtype=torch.float32, device=u.device)
+        native.call("ctvae_pair_mlp_backward", u.data_ptr(), v.data_ptr(), w2.data_ptr(), out.data_ptr(), g.data_ptr(),
+                    du.data_ptr(), dv.data_ptr(), dw2p.data_ptr(), db2p.data_ptr(), B, N, H, PairMLP.SLOPE)
+        return du, dv, dw2p.sum(0), db2p.sum().reshape(1)
+
+
 class GumbelBernoulliST(Function):
     """Straight-through Bernoulli(p) sample via hard 2-class Gumbel-softmax (ct_mcq_vae.py:177-183); noise [...,2]."""
 

@@ -137,6 +137,9 @@ class CausalTransition(nn.Module):
         lin1, lin2 = disc[0], disc[2]
         u = F.linear(x, lin1.weight[:, :D])                    # x_i half
         v = F.linear(x, lin1.weight[:, D:], lin1.bias)         # x_j half (+ bias)
+        if x.is_cuda and x.size(1) <= 64:
+            # HIP: lrelu(u_i + v_j) . w2 + b2 -> sigmoid for every pair without the [B,N,N,hidden] intermediates
+            return K.PairMLP.apply(u, v, lin2.weight.view(-1), lin2.bias)
         h = F.leaky_relu(u.unsqueeze(2) + v.unsqueeze(1))      # [B,N,N,hidden]
         return torch.sigmoid(F.linear(h, lin2.weight, lin2.bias)).squeeze(-1)
 

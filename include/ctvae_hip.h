@@ -113,6 +113,16 @@ int ctvae_bn_backward(const float* g_a, const float* beta, const float* y, int R
                       float* dbeta, int accumulate, const float* part_in, int part_rows, float* coef_out, float* ws,
                       size_t ws_bytes, void* stream);
 
+/* Pairwise edge scorer of CausalTransition.graph_discovers[k] (ct_mcq_vae.py:86-95,147-151), after the separable first
+ * Linear: u = x W1[:, :D]^T, v = x W1[:, D:]^T + b1 ([B,N,H] each, computed by the caller):
+ *   out[b,i,j] = sigmoid(b2 + sum_h w2[h] * leaky_relu(u[b,i,h] + v[b,j,h], slope))        out [B,N,N]
+ * No [B,N,N,H] tensor is ever materialised.  Backward (N <= 64): d_u, d_v [B,N,H]; d_w2_part [B][H] and d_b2_part [B]
+ * are per-sample partials the caller sums over B (deterministic, no atomics). */
+int ctvae_pair_mlp_forward(const float* u, const float* v, const float* w2, const float* b2, float* out, int B, int N, int H,
+                           float slope, void* stream);
+int ctvae_pair_mlp_backward(const float* u, const float* v, const float* w2, const float* out, const float* g_out, float* d_u,
+                            float* d_v, float* d_w2_part, float* d_b2_part, int B, int N, int H, float slope, void* stream);
+
 /* layout change at the NCHW API boundary: to_nhwc=1: in [B,C,P] -> out [B,P,C]; 0: the inverse
  * (torch.flatten on NCHW, vanilla_vae.py:85; .view(-1,512,2,2), vanilla_vae.py:102) */
 int ctvae_permute(const float* in, float* out, int B, int C, int P, int to_nhwc, void* stream);

@@ -146,3 +146,27 @@ def test_runner_consumes_yaml(dev, tmp_path):
     ck = torch.load(tmp_path / "MCQVAE" / "checkpoints" / "last.ckpt", weights_only=True)
     assert all(k.startswith("model.") for k in ck["state_dict"])
     assert ck["state_dict"]["model.encoder.0.0.weight"].shape == (64, 3, 4, 4)
+
+
+@pytest.mark.parametrize("B,N,H", [(3, 64, 800), (2, 37, 70)])
+def test_pair_mlp_kernel(dev, B, N, H):
+    """ctvae_pair_mlp_forward/backward against the torch expression of CausalTransition._pair_coeffs
+    (ct_mcq_vae.py:86-95 on all ordered pairs): values and all four gradients."""
+    import torch.nn.functional as F
+    from ctvae_amd import kernels as K
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    u = (0.5 * torch.randn(B, N, H, generator=g)).requires_grad_(True)
+    v = (0.5 * torch.randn(B, N, H, generator=g)).requires_grad_(True)
+    w2 = (torch.randn(H, generator=g) / H ** 0.5).requires_grad_(True)
+    b2 = torch.randn(1, generator=g).requires_grad_(True)
+    h = F.leaky_relu(u.unsqueeze(2) + v.unsqueeze(1))
+    ref = torch.sigmoid(F.linear(h, w2.view(1, -1), b2)).squeeze(-1)
+    go = torch.randn(B, N, N, generator=g)
+    ref.backward(go)
+    ud, vd, wd, bd = (t.detach().to(dev).requires_grad_(True) for t in (u, v, w2, b2))
+    out = K.PairMLP.apply(ud, vd, wd, bd)
+    out.backward(go.to(dev))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-6, rtol=1e-5)
+    for got, want in ((ud.grad, u.grad), (vd.grad, v.grad), (wd.grad, w2.grad), (bd.grad, b2.grad)):
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=1e-5 * max(1.0, float(want.abs().max())), rtol=1e-4)
