@@ -30,6 +30,11 @@ int launch_bn_backward(const float* ga, const float* beta, const float* y, int R
                        float* coef_out = nullptr);
 bool upconv_wgrad_supported(const ConvGeom& g);
 int launch_permute(const float* in, float* out, int B, int C, int P, int to_nhwc, hipStream_t st);
+int launch_gat_score(int mode, const float* xl, const float* xr, const float* attr, const float* we, const float* att, float* out,
+                     int B, int N, int H, int C, float slope, hipStream_t st);
+int launch_gat_score_backward(const float* xl, const float* xr, const float* attr, const float* we, const float* att,
+                              const float* g, float* dxl, float* dxr, float* datt_part, float* dwe_part, int B, int N, int H,
+                              int C, float slope, hipStream_t st);
 int launch_pair_mlp_forward(const float* u, const float* v, const float* w2, const float* b2, float* out, int B, int N, int H,
                             float slope, hipStream_t st);
 int launch_pair_mlp_backward(const float* u, const float* v, const float* w2, const float* out, const float* g_out, float* dU,
@@ -201,6 +206,20 @@ int ctvae_bn_backward(const float* g_a, const float* beta, const float* y, int R
   if ((part_in != nullptr) != (part_rows > 0)) return kErrBadArg;
   return launch_bn_backward(g_a, beta, y, R, C, gamma, save_mean, save_invstd, act, g_y, dgamma, dbeta, accumulate, ws,
                             ws_bytes, part_in, part_rows, (hipStream_t)stream, coef_out);
+}
+
+int ctvae_gat_score(int mode, const float* xl, const float* xr, const float* attr, const float* we, const float* att, float* out,
+                    int B, int N, int H, int C, float slope, void* stream) {
+  if (!xl || !xr || !attr || !we || !att || !out || (mode != 0 && mode != 1)) return kErrBadArg;
+  return launch_gat_score(mode, xl, xr, attr, we, att, out, B, N, H, C, slope, (hipStream_t)stream);
+}
+
+int ctvae_gat_score_backward(const float* xl, const float* xr, const float* attr, const float* we, const float* att,
+                             const float* g, float* d_xl, float* d_xr, float* d_att_part, float* d_we_part, int B, int N, int H,
+                             int C, float slope, void* stream) {
+  if (!xl || !xr || !attr || !we || !att || !g || !d_xl || !d_xr || !d_att_part || !d_we_part) return kErrBadArg;
+  return launch_gat_score_backward(xl, xr, attr, we, att, g, d_xl, d_xr, d_att_part, d_we_part, B, N, H, C, slope,
+                                   (hipStream_t)stream);
 }
 
 int ctvae_pair_mlp_forward(const float* u, const float* v, const float* w2, const float* b2, float* out, int B, int N, int H,

@@ -1,0 +1,168 @@
+// Attention scores of the dense GATv2 layers inside CausalTransition.graph_transitioner (ct_mcq_vae.py:103-114,
+// `gnn.GATv2Conv(..., heads, edge_dim=1)` on B x (N+1)-node dense weighted graphs):
+//
+//     S[b,h,r,c] = sum_k att[h,k] * leaky_relu(xl[b,r,h,k] + xr[b,c,h,k] + attr[b,r,c] * we[h,k], 0.2)
+//
+// for every source r / target c / head h.  As torch ops this materialises a [B,N,N,C] tensor per head several times
+// (216 MB per head at B = 128) and was 70 % of a CT-MCQ-VAE step; here nothing of size N*N*C touches memory.
+//   gat_score_kernel<0>  thread = (r,c) pairs of one (b,h), xl/xr of that head staged transposed in LDS, k-sum in-thread
+//   gat_score_kernel<1>  same walk, returns T = sum_k att*we*lrelu'(.) so that d attr = sum_h g*T (the caller's product)
+//   gat_score_bwd_kernel thread = channel k of one (b,h): d xl[b,r,h,k] and d xr[b,c,h,k] are produced by exactly one
+//                        thread each (no atomics, bit-reproducible); d att / d we leave as per-sample partials.
+// Masked softmax over sources and the alpha-weighted aggregation stay as small torch ops on [B,H,N,N].
+#include "common.hpp"
+#include "prof.hpp"
+
+namespace ctvae {
+
+namespace {
+
+constexpr int PMAX = 17;    // (r,c) pairs per thread: N*N <= 17*256 -> N <= 65 (64 latent nodes + the action node)
+constexpr int NB = 68;      // backward: rows padded to a multiple of 4 (b128 broadcast reads)
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gat_score_kernel(const float* __restrict__ xl, const float* __restrict__ xr,
+                                                       const float* __restrict__ attr, const float* __restrict__ we,
+                                                       const float* __restrict__ att, float* __restrict__ out, int N, int H,
+                                                       int C, float slope) {
+  extern __shared__ float smem[];
+  const int NP = N | 1;                 // odd row length: conflict-free for consecutive c, broadcast for equal r
+  float* sL = smem;                     // [C][NP]
+  float* sR = smem + C * NP;            // [C][NP]
+  float* sWe = sR + C * NP;             // [C]
+  float* sAt = sWe + C;                 // [C]
+  const int tid = threadIdx.x, h = blockIdx.x, b = blockIdx.y;
+  for (int e = tid; e < N * C; e += 256) {          // coalesced along k, transposed into LDS
+    const int n = e / C, k = e - n * C;
+    const long src = (((long)b * N + n) * H + h) * C + k;
+    sL[k * NP + n] = xl[src];
+    sR[k * NP + n] = xr[src];
+  }
+  for (int k = tid; k < C; k += 256) {
+    sWe[k] = we[h * C + k];
+    sAt[k] = att[h * C + k];
+  }
+  int rr[PMAX], cc[PMAX];
+  float at[PMAX], acc[PMAX];
+#pragma unroll
+  for (int q = 0; q < PMAX; ++q) {
+    const int p = tid + 256 * q;
+    const bool ok = p < N * N;
+    const int r = ok ? p / N : 0, c = ok ? p - r * N : 0;
+    rr[q] = r;
+    cc[q] = c;
+    at[q] = ok ? attr[((long)b * N + r) * N + c] : 0.f;
+    acc[q] = 0.f;
+  }
+  __syncthreads();
+  for (int k = 0; k < C; ++k) {
+    const float wk = sWe[k], ak = sAt[k];
+    const float* l = sL + k * NP;
+    const float* r_ = sR + k * NP;
+#pragma unroll
+    for (int q = 0; q < PMAX; ++q) {
+      const float m = l[rr[q]] + r_[cc[q]] + at[q] * wk;
+      if (MODE == 0) acc[q] += ak * fmaxf(m, m * slope);   // slope < 1
+      else acc[q] += (ak * wk) * (m > 0.f ? 1.f : slope);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < PMAX; ++q) {
+    const int p = tid + 256 * q;
+    if (p < N * N) out[(((long)b * H + h) * N) * N + p] = acc[q];
+  }
+}
+
+// grid (H, B), 128 threads: thread k < C.  g [B,H,N,N] (r,c).  datt_part / dwe_part [B][H][C].
+__global__ __launch_bounds__(128) void gat_score_bwd_kernel(const float* __restrict__ xl, const float* __restrict__ xr,
+                                                           const float* __restrict__ attr, const float* __restrict__ we,
+                                                           const float* __restrict__ att, const float* __restrict__ g,
+                                                           float* __restrict__ dxl, float* __restrict__ dxr,
+                                                           float* __restrict__ datt_part, float* __restrict__ dwe_part, int N,
+                                                           int H, int C, float slope) {
+  __shared__ __attribute__((aligned(16))) float sG[NB][NB];   // [c][r]
+  __shared__ __attribute__((aligned(16))) float sA[NB][NB];   // [c][r]
+  const int tid = threadIdx.x, h = blockIdx.x, b = blockIdx.y, k = tid;
+  const bool kok = k < C;
+  for (int e = tid; e < NB * NB; e += 128) {
+    const int r = e / NB, c = e - r * NB;     // reads coalesced along c
+    float gv = 0.f, av = 0.f;
+    if (r < N && c < N) {
+      gv = g[(((long)b * H + h) * N + r) * N + c];
+      av = attr[((long)b * N + r) * N + c];
+    }
+    sG[c][r] = gv;
+    sA[c][r] = av;
+  }
+  float xlr[NB], dl[NB];
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    xlr[r] = (kok && r < N) ? xl[(((long)b * N + r) * H + h) * C + k] : 0.f;
+    dl[r] = 0.f;
+  }
+  const float wk = kok ? we[h * C + k] : 0.f, ak = kok ? att[h * C + k] : 0.f;
+  float datt = 0.f, dwe = 0.f;
+  __syncthreads();
+  for (int c = 0; c < N; ++c) {
+    const float xrc = kok ? xr[(((long)b * N + c) * H + h) * C + k] : 0.f;
+    float dr = 0.f;
+#pragma unroll
+    for (int r4 = 0; r4 < NB; r4 += 4) {
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(&sG[c][r4]);   // same address in every lane: broadcast
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(&sA[c][r4]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float m = xlr[r4 + q] + xrc + a4[q] * wk;
+        const float sl = m > 0.f ? 1.f : slope;
+        const float gs = g4[q] * sl;        // g * lrelu'(m)
+        datt += gs * m;                     // g * lrelu(m)
+        const float gd = gs * ak;           // d m
+        dl[r4 + q] += gd;
+        dr += gd;
+        dwe += gd * a4[q];
+      }
+    }
+    if (kok) dxr[(((long)b * N + c) * H + h) * C + k] = dr;
+  }
+  if (kok) {
+#pragma unroll
+    for (int r = 0; r < NB; ++r)
+      if (r < N) dxl[(((long)b * N + r) * H + h) * C + k] = dl[r];
+    datt_part[((long)b * H + h) * C + k] = datt;
+    dwe_part[((long)b * H + h) * C + k] = dwe;
+  }
+}
+
+}  // namespace
+
+int launch_gat_score(int mode, const float* xl, const float* xr, const float* attr, const float* we, const float* att, float* out,
+                     int B, int N, int H, int C, float slope, hipStream_t st) {
+  if (B <= 0 || N <= 0 || H <= 0 || C <= 0 || N * N > PMAX * 256 || slope >= 1.f) return kErrBadArg;
+  const size_t smem = ((size_t)2 * C * (N | 1) + 2 * C) * 4;
+  if (smem > 160 * 1024) return kErrBadArg;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_score_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_score_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  ProfScope ps(mode == 0 ? "gat_score_kernel<0>" : "gat_score_kernel<1>", st, 4.0 * B * H * (double)N * N * C,
+               4.0 * B * H * (2.0 * N * C + (double)N * N));
+  if (mode == 0) hipLaunchKernelGGL(gat_score_kernel<0>, dim3(H, B), dim3(256), smem, st, xl, xr, attr, we, att, out, N, H, C, slope);
+  else hipLaunchKernelGGL(gat_score_kernel<1>, dim3(H, B), dim3(256), smem, st, xl, xr, attr, we, att, out, N, H, C, slope);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_gat_score_backward(const float* xl, const float* xr, const float* attr, const float* we, const float* att,
+                              const float* g, float* dxl, float* dxr, float* datt_part, float* dwe_part, int B, int N, int H,
+                              int C, float slope, hipStream_t st) {
+  if (B <= 0 || N <= 0 || N > NB - 3 || H <= 0 || C <= 0 || C > 128) return kErrBadArg;
+  ProfScope ps("gat_score_bwd_kernel", st, 10.0 * B * H * (double)N * N * C, 4.0 * B * H * (4.0 * N * C + (double)N * N));
+  hipLaunchKernelGGL(gat_score_bwd_kernel, dim3(H, B), dim3(128), 0, st, xl, xr, attr, we, att, g, dxl, dxr, datt_part, dwe_part,
+                     N, H, C, slope);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace ctvae

@@ -588,6 +588,41 @@ class PairMLP(Function):
         return du, dv, dw2p.sum(0), db2p.sum().reshape(1)
 
 
+class GATScore(Function):
+    """S[b,h,r,c] = sum_k att[h,k] * leaky_relu(xl[b,r,h,k] + xr[b,c,h,k] + attr[b,r,c]*we[h,k], slope): GATv2 attention
+    logits on a batch of dense graphs (ct_mcq_vae.py:103-114) without the [B,N,N,C]-per-head intermediates."""
+
+    @staticmethod
+    def forward(ctx, xl, xr, attr, we, att, slope):
+        _req_cuda(xl, xr, attr, we, att)
+        xl, xr, attr, we, att = _c(xl), _c(xr), _c(attr), _c(we), _c(att)
+        B, N, H, C = xl.shape
+        out = torch.empty((B, H, N, N), dtype=torch.float32, device=xl.device)
+        native.call("ctvae_gat_score", 0, xl.data_ptr(), xr.data_ptr(), attr.data_ptr(), we.data_ptr(), att.data_ptr(),
+                    out.data_ptr(), B, N, H, C, float(slope))
+        ctx.save_for_backward(xl, xr, attr, we, att)
+        ctx.slope = float(slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xl, xr, attr, we, att = ctx.saved_tensors
+        B, N, H, C = xl.shape
+        g = _c(g)
+        dxl, dxr = torch.empty_like(xl), torch.empty_like(xr)
+        dattp = torch.empty((B, H, C), dtype=torch.float32, device=xl.device)
+        dwep = torch.empty((B, H, C), dtype=torch.float32, device=xl.device)
+        native.call("ctvae_gat_score_backward", xl.data_ptr(), xr.data_ptr(), attr.data_ptr(), we.data_ptr(), att.data_ptr(),
+                    g.data_ptr(), dxl.data_ptr(), dxr.data_ptr(), dattp.data_ptr(), dwep.data_ptr(), B, N, H, C, ctx.slope)
+        dattr = None
+        if ctx.needs_input_grad[2]:
+            t = torch.empty((B, H, N, N), dtype=torch.float32, device=xl.device)
+            native.call("ctvae_gat_score", 1, xl.data_ptr(), xr.data_ptr(), attr.data_ptr(), we.data_ptr(), att.data_ptr(),
+                        t.data_ptr(), B, N, H, C, ctx.slope)
+            dattr = (g * t).sum(1)
+        return dxl, dxr, dattr, dwep.sum(0), dattp.sum(0), None
+
+
 class GumbelBernoulliST(Function):
     """Straight-through Bernoulli(p) sample via hard 2-class Gumbel-softmax (ct_mcq_vae.py:177-183); noise [...,2]."""
 

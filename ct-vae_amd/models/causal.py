@@ -70,6 +70,11 @@ class DenseGATv2(nn.Module):
         attr = w + torch.diag_embed(w.sum(1) / deg)   # self loops carry the mean incoming attribute
         keep = edge | eye
         we = self.lin_edge.weight.view(H, C)
+        if x.is_cuda and N * N <= 17 * 256 and C <= 128:
+            # HIP: all heads' attention logits in one launch, no [B,N,N,C] tensors (kernels.GATScore / csrc/gat.hip)
+            s = K.GATScore.apply(xl, xr, attr, we, self.att[0], self.negative_slope)               # [B,H,N(r),N(c)]
+            alpha = torch.softmax(s.masked_fill(~keep.unsqueeze(1), float('-inf')), dim=2)           # over sources r
+            return torch.einsum('bhrc,brhk->bchk', alpha, xl).reshape(B, N, H * C) + self.bias
         outs = []
         for h in range(H):                        # head by head keeps the [B,N,N,C] score tensor small
             m = xl[:, :, None, h, :] + xr[:, None, :, h, :] + attr.unsqueeze(-1) * we[h]

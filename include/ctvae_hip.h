@@ -123,6 +123,19 @@ int ctvae_pair_mlp_forward(const float* u, const float* v, const float* w2, cons
 int ctvae_pair_mlp_backward(const float* u, const float* v, const float* w2, const float* out, const float* g_out, float* d_u,
                             float* d_v, float* d_w2_part, float* d_b2_part, int B, int N, int H, float slope, void* stream);
 
+/* GATv2 attention scores of CausalTransition.graph_transitioner (ct_mcq_vae.py:103-114; torch_geometric GATv2Conv with
+ * edge_dim=1 on dense graphs): xl, xr [B,N,H,C] = lin_l(x), lin_r(x); attr [B,N,N] edge attribute of r -> c (self loops
+ * included); we, att [H,C].
+ *   mode 0: out[b,h,r,c] = sum_k att[h,k] * leaky_relu(xl[b,r,h,k] + xr[b,c,h,k] + attr[b,r,c]*we[h,k], slope)
+ *   mode 1: out[b,h,r,c] = sum_k att[h,k] * we[h,k] * leaky_relu'(same argument)          (d out / d attr)
+ * N*N <= 4352 (N <= 65), slope < 1.  Backward (C <= 128): d_xl, d_xr [B,N,H,C]; d_att_part, d_we_part [B][H][C] are
+ * per-sample partials for the caller to sum; d attr = sum_h g * (mode 1 output). */
+int ctvae_gat_score(int mode, const float* xl, const float* xr, const float* attr, const float* we, const float* att, float* out,
+                    int B, int N, int H, int C, float slope, void* stream);
+int ctvae_gat_score_backward(const float* xl, const float* xr, const float* attr, const float* we, const float* att,
+                             const float* g, float* d_xl, float* d_xr, float* d_att_part, float* d_we_part, int B, int N, int H,
+                             int C, float slope, void* stream);
+
 /* layout change at the NCHW API boundary: to_nhwc=1: in [B,C,P] -> out [B,P,C]; 0: the inverse
  * (torch.flatten on NCHW, vanilla_vae.py:85; .view(-1,512,2,2), vanilla_vae.py:102) */
 int ctvae_permute(const float* in, float* out, int B, int C, int P, int to_nhwc, void* stream);

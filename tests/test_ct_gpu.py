@@ -170,3 +170,33 @@ def test_pair_mlp_kernel(dev, B, N, H):
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-6, rtol=1e-5)
     for got, want in ((ud.grad, u.grad), (vd.grad, v.grad), (wd.grad, w2.grad), (bd.grad, b2.grad)):
         np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=1e-5 * max(1.0, float(want.abs().max())), rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,N,Hh,C", [(2, 65, 13, 100), (3, 65, 13, 64), (2, 9, 3, 20)])
+def test_gat_score_kernel_and_layer(dev, B, N, Hh, C):
+    """ctvae_gat_score(+backward) against the head-by-head torch expression of DenseGATv2 (GATv2Conv attention logits,
+    ct_mcq_vae.py:103-114): the whole layer output and the gradients of x, adj and every parameter must agree."""
+    from ctvae_amd.models.causal import DenseGATv2
+    torch.manual_seed(50 + N + C)
+    layer = DenseGATv2(24, C, Hh)
+    with torch.no_grad():
+        layer.bias.uniform_(-0.1, 0.1)
+    x = torch.randn(B, N, 24, requires_grad=True)
+    adj = (torch.rand(B, N, N) * (torch.rand(B, N, N) > 0.3)).requires_grad_(True)
+    ref = layer(x, adj)                                    # CPU tensors -> torch path
+    go = torch.randn_like(ref)
+    ref.backward(go)
+    want = {k: p.grad.clone() for k, p in layer.named_parameters()}
+    gx, gadj = x.grad.clone(), adj.grad.clone()
+    layer_d = DenseGATv2(24, C, Hh).to(dev)
+    layer_d.load_state_dict(layer.state_dict())
+    xd, ad = x.detach().to(dev).requires_grad_(True), adj.detach().to(dev).requires_grad_(True)
+    out = layer_d(xd, ad)                                  # CUDA tensors -> HIP score kernels
+    out.backward(go.to(dev))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), gx.numpy(), atol=1e-4 * max(1.0, float(gx.abs().max())), rtol=1e-3)
+    np.testing.assert_allclose(ad.grad.cpu().numpy(), gadj.numpy(), atol=1e-4 * max(1.0, float(gadj.abs().max())), rtol=1e-3)
+    for k, p in layer_d.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), want[k].numpy(), atol=1e-4 * max(1.0, float(want[k].abs().max())),
+                                   rtol=1e-3, err_msg=k)
