@@ -36,9 +36,10 @@ int launch_gat_score_backward(const float* xl, const float* xr, const float* att
                               const float* g, float* dxl, float* dxr, float* datt_part, float* dwe_part, int B, int N, int H,
                               int C, float slope, hipStream_t st);
 int launch_pair_mlp_forward(const float* u, const float* v, const float* w2, const float* b2, float* out, int B, int N, int H,
-                            float slope, hipStream_t st);
+                            float slope, int per_sample, hipStream_t st);
 int launch_pair_mlp_backward(const float* u, const float* v, const float* w2, const float* out, const float* g_out, float* dU,
-                             float* dV, float* dw2_part, float* db2_part, int B, int N, int H, float slope, hipStream_t st);
+                             float* dV, float* dw2_part, float* db2_part, int B, int N, int H, float slope, int per_sample,
+                             hipStream_t st);
 int launch_act_bwd(const float* gout, const float* out, float* gin, long n, int act, hipStream_t st);
 int launch_act_fwd(const float* in, float* out, long n, int act, hipStream_t st);
 int launch_reparam_fwd(const float* mu, long mu_rs, const float* lv, long lv_rs, const float* eps, float* z, int B, int L,
@@ -223,15 +224,17 @@ int ctvae_gat_score_backward(const float* xl, const float* xr, const float* attr
 }
 
 int ctvae_pair_mlp_forward(const float* u, const float* v, const float* w2, const float* b2, float* out, int B, int N, int H,
-                           float slope, void* stream) {
+                           float slope, int per_sample, void* stream) {
   if (!u || !v || !w2 || !out) return kErrBadArg;
-  return launch_pair_mlp_forward(u, v, w2, b2, out, B, N, H, slope, (hipStream_t)stream);
+  return launch_pair_mlp_forward(u, v, w2, b2, out, B, N, H, slope, per_sample, (hipStream_t)stream);
 }
 
 int ctvae_pair_mlp_backward(const float* u, const float* v, const float* w2, const float* out, const float* g_out, float* d_u,
-                            float* d_v, float* d_w2_part, float* d_b2_part, int B, int N, int H, float slope, void* stream) {
+                            float* d_v, float* d_w2_part, float* d_b2_part, int B, int N, int H, float slope, int per_sample,
+                            void* stream) {
   if (!u || !v || !w2 || !out || !g_out || !d_u || !d_v || !d_w2_part || !d_b2_part) return kErrBadArg;
-  return launch_pair_mlp_backward(u, v, w2, out, g_out, d_u, d_v, d_w2_part, d_b2_part, B, N, H, slope, (hipStream_t)stream);
+  return launch_pair_mlp_backward(u, v, w2, out, g_out, d_u, d_v, d_w2_part, d_b2_part, B, N, H, slope, per_sample,
+                                  (hipStream_t)stream);
 }
 
 int ctvae_permute(const float* in, float* out, int B, int C, int P, int to_nhwc, void* stream) {

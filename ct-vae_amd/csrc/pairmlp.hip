@@ -26,7 +26,8 @@ constexpr int NMAX = 64;  // backward keeps u[i], dU[i] of one h in registers
 
 __global__ __launch_bounds__(256) void pair_mlp_fwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
                                                           const float* __restrict__ w2, const float* __restrict__ b2,
-                                                          float* __restrict__ out, int N, int H, float slope) {
+                                                          float* __restrict__ out, int N, int H, float slope, int w2_bs,
+                                                          int b2_bs) {
   __shared__ float sV[HC][JT + 1];
   __shared__ float sU[IT][HC];
   __shared__ float sW[HC];
@@ -34,7 +35,8 @@ __global__ __launch_bounds__(256) void pair_mlp_fwd_kernel(const float* __restri
   const int b = blockIdx.y, i = blockIdx.x * IT + i_l;
   const float* ub = u + (long)b * N * H;
   const float* vb = v + (long)b * N * H;
-  const float bias = b2 != nullptr ? b2[0] : 0.f;
+  const float bias = b2 != nullptr ? b2[(long)b * b2_bs] : 0.f;
+  w2 += (long)b * w2_bs;               // per-sample scorer (w2_bs = H) or one shared scorer (0)
   for (int j0 = 0; j0 < N; j0 += JT) {
     float acc = 0.f;
     for (int h0 = 0; h0 < H; h0 += HC) {
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void pair_mlp_bwd_kernel(const float* __restri
                                                           const float* __restrict__ w2, const float* __restrict__ out,
                                                           const float* __restrict__ g_out, float* __restrict__ dU,
                                                           float* __restrict__ dV, float* __restrict__ dw2_part,
-                                                          float* __restrict__ db2_part, int N, int H, float slope) {
+                                                          float* __restrict__ db2_part, int N, int H, float slope, int w2_bs) {
   __shared__ __attribute__((aligned(16))) float sG[NMAX][NMAX];   // [j][i] = g * s * (1 - s)
   __shared__ float sRed[4];
   const int tid = threadIdx.x, b = blockIdx.y, h = blockIdx.x * 256 + tid;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void pair_mlp_bwd_kernel(const float* __restri
     ur[i] = (hok && i < N) ? u[bo + (long)i * H + h] : 0.f;
     du[i] = 0.f;
   }
-  const float wh = hok ? w2[h] : 0.f;
+  const float wh = hok ? w2[(long)b * w2_bs + h] : 0.f;
   float dw = 0.f;
   for (int j = 0; j < N; ++j) {
     const float vj = hok ? v[bo + (long)j * H + h] : 0.f;
@@ -125,20 +127,22 @@ __global__ __launch_bounds__(256) void pair_mlp_bwd_kernel(const float* __restri
 }  // namespace
 
 int launch_pair_mlp_forward(const float* u, const float* v, const float* w2, const float* b2, float* out, int B, int N, int H,
-                            float slope, hipStream_t st) {
+                            float slope, int per_sample, hipStream_t st) {
   if (B <= 0 || N <= 0 || H <= 0) return kErrBadArg;
   ProfScope ps("pair_mlp_fwd_kernel", st, 3.0 * B * (double)N * N * H, 4.0 * B * (2.0 * N * H + (double)N * N));
-  hipLaunchKernelGGL(pair_mlp_fwd_kernel, dim3((N + IT - 1) / IT, B), dim3(256), 0, st, u, v, w2, b2, out, N, H, slope);
+  hipLaunchKernelGGL(pair_mlp_fwd_kernel, dim3((N + IT - 1) / IT, B), dim3(256), 0, st, u, v, w2, b2, out, N, H, slope,
+                     per_sample ? H : 0, per_sample ? 1 : 0);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_pair_mlp_backward(const float* u, const float* v, const float* w2, const float* out, const float* g_out, float* dU,
-                             float* dV, float* dw2_part, float* db2_part, int B, int N, int H, float slope, hipStream_t st) {
+                             float* dV, float* dw2_part, float* db2_part, int B, int N, int H, float slope, int per_sample,
+                             hipStream_t st) {
   if (B <= 0 || N <= 0 || H <= 0 || N > NMAX) return kErrBadArg;
   ProfScope ps("pair_mlp_bwd_kernel", st, 7.0 * B * (double)N * N * H, 4.0 * B * (4.0 * N * H + 2.0 * N * N));
   hipLaunchKernelGGL(pair_mlp_bwd_kernel, dim3((H + 255) / 256, B), dim3(256), 0, st, u, v, w2, out, g_out, dU, dV, dw2_part,
-                     db2_part, N, H, slope);
+                     db2_part, N, H, slope, per_sample ? H : 0);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }

@@ -559,20 +559,26 @@ class VAELoss(Function):
 
 class PairMLP(Function):
     """out[b,i,j] = sigmoid(b2 + sum_h w2[h] * leaky_relu(u[b,i,h] + v[b,j,h])): the all-pairs tail of
-    ``CausalTransition.graph_discovers[k]`` (ct_mcq_vae.py:86-95,147-151) without the [B,N,N,H] intermediates."""
+    ``CausalTransition.graph_discovers[k]`` (ct_mcq_vae.py:86-95,147-151) without the [B,N,N,H] intermediates.
+    w2 [H] / b2 [1]: one scorer for the batch; w2 [B,H] / b2 [B]: one scorer per sample (per-action discoverers)."""
 
     SLOPE = 0.01   # nn.LeakyReLU() default
 
     @staticmethod
     def forward(ctx, u, v, w2, b2):
         _req_cuda(u, v, w2)
-        u, v, w2 = _c(u), _c(v), _c(w2.reshape(-1))
         B, N, H = u.shape
+        per_sample = w2.dim() == 2
+        if per_sample and (tuple(w2.shape) != (B, H) or b2.numel() != B):
+            raise RuntimeError("PairMLP: per-sample scorer needs w2 [B,H] and b2 [B]")
+        u, v = _c(u), _c(v)
+        w2 = _c(w2) if per_sample else _c(w2.reshape(-1))
+        b2 = _c(b2.reshape(-1))
         out = torch.empty((B, N, N), dtype=torch.float32, device=u.device)
-        native.call("ctvae_pair_mlp_forward", u.data_ptr(), v.data_ptr(), w2.data_ptr(), native.ptr(b2), out.data_ptr(),
-                    B, N, H, PairMLP.SLOPE)
+        native.call("ctvae_pair_mlp_forward", u.data_ptr(), v.data_ptr(), w2.data_ptr(), b2.data_ptr(), out.data_ptr(),
+                    B, N, H, PairMLP.SLOPE, 1 if per_sample else 0)
         ctx.save_for_backward(u, v, w2, out)
-        ctx.w2_shape = None
+        ctx.per_sample = per_sample
         return out
 
     @staticmethod
@@ -584,7 +590,10 @@ class PairMLP(Function):
         dw2p = torch.empty((B, H), dtype=torch.float32, device=u.device)
         db2p = torch.empty(B, dtype=torch.float32, device=u.device)
         native.call("ctvae_pair_mlp_backward", u.data_ptr(), v.data_ptr(), w2.data_ptr(), out.data_ptr(), g.data_ptr(),
-                    du.data_ptr(), dv.data_ptr(), dw2p.data_ptr(), db2p.data_ptr(), B, N, H, PairMLP.SLOPE)
+                    du.data_ptr(), dv.data_ptr(), dw2p.data_ptr(), db2p.data_ptr(), B, N, H, PairMLP.SLOPE,
+                    1 if ctx.per_sample else 0)
+        if ctx.per_sample:
+            return du, dv, dw2p, db2p
         return du, dv, dw2p.sum(0), db2p.sum().reshape(1)
 
 

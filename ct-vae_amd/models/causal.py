@@ -161,6 +161,19 @@ class CausalTransition(nn.Module):
         if mask is None:
             return no_inter
         ids = torch.argmax(action, dim=-1)
+        if latent.is_cuda and latent.size(1) <= 64:
+            # one launch for the whole batch: every sample is scored by the discoverer of its own action (weights
+            # gathered per sample), instead of one masked call per distinct action (no host sync on the action ids)
+            D = latent.size(-1)
+            discs = self.graph_discovers[1:]
+            w1 = torch.stack([d[0].weight for d in discs])[ids]            # [B,hidden,2D]
+            b1 = torch.stack([d[0].bias for d in discs])[ids]              # [B,hidden]
+            w2 = torch.stack([d[2].weight.view(-1) for d in discs])[ids]   # [B,hidden]
+            b2 = torch.stack([d[2].bias.view(()) for d in discs])[ids]     # [B]
+            u = torch.bmm(latent, w1[:, :, :D].transpose(1, 2))
+            v = torch.bmm(latent, w1[:, :, D:].transpose(1, 2)) + b1.unsqueeze(1)
+            inter = K.PairMLP.apply(u, v, w2, b2)
+            return no_inter * (1 - mask) + inter * mask
         inter = torch.zeros_like(no_inter)
         for i in set(ids.tolist()):
             sel = torch.where(ids == i)[0]

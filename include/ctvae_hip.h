@@ -117,11 +117,14 @@ int ctvae_bn_backward(const float* g_a, const float* beta, const float* y, int R
  * Linear: u = x W1[:, :D]^T, v = x W1[:, D:]^T + b1 ([B,N,H] each, computed by the caller):
  *   out[b,i,j] = sigmoid(b2 + sum_h w2[h] * leaky_relu(u[b,i,h] + v[b,j,h], slope))        out [B,N,N]
  * No [B,N,N,H] tensor is ever materialised.  Backward (N <= 64): d_u, d_v [B,N,H]; d_w2_part [B][H] and d_b2_part [B]
- * are per-sample partials the caller sums over B (deterministic, no atomics). */
+ * are per-sample partials the caller sums over B (deterministic, no atomics).
+ * per_sample = 1: w2 is [B][H] and b2 [B] -- every sample has its own scorer (the per-action discoverers of one batch in
+ * ONE launch, ct_mcq_vae.py:149-151); the partials then ARE the gradients of those rows. */
 int ctvae_pair_mlp_forward(const float* u, const float* v, const float* w2, const float* b2, float* out, int B, int N, int H,
-                           float slope, void* stream);
+                           float slope, int per_sample, void* stream);
 int ctvae_pair_mlp_backward(const float* u, const float* v, const float* w2, const float* out, const float* g_out, float* d_u,
-                            float* d_v, float* d_w2_part, float* d_b2_part, int B, int N, int H, float slope, void* stream);
+                            float* d_v, float* d_w2_part, float* d_b2_part, int B, int N, int H, float slope, int per_sample,
+                            void* stream);
 
 /* GATv2 attention scores of CausalTransition.graph_transitioner (ct_mcq_vae.py:103-114; torch_geometric GATv2Conv with
  * edge_dim=1 on dense graphs): xl, xr [B,N,H,C] = lin_l(x), lin_r(x); attr [B,N,N] edge attribute of r -> c (self loops

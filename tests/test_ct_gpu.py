@@ -200,3 +200,46 @@ def test_gat_score_kernel_and_layer(dev, B, N, Hh, C):
     for k, p in layer_d.named_parameters():
         np.testing.assert_allclose(p.grad.cpu().numpy(), want[k].numpy(), atol=1e-4 * max(1.0, float(want[k].abs().max())),
                                    rtol=1e-3, err_msg=k)
+
+
+def test_pair_mlp_per_sample_scorers_and_compute_adj(dev):
+    """per_sample mode of ctvae_pair_mlp_* (every sample scored by its own w2/b2) and the batched per-action
+    discoverer evaluation built on it (CausalTransition._compute_adj) against the reference-shaped loop on the CPU."""
+    import torch.nn.functional as F
+    from ctvae_amd import kernels as K
+    from ctvae_amd.models.causal import CausalTransition
+    g = torch.Generator().manual_seed(77)
+    B, N, Hd = 5, 64, 96
+    u = (0.5 * torch.randn(B, N, Hd, generator=g)).requires_grad_(True)
+    v = (0.5 * torch.randn(B, N, Hd, generator=g)).requires_grad_(True)
+    w2 = (torch.randn(B, Hd, generator=g) / Hd ** 0.5).requires_grad_(True)
+    b2 = torch.randn(B, generator=g).requires_grad_(True)
+    h = F.leaky_relu(u.unsqueeze(2) + v.unsqueeze(1))
+    ref = torch.sigmoid((h * w2[:, None, None, :]).sum(-1) + b2[:, None, None])
+    go = torch.randn(B, N, N, generator=g)
+    ref.backward(go)
+    ud, vd, wd, bd = (t.detach().to(dev).requires_grad_(True) for t in (u, v, w2, b2))
+    out = K.PairMLP.apply(ud, vd, wd, bd)
+    out.backward(go.to(dev))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-6, rtol=1e-5)
+    for got, want in ((ud.grad, u.grad), (vd.grad, v.grad), (wd.grad, w2.grad), (bd.grad, b2.grad)):
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=1e-5 * max(1.0, float(want.abs().max())), rtol=1e-4)
+
+    # whole _compute_adj: CPU = one masked call per distinct action (reference structure), GPU = one batched launch
+    torch.manual_seed(3)
+    ct = CausalTransition(64, 12, [48, 10])
+    lat = torch.rand(7, 64, 64)
+    act = F.one_hot(torch.tensor([0, 3, 3, 11, 5, 0, 7]), 12).float()
+    mask = (torch.rand(7, 64, 1) > 0.5).float()
+    a_ref = ct._compute_adj(lat, act, mask)
+    a_ref.sum().backward()
+    want = {k: p.grad.clone() for k, p in ct.named_parameters() if p.grad is not None}
+    ct_d = CausalTransition(64, 12, [48, 10]).to(dev)
+    ct_d.load_state_dict(ct.state_dict())
+    a_gpu = ct_d._compute_adj(lat.to(dev), act.to(dev), mask.to(dev))
+    a_gpu.sum().backward()
+    np.testing.assert_allclose(a_gpu.detach().cpu().numpy(), a_ref.detach().numpy(), atol=2e-6, rtol=1e-5)
+    for k, p in ct_d.named_parameters():
+        if k in want:
+            np.testing.assert_allclose(p.grad.cpu().numpy(), want[k].numpy(), atol=1e-5 * max(1.0, float(want[k].abs().max())),
+                                       rtol=1e-3, err_msg=k)
