@@ -58,7 +58,7 @@ int launch_vq_inds(const float* lat, const float* cb, long long* inds, int B, in
 int launch_vq_lookup(const float* lat, const float* cb, const long long* inds, float* out, float* vq_loss, float beta, int B,
                      int HW, int D, int K, int C, float* ws, size_t ws_bytes, hipStream_t st);
 int launch_vq_backward(const float* gq, const float* gvq, const float* lat, const float* cb, const long long* inds,
-                       float* glat, float* dcb, int accumulate, float beta, int B, int HW, int D, int K, int C,
+                       float* glat, float* dcb, int accumulate, float beta, int B, int HW, int D, int K, int C, float* ws, size_t ws_bytes,
                        hipStream_t st);
 }  // namespace ctvae
 
@@ -299,10 +299,10 @@ int ctvae_vq_lookup(const float* latents, const float* codebooks, const int64_t*
 
 int ctvae_vq_backward(const float* g_quantized, const float* g_vq_loss, const float* latents, const float* codebooks,
                       const int64_t* inds, float* g_latents, float* d_codebooks, int accumulate, float beta, int B, int HW,
-                      int D, int K, int C, void* stream) {
+                      int D, int K, int C, float* ws, size_t ws_bytes, void* stream) {
   if (!latents || !codebooks || !inds || C <= 0) return kErrBadArg;
   return launch_vq_backward(g_quantized, g_vq_loss, latents, codebooks, (const long long*)inds, g_latents, d_codebooks,
-                            accumulate, beta, B, HW, D, K, C, (hipStream_t)stream);
+                            accumulate, beta, B, HW, D, K, C, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int ctvae_gumbel_st_forward(const float* p, const float* gumbel_noise, float* sample, float* soft, long n, void* stream) {

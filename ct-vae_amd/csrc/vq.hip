@@ -139,21 +139,25 @@ __global__ __launch_bounds__(256) void vq_bwd_latents_kernel(const float* __rest
   }
 }
 
-// dE_i[k][d] (+)= g_vq * 2 * (cnt*E_i[k][d] - sum_{p: idx=k} x[p][i+d]) / (P*Dc)      grid (K, C), block 256
+// dE_i[k][d] (+)= g_vq * 2 * (cnt*E_i[k][d] - sum_{p: idx=k} x[p][i+d]) / (P*Dc)      grid (K, C, S), block 256
+// S > 1: slice z covers positions [z*Ps, (z+1)*Ps) and writes its (linear) share to part[z][C*K*Dc]; the shares are
+// summed in a fixed order by vq_cb_reduce_kernel (64 codes x 1 codebook alone would use 64 of the 256 CUs).
 __global__ __launch_bounds__(256) void vq_bwd_codebook_kernel(const float* __restrict__ gvq, const float* __restrict__ lat,
                                                               const float* __restrict__ cb, const long long* __restrict__ inds,
                                                               float* __restrict__ dcb, int P, int D, int K, int Dc, int C,
-                                                              int HW, int accumulate) {
+                                                              int HW, int accumulate, float* __restrict__ part, int Ps) {
   __shared__ float sAcc[4][256];
   __shared__ int sCnt[4];
   const int k = blockIdx.x, i = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};  // d = lane + 64*u, Dc <= 256
   int cnt = 0;
-  for (int base = wave * 64; base < P; base += 256) {
+  const int p_lo = part != nullptr ? blockIdx.z * Ps : 0;
+  const int p_hi = part != nullptr ? (p_lo + Ps < P ? p_lo + Ps : P) : P;
+  for (int base = p_lo + wave * 64; base < p_hi; base += 256) {
     const int p = base + lane;
     bool hit = false;
-    if (p < P) {
+    if (p < p_hi) {
       int b = p / HW, hw = p - b * HW;
       hit = inds[((size_t)b * C + i) * HW + hw] == (long long)k;
     }
@@ -180,8 +184,18 @@ __global__ __launch_bounds__(256) void vq_bwd_codebook_kernel(const float* __res
     const size_t o = ((size_t)i * K + k) * Dc + tid;
     const float sc = (gvq != nullptr ? gvq[0] : 0.f) * 2.f / ((float)P * (float)Dc);
     const float g = sc * (c * cb[o] - sx);
-    dcb[o] = (accumulate ? dcb[o] : 0.f) + g;
+    if (part != nullptr) part[(size_t)blockIdx.z * ((size_t)C * K * Dc) + o] = g;
+    else dcb[o] = (accumulate ? dcb[o] : 0.f) + g;
   }
+}
+
+__global__ __launch_bounds__(256) void vq_cb_reduce_kernel(const float* __restrict__ part, float* __restrict__ dcb, int n, int S,
+                                                          int accumulate) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= n) return;
+  float v = accumulate ? dcb[o] : 0.f;
+  for (int z = 0; z < S; ++z) v += part[(size_t)z * n + o];
+  dcb[o] = v;
 }
 
 size_t vq_workspace_floats(int C) { return (size_t)1024 * C; }
@@ -222,8 +236,8 @@ int launch_vq_lookup(const float* lat, const float* cb, const long long* inds, f
 }
 
 int launch_vq_backward(const float* gq, const float* gvq, const float* lat, const float* cb, const long long* inds,
-                       float* glat, float* dcb, int accumulate, float beta, int B, int HW, int D, int K, int C,
-                       hipStream_t st) {
+                       float* glat, float* dcb, int accumulate, float beta, int B, int HW, int D, int K, int C, float* ws,
+                       size_t ws_bytes, hipStream_t st) {
   if (D % C != 0 || C > 8 || D / C > 256) return kErrBadArg;
   const int Dc = D / C, P = B * HW;
   if (glat != nullptr) {
@@ -234,9 +248,20 @@ int launch_vq_backward(const float* gq, const float* gvq, const float* lat, cons
     CTVAE_LAUNCH_CHECK();
   }
   if (dcb != nullptr) {
-    hipLaunchKernelGGL(vq_bwd_codebook_kernel, dim3(K, C), dim3(256), 0, st, gvq, lat, cb, inds, dcb, P, D, K, Dc, C, HW,
-                       accumulate);
+    // enough slices of the position range for ~1024 workgroups (each slice >= 512 positions), if scratch is available
+    int S = 1024 / (K * C);
+    if (S > P / 512) S = P / 512;
+    const size_t n = (size_t)C * K * Dc;
+    if (ws == nullptr || S < 2 || ws_bytes / sizeof(float) < (size_t)S * n) S = 1;
+    const int Ps = ceil_div(P, S);
+    ProfScope ps("vq_bwd_codebook_kernel", st, 0.0, 4.0 * (double)P * D + 8.0 * (double)P * C * (double)K / S);
+    hipLaunchKernelGGL(vq_bwd_codebook_kernel, dim3(K, C, S), dim3(256), 0, st, gvq, lat, cb, inds, dcb, P, D, K, Dc, C, HW,
+                       accumulate, S > 1 ? ws : nullptr, Ps);
     CTVAE_LAUNCH_CHECK();
+    if (S > 1) {
+      hipLaunchKernelGGL(vq_cb_reduce_kernel, dim3(ceil_div((int)n, 256)), dim3(256), 0, st, ws, dcb, (int)n, S, accumulate);
+      CTVAE_LAUNCH_CHECK();
+    }
   }
   return 0;
 }

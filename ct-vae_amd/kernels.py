@@ -710,8 +710,9 @@ class VQLookup(Function):
             for i in range(1, C):
                 if flags[i][0].data_ptr() != dcb.data_ptr() + i * cb0.numel() * 4:
                     raise RuntimeError("codebook gradients must be stored back to back (flat gradient buffer)")
+        ws = native.workspace(lat.device)
         native.call("ctvae_vq_backward", native.ptr(g_q), native.ptr(g_vq), lat.data_ptr(), cb0.data_ptr(), inds.data_ptr(),
-                    native.ptr(g_lat), native.ptr(dcb), acc, beta, B, H * W, D, K, C)
+                    native.ptr(g_lat), native.ptr(dcb), acc, beta, B, H * W, D, K, C, ws.data_ptr(), ws.numel() * 4)
         return (g_lat, None, None, None, None) + (None,) * len(ctx.codebooks)
 
 

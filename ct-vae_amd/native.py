@@ -39,7 +39,7 @@ SIGNATURES = {
     "ctvae_kl_backward": [_fp, _l, _fp, _l, _fp, _fp, _fp, _i, _i, _f, _vp],
     "ctvae_vq_inds": [_fp, _fp, _fp, _i, _i, _i, _i, _i, _vp],
     "ctvae_vq_lookup": [_fp, _fp, _fp, _fp, _fp, _f, _i, _i, _i, _i, _i, _fp, _sz, _vp],
-    "ctvae_vq_backward": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _f, _i, _i, _i, _i, _i, _vp],
+    "ctvae_vq_backward": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _f, _i, _i, _i, _i, _i, _fp, _sz, _vp],
     "ctvae_gumbel_st_forward": [_fp, _fp, _fp, _fp, _l, _vp],
     "ctvae_gumbel_st_backward": [_fp, _fp, _fp, _fp, _l, _vp],
     "ctvae_adam_step": [_fp, _fp, _fp, _fp, _fp, _l, _f, _vp],

@@ -167,10 +167,11 @@ int ctvae_vq_inds(const float* latents, const float* codebooks, int64_t* inds, i
                   void* stream);
 int ctvae_vq_lookup(const float* latents, const float* codebooks, const int64_t* inds, float* quantized, float* vq_loss,
                     float beta, int B, int HW, int D, int K, int C, float* ws, size_t ws_bytes, void* stream);
-/* g_latents (may be NULL) = straight-through g_q + commitment term; d_codebooks (may be NULL) (+)= embedding term */
+/* g_latents (may be NULL) = straight-through g_q + commitment term; d_codebooks (may be NULL) (+)= embedding term.
+ * ws (may be NULL): scratch that lets the codebook pass split the positions over more workgroups (fixed-order sum). */
 int ctvae_vq_backward(const float* g_quantized, const float* g_vq_loss, const float* latents, const float* codebooks,
                       const int64_t* inds, float* g_latents, float* d_codebooks, int accumulate, float beta, int B, int HW,
-                      int D, int K, int C, void* stream);
+                      int D, int K, int C, float* ws, size_t ws_bytes, void* stream);
 
 /* Straight-through Bernoulli(p) sample = F.gumbel_softmax(log(clamp([1-p,p],1e-4)), tau=1, hard=True)[...,1]
  * (ct_mcq_vae.py:126,177-183).  gumbel_noise [n][2] standard Gumbel draws (injectable);
