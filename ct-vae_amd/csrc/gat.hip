@@ -7,8 +7,9 @@
 // (216 MB per head at B = 128) and was 70 % of a CT-MCQ-VAE step; here nothing of size N*N*C touches memory.
 //   gat_score_kernel<0>  thread = (r,c) pairs of one (b,h), xl/xr of that head staged transposed in LDS, k-sum in-thread
 //   gat_score_kernel<1>  same walk, returns T = sum_k att*we*lrelu'(.) so that d attr = sum_h g*T (the caller's product)
-//   gat_score_bwd_kernel thread = channel k of one (b,h): d xl[b,r,h,k] and d xr[b,c,h,k] are produced by exactly one
-//                        thread each (no atomics, bit-reproducible); d att / d we leave as per-sample partials.
+//   gat_score_bwd_kernel thread = (channel k, half of the sources) of one (b,h): every d xl[b,r,h,k] has one producer, the
+//                        two halves of d xr[b,c,h,k] meet in a shuffle (no atomics, bit-reproducible); d att / d we
+//                        leave as per-sample partials.
 // Masked softmax over sources and the alpha-weighted aggregation stay as small torch ops on [B,H,N,N].
 #include "common.hpp"
 #include "prof.hpp"
@@ -73,18 +74,23 @@ __global__ __launch_bounds__(256) void gat_score_kernel(const float* __restrict_
   }
 }
 
-// grid (H, B), 128 threads: thread k < C.  g [B,H,N,N] (r,c).  datt_part / dwe_part [B][H][C].
-__global__ __launch_bounds__(128) void gat_score_bwd_kernel(const float* __restrict__ xl, const float* __restrict__ xr,
+// grid (H, B), 256 threads: thread = (channel k < C, half of the source range).  Two lanes of a pair share k and split
+// the sources r, which halves the registers holding xl[r] / d xl[r] (34 + 34 instead of 68 + 68: three waves per SIMD
+// instead of one); their partial sums over r meet through one shuffle.  g [B,H,N,N] (r,c).  d*_part [B][H][C].
+constexpr int NH = NB / 2;   // 34 sources per lane
+
+__global__ __launch_bounds__(256, 2) void gat_score_bwd_kernel(const float* __restrict__ xl, const float* __restrict__ xr,
                                                            const float* __restrict__ attr, const float* __restrict__ we,
                                                            const float* __restrict__ att, const float* __restrict__ g,
                                                            float* __restrict__ dxl, float* __restrict__ dxr,
                                                            float* __restrict__ datt_part, float* __restrict__ dwe_part, int N,
                                                            int H, int C, float slope) {
-  __shared__ __attribute__((aligned(16))) float sG[NB][NB];   // [c][r]
-  __shared__ __attribute__((aligned(16))) float sA[NB][NB];   // [c][r]
-  const int tid = threadIdx.x, h = blockIdx.x, b = blockIdx.y, k = tid;
+  __shared__ __attribute__((aligned(16))) float sG[NB][NB];   // [c][r]; read as float2 (r0 = 34 is 8-B aligned)
+  __shared__ __attribute__((aligned(16))) float sA[NB][NB];
+  const int tid = threadIdx.x, h = blockIdx.x, b = blockIdx.y, k = tid >> 1, half = tid & 1;
   const bool kok = k < C;
-  for (int e = tid; e < NB * NB; e += 128) {
+  const int r0 = half * NH;
+  for (int e = tid; e < NB * NB; e += 256) {
     const int r = e / NB, c = e - r * NB;     // reads coalesced along c
     float gv = 0.f, av = 0.f;
     if (r < N && c < N) {
@@ -94,11 +100,12 @@ __global__ __launch_bounds__(128) void gat_score_bwd_kernel(const float* __restr
     sG[c][r] = gv;
     sA[c][r] = av;
   }
-  float xlr[NB], dl[NB];
+  float xlr[NH], dl[NH];
 #pragma unroll
-  for (int r = 0; r < NB; ++r) {
-    xlr[r] = (kok && r < N) ? xl[(((long)b * N + r) * H + h) * C + k] : 0.f;
-    dl[r] = 0.f;
+  for (int i = 0; i < NH; ++i) {
+    const int r = r0 + i;
+    xlr[i] = (kok && r < N) ? xl[(((long)b * N + r) * H + h) * C + k] : 0.f;
+    dl[i] = 0.f;
   }
   const float wk = kok ? we[h * C + k] : 0.f, ak = kok ? att[h * C + k] : 0.f;
   float datt = 0.f, dwe = 0.f;
@@ -107,29 +114,35 @@ __global__ __launch_bounds__(128) void gat_score_bwd_kernel(const float* __restr
     const float xrc = kok ? xr[(((long)b * N + c) * H + h) * C + k] : 0.f;
     float dr = 0.f;
 #pragma unroll
-    for (int r4 = 0; r4 < NB; r4 += 4) {
-      const f32x4 g4 = *reinterpret_cast<const f32x4*>(&sG[c][r4]);   // same address in every lane: broadcast
-      const f32x4 a4 = *reinterpret_cast<const f32x4*>(&sA[c][r4]);
+    for (int i2 = 0; i2 < NH; i2 += 2) {
+      const float2 g2 = *reinterpret_cast<const float2*>(&sG[c][r0 + i2]);   // two addresses per wave: broadcast reads
+      const float2 a2 = *reinterpret_cast<const float2*>(&sA[c][r0 + i2]);
+      const float gq[2] = {g2.x, g2.y}, aq[2] = {a2.x, a2.y};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float m = xlr[r4 + q] + xrc + a4[q] * wk;
+      for (int q = 0; q < 2; ++q) {
+        const float m = xlr[i2 + q] + xrc + aq[q] * wk;
         const float sl = m > 0.f ? 1.f : slope;
-        const float gs = g4[q] * sl;        // g * lrelu'(m)
+        const float gs = gq[q] * sl;        // g * lrelu'(m)
         datt += gs * m;                     // g * lrelu(m)
         const float gd = gs * ak;           // d m
-        dl[r4 + q] += gd;
+        dl[i2 + q] += gd;
         dr += gd;
-        dwe += gd * a4[q];
+        dwe += gd * aq[q];
       }
     }
-    if (kok) dxr[(((long)b * N + c) * H + h) * C + k] = dr;
+    dr += __shfl_xor(dr, 1, 64);
+    if (kok && half == 0) dxr[(((long)b * N + c) * H + h) * C + k] = dr;
   }
+  datt += __shfl_xor(datt, 1, 64);
+  dwe += __shfl_xor(dwe, 1, 64);
   if (kok) {
 #pragma unroll
-    for (int r = 0; r < NB; ++r)
-      if (r < N) dxl[(((long)b * N + r) * H + h) * C + k] = dl[r];
-    datt_part[((long)b * H + h) * C + k] = datt;
-    dwe_part[((long)b * H + h) * C + k] = dwe;
+    for (int i = 0; i < NH; ++i)
+      if (r0 + i < N) dxl[(((long)b * N + r0 + i) * H + h) * C + k] = dl[i];
+    if (half == 0) {
+      datt_part[((long)b * H + h) * C + k] = datt;
+      dwe_part[((long)b * H + h) * C + k] = dwe;
+    }
   }
 }
 
@@ -159,7 +172,7 @@ int launch_gat_score_backward(const float* xl, const float* xr, const float* att
                               int C, float slope, hipStream_t st) {
   if (B <= 0 || N <= 0 || N > NB - 3 || H <= 0 || C <= 0 || C > 128) return kErrBadArg;
   ProfScope ps("gat_score_bwd_kernel", st, 10.0 * B * H * (double)N * N * C, 4.0 * B * H * (4.0 * N * C + (double)N * N));
-  hipLaunchKernelGGL(gat_score_bwd_kernel, dim3(H, B), dim3(128), 0, st, xl, xr, attr, we, att, g, dxl, dxr, datt_part, dwe_part,
+  hipLaunchKernelGGL(gat_score_bwd_kernel, dim3(H, B), dim3(256), 0, st, xl, xr, attr, we, att, g, dxl, dxr, datt_part, dwe_part,
                      N, H, C, slope);
   CTVAE_LAUNCH_CHECK();
   return 0;
