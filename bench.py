@@ -47,6 +47,8 @@ def parse():
                     help="N>1: one backward graph, then the all-reduce (default: backward cut at the latent, the "
                          "decoder-side buckets are exchanged while the encoder's backward runs)")
     ap.add_argument("--split-backward", action="store_true", help="use the two-stage backward even at N=1 (diagnostic)")
+    ap.add_argument("--rehearse-ddp", action="store_true",
+                    help="N=1 only: initialise a 1-rank RCCL group and run the exact N>1 step (diagnostic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -126,6 +128,12 @@ def cpu_baseline(model_name, seconds):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE JSON line (rank 0).  Native libraries write there too (RCCL prints a five-line version
+    # banner to fd 1 when its communicator comes up), so fd 1 is pointed at stderr for the whole run and the result line
+    # goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -135,9 +143,12 @@ def main():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # --rehearse-ddp: run the N>1 code path (graphs + RCCL collectives on the communication stream) in a 1-rank group
+    ddp_on = multi = world > 1 or args.rehearse_ddp
+    if ddp_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from ctvae_amd import filler, native
     from ctvae_amd.ddp import GradBucketAllReduce
@@ -150,7 +161,7 @@ def main():
         args.no_graph = True
     model = build_model(args.model, dev, seed)
     opt = FlatAdam(model, lr=0.005 if args.model == "VanillaVAE" else 0.0005)
-    ddp = GradBucketAllReduce(model) if world > 1 else None
+    ddp = GradBucketAllReduce(model, force=args.rehearse_ddp) if ddp_on else None
     kld_w = 0.00025
     # 4 rotating synthetic batches per rank, resident in HBM, NCHW-contiguous like a DataLoader would hand over
     batches = [filler.synthetic_batch(seed + 1000 * rank + i, B)[0].to(dev) for i in range(4)]
@@ -169,14 +180,14 @@ def main():
 
     def local_step():
         l = fwd_bwd()
-        if world == 1:
+        if not multi:
             opt.step()
         return l
 
     # N>1: the backward pass is cut at the latent (ddp.SplitBackward): the decoder-side gradient range is all-reduced
     # on the communication stream while the encoder's backward (second graph) runs
     split = None
-    if args.model == "VanillaVAE" and ((world > 1 and not args.no_overlap) or args.split_backward):
+    if args.model == "VanillaVAE" and ((multi and not args.no_overlap) or args.split_backward):
         from ctvae_amd.ddp import SplitBackward
         split = SplitBackward(model)
 
@@ -194,7 +205,7 @@ def main():
                 if split is not None:
                     stage1()
                     split.stage2()
-                    if world == 1:
+                    if not multi:
                         opt.step()
                 else:
                     local_step()
@@ -207,7 +218,7 @@ def main():
             graph2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph2, pool=graph.pool()):
                 split.stage2()
-                if world == 1:
+                if not multi:
                     opt.step()
         else:
             with torch.cuda.graph(graph):
@@ -220,14 +231,14 @@ def main():
                 graph.replay()
             else:
                 stage1()
-            works = ddp.all_reduce_range(split.split, split.total) if world > 1 else []
+            works = ddp.all_reduce_range(split.split, split.total) if multi else []
             if graph2 is not None:
                 graph2.replay()
             else:
                 split.stage2()
-                if world == 1:
+                if not multi:
                     opt.step()
-            if world > 1:
+            if multi:
                 works += ddp.all_reduce_range(0, split.split)
                 ddp.wait(works)
                 opt.step(grad_scale=ddp.grad_scale)
@@ -236,25 +247,25 @@ def main():
             graph.replay()
         else:
             local_step()
-        if world > 1:
+        if multi:
             ddp.all_reduce()
             opt.step(grad_scale=ddp.grad_scale)
 
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -341,8 +352,9 @@ def main():
         }
         if kernels is not None:
             line["kernels"] = kernels
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
+    if multi:
         dist.destroy_process_group()
 
 

@@ -14,13 +14,15 @@ import torch.distributed as dist
 
 
 class GradBucketAllReduce:
-    def __init__(self, model, process_group=None, bucket_bytes=32 << 20, broadcast_from=0):
+    def __init__(self, model, process_group=None, bucket_bytes=32 << 20, broadcast_from=0, force=False):
+        """force: issue the collectives even in a 1-rank group (rehearsal of the N>1 call pattern on one GPU)."""
         self.model = model
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.comm_stream = None
-        if self.world > 1 and broadcast_from is not None:
+        if self.active and broadcast_from is not None:
             self.broadcast_parameters(broadcast_from)
 
     # C3: parameters (and buffers) from rank 0 once at construction
@@ -42,7 +44,7 @@ class GradBucketAllReduce:
 
     def all_reduce(self, async_op=False):
         """SUM all-reduce of every bucket (division by world size is the caller's grad_scale)."""
-        if self.world == 1:
+        if not self.active:
             return []
         g = self.model.flat_grads
         if g.is_cuda:
@@ -62,7 +64,7 @@ class GradBucketAllReduce:
     def all_reduce_range(self, lo, hi):
         """Asynchronous SUM all-reduce of flat_grads[lo:hi] (bucketed) on the communication stream, ordered behind
         everything issued so far on the current stream.  Returns the work handles for wait()."""
-        if self.world == 1 or hi <= lo:
+        if not self.active or hi <= lo:
             return []
         g = self.model.flat_grads
         parts, off = [], lo
