@@ -244,9 +244,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
 constexpr unsigned kOOBw = 0x80000000u;
 
-template <int WK, int WN>
+// TK x TN: 32x32 MFMA tiles per wave.  <2,2,1,1> = 64x64 output tile; <2,2,2,2> = 128x128 for the wide layers of
+// MCQ / CT-MCQ-VAE (rows and N multiples of 128): per MFMA half the LDS reads and half the L2->LDS bytes per FLOP
+// (a 64x64 tile streams 1/16 B/FLOP, i.e. ~6 TB/s of L2 traffic at 95 TFLOP/s -- that, not the MFMA pipe, capped it).
+template <int WK, int WN, int TK, int TN>
 __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradArgs a, int lgQw, int lgQhw, int lgC) {
-  constexpr int KT = WK * 32, NT = WN * 32;
+  constexpr int KT = WK * TK * 32, NT = WN * TN * 32;
   static_assert(WK * WN == 4, "4 waves");
   __shared__ __attribute__((aligned(16))) float sX[MC * KT];
   __shared__ __attribute__((aligned(16))) float sD[MC * NT];
@@ -359,9 +362,13 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradArgs a, int 
     for (int j = 0; j < D_V; ++j) *reinterpret_cast<f32x4*>(&sD[(tid / DQ + (256 / DQ) * j) * NT + 4 * (tid % DQ)]) = rd[j];
   };
 
-  f32x16 acc;
+  f32x16 acc[TK][TN];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int i = 0; i < TK; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float bsum = 0.f;
   const bool do_bias = (a.pbias != nullptr) && (kt0 == 0) && (tid < NT);
 
@@ -377,9 +384,15 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradArgs a, int 
       if (c + 2 < nch) rowinfo(c + 2, c & 1);
 #pragma unroll
       for (int s = 0; s < MC / 2; ++s) {
-        const float av = sX[(2 * s + lh) * KT + wk * 32 + li];
-        const float bv = sD[(2 * s + lh) * NT + wn * 32 + li];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        float av[TK], bv[TN];
+#pragma unroll
+        for (int i = 0; i < TK; ++i) av[i] = sX[(2 * s + lh) * KT + (wk * TK + i) * 32 + li];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bv[j] = sD[(2 * s + lh) * NT + (wn * TN + j) * 32 + li];
+#pragma unroll
+        for (int i = 0; i < TK; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
       }
       if (do_bias) {
         float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
@@ -397,18 +410,23 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradArgs a, int 
     }
   }
 
-  const int col = n0 + wn * 32 + li;
 #pragma unroll
-  for (int q4 = 0; q4 < 4; ++q4) {
-    const int k0 = kt0 + wk * 32 + 8 * q4 + 4 * lh;      // 4 consecutive k rows: same tap when gC % 4 == 0
-    if (k0 < Ktot && col < N) {
-      const int t = lgC >= 0 ? (k0 >> lgC) : (k0 / gC);
-      const int wrow0 = g.taps[cls][t].wtap * gC + (k0 - t * gC);
-      float* dst = a.part + ((long)split * a.rows_total + wrow0) * N + col;
+  for (int i = 0; i < TK; ++i)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) dst[(long)q * N] = acc[4 * q4 + q];
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + li;
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int k0 = kt0 + (wk * TK + i) * 32 + 8 * q4 + 4 * lh;      // 4 consecutive k rows: same tap when gC % 4 == 0
+        if (k0 < Ktot && col < N) {
+          const int t = lgC >= 0 ? (k0 >> lgC) : (k0 / gC);
+          const int wrow0 = g.taps[cls][t].wtap * gC + (k0 - t * gC);
+          float* dst = a.part + ((long)split * a.rows_total + wrow0) * N + col;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dst[(long)q * N] = acc[i][j][4 * q4 + q];
+        }
+      }
     }
-  }
   if (do_bias && n0 + tid < N) a.pbias[(long)(split * g.ncls + cls) * N + n0 + tid] = bsum;
 }
 
@@ -515,13 +533,13 @@ size_t wgrad_workspace_floats(const ConvGeom& g, int S) {
 }
 
 // choose the number of m-splits so that the grid has ~1024 workgroups
-static int choose_splits(const ConvGeom& g, int KT, int NT, size_t ws_floats) {
+static int choose_splits(const ConvGeom& g, int KT, int NT, size_t ws_floats, int target_wgs = 1024) {
   int ktiles = 0;
   for (int c = 0; c < g.ncls; ++c) ktiles += ceil_div(g.ntaps[c] * g.gC, KT);
   int tiles = ktiles * ceil_div(g.sC, NT);
   int Mc = g.B * g.Qh * g.Qw;
   int nchunks = ceil_div(Mc, MC);
-  int S = 1024 / (tiles > 0 ? tiles : 1);
+  int S = target_wgs / (tiles > 0 ? tiles : 1);
   if (S < 1) S = 1;
   int maxS = ceil_div(nchunks, 4);  // at least 4 chunks per split
   if (maxS < 1) maxS = 1;
@@ -598,9 +616,20 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
   a.rows_total = taps_total * g.gC;
   const bool xvec = (g.gC % 4) == 0, dvec = (a.N % 4) == 0;
   const bool narrow = a.N <= 32;
-  const int KT = narrow ? 128 : 64, NT = narrow ? 32 : 64;
+  // 128x128 tiles for wide layers whose pixel range still leaves >= 8 chunks per workgroup at ~1024 workgroups
+  bool big = xvec && dvec && (a.N % 128) == 0 && a.Mc >= 8192;
+  for (int c = 0; c < g.ncls && big; ++c) big = (g.ntaps[c] * g.gC) % 128 == 0;
+  if (big) {
+    int tiles128 = 0;
+    for (int c = 0; c < g.ncls; ++c) tiles128 += g.ntaps[c] * g.gC / 128;
+    tiles128 *= a.N / 128;
+    big = tiles128 >= 16 && (long)ceil_div(a.Mc, MC) * tiles128 >= 8L * 1024;
+  }
+  const int KT = big ? 128 : (narrow ? 128 : 64), NT = big ? 128 : (narrow ? 32 : 64);
   const size_t ws_floats = ws_bytes / sizeof(float);
-  const int S = choose_splits(g, KT, NT, ws_floats);
+  // 128x128 tiles hold two workgroups per CU (64 accumulator + 134 other registers): one resident round, and half the
+  // partial slabs for the reduce pass
+  const int S = choose_splits(g, KT, NT, ws_floats, big ? 512 : 1024);
   if (wgrad_workspace_floats(g, S) > ws_floats) return kErrWorkspace;
   a.S = S;
   const int nchunks = ceil_div(a.Mc, MC);
@@ -617,7 +646,8 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
   dim3 grid(kt * a.ntiles, S), block(256);
   {
   char name[160];
-  if (xvec && dvec && !narrow) snprintf(name, sizeof name, "wgrad_fast_kernel<%d,%d>", narrow ? 4 : 2, narrow ? 1 : 2);
+  if (big) snprintf(name, sizeof name, "wgrad_fast_kernel<2,2,2,2>");
+  else if (xvec && dvec && !narrow) snprintf(name, sizeof name, "wgrad_fast_kernel<%d,%d>", narrow ? 4 : 2, narrow ? 1 : 2);
   else snprintf(name, sizeof name, "wgrad_kernel<%d,%d,%s,%s>", narrow ? 4 : 2, narrow ? 1 : 2, xvec ? "true" : "false",
                 dvec ? "true" : "false");
   const double macs = (double)a.Mc * a.N * a.rows_total;
@@ -639,7 +669,8 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
     const int lw = lg2(g.Qw), lh2 = lg2(g.Qh);
     const int lgQw = (lw >= 0 && lh2 >= 0) ? lw : -1, lgQhw = (lw >= 0 && lh2 >= 0) ? lw + lh2 : -1;
     const int lgC = lg2(g.gC);
-    hipLaunchKernelGGL((wgrad_fast_kernel<2, 2>), grid, block, 0, st, a, lgQw, lgQhw, lgC);
+    if (big) hipLaunchKernelGGL((wgrad_fast_kernel<2, 2, 2, 2>), grid, block, 0, st, a, lgQw, lgQhw, lgC);
+    else hipLaunchKernelGGL((wgrad_fast_kernel<2, 2, 1, 1>), grid, block, 0, st, a, lgQw, lgQhw, lgC);
   } else if (narrow) CTVAE_WG(4, 1);
   else CTVAE_WG(2, 2);
 #undef CTVAE_WG
