@@ -194,3 +194,33 @@ def test_split_backward_matches_single_backward():
     scale = float(g_ref.abs().max())
     assert float((m.flat_grads - g_ref).abs().max()) <= 1e-5 * max(1.0, scale)
     assert not torch.equal(rm_ref, torch.zeros_like(rm_ref))
+
+
+def test_eval_mode_final_block_matches_unfused_path():
+    """Eval mode (running statistics) through the fused final block (BatchNorm applied on load by the 3-channel conv)
+    against the same model with the fusion switched off, and train-mode parity of both paths."""
+    import torch
+    from ctvae_amd import filler, kernels as K
+    from ctvae_amd.models import vae_models
+    dev = torch.device("cuda")
+    m = vae_models["VanillaVAE"](in_channels=3, latent_dim=128)
+    m.load_state_dict(filler.fill_state(filler.specs_of(m), 91))
+    m = m.to(dev)
+    x, eps = filler.synthetic_batch(90, 4)
+    x, eps = x.to(dev), eps.to(dev)
+    m.train()
+    for _ in range(2):                      # move the running statistics away from their init
+        m(x, eps=eps)
+    outs = {}
+    real = K.input_transform_supported
+    try:
+        for fused in (True, False):
+            K.input_transform_supported = real if fused else (lambda *a, **k: False)
+            m.eval()
+            with torch.no_grad():
+                outs[("eval", fused)] = m(x, eps=eps)[0].clone()
+            sample = m.sample(2, dev)
+            assert sample.shape == (2, 3, 64, 64) and torch.isfinite(sample).all()
+    finally:
+        K.input_transform_supported = real
+    assert float((outs[("eval", True)] - outs[("eval", False)]).abs().max()) < 1e-5
