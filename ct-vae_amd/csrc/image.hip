@@ -17,10 +17,23 @@
 // there (lazy BatchNorm apply: the normalised activation never exists in HBM).  The data gradient also emits the
 // BatchNorm's backward sums per workgroup (see TapGemmArgs::bnb_*), reading y with the same 128-B-per-pixel pattern
 // it writes ga with.  All reductions run in a fixed order: bit-reproducible.
+#include <type_traits>
+
 #include "common.hpp"
 #include "prof.hpp"
 
 namespace ctvae {
+
+#ifdef CTVAE_PHASE_TIMING
+// diagnostic build only (tools/phase_probe.py): timestamps of the phases of the first tiles of each workgroup
+__device__ unsigned long long g_img_phase[1024 * 32];
+#define IPHASE(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024 && (i) < 32) g_img_phase[blockIdx.x * 32 + (i)] = wall_clock64(); } while (0)
+extern "C" int ctvae_debug_img_phase_read(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_img_phase), (size_t)n * 8);
+}
+#else
+#define IPHASE(i) do {} while (0)
+#endif
 
 namespace {
 
@@ -96,7 +109,8 @@ struct Patch {
   unsigned ok;   // bit j: load j is inside the image
 };
 
-__device__ __forceinline__ void patch_load(const ImgArgs& a, __amdgpu_buffer_rsrc_t rX, const TileXY& t, Patch& p) {
+// slot arithmetic redone per tile: fewer live registers (img_fwd_kernel runs at 3 waves per SIMD, 170 VGPRs)
+__device__ __forceinline__ void patch_load_calc(const ImgArgs& a, __amdgpu_buffer_rsrc_t rX, const TileXY& t, Patch& p) {
   unsigned okm = 0;
 #pragma unroll
   for (int j = 0; j < NLD; ++j) {
@@ -106,6 +120,36 @@ __device__ __forceinline__ void patch_load(const ImgArgs& a, __amdgpu_buffer_rsr
     const int iy = t.y0 - 1 + py, ix = t.x0 - 1 + px;
     const bool ok = e < NP * 8 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
     p.v[j] = ld4(rX, ok ? (unsigned)(((t.b * a.H + iy) * a.W + ix) * C + 4 * c4) * 4u : kOOBi);
+    okm |= (ok ? 1u : 0u) << j;
+  }
+  p.ok = okm;
+}
+
+// per-thread constants of the 11 patch slots (tile independent): byte offset relative to the patch origin and (py, px)
+struct PatchIdx {
+  unsigned rel[NLD];
+  int pyx[NLD];   // py << 16 | px, or -1 for the unused tail slots
+};
+__device__ __forceinline__ void patch_index(const ImgArgs& a, PatchIdx& ix) {
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const int e = threadIdx.x + 256 * j;
+    const int pp = e >> 3, c4 = e & 7;
+    const int py = (pp * 241) >> 13, px = pp - py * PW;   // pp / 34 for pp < 352
+    ix.rel[j] = (unsigned)((py * a.W + px) * C + 4 * c4) * 4u;
+    ix.pyx[j] = e < NP * 8 ? ((py << 16) | px) : -1;
+  }
+}
+__device__ __forceinline__ void patch_load(const ImgArgs& a, __amdgpu_buffer_rsrc_t rX, const TileXY& t, const PatchIdx& ix,
+                                           Patch& p) {
+  // origin = pixel (y0 - 1, x0 - 1); it may lie outside the image (negative offset), every in-range slot adds back >= that
+  const unsigned origin = (unsigned)(((t.b * a.H + t.y0 - 1) * a.W + t.x0 - 1) * C) * 4u;
+  unsigned okm = 0;
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const int py = ix.pyx[j] >> 16, px = ix.pyx[j] & 0xffff;
+    const bool ok = ix.pyx[j] >= 0 && (unsigned)(t.y0 - 1 + py) < (unsigned)a.H && (unsigned)(t.x0 - 1 + px) < (unsigned)a.W;
+    p.v[j] = ld4(rX, ok ? origin + ix.rel[j] : kOOBi);
     okm |= (ok ? 1u : 0u) << j;
   }
   p.ok = okm;
@@ -182,13 +226,13 @@ __global__ __launch_bounds__(256, 3) void img_fwd_kernel(const ImgArgs a) {
   Patch pt;
   int tile = blockIdx.x;
   TileXY cur = tile_xy(a, tile < a.ntiles ? tile : 0);
-  if (tile < a.ntiles) patch_load(a, rX, cur, pt);
+  if (tile < a.ntiles) patch_load_calc(a, rX, cur, pt);
   for (; tile < a.ntiles; tile += gridDim.x) {
     patch_store(a, pt, sA);
     __syncthreads();
     const int next = tile + gridDim.x;
     const TileXY nxt = tile_xy(a, next < a.ntiles ? next : 0);
-    if (next < a.ntiles) patch_load(a, rX, nxt, pt);   // in flight during the MFMA / gather phases
+    if (next < a.ntiles) patch_load_calc(a, rX, nxt, pt);   // in flight during the MFMA / gather phases
 
     // ---- Z = patch x W' : wave w takes the 32-row blocks w, w+4, w+8 ----
     f32x16 acc[3];
@@ -251,6 +295,7 @@ __global__ __launch_bounds__(256) void img_wgrad_kernel(const ImgArgs a) {
   const __amdgpu_buffer_rsrc_t rG = rsrc(a.dY, (long)a.B * a.H * a.W * NO * 4);
 
   for (int e = tid; e < GH * GW * 4; e += 256) sG[e] = 0.f;
+  for (int e = tid; e < (NPP - NP) * LDA; e += 256) sA[NP * LDA + e] = 0.f;   // K-loop padding steps read these rows
   // lane j = li = 3t + co reads g[p' - off_t][co]: patch pixel (py,px) <-> grid cell (py + 1 - dy_t, px + 1 - dx_t)
   const int t_l = li / 3, co_l = li - 3 * t_l;
   const bool jvalid = li < NJ;
@@ -268,15 +313,20 @@ __global__ __launch_bounds__(256) void img_wgrad_kernel(const ImgArgs a) {
 #pragma unroll
     for (int n = 0; n < NO; ++n) gv[n] = ld1(rG, off + 4u * n);
   };
+  PatchIdx pix;
+  patch_index(a, pix);
   int tile = blockIdx.x;
   if (tile < a.ntiles) {
     const TileXY c0 = tile_xy(a, tile);
-    patch_load(a, rX, c0, pt);
+    patch_load(a, rX, c0, pix, pt);
     g_load(c0);
   }
   __syncthreads();   // sG ring zeroed
-  for (; tile < a.ntiles; tile += gridDim.x) {
+  int it = 0;
+  IPHASE(0);
+  for (; tile < a.ntiles; tile += gridDim.x, ++it) {
     patch_store(a, pt, sA);
+    IPHASE(1 + 5 * it);
     {
       float* cell = &sG[((ly + 2) * GW + lx + 2) * 4];
 #pragma unroll
@@ -286,22 +336,56 @@ __global__ __launch_bounds__(256) void img_wgrad_kernel(const ImgArgs a) {
       }
     }
     __syncthreads();
+    IPHASE(2 + 5 * it);
     const int next = tile + gridDim.x;
     if (next < a.ntiles) {
       const TileXY nxt = tile_xy(a, next);
-      patch_load(a, rX, nxt, pt);
+      patch_load(a, rX, nxt, pix, pt);
       g_load(nxt);
     }
-    // K loop over the 340 patch pixels, two per MFMA (lh picks the odd one); the 170 steps are dealt to the 4 waves
-#pragma unroll 2
-    for (int i = wave; i < PH * (PW / 2); i += 4) {
-      const int py = (i * 241) >> 12, j = i - py * (PW / 2);   // i / 17
-      const float av = sA[(py * PW + 2 * j + lh) * LDA + li];
-      float g = sG[gbase + (py * GW + 2 * j) * 4];
-      g = jvalid ? g : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, g, acc, 0, 0, 0);
+    IPHASE(3 + 5 * it);
+    // K loop over the 340 patch pixels, two per MFMA (lh picks the odd one).  Wave w takes the patch rows w, w+4, w+8:
+    // inside a row every operand address is base + compile-time offset, so a step is two ds_read_b32 with immediate
+    // offsets and one MFMA -- no index arithmetic, no branches, nothing between a load and its MFMA (dealing the 170
+    // steps round-robin instead cost ~25 scalar instructions per step and ran at 255 cycles per 64-cycle MFMA).
+    // Rows are double-buffered in registers: row r+1 is read while the 17 MFMAs of row r run.
+    {
+      constexpr int RS = PW / 2;   // 17 steps per patch row
+      const int a_lane = lh * LDA + li;
+      const int g_lane = jvalid ? gbase : 0;   // lanes j >= 27 walk the (zero) top ring row of the gradient grid
+      float av[2][RS], gv[2][RS];
+      auto rd = [&](int py, auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
+        const float* ap = sA + py * PW * LDA + a_lane;
+        const float* gp = sG + (jvalid ? py * GW * 4 : 0) + g_lane;
+#pragma unroll
+        for (int j = 0; j < RS; ++j) {
+          av[slot][j] = ap[2 * j * LDA];
+          gv[slot][j] = gp[2 * j * 4];
+        }
+      };
+      auto mm = [&](auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
+#pragma unroll
+        for (int j = 0; j < RS; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[slot][j], gv[slot][j], acc, 0, 0, 0);
+      };
+      using S0 = std::integral_constant<int, 0>;
+      using S1 = std::integral_constant<int, 1>;
+      const int wv = __builtin_amdgcn_readfirstlane(wave);
+      rd(wv, S0{});
+      rd(wv + 4, S1{});
+      __builtin_amdgcn_sched_barrier(0);
+      mm(S0{});
+      __builtin_amdgcn_sched_barrier(0);
+      if (wv + 8 < PH) rd(wv + 8, S0{});
+      __builtin_amdgcn_sched_barrier(0);
+      mm(S1{});
+      __builtin_amdgcn_sched_barrier(0);
+      if (wv + 8 < PH) mm(S0{});
     }
+    IPHASE(4 + 5 * it);
     __syncthreads();
+    IPHASE(5 + 5 * it);
   }
   // ---- merge the 4 waves in a fixed order ----
   float* sR = sA;   // [4][32][32]
