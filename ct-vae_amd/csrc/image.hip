@@ -227,13 +227,18 @@ __global__ __launch_bounds__(256, 3) void img_fwd_kernel(const ImgArgs a) {
   int tile = blockIdx.x;
   TileXY cur = tile_xy(a, tile < a.ntiles ? tile : 0);
   if (tile < a.ntiles) patch_load_calc(a, rX, cur, pt);
-  for (; tile < a.ntiles; tile += gridDim.x) {
+  int it = 0;
+  IPHASE(0);
+  for (; tile < a.ntiles; tile += gridDim.x, ++it) {
     patch_store(a, pt, sA);
+    IPHASE(1 + 6 * it);
     __syncthreads();
+    IPHASE(2 + 6 * it);
     const int next = tile + gridDim.x;
     const TileXY nxt = tile_xy(a, next < a.ntiles ? next : 0);
     if (next < a.ntiles) patch_load_calc(a, rX, nxt, pt);   // in flight during the MFMA / gather phases
 
+    IPHASE(3 + 6 * it);
     // ---- Z = patch x W' : wave w takes the 32-row blocks w, w+4, w+8 ----
     f32x16 acc[3];
 #pragma unroll
@@ -250,6 +255,7 @@ __global__ __launch_bounds__(256, 3) void img_fwd_kernel(const ImgArgs a) {
         }
       }
     }
+    IPHASE(4 + 6 * it);
     __syncthreads();   // every wave is done reading the patch: its memory becomes Z
     float* sZ = sA;
 #pragma unroll
@@ -264,6 +270,7 @@ __global__ __launch_bounds__(256, 3) void img_fwd_kernel(const ImgArgs a) {
       }
     }
     __syncthreads();
+    IPHASE(5 + 6 * it);
     // ---- gather: one thread per output pixel ----
     {
       const int ly = tid >> 5, lx = tid & 31;
@@ -279,6 +286,7 @@ __global__ __launch_bounds__(256, 3) void img_fwd_kernel(const ImgArgs a) {
 #pragma unroll
       for (int n = 0; n < NO; ++n) st1(rO, off + 4u * n, act_fwd(o[n], a.act));
     }
+    IPHASE(6 + 6 * it);
     __syncthreads();   // Z consumed before the next patch lands
     cur = nxt;
   }
