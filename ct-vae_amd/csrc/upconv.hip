@@ -116,55 +116,83 @@ __global__ __launch_bounds__(256, 2) void up_fwd_kernel(const UpArgs a) {
     const int next = tile + gridDim.x;
     const TileXY nxt = tile_xy(a, next < a.ntiles ? next : 0);
     if (next < a.ntiles) patch_load(a, rX, nxt, pt);
+    // Nine tap-GEMMs per 32-pixel row in the fixed class order {1,2,2,4} taps (host-checked).  The LDS fragments of tap
+    // k+1 are read while the 16 MFMAs of tap k run (two register sets, sched_barrier keeps the order).
+    struct Frag {
+      f32x4 af[4];
+      float bf[4][4];
+    };
+    auto read_tap = [&](int ly, int c, int t, Frag& f) {
+      const float* ap = &sA[((ly + a.tdy[c][t]) * PW + li + a.tdx[c][t]) * LDA + 4 * lh];
+      const float* wp = &sW[(a.twt[c][t] * C + 4 * lh) * C + li];
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg) {
+        f.af[kg] = *reinterpret_cast<const f32x4*>(ap + kg * 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f.bf[kg][q] = wp[(kg * 8 + q) * C];
+      }
+    };
+    auto mfma_tap = [&](const Frag& f, f32x16& acc) {
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.af[kg][q], f.bf[kg][q], acc, 0, 0, 0);
+    };
+    auto epilogue = [&](int ly, int c, f32x16& acc) {
+      // bias, statistics, 128 B per pixel out
+      const unsigned rowoff = (unsigned)((((cur.b * OH + 2 * (cur.y0 + ly) + a.cpy[c]) * OW + 2 * cur.x0 + a.cpx[c]) * C + li)) * 4u;
+      float m1 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[r] += bv;
+        m1 += acc[r];
+        st1(rO, rowoff + (unsigned)((8 * (r >> 2) + 4 * lh + (r & 3)) * 2 * C) * 4u, act_fwd(acc[r], a.act));
+      }
+      if (a.bn_part != nullptr) {
+        m1 *= (1.f / 16.f);
+        float q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) q += (acc[r] - m1) * (acc[r] - m1);
+        const float ntot = sn + 16.f, d = m1 - smean;
+        smean += d * (16.f / ntot);
+        sm2 += q + d * d * (sn * 16.f / ntot);
+        sn = ntot;
+      }
+    };
+    auto zero = [](f32x16& acc) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    };
+#define UP_STEP(LY, C_, T_, CUR, NXT, NLY, NC, NT_, HAS_NEXT)          \
+    if (HAS_NEXT) read_tap(NLY, NC, NT_, NXT);                          \
+    __builtin_amdgcn_sched_barrier(0);                                  \
+    mfma_tap(CUR, acc);                                                 \
+    __builtin_amdgcn_sched_barrier(0);
+    Frag fa, fb;
 #pragma unroll 1
     for (int i = 0; i < 2; ++i) {
       const int ly = wave + 4 * i;
-#pragma unroll
-      for (int c = 0; c < NCLS; ++c) {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const int nt = a.ntaps[c];
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
-          if (t < nt) {
-            const float* ap = &sA[((ly + a.tdy[c][t]) * PW + li + a.tdx[c][t]) * LDA + 4 * lh];
-            const float* wp = &sW[(a.twt[c][t] * C + 4 * lh) * C + li];
-            f32x4 af[4];
-            float bf[4][4];
-#pragma unroll
-            for (int kg = 0; kg < 4; ++kg) {
-              af[kg] = *reinterpret_cast<const f32x4*>(ap + kg * 8);
-#pragma unroll
-              for (int q = 0; q < 4; ++q) bf[kg][q] = wp[(kg * 8 + q) * C];
-            }
-#pragma unroll
-            for (int kg = 0; kg < 4; ++kg)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kg][q], bf[kg][q], acc, 0, 0, 0);
-          }
-        }
-        // ---- epilogue of this (row, class): bias, statistics, 128 B per pixel out ----
-        const unsigned rowoff = (unsigned)((((cur.b * OH + 2 * (cur.y0 + ly) + a.cpy[c]) * OW + 2 * cur.x0 + a.cpx[c]) * C + li)) * 4u;
-        float m1 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          acc[r] += bv;
-          m1 += acc[r];
-          st1(rO, rowoff + (unsigned)((8 * (r >> 2) + 4 * lh + (r & 3)) * 2 * C) * 4u, act_fwd(acc[r], a.act));
-        }
-        if (a.bn_part != nullptr) {
-          m1 *= (1.f / 16.f);
-          float q = 0.f;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) q += (acc[r] - m1) * (acc[r] - m1);
-          const float ntot = sn + 16.f, d = m1 - smean;
-          smean += d * (16.f / ntot);
-          sm2 += q + d * d * (sn * 16.f / ntot);
-          sn = ntot;
-        }
-      }
+      f32x16 acc;
+      read_tap(ly, 0, 0, fa);
+      zero(acc);
+      UP_STEP(ly, 0, 0, fa, fb, ly, 1, 0, true)
+      epilogue(ly, 0, acc);
+      zero(acc);
+      UP_STEP(ly, 1, 0, fb, fa, ly, 1, 1, true)
+      UP_STEP(ly, 1, 1, fa, fb, ly, 2, 0, true)
+      epilogue(ly, 1, acc);
+      zero(acc);
+      UP_STEP(ly, 2, 0, fb, fa, ly, 2, 1, true)
+      UP_STEP(ly, 2, 1, fa, fb, ly, 3, 0, true)
+      epilogue(ly, 2, acc);
+      zero(acc);
+      UP_STEP(ly, 3, 0, fb, fa, ly, 3, 1, true)
+      UP_STEP(ly, 3, 1, fa, fb, ly, 3, 2, true)
+      UP_STEP(ly, 3, 2, fb, fa, ly, 3, 3, true)
+      UP_STEP(ly, 3, 3, fa, fb, ly, 0, 0, false)
+      epilogue(ly, 3, acc);
     }
+#undef UP_STEP
     __syncthreads();
     cur = nxt;
   }
@@ -394,12 +422,11 @@ bool upconv_supported(const ConvGeom& g) {
       if (tp.dy < 0 || tp.dy > 1 || tp.dx < 0 || tp.dx > 1 || tp.wtap < 0 || tp.wtap >= NT) return false;
     }
   }
+  // both kernels walk the classes in the k3 s2 p1 pattern: {1,2,2,4} taps
+  if (g.ntaps[0] != 1 || g.ntaps[1] != 2 || g.ntaps[2] != 2 || g.ntaps[3] != 4) return false;
   return total == NT && (long)g.B * g.sH * g.sW * C < (1L << 29);
 }
-// the weight-gradient kernel additionally relies on the {1,2,2,4} taps-per-class pattern of k3 s2 p1
-bool upconv_wgrad_supported(const ConvGeom& g) {
-  return upconv_supported(g) && g.ntaps[0] == 1 && g.ntaps[1] == 2 && g.ntaps[2] == 2 && g.ntaps[3] == 4;
-}
+bool upconv_wgrad_supported(const ConvGeom& g) { return upconv_supported(g); }
 
 constexpr int kUpWgs = 512;
 int upconv_rows(const ConvGeom& g) {
