@@ -10,9 +10,10 @@
 //   * per-row offsets and the separable y/x validity masks of the im2col gather are computed once per tile;
 //   * the epilogue uses 32-bit indices, drops stores by sending them out of range (no branches), and takes
 //     per-row scatter indices from arithmetic (dense scatter) or one 16-byte LDS read per 4 rows (parity classes);
-//   * fragments of the next 8-deep k-group are read from LDS before the MFMAs of the current one.
-// Workgroup = 4 waves, tile BM x BN = (WM*TM*32) x (WN*TN*32), K chunks of 32, optional LDS double buffering
-// for grids with <= 2 workgroups per CU (otherwise occupancy hides the global-load latency).
+//   * fragments of the next 8-deep k-group are read from LDS before the MFMAs of the current one;
+//   * per-tap constants sit in lanes and are fetched with v_readlane (no scalar loads, no division in the loop).
+// Workgroup = 4 waves, tile BM x BN = (WM*TM*32) x (WN*TN*32), K chunks of 32; grids with <= 4 workgroups per CU run
+// the double-buffered, explicitly software-pipelined loop (PF = 3), larger grids the single-buffer loop (PF = 0).
 #include <type_traits>
 
 #include "prof.hpp"
@@ -49,9 +50,9 @@ extern "C" int ctvae_debug_phase_read(unsigned long long* out, int n) {
 
 template <int WM, int WN, int TM, int TN, bool WT, int PF>
 __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) {
-  constexpr bool DB = PF >= 1;      // PF: 0 single LDS buffer, 1 double buffer, 2 double buffer + loads two chunks ahead,
-                                    //     3 double buffer, explicitly software-pipelined (see the main loop)
-  constexpr int NSET = PF == 2 ? 2 : 1;
+  static_assert(PF == 0 || PF == 3, "PF: 0 single LDS buffer, 3 double buffer + explicit software pipeline");
+  constexpr bool DB = PF == 3;
+  constexpr int NSET = 1;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int SA = BM * LDK, SB = WT ? BN * LDK : KC * BN;
@@ -137,23 +138,6 @@ __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) 
   }
 
   f32x4 ra[NSET][A_V], rb[NSET][B_V];
-  auto load_chunk = [&](int c, auto set_c) {
-    constexpr int set = decltype(set_c)::value;
-    const int k0 = c * KC;
-    const int t = k0 / gC;
-    const int ci0 = k0 - t * gC;
-    const Tap tp = g.taps[cls][t];
-    const unsigned tapoff = (unsigned)(((tp.dy * g.gW + tp.dx) * gC + ci0) * 4);   // wave-uniform, may wrap (two's complement)
-    const int sy = tp.dy + 3, sx = tp.dx + 11;
-#pragma unroll
-    for (int j = 0; j < A_V; ++j) {
-      const bool ok = ((a_ok[j] >> sy) & (a_ok[j] >> sx) & 1u) != 0;
-      ra[set][j] = buf_load4(rG, ok ? a_off[j] + tapoff : kOOB, 0);
-    }
-    const unsigned wsoff = WT ? (unsigned)(tp.wtap * g.wCi * g.wCo + ci0) * 4u : (unsigned)((tp.wtap * g.wCi + ci0) * g.wCo) * 4u;
-#pragma unroll
-    for (int j = 0; j < B_V; ++j) rb[set][j] = buf_load4(rW, b_off[j], wsoff);
-  };
   auto store_chunk = [&](int buf, auto set_c) {
     constexpr int set = decltype(set_c)::value;
     float* sA = sAbuf + buf * SA;
@@ -188,7 +172,6 @@ __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) 
     c1 = c0 + cps < nch ? c0 + cps : nch;
   }
   using S0 = std::integral_constant<int, 0>;
-  using S1 = std::integral_constant<int, NSET - 1>;
   auto compute_chunk = [&](int cur) {
     const float* sA = sAbuf + cur * SA;
     const float* sB = sBbuf + cur * SB;
@@ -223,6 +206,31 @@ __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) 
     }
   };
 
+  // Tap constants live in lanes (lane t = tap t) and are fetched with v_readlane: no scalar loads in the loop (an
+  // s_load forces an lgkmcnt(0) drain that also waits for every LDS read in flight) and no integer division.
+  unsigned tv_off = 0, tv_sh = 0, tv_w = 0;
+  if (lane < ntaps) {
+    const Tap tp = g.taps[cls][lane];
+    tv_off = (unsigned)(((tp.dy * g.gW + tp.dx) * gC) * 4);
+    tv_sh = (unsigned)(tp.dy + 3) | ((unsigned)(tp.dx + 11) << 8);
+    tv_w = WT ? (unsigned)(tp.wtap * g.wCi * g.wCo) * 4u : (unsigned)(tp.wtap * g.wCi * g.wCo) * 4u;
+  }
+  int lt = (c0 * KC) / gC, lci = c0 * KC - lt * gC;    // tap / channel offset of the next chunk to load
+  auto load_next = [&]() {
+    const unsigned tapoff = (unsigned)__builtin_amdgcn_readlane((int)tv_off, lt) + (unsigned)lci * 4u;
+    const unsigned sh = (unsigned)__builtin_amdgcn_readlane((int)tv_sh, lt);
+    const unsigned wsoff = (unsigned)__builtin_amdgcn_readlane((int)tv_w, lt) + (WT ? (unsigned)lci * 4u : (unsigned)(lci * g.wCo) * 4u);
+    const unsigned sy = sh & 0xff, sx = sh >> 8;
+#pragma unroll
+    for (int j = 0; j < A_V; ++j) {
+      const bool ok = ((a_ok[j] >> sy) & (a_ok[j] >> sx) & 1u) != 0;
+      ra[0][j] = buf_load4(rG, ok ? a_off[j] + tapoff : kOOB, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < B_V; ++j) rb[0][j] = buf_load4(rW, b_off[j], wsoff);
+    lci += KC;
+    if (lci == gC) { lci = 0; ++lt; }
+  };
   if constexpr (PF == 3) {
     // ---- software-pipelined loop: one barrier per chunk, no exposed latency ---------------------------------
     // iteration c:  A) chunk c+1 registers -> other LDS buffer, global loads of chunk c+2, LDS reads of k-groups
@@ -233,29 +241,6 @@ __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) 
     // read -> wait -> MFMA and leaves the matrix pipe idle for an LDS latency 6x per chunk).
     // Tap constants live in lanes (lane t = tap t) and are fetched with v_readlane: no scalar loads, hence no
     // lgkmcnt(0) drains, and no integer division in the loop.
-    unsigned tv_off = 0, tv_sh = 0, tv_w = 0;
-    if (lane < ntaps) {
-      const Tap tp = g.taps[cls][lane];
-      tv_off = (unsigned)(((tp.dy * g.gW + tp.dx) * gC) * 4);
-      tv_sh = (unsigned)(tp.dy + 3) | ((unsigned)(tp.dx + 11) << 8);
-      tv_w = WT ? (unsigned)(tp.wtap * g.wCi * g.wCo) * 4u : (unsigned)(tp.wtap * g.wCi * g.wCo) * 4u;
-    }
-    int lt = (c0 * KC) / gC, lci = c0 * KC - lt * gC;    // tap / channel offset of the next chunk to load
-    auto load_next = [&]() {
-      const unsigned tapoff = (unsigned)__builtin_amdgcn_readlane((int)tv_off, lt) + (unsigned)lci * 4u;
-      const unsigned sh = (unsigned)__builtin_amdgcn_readlane((int)tv_sh, lt);
-      const unsigned wsoff = (unsigned)__builtin_amdgcn_readlane((int)tv_w, lt) + (WT ? (unsigned)lci * 4u : (unsigned)(lci * g.wCo) * 4u);
-      const unsigned sy = sh & 0xff, sx = sh >> 8;
-#pragma unroll
-      for (int j = 0; j < A_V; ++j) {
-        const bool ok = ((a_ok[j] >> sy) & (a_ok[j] >> sx) & 1u) != 0;
-        ra[0][j] = buf_load4(rG, ok ? a_off[j] + tapoff : kOOB, 0);
-      }
-#pragma unroll
-      for (int j = 0; j < B_V; ++j) rb[0][j] = buf_load4(rW, b_off[j], wsoff);
-      lci += KC;
-      if (lci == gC) { lci = 0; ++lt; }
-    };
     f32x4 af[4][TM];
     float bf[4][TN][4];
     auto read_kg = [&](int buf, auto kg_c) {
@@ -325,47 +310,21 @@ __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) 
       __builtin_amdgcn_sched_barrier(0);
     }
   } else {
-  if (c0 < c1) {
-    load_chunk(c0, S0{});
-    store_chunk(0, S0{});
-    if constexpr (PF >= 2) {
-      if (c0 + 1 < c1) load_chunk(c0 + 1, S1{});
+    // single LDS buffer: grids with many workgroups per CU hide the latency by occupancy (a second buffer would cost it)
+    if (c0 < c1) {
+      load_next();
+      store_chunk(0, S0{});
     }
-  }
-  __syncthreads();
-  if constexpr (PF >= 2) {
-    // chunk c sits in LDS buffer (c-c0)&1; register set (c-c0)&1 is free again once chunk c was stored, and
-    // takes chunk c+2 while chunk c+1 (other set) is still in flight: two chunk-times of load latency hidden.
-    for (int c = c0; c < c1; c += 2) {
-      if (c + 2 < c1) load_chunk(c + 2, S0{});
+    __syncthreads();
+    for (int c = c0; c < c1; ++c) {
+      if (c + 1 < c1) load_next();
       compute_chunk(0);
-      if (c + 1 < c1) store_chunk(1, S1{});
       __syncthreads();
       if (c + 1 < c1) {
-        if (c + 3 < c1) load_chunk(c + 3, S1{});
-        compute_chunk(1);
-        if (c + 2 < c1) store_chunk(0, S0{});
+        store_chunk(0, S0{});
         __syncthreads();
       }
     }
-  } else {
-    for (int c = c0; c < c1; ++c) {
-      const int cur = DB ? ((c - c0) & 1) : 0;
-      if (c + 1 < c1) load_chunk(c + 1, S0{});
-      compute_chunk(cur);
-      if constexpr (DB) {
-        // the other buffer was last read in iteration c-1, which every wave left through the barrier below
-        if (c + 1 < c1) store_chunk(cur ^ 1, S0{});
-        __syncthreads();
-      } else {
-        __syncthreads();
-        if (c + 1 < c1) {
-          store_chunk(0, S0{});
-          __syncthreads();
-        }
-      }
-    }
-  }
   }   // PF != 3
 
   // ---- epilogue -----------------------------------------------------------------------------------------
