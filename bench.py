@@ -306,7 +306,9 @@ def main():
             roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                         "avg_launch_us": round(top["ms"] / top["count"] * 1e3, 2),
-                        "launches_per_step": top["count"] / nprof}
+                        "launches_per_step": top["count"] / nprof,
+                        "algorithmic_flop_per_launch": round(top["flops"] / top["count"]),
+                        "algorithmic_bytes_per_launch": round(top["bytes"] / top["count"])}
         else:
             ach = top["bytes"] / (top["ms"] * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",

@@ -647,7 +647,7 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
   {
   char name[160];
   if (big) snprintf(name, sizeof name, "wgrad_fast_kernel<2,2,2,2>");
-  else if (xvec && dvec && !narrow) snprintf(name, sizeof name, "wgrad_fast_kernel<%d,%d>", narrow ? 4 : 2, narrow ? 1 : 2);
+  else if (xvec && dvec && !narrow) snprintf(name, sizeof name, "wgrad_fast_kernel<%d,%d,1,1>", narrow ? 4 : 2, narrow ? 1 : 2);
   else snprintf(name, sizeof name, "wgrad_kernel<%d,%d,%s,%s>", narrow ? 4 : 2, narrow ? 1 : 2, xvec ? "true" : "false",
                 dvec ? "true" : "false");
   const double macs = (double)a.Mc * a.N * a.rows_total;
