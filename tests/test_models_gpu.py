@@ -224,3 +224,31 @@ def test_eval_mode_final_block_matches_unfused_path():
     finally:
         K.input_transform_supported = real
     assert float((outs[("eval", True)] - outs[("eval", False)]).abs().max()) < 1e-5
+
+
+def test_harness_hipgraph_training_matches_eager():
+    """VAEXperiment.fit with the hipGraph-captured training step (3 eager warm-up steps, then replays) must follow the
+    eager trajectory exactly; MCQVAE has no random draw in its step, so parameters can be compared bit for bit."""
+    import torch
+    from ctvae_amd import filler
+    from ctvae_amd.experiment import VAEXperiment
+    from ctvae_amd.models import vae_models
+    from tests import helpers as H
+    dev = torch.device("cuda")
+    batches = [(filler.synthetic_batch(500 + i, 8)[0].to(dev), torch.zeros(8, device=dev)) for i in range(7)]
+    finals = []
+    for use_graph in (False, True):
+        cfg = {**H.MCQ_CFG, "hidden_dims": list(H.MCQ_CFG["hidden_dims"])}    # the constructor reverses the list in place
+        sd = filler.fill_state(H.mcq_specs(cfg), 501)
+        m = vae_models["MCQVAE"](**cfg)
+        m.load_state_dict(sd)
+        m = m.to(dev).train()
+        exp = VAEXperiment(m, {"LR": 0.0005, "weight_decay": 0.0, "scheduler_gamma": 0.95, "kld_weight": 0.00025,
+                               "hipgraph": use_graph})
+        exp.fit(lambda: iter(batches), None, max_epochs=1)
+        torch.cuda.synchronize()
+        assert exp.global_step == len(batches)
+        if use_graph:
+            assert any(g.graph is not None for g in exp._graphed.values()), "no hipGraph was captured"
+        finals.append(m.flat_params.clone())
+    assert torch.equal(finals[0], finals[1])
