@@ -46,6 +46,12 @@ CASES = [
     (True, 32, 32, 32, 3, 2, 1, 1, 2),     # final_layer.0
     (True, 256, 128, 8, 4, 2, 1, 0, 3),    # mcq decoder.8
     (True, 64, 3, 32, 4, 2, 1, 0, 2),      # mcq final
+    # image-side / transposed-conv kernels at their smallest tile grids, and neighbours that must fall back to tap-GEMM
+    (False, 32, 3, 32, 3, 1, 1, 0, 1),     # image.hip forward/wgrad/dgrad: 4 x 1 tiles, B = 1
+    (False, 32, 3, 24, 3, 1, 1, 0, 2),     # W % 32 != 0 -> masked tap-GEMM
+    (False, 3, 32, 48, 3, 2, 1, 0, 2),     # encoder.0-like with a 24 x 24 output -> masked tap-GEMM
+    (True, 32, 32, 12, 3, 2, 1, 1, 2),     # final_layer.0-like with H % 8 != 0 -> tap-GEMM classes
+    (True, 32, 32, 64, 3, 2, 1, 1, 1),     # upconv.hip with 8 x 2 tiles, B = 1
 ]
 
 
