@@ -163,6 +163,33 @@ __global__ __launch_bounds__(256) void bn_apply_act_kernel(const float* __restri
                                                            const float* __restrict__ shift, float* __restrict__ out,
                                                            long n4, int C, int act) {
   const long stride = (long)gridDim.x * 256;
+  if (1024 % C == 0) {
+    // the grid stride (a multiple of 256 float4) is a multiple of C: a thread keeps its channel quad for the whole
+    // launch -> coefficients in registers, no 64-bit modulo per element, two float4 in flight per iteration
+    const int c = (int)((threadIdx.x * 4) % C);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {
+      const f32x4 v0 = reinterpret_cast<const f32x4*>(y)[i], v1 = reinterpret_cast<const f32x4*>(y)[i + stride];
+      f32x4 o0, o1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        o0[k] = act_fwd(v0[k] * sc[k] + sh[k], act);
+        o1[k] = act_fwd(v1[k] * sc[k] + sh[k], act);
+      }
+      reinterpret_cast<f32x4*>(out)[i] = o0;
+      reinterpret_cast<f32x4*>(out)[i + stride] = o1;
+    }
+    if (i < n4) {
+      const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+      f32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = act_fwd(v[k] * sc[k] + sh[k], act);
+      reinterpret_cast<f32x4*>(out)[i] = o;
+    }
+    return;
+  }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     const int c = (int)((i * 4) % C);
     f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
@@ -281,6 +308,37 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ coef, float* __restrict__ gy, long n4,
                                                            int C, int act) {
   const long stride = (long)gridDim.x * 256;
+  if (1024 % C == 0) {   // channel quad fixed per thread (see bn_apply_act_kernel)
+    const int c = (int)((threadIdx.x * 4) % C);
+    const f32x4 k1 = *reinterpret_cast<const f32x4*>(coef + c);
+    const f32x4 k2 = *reinterpret_cast<const f32x4*>(coef + C + c);
+    const f32x4 k3 = *reinterpret_cast<const f32x4*>(coef + 2 * C + c);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(coef + 3 * C + c);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(coef + 4 * C + c);
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {
+      const f32x4 g0 = reinterpret_cast<const f32x4*>(ga)[i], g1 = reinterpret_cast<const f32x4*>(ga)[i + stride];
+      const f32x4 y0 = reinterpret_cast<const f32x4*>(y)[i], y1 = reinterpret_cast<const f32x4*>(y)[i + stride];
+      f32x4 o0, o1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        o0[k] = k1[k] * (g0[k] * act_bwd_from_out(act_fwd(y0[k] * sc[k] + sh[k], act), act)) + k2[k] * y0[k] + k3[k];
+        o1[k] = k1[k] * (g1[k] * act_bwd_from_out(act_fwd(y1[k] * sc[k] + sh[k], act), act)) + k2[k] * y1[k] + k3[k];
+      }
+      reinterpret_cast<f32x4*>(gy)[i] = o0;
+      reinterpret_cast<f32x4*>(gy)[i + stride] = o1;
+    }
+    if (i < n4) {
+      const f32x4 g = reinterpret_cast<const f32x4*>(ga)[i];
+      const f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
+      f32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        o[k] = k1[k] * (g[k] * act_bwd_from_out(act_fwd(yv[k] * sc[k] + sh[k], act), act)) + k2[k] * yv[k] + k3[k];
+      reinterpret_cast<f32x4*>(gy)[i] = o;
+    }
+    return;
+  }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     const int c = (int)((i * 4) % C);
     f32x4 g = reinterpret_cast<const f32x4*>(ga)[i];
