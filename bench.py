@@ -47,6 +47,7 @@ def parse():
                     help="N>1: one backward graph, then the all-reduce (default: backward cut at the latent, the "
                          "decoder-side buckets are exchanged while the encoder's backward runs)")
     ap.add_argument("--split-backward", action="store_true", help="use the two-stage backward even at N=1 (diagnostic)")
+    ap.add_argument("--ct-graph", action="store_true", help="CTMCQVAE: try to capture the step into a hipGraph (diagnostic)")
     ap.add_argument("--rehearse-ddp", action="store_true",
                     help="N=1 only: initialise a 1-rank RCCL group and run the exact N>1 step (diagnostic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -157,7 +158,7 @@ def main():
 
     B = args.batch
     seed = {"VanillaVAE": 1265, "MCQVAE": 1320, "CTMCQVAE": 1250}[args.model]
-    if args.model == "CTMCQVAE":
+    if args.model == "CTMCQVAE" and not args.ct_graph:
         args.no_graph = True
     model = build_model(args.model, dev, seed)
     opt = FlatAdam(model, lr=0.005 if args.model == "VanillaVAE" else 0.0005)

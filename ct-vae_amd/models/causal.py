@@ -239,7 +239,7 @@ class CausalTransition(nn.Module):
             y = self.forward_action(latent, a)[0]
             y_log = y.permute(0, 2, 3, 1).reshape(-1, latent_y.size(1)).clamp(min=1e-4).log()
             dist.append(F.cross_entropy(y_log, y_inds, reduction='none').view(B, -1).mean(dim=-1))
-        return [F.softmin(torch.stack(dist, 1), dim=-1), torch.tensor(0.0), {}]
+        return [F.softmin(torch.stack(dist, 1), dim=-1), torch.zeros((), device=latent.device), {}]
 
     # ---- losses / metrics (ct_mcq_vae.py:297-333) --------------------------------------------------
     def latent_loss(self, latent, latent_y):

@@ -83,8 +83,8 @@ class CTMCQVAE(BaseVAE):
         q, vq_loss = self.vq_layer.compute_latents(latents, encoding_inds if self.skip_transition else ct_inds)
         dev = input.device
         return [self.decode(q), input, vq_loss, ct_loss,
-                {**{"causal_acc": torch.tensor(0.0, device=dev), "causal_nodir_acc": torch.tensor(0.0, device=dev),
-                    "mode": "base", "mode_id": torch.tensor(0.0, device=dev)}, **ct_metrics[0]}]
+                {**{"causal_acc": torch.full((), 0.0, device=dev), "causal_nodir_acc": torch.full((), 0.0, device=dev),
+                    "mode": "base", "mode_id": torch.full((), 0.0, device=dev)}, **ct_metrics[0]}]
 
     def forward_action(self, input: Tensor, action: Tensor, input_y: Tensor = None, **kwargs) -> List[Tensor]:
         latents = self.encode(input)[0]
@@ -98,9 +98,9 @@ class CTMCQVAE(BaseVAE):
         ct_inds = self.ct_postprocess(ct_encodings, shape)
         q, _ = self.vq_layer.compute_latents(latents, encoding_inds if self.skip_transition else ct_inds)
         dev = input.device
-        return [self.decode(q), input_y, torch.tensor(0.0, device=dev), ct_loss,
-                {**{"causal_acc": torch.tensor(0.0, device=dev), "causal_nodir_acc": torch.tensor(0.0, device=dev),
-                    "mode": "action", "mode_id": torch.tensor(1.0, device=dev)}, **ct_metrics[0]}]
+        return [self.decode(q), input_y, torch.full((), 0.0, device=dev), ct_loss,
+                {**{"causal_acc": torch.full((), 0.0, device=dev), "causal_nodir_acc": torch.full((), 0.0, device=dev),
+                    "mode": "action", "mode_id": torch.full((), 1.0, device=dev)}, **ct_metrics[0]}]
 
     def forward_causal(self, input: Tensor, input_y: Tensor, action: Tensor = None, **kwargs) -> List[Tensor]:
         lat_x = self.encode(input)[0]
@@ -113,8 +113,8 @@ class CTMCQVAE(BaseVAE):
         nodir = self.ct_layer.causal_undirected_accuracy(recons_action, action)
         acc = self.ct_layer.causal_accuracy(recons_action, action)
         dev = input.device
-        return [recons_action, action, torch.tensor(0.0, device=dev), ct_reg.to(dev),
-                {**{"causal_acc": acc, "causal_nodir_acc": nodir, "mode": "causal", "mode_id": torch.tensor(2.0, device=dev)},
+        return [recons_action, action, torch.full((), 0.0, device=dev), ct_reg.to(dev),
+                {**{"causal_acc": acc, "causal_nodir_acc": nodir, "mode": "causal", "mode_id": torch.full((), 2.0, device=dev)},
                  **ct_metrics[0]}]
 
     FORWARD_MODES = {"base": forward_base, "action": forward_action, "causal": forward_causal}
