@@ -1,0 +1,596 @@
+// Winograd F(2x2, 3x3) for the 3x3 / stride-1 / pad-1 convolutions of the residual stacks (mcq_vae.py:57-70 via
+// vq_vae.ResidualLayer, 13 of them per MCQ-VAE / CT-MCQ-VAE step, forward + data gradient):
+//
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A        per 2x2 output tile, 4x4 input patch d, 3x3 filter g
+//
+// 16 multiplies per 4 outputs and channel pair instead of 36: the sixteen "frequency" GEMMs
+//     M[f][tile][n] = sum_c V[f][tile][c] * U[f][c][n]
+// together are 2.25x less MFMA work than the direct 9-tap GEMM.  On gfx950 the f32 MFMA pipe is the bound of these
+// layers, so the saving is real time.  fp32 Winograd F(2,3) adds a relative error of a few 1e-7 per
+// transform stage -- far inside the 1e-4 parity bound (tests/test_ops_gpu.py::test_winograd_*).
+//
+// One kernel does everything between the NHWC input and the NHWC output:
+//   workgroup = 64 tiles x 64 output channels, 4 waves as 2 (tiles) x 2 (channels); a wave keeps all 16 frequency
+//   accumulators of its 32 x 32 block in registers (16 x f32x16 = 256 accumulator registers, one wave per SIMD);
+//   per chunk of 8 input channels: raw pixels of the workgroup's tile block (+1 halo, every pixel read once) -> LDS,
+//   B^T d B per (tile, channel pair) LDS -> registers -> LDS as V[f][tile][8], pre-transformed filters U[f][n][8]
+//   (wino_weight_kernel, a few MB per layer and step) -> LDS, then 16 x 4 MFMA 32x32x2 per wave;
+//   epilogue: A^T M A is LANE-LOCAL (a lane holds the same (tile, n) element of all 16 accumulators), then bias /
+//   activation and 128-byte stores.
+// The data gradient of the same layer is the same computation with the filter taps mirrored and Ci/Co swapped: only
+// the weight transform differs (tap table + transposed read).
+#include "common.hpp"
+#include "prof.hpp"
+
+namespace ctvae {
+
+namespace {
+
+constexpr int MT = 64;        // tiles per workgroup
+constexpr int NT = 64;        // output channels per workgroup
+constexpr int KC8 = 8;        // input channels per chunk
+constexpr int LDV = 12;       // padded row of V / U in LDS (floats): conflict-free ds_read_b128 over 16 consecutive rows
+constexpr int RS = 8;         // raw pixel row in LDS (floats)
+constexpr int NPMAX = 640;    // raw pixels per workgroup block (incl. halo)
+constexpr int RAW_ITEMS = (NPMAX * 2 + 255) / 256;   // float4 loads per thread and chunk
+
+constexpr unsigned kOOBw = 0x80000000u;
+
+__device__ __forceinline__ f32x4 wld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wrsrc(const void* p, long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+struct WinoArgs {
+  const float* X;      // [B][H][W][K]
+  const float* Ut;     // [16][K/8][N][8]
+  const float* bias;   // [N] or null
+  float* Y;            // [B][H][W][N]
+  int B, H, W, K, N;
+  int bh, bw, nb;      // workgroup block: nb images x (bh x bw) tiles, nb*bh*bw == 64
+  int by_n, bx_n;      // blocks per image (TH/bh, TW/bw)
+  int act;
+};
+
+// ---- filter transform ------------------------------------------------------------------------------------------
+// W packed [9][wCi][wCo].  Effective filter g[ky][kx] (k = gathered channel, n = produced channel) =
+//   wT == 0: W[tap[ky][kx]][k][n]     wT == 1: W[tap[ky][kx]][n][k]
+// Ut[f = 4i+j][k/8][n][k%8] = (G g G^T)[i][j].  thread = (n fastest, k).
+struct WTaps { int t[9]; };
+
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ Wp, float* __restrict__ Ut, int K, int N,
+                                                          int wCi, int wCo, int wT, WTaps taps) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)K * N) return;
+  int k, n;
+  if (wT == 0) { n = (int)(e % N); k = (int)(e / N); }     // reads contiguous along n
+  else { k = (int)(e % K); n = (int)(e / K); }             // W[t][n][k]: reads contiguous along k
+  float g[3][3];
+#pragma unroll
+  for (int a = 0; a < 9; ++a) {
+    const long idx = wT == 0 ? ((long)taps.t[a] * wCi + k) * wCo + n : ((long)taps.t[a] * wCi + n) * wCo + k;
+    g[a / 3][a % 3] = Wp[idx];
+  }
+  float t[4][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    t[0][j] = g[0][j];
+    t[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
+    t[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
+    t[3][j] = g[2][j];
+  }
+  float* dst = Ut + (((long)(k >> 3)) * N + n) * 8 + (k & 7);
+  const long fs = (long)(K >> 3) * N * 8;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float u0 = t[i][0], u1 = 0.5f * (t[i][0] + t[i][1] + t[i][2]), u2 = 0.5f * (t[i][0] - t[i][1] + t[i][2]), u3 = t[i][2];
+    dst[(long)(4 * i + 0) * fs] = u0;
+    dst[(long)(4 * i + 1) * fs] = u1;
+    dst[(long)(4 * i + 2) * fs] = u2;
+    dst[(long)(4 * i + 3) * fs] = u3;
+  }
+}
+
+// ---- the GEMM --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sV = smem;                          // [16][MT][LDV]
+  float* sU = sV + 16 * MT * LDV;            // [16][NT][LDV]
+  float* sRaw = sU + 16 * NT * LDV;          // [NPMAX][RS]
+  int* sOut = reinterpret_cast<int*>(sRaw + NPMAX * RS);   // [MT] output pixel index of the tile's (0,0) output, -1 = none
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int ntiles = a.N / NT;
+  const int mt = blockIdx.x / ntiles, nt = blockIdx.x - mt * ntiles;
+  const int PH = 2 * a.bh + 2, PW = 2 * a.bw + 2, NP = a.nb * PH * PW;
+  const int K = a.K, N = a.N;
+
+  // block origin
+  int b0, y0, x0;
+  if (a.nb > 1) { b0 = mt * a.nb; y0 = 0; x0 = 0; }
+  else {
+    const int per = a.by_n * a.bx_n;
+    b0 = mt / per;
+    const int r = mt - b0 * per;
+    y0 = (r / a.bx_n) * 2 * a.bh;
+    x0 = (r - (r / a.bx_n) * a.bx_n) * 2 * a.bw;
+  }
+
+  const __amdgpu_buffer_rsrc_t rX = wrsrc(a.X, (long)a.B * a.H * a.W * K * 4);
+  const __amdgpu_buffer_rsrc_t rU = wrsrc(a.Ut, (long)16 * K * N * 4);
+
+  // raw-load items: e -> (pixel p = e>>1, half = e&1)
+  unsigned roff[RAW_ITEMS];
+#pragma unroll
+  for (int i = 0; i < RAW_ITEMS; ++i) {
+    const int e = tid + 256 * i, p = e >> 1, half = e & 1;
+    unsigned off = kOOBw;
+    if (p < NP) {
+      const int img = p / (PH * PW), r = p - img * (PH * PW), py = r / PW, px = r - py * PW;
+      const int b = b0 + img, y = y0 + py - 1, x = x0 + px - 1;
+      if (b < a.B && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
+        off = ((unsigned)((b * a.H + y) * a.W + x) * (unsigned)K + 4u * half) * 4u;
+    }
+    roff[i] = off;
+  }
+  // U-load items: e = tid + 256*i -> f = e>>7, r = e&127 (float4 r of the 512-float row block of frequency f)
+  const unsigned u_fs = (unsigned)(K >> 3) * (unsigned)N * 8u * 4u;            // bytes between frequencies
+  const unsigned u_base = ((unsigned)nt * NT * 8u + 4u * (tid & 127)) * 4u + (unsigned)(tid >> 7) * u_fs;
+
+  // transform role: tile m_t = tid>>2, channel pair q = tid&3
+  const int m_t = tid >> 2, q = tid & 3;
+  int rp0;
+  {
+    const int per = a.bh * a.bw;
+    const int img = m_t / per, r = m_t - img * per, ty = r / a.bw, tx = r - ty * a.bw;
+    rp0 = (img * PH + 2 * ty) * PW + 2 * tx;
+    if (q == 0) {
+      const int b = b0 + img;
+      sOut[m_t] = b < a.B ? (b * a.H + y0 + 2 * ty) * a.W + x0 + 2 * tx : -1;
+    }
+  }
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int f = 0; f < 16; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+  f32x4 rr[RAW_ITEMS], ru[8];
+  auto load_regs = [&](int c) {
+    const unsigned coff = (unsigned)c * 32u;                      // 8 channels * 4 B
+#pragma unroll
+    for (int i = 0; i < RAW_ITEMS; ++i) rr[i] = wld4(rX, roff[i] == kOOBw ? kOOBw : roff[i] + coff);
+    const unsigned uoff = u_base + (unsigned)c * (unsigned)N * 32u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ru[i] = wld4(rU, uoff + (unsigned)(2 * i) * u_fs);
+  };
+
+  const int nchunks = K / KC8;
+  load_regs(0);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();                                             // previous chunk's readers of sV / sU / sRaw are done
+#pragma unroll
+    for (int i = 0; i < RAW_ITEMS; ++i) {
+      const int e = tid + 256 * i;
+      if (e < 2 * NP) *reinterpret_cast<f32x4*>(sRaw + (e >> 1) * RS + 4 * (e & 1)) = rr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int f = 2 * i + (tid >> 7), r = tid & 127;
+      *reinterpret_cast<f32x4*>(sU + (f * NT + (r >> 1)) * LDV + 4 * (r & 1)) = ru[i];
+    }
+    __syncthreads();
+    if (c + 1 < nchunks) load_regs(c + 1);
+    // ---- B^T d B for (tile m_t, channels 2q, 2q+1) ----
+    {
+      f32x2 d[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const f32x2*>(sRaw + (rp0 + i * PW + j) * RS + 2 * q);
+      f32x2 t[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t[0][j] = d[0][j] - d[2][j];
+        t[1][j] = d[1][j] + d[2][j];
+        t[2][j] = d[2][j] - d[1][j];
+        t[3][j] = d[1][j] - d[3][j];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x2 v0 = t[i][0] - t[i][2], v1 = t[i][1] + t[i][2], v2 = t[i][2] - t[i][1], v3 = t[i][1] - t[i][3];
+        float* dst = sV + ((4 * i) * MT + m_t) * LDV + 2 * q;
+        *reinterpret_cast<f32x2*>(dst) = v0;
+        *reinterpret_cast<f32x2*>(dst + MT * LDV) = v1;
+        *reinterpret_cast<f32x2*>(dst + 2 * MT * LDV) = v2;
+        *reinterpret_cast<f32x2*>(dst + 3 * MT * LDV) = v3;
+      }
+    }
+    __syncthreads();
+    // ---- 16 frequencies x 4 k-steps ----
+    const float* pa = sV + (wm * 32 + li) * LDV + 4 * lh;
+    const float* pb = sU + (wn * 32 + li) * LDV + 4 * lh;
+    f32x4 fa = *reinterpret_cast<const f32x4*>(pa), fb = *reinterpret_cast<const f32x4*>(pb);
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+      f32x4 na = fa, nb = fb;
+      if (f + 1 < 16) {
+        na = *reinterpret_cast<const f32x4*>(pa + (f + 1) * MT * LDV);
+        nb = *reinterpret_cast<const f32x4*>(pb + (f + 1) * NT * LDV);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s], acc[f], 0, 0, 0);
+      fa = na;
+      fb = nb;
+    }
+  }
+
+  // ---- epilogue: A^T M A, lane-local ----
+  const int col = nt * NT + wn * 32 + li;
+  const float bv = a.bias != nullptr ? a.bias[col] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = wm * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+    const int op = sOut[row];
+    float t0[4], t1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      t0[j] = acc[j][r] + acc[4 + j][r] + acc[8 + j][r];
+      t1[j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+    }
+    const float y00 = t0[0] + t0[1] + t0[2], y01 = t0[1] - t0[2] - t0[3];
+    const float y10 = t1[0] + t1[1] + t1[2], y11 = t1[1] - t1[2] - t1[3];
+    if (op >= 0) {
+      float* dst = a.Y + (long)op * N + col;
+      dst[0] = act_fwd(y00 + bv, a.act);
+      dst[N] = act_fwd(y01 + bv, a.act);
+      dst[(long)a.W * N] = act_fwd(y10 + bv, a.act);
+      dst[(long)a.W * N + N] = act_fwd(y11 + bv, a.act);
+    }
+  }
+}
+
+// ---- weight gradient: F(3x3, 2x2) ---------------------------------------------------------------------------------
+//     dW = sum_tiles A'^T [ (B^T d B) (.) (G dy G^T) ] A'     d = 4x4 input patch, dy = 2x2 output-gradient tile
+// with the SAME B^T as the forward pass, G = [[1,0],[.5,.5],[.5,-.5],[0,1]], A'^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]].
+// The sixteen GEMMs now reduce over TILES: Mw[f][ci][co] = sum_t Vx[f][t][ci] * Vy[f][t][co].
+// workgroup = 64 ci x 64 co x one slice of the tile range (split over workgroups, slabs reduced by
+// reduce_partials_kernel like every other weight gradient); per chunk of 8 tiles (a 2 x 4 tile block, or two 2 x 2-tile
+// images): raw X pixels (+halo) and raw dY pixels -> LDS, both transforms LDS -> registers -> LDS as [f][channel][8],
+// 16 x 4 MFMA per wave; epilogue A'^T Mw A' lane-local -> slab[9][Ci][Co].
+constexpr int WG_XPIX = 72;    // raw X pixels per chunk: 6 x 10 (2x4 tiles + halo) or 2 x 6 x 6
+constexpr int WG_YPIX = 32;    // raw dY pixels per chunk: 8 tiles x 4
+constexpr int RSW = 64;        // channels per raw pixel row
+
+struct WinoWgArgs {
+  const float* X;      // [B][H][W][Ci]
+  const float* dY;     // [B][H][W][Co]
+  float* part;         // [S][9][Ci][Co]
+  int B, H, W, Ci, Co;
+  int ch, cw, nbk;     // chunk: nbk images x (ch x cw) tiles, nbk*ch*cw == 8
+  int cy_n, cx_n;      // chunks per image (TH/ch, TW/cw) when nbk == 1
+  int nchunks, chunks_per_split;
+};
+
+__global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sVx = smem;                         // [16][64][LDV]
+  float* sVy = sVx + 16 * 64 * LDV;          // [16][64][LDV]
+  float* sRX = sVy + 16 * 64 * LDV;          // [WG_XPIX][RSW]
+  float* sRY = sRX + WG_XPIX * RSW;          // [WG_YPIX][RSW]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, split = blockIdx.z;
+  const int PH = 2 * a.ch + 2, PW = 2 * a.cw + 2, NPX = a.nbk * PH * PW;
+  const int Ci = a.Ci, Co = a.Co;
+  const __amdgpu_buffer_rsrc_t rX = wrsrc(a.X, (long)a.B * a.H * a.W * Ci * 4);
+  const __amdgpu_buffer_rsrc_t rY = wrsrc(a.dY, (long)a.B * a.H * a.W * Co * 4);
+
+  // raw-load roles.  X: item e = tid + 256*i -> pixel e>>4, float4 e&15 (NPX*16 <= 1152 items: 5 per thread)
+  //                  dY: item e -> pixel e>>4 (32 pixels: tile e>>6, 2x2 position (e>>4)&3), float4 e&15: 2 per thread
+  // transform roles: tile tt = tid>>5, channels q and q+32
+  const int tt = tid >> 5, q = tid & 31;
+  int xp0;   // raw X pixel of the patch origin of tile tt
+  {
+    const int per = a.ch * a.cw;
+    const int img = tt / per, r = tt - img * per, ty = r / a.cw, tx = r - ty * a.cw;
+    xp0 = (img * PH + 2 * ty) * PW + 2 * tx;
+  }
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int f = 0; f < 16; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+  f32x4 rx[5], ry[2];
+  auto load_regs = [&](int c) {
+    int b0, y0, x0;
+    if (a.nbk > 1) { b0 = c * a.nbk; y0 = 0; x0 = 0; }
+    else {
+      const int per = a.cy_n * a.cx_n;
+      b0 = c / per;
+      const int r = c - b0 * per;
+      y0 = (r / a.cx_n) * 2 * a.ch;
+      x0 = (r - (r / a.cx_n) * a.cx_n) * 2 * a.cw;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int e = tid + 256 * i, p = e >> 4;
+      unsigned off = kOOBw;
+      if (p < NPX) {
+        const int img = p / (PH * PW), r = p - img * (PH * PW), py = r / PW, px = r - py * PW;
+        const int b = b0 + img, y = y0 + py - 1, x = x0 + px - 1;
+        if (b < a.B && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
+          off = ((unsigned)((b * a.H + y) * a.W + x) * (unsigned)Ci + (unsigned)ci0 + 4u * (e & 15)) * 4u;
+      }
+      rx[i] = wld4(rX, off);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + 256 * i, t = e >> 6, pos = (e >> 4) & 3;
+      const int per = a.ch * a.cw;
+      const int img = t / per, r = t - img * per, ty = r / a.cw, tx = r - ty * a.cw;
+      const int b = b0 + img, y = y0 + 2 * ty + (pos >> 1), x = x0 + 2 * tx + (pos & 1);
+      unsigned off = kOOBw;
+      if (b < a.B) off = ((unsigned)((b * a.H + y) * a.W + x) * (unsigned)Co + (unsigned)co0 + 4u * (e & 15)) * 4u;
+      ry[i] = wld4(rY, off);
+    }
+  };
+
+  const int c_begin = split * a.chunks_per_split;
+  int c_end = c_begin + a.chunks_per_split;
+  if (c_end > a.nchunks) c_end = a.nchunks;
+  if (c_begin < c_end) load_regs(c_begin);
+  for (int c = c_begin; c < c_end; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int e = tid + 256 * i;
+      if (e < NPX * 16) *reinterpret_cast<f32x4*>(sRX + (e >> 4) * RSW + 4 * (e & 15)) = rx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + 256 * i;
+      *reinterpret_cast<f32x4*>(sRY + (e >> 4) * RSW + 4 * (e & 15)) = ry[i];
+    }
+    __syncthreads();
+    if (c + 1 < c_end) load_regs(c + 1);
+    // ---- X: B^T d B for (tile tt, channels q, q+32) -> sVx[f][channel][tt] ----
+#pragma unroll
+    for (int hsel = 0; hsel < 2; ++hsel) {
+      const int chn = q + 32 * hsel;
+      float d[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[i][j] = sRX[(xp0 + i * PW + j) * RSW + chn];
+      float t[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t[0][j] = d[0][j] - d[2][j];
+        t[1][j] = d[1][j] + d[2][j];
+        t[2][j] = d[2][j] - d[1][j];
+        t[3][j] = d[1][j] - d[3][j];
+      }
+      float* dst = sVx + chn * LDV + tt;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        dst[(4 * i + 0) * 64 * LDV] = t[i][0] - t[i][2];
+        dst[(4 * i + 1) * 64 * LDV] = t[i][1] + t[i][2];
+        dst[(4 * i + 2) * 64 * LDV] = t[i][2] - t[i][1];
+        dst[(4 * i + 3) * 64 * LDV] = t[i][1] - t[i][3];
+      }
+    }
+    // ---- dY: G dy G^T for (tile tt, channels q, q+32) -> sVy[f][channel][tt] ----
+#pragma unroll
+    for (int hsel = 0; hsel < 2; ++hsel) {
+      const int chn = q + 32 * hsel;
+      const float e00 = sRY[(tt * 4 + 0) * RSW + chn], e01 = sRY[(tt * 4 + 1) * RSW + chn];
+      const float e10 = sRY[(tt * 4 + 2) * RSW + chn], e11 = sRY[(tt * 4 + 3) * RSW + chn];
+      // rows: G e  (4 x 2)
+      const float r0[2] = {e00, e01};
+      const float r1[2] = {0.5f * (e00 + e10), 0.5f * (e01 + e11)};
+      const float r2[2] = {0.5f * (e00 - e10), 0.5f * (e01 - e11)};
+      const float r3[2] = {e10, e11};
+      float* dst = sVy + chn * LDV + tt;
+      auto put = [&](int i, const float* r) {
+        dst[(4 * i + 0) * 64 * LDV] = r[0];
+        dst[(4 * i + 1) * 64 * LDV] = 0.5f * (r[0] + r[1]);
+        dst[(4 * i + 2) * 64 * LDV] = 0.5f * (r[0] - r[1]);
+        dst[(4 * i + 3) * 64 * LDV] = r[1];
+      };
+      put(0, r0); put(1, r1); put(2, r2); put(3, r3);
+    }
+    __syncthreads();
+    const float* pa = sVx + (wm * 32 + li) * LDV + 4 * lh;
+    const float* pb = sVy + (wn * 32 + li) * LDV + 4 * lh;
+    f32x4 fa = *reinterpret_cast<const f32x4*>(pa), fb = *reinterpret_cast<const f32x4*>(pb);
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+      f32x4 na = fa, nb = fb;
+      if (f + 1 < 16) {
+        na = *reinterpret_cast<const f32x4*>(pa + (f + 1) * 64 * LDV);
+        nb = *reinterpret_cast<const f32x4*>(pb + (f + 1) * 64 * LDV);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s], acc[f], 0, 0, 0);
+      fa = na;
+      fb = nb;
+    }
+  }
+
+  // ---- epilogue: dW[ky][kx] = A'^T Mw A', A'^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]] ----
+  float* slab = a.part + (long)split * 9 * Ci * Co;
+  const int col = co0 + wn * 32 + li;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = ci0 + wm * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+    float t[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      t[0][j] = acc[j][r] + acc[4 + j][r] + acc[8 + j][r];
+      t[1][j] = acc[4 + j][r] - acc[8 + j][r];
+      t[2][j] = acc[4 + j][r] + acc[8 + j][r] - acc[12 + j][r];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float* dst = slab + ((long)(3 * i) * Ci + row) * Co + col;
+      dst[0] = t[i][0] + t[i][1] + t[i][2];
+      dst[(long)Ci * Co] = t[i][1] - t[i][2];
+      dst[2L * Ci * Co] = t[i][1] + t[i][2] - t[i][3];
+    }
+  }
+}
+
+// 3x3, stride 1, "same" padding, one class: effective tap table (ky' = dy + 1, kx' = dx + 1) or false
+bool wino_taps(const ConvGeom& g, WTaps& wt) {
+  if (g.is != 1 || g.os != 1 || g.ncls != 1 || g.ntaps[0] != 9 || g.gH != g.sH || g.gW != g.sW) return false;
+  bool seen[9] = {};
+  for (int t = 0; t < 9; ++t) {
+    const Tap& tp = g.taps[0][t];
+    if (tp.dy < -1 || tp.dy > 1 || tp.dx < -1 || tp.dx > 1) return false;
+    const int a = (tp.dy + 1) * 3 + tp.dx + 1;
+    if (seen[a]) return false;
+    seen[a] = true;
+    wt.t[a] = tp.wtap;
+  }
+  return true;
+}
+
+bool wino_block(const ConvGeom& g, int& bh, int& bw, int& nb) {
+  const int H = g.gH, W = g.gW;
+  if (H % 2 || W % 2) return false;
+  const int TH = H / 2, TW = W / 2;
+  if (TH * TW <= MT) {
+    if (MT % (TH * TW)) return false;
+    bh = TH; bw = TW; nb = MT / (TH * TW);
+  } else {
+    if (TH % 8 || TW % 8) return false;
+    bh = bw = 8; nb = 1;
+  }
+  return nb * (2 * bh + 2) * (2 * bw + 2) <= NPMAX;
+}
+
+}  // namespace
+
+size_t wino_ws_floats(const ConvGeom& g) { return (size_t)16 * g.gC * g.sC; }
+
+// Is this launch a Winograd candidate?  (the caller still decides on epilogue features)
+bool wino_supported(const ConvGeom& g, size_t ws_floats) {
+  WTaps wt;
+  int bh, bw, nb;
+  if (!wino_taps(g, wt) || !wino_block(g, bh, bw, nb)) return false;
+  if (g.gC % KC8 || g.gC < 64 || g.sC % NT) return false;
+  if ((long)g.B * g.gH * g.gW * g.gC >= (1L << 29) || (long)g.B * g.sH * g.sW * g.sC >= (1L << 29)) return false;
+  if ((long)16 * g.gC * g.sC >= (1L << 29)) return false;
+  const int tiles = g.B * (g.gH / 2) * (g.gW / 2);
+  const long wgs = (long)ceil_div(tiles, MT) * (g.sC / NT);
+  if (wgs < 128) return false;                     // too few workgroups: the split-K direct kernel fills the chip better
+  return wino_ws_floats(g) <= ws_floats;
+}
+
+int launch_wino_conv(const ConvGeom& g, const float* X, const float* Wp, const float* bias, float* Y, int act, float* ws,
+                     size_t ws_floats, hipStream_t st) {
+  WTaps wt;
+  int bh, bw, nb;
+  if (!wino_supported(g, ws_floats) || !wino_taps(g, wt) || !wino_block(g, bh, bw, nb)) return kErrBadArg;
+  const int K = g.gC, N = g.sC;
+  {
+    ProfScope ps("wino_weight_kernel", st, 0.0, 4.0 * (9.0 + 16.0) * K * N);
+    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)(((long)K * N + 255) / 256)), dim3(256), 0, st, Wp, ws, K, N, g.wCi,
+                       g.wCo, g.wT, wt);
+    CTVAE_LAUNCH_CHECK();
+  }
+  WinoArgs a{};
+  a.X = X; a.Ut = ws; a.bias = bias; a.Y = Y;
+  a.B = g.B; a.H = g.gH; a.W = g.gW; a.K = K; a.N = N;
+  a.bh = bh; a.bw = bw; a.nb = nb;
+  a.by_n = (g.gH / 2) / bh; a.bx_n = (g.gW / 2) / bw;
+  a.act = act;
+  const int mtiles = nb > 1 ? ceil_div(g.B, nb) : g.B * a.by_n * a.bx_n;
+  const size_t smem = (size_t)(16 * MT * LDV + 16 * NT * LDV + NPMAX * RS) * 4 + MT * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
+  char name[128];
+  snprintf(name, sizeof name, "wino_conv_kernel");
+  if (prof_detailed()) snprintf(name, sizeof name, "wino_conv_kernel B=%d %dx%d K=%d N=%d wT=%d", g.B, g.gH, g.gW, K, N, g.wT);
+  // flops are counted as the direct convolution's (what the layer computes), bytes as input + output + filters
+  ProfScope ps(name, st, 2.0 * 9.0 * (double)g.B * g.gH * g.gW * K * N,
+               4.0 * ((double)g.B * g.gH * g.gW * (K + N) + 16.0 * K * N));
+  hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)(mtiles * (N / NT))), dim3(256), smem, st, a);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+
+static bool wino_wgrad_chunk(const ConvGeom& g, int& ch, int& cw, int& nbk) {
+  if (g.gH % 2 || g.gW % 2) return false;
+  const int TH = g.gH / 2, TW = g.gW / 2;
+  if (TW % 4 == 0 && TH % 2 == 0) { ch = 2; cw = 4; nbk = 1; return true; }
+  if (TW == 2 && TH == 2) { ch = 2; cw = 2; nbk = 2; return true; }
+  return false;
+}
+
+// weight gradient of a 3x3 / stride 1 / same-padding conv, bias-free caller (geometry of kind 0)
+bool wino_wgrad_supported(const ConvGeom& g, size_t ws_floats, int* splits) {
+  WTaps wt;
+  int ch, cw, nbk;
+  if (g.wT != 0 || !wino_taps(g, wt) || !wino_wgrad_chunk(g, ch, cw, nbk)) return false;
+  for (int a = 0; a < 9; ++a)
+    if (wt.t[a] != a) return false;                 // dW is written as [ky*3+kx][Ci][Co]
+  if (g.gC % 64 || g.sC % 64) return false;
+  if ((long)g.B * g.gH * g.gW * g.gC >= (1L << 29) || (long)g.B * g.sH * g.sW * g.sC >= (1L << 29)) return false;
+  const int tiles = g.B * (g.gH / 2) * (g.gW / 2);
+  const int nchunks = nbk > 1 ? ceil_div(g.B, nbk) : tiles / 8;
+  const int out_tiles = (g.gC / 64) * (g.sC / 64);
+  int S = ceil_div(256, out_tiles);                 // one workgroup per CU
+  if (S > nchunks / 8) S = nchunks / 8;             // at least 8 chunks per workgroup
+  if (S < 1) return false;
+  if ((long)S * out_tiles < 128) return false;
+  while (S > 1 && (size_t)S * 9 * g.gC * g.sC > ws_floats) --S;
+  if ((size_t)S * 9 * g.gC * g.sC > ws_floats) return false;
+  if (splits != nullptr) *splits = S;
+  return true;
+}
+
+int launch_wino_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, size_t ws_floats, int* nparts,
+                      hipStream_t st) {
+  int S = 0, ch, cw, nbk;
+  if (!wino_wgrad_supported(g, ws_floats, &S) || !wino_wgrad_chunk(g, ch, cw, nbk)) return kErrBadArg;
+  WinoWgArgs a{};
+  a.X = X; a.dY = dY; a.part = ws;
+  a.B = g.B; a.H = g.gH; a.W = g.gW; a.Ci = g.gC; a.Co = g.sC;
+  a.ch = ch; a.cw = cw; a.nbk = nbk;
+  a.cy_n = (g.gH / 2) / ch; a.cx_n = (g.gW / 2) / cw;
+  a.nchunks = nbk > 1 ? ceil_div(g.B, nbk) : g.B * a.cy_n * a.cx_n;
+  a.chunks_per_split = ceil_div(a.nchunks, S);
+  S = ceil_div(a.nchunks, a.chunks_per_split);
+  *nparts = S;
+  char name[128];
+  snprintf(name, sizeof name, "wino_wgrad_kernel");
+  if (prof_detailed()) snprintf(name, sizeof name, "wino_wgrad_kernel B=%d %dx%d Ci=%d Co=%d S=%d", g.B, g.gH, g.gW, a.Ci, a.Co, S);
+  ProfScope ps(name, st, 2.0 * 9.0 * (double)g.B * g.gH * g.gW * a.Ci * a.Co,
+               4.0 * ((double)g.B * g.gH * g.gW * (a.Ci + a.Co) + 9.0 * S * a.Ci * a.Co));
+  const size_t smem = (size_t)(2 * 16 * 64 * LDV + (WG_XPIX + WG_YPIX) * RSW) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wino_wgrad_kernel, dim3(a.Ci / 64, a.Co / 64, S), dim3(256), smem, st, a);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace ctvae

@@ -270,3 +270,49 @@ def test_bn_backward_sums_fused_into_dgrad(K, transposed, B, H):
         err = float((got.cpu() - want).norm() / want.norm())
         assert err < 2e-3, err
     # (conv biases in front of train-mode BN have an analytically zero gradient -- pure summation noise, not compared)
+
+
+WINO_CASES = [
+    # B, H, Ci, Co
+    (128, 8, 256, 256),    # the MCQ-VAE residual 3x3 at its bench batch / 2: four images per workgroup block
+    (130, 8, 256, 256),    # batch not a multiple of the images per block
+    (64, 16, 128, 128),    # one image per block
+    (32, 32, 64, 64),      # 2 x 2 blocks of 8 x 8 tiles per image
+    (512, 4, 256, 256),    # sixteen images per block
+]
+
+
+@pytest.mark.parametrize("with_bias", [True, False])
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_winograd_conv3x3(K, case, with_bias):
+    """3x3 / stride 1 / pad 1 layers run Winograd (wino.hip): F(2x2,3x3) for forward and data gradient, F(3x3,2x2) for
+    the weight gradient of bias-free layers (the residual blocks).  Against torch's direct convolution within the 1e-4
+    bound, and the kernels must really have been the ones that ran."""
+    from ctvae_amd import native
+    B, H, Ci, Co = case
+    g = torch.Generator().manual_seed(500 + B + H)
+    x = torch.randn(B, Ci, H, H, generator=g).requires_grad_(True)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5).requires_grad_(True)
+    b = torch.randn(Co, generator=g).requires_grad_(True) if with_bias else None
+    ya = F.relu(F.conv2d(x, w, b, stride=1, padding=1))
+    gy = torch.randn(ya.shape, generator=g)
+    ya.backward(gy)
+
+    dev = torch.device("cuda")
+    spec = K.ConvSpec(K.CONV, Ci, Co, 3, 1, 1, 0, K.ACT_RELU)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+    wp = as_param(pack(w.detach(), False).to(dev), False)
+    bp = torch.nn.Parameter(b.detach().to(dev)) if with_bias else None
+    native.prof_enable(True)
+    out = K.ConvAct.apply(xd, wp, bp, None, spec)
+    out.backward(gy.permute(0, 2, 3, 1).contiguous().to(dev))
+    torch.cuda.synchronize()
+    native.prof_enable(False)
+    rep = native.prof_report()
+    assert rep["wino_conv_kernel"]["count"] == 2, sorted(rep)          # forward + data gradient
+    assert ("wino_wgrad_kernel" in rep) == (not with_bias), sorted(rep)
+    np.testing.assert_allclose(out.detach().cpu().permute(0, 3, 1, 2).numpy(), ya.detach().numpy(), atol=TOL, rtol=1e-4)
+    sc = max(1.0, float(x.grad.abs().max()))
+    np.testing.assert_allclose(xd.grad.cpu().permute(0, 3, 1, 2).numpy(), x.grad.numpy(), atol=TOL * sc, rtol=1e-4)
+    scale = max(1.0, float(w.grad.abs().max()))
+    np.testing.assert_allclose(wp.grad.cpu().numpy(), w.grad.numpy(), atol=TOL * scale, rtol=1e-4)
