@@ -33,6 +33,7 @@ constexpr int LDV = 12;       // padded row of V / U in LDS (floats): conflict-f
 constexpr int RS = 8;         // raw pixel row in LDS (floats)
 constexpr int NPMAX = 640;    // raw pixels per workgroup block (incl. halo)
 constexpr int RAW_ITEMS = (NPMAX * 2 + 255) / 256;   // float4 loads per thread and chunk
+static_assert(RAW_ITEMS * 128 <= NPMAX, "raw staging writes every item unconditionally");
 
 constexpr unsigned kOOBw = 0x80000000u;
 
@@ -42,6 +43,17 @@ __device__ __forceinline__ f32x4 wld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wrsrc(const void* p, long bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
+
+#ifdef CTVAE_PHASE_TIMING
+// diagnostic build only (tools/wino_phase_probe.py): shader-clock cycles per loop phase, summed over the chunks, per wave
+__device__ long long g_wino_phase[8 * 4096];
+#define WPH(i) do { const long long now_ = clock64(); if (lane == 0) tph[i] += now_ - tlast; tlast = clock64(); } while (0)
+extern "C" int ctvae_debug_wino_phase_read(long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wino_phase), (size_t)n * 8);
+}
+#else
+#define WPH(i) do {} while (0)
+#endif
 
 struct WinoArgs {
   const float* X;      // [B][H][W][K]
@@ -96,9 +108,9 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 // ---- the GEMM --------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sV = smem;                          // [16][MT][LDV]
-  float* sU = sV + 16 * MT * LDV;            // [16][NT][LDV]
-  float* sRaw = sU + 16 * NT * LDV;          // [NPMAX][RS]
+  float* sV = smem;                          // [2][16][MT][8]  (double-buffered, rows swizzled, see a_rd)
+  float* sU = sV + 2 * 16 * MT * 8;          // [2][16][NT][8]
+  float* sRaw = sU + 2 * 16 * NT * 8;        // [NPMAX][RS]
   int* sOut = reinterpret_cast<int*>(sRaw + NPMAX * RS);   // [MT] output pixel index of the tile's (0,0) output, -1 = none
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -160,74 +172,157 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
     for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
 
   f32x4 rr[RAW_ITEMS], ru[8];
-  auto load_regs = [&](int c) {
-    const unsigned coff = (unsigned)c * 32u;                      // 8 channels * 4 B
-#pragma unroll
-    for (int i = 0; i < RAW_ITEMS; ++i) rr[i] = wld4(rX, roff[i] == kOOBw ? kOOBw : roff[i] + coff);
-    const unsigned uoff = u_base + (unsigned)c * (unsigned)N * 32u;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ru[i] = wld4(rU, uoff + (unsigned)(2 * i) * u_fs);
-  };
-
   const int nchunks = K / KC8;
-  load_regs(0);
-  for (int c = 0; c < nchunks; ++c) {
-    __syncthreads();                                             // previous chunk's readers of sV / sU / sRaw are done
+  // LDS element offsets (floats) inside one [16][64][8] buffer; rows are 8 floats, the two 4-float halves of a row are
+  // swapped for rows 8..15 (mod 16) so that ds_read_b128 over 16 consecutive rows touches all 64 banks once
+  const int swz_t = (m_t >> 3) & 1;
+  const int v_st = m_t * 8 + ((((q >> 1) ^ swz_t)) << 2) + (q & 1) * 2;          // transform store of channels 2q, 2q+1
+  const int u_row = (tid & 127) >> 1;
+  const int u_st = u_row * 8 + ((((tid & 1) ^ ((u_row >> 3) & 1))) << 2);        // U store of float4 (tid&127) of a frequency
+  const int ma = wm * 32 + li, nbr = wn * 32 + li;
+  const int a_rd = ma * 8 + ((lh ^ ((ma >> 3) & 1)) << 2);
+  const int b_rd = nbr * 8 + ((lh ^ ((nbr >> 3) & 1)) << 2);
+  constexpr int FB = MT * 8;           // floats per frequency
+  constexpr int BUF = 16 * FB;         // floats per buffer
+
+  // One chunk = 16 steps of (4 MFMA of frequency f) + a slice of the data movement for the NEXT chunks.  Everything that
+  // moves data (13 LDS stores of the prefetched raw/U registers, 13 global loads two chunks ahead, 16 patch reads, the
+  // transform and its 16 stores) is issued between MFMA groups: measured per chunk, the same instructions issued as
+  // separate phases cost 855 + 725 cycles (LDS store and texture-address bandwidth shared by the 4 waves) next to 4096
+  // cycles of MFMA, with one wave per SIMD and nothing to overlap them with.
+  auto st_raw = [&](int i) {      // items beyond NP hold zeros and land in the unused tail of sRaw (RAW_ITEMS*128 <= NPMAX)
+    const int e = tid + 256 * i;
+    *reinterpret_cast<f32x4*>(sRaw + (e >> 1) * RS + 4 * (e & 1)) = rr[i];
+  };
+  auto st_u = [&](float* su, int i) { *reinterpret_cast<f32x4*>(su + (2 * i + (tid >> 7)) * FB + u_st) = ru[i]; };
+  auto ld_raw = [&](int c, int i) {
+    rr[i] = wld4(rX, roff[i] == kOOBw ? kOOBw : roff[i] + (unsigned)c * 32u);
+  };
+  auto ld_u = [&](int c, int i) { ru[i] = wld4(rU, u_base + (unsigned)c * (unsigned)N * 32u + (unsigned)(2 * i) * u_fs); };
+  f32x2 d[4][4], t[4][4];
+  auto rd_patch = [&](int i) {
 #pragma unroll
-    for (int i = 0; i < RAW_ITEMS; ++i) {
-      const int e = tid + 256 * i;
-      if (e < 2 * NP) *reinterpret_cast<f32x4*>(sRaw + (e >> 1) * RS + 4 * (e & 1)) = rr[i];
+    for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const f32x2*>(sRaw + (rp0 + i * PW + j) * RS + 2 * q);
+  };
+  auto tf_rows = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      t[0][j] = d[0][j] - d[2][j];
+      t[1][j] = d[1][j] + d[2][j];
+      t[2][j] = d[2][j] - d[1][j];
+      t[3][j] = d[1][j] - d[3][j];
     }
+  };
+  auto tf_store = [&](float* sv, int i) {
+    float* dst = sv + (4 * i) * FB + v_st;
+    *reinterpret_cast<f32x2*>(dst) = t[i][0] - t[i][2];
+    *reinterpret_cast<f32x2*>(dst + FB) = t[i][1] + t[i][2];
+    *reinterpret_cast<f32x2*>(dst + 2 * FB) = t[i][2] - t[i][1];
+    *reinterpret_cast<f32x2*>(dst + 3 * FB) = t[i][1] - t[i][3];
+  };
+  f32x4 fa, fb, na, nb;
+  auto rd_frag = [&](const float* sv, const float* su, int f) {
+    na = *reinterpret_cast<const f32x4*>(sv + f * FB + a_rd);
+    nb = *reinterpret_cast<const f32x4*>(su + f * FB + b_rd);
+  };
+#define WINO_MFMA4(f)                                                                                   \
+  _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_)                                                      \
+      acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s_], fb[s_], acc[f], 0, 0, 0)
+#define WINO_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+  // prologue: chunk 0 -> buffer 0, chunk 1 -> registers
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int f = 2 * i + (tid >> 7), r = tid & 127;
-      *reinterpret_cast<f32x4*>(sU + (f * NT + (r >> 1)) * LDV + 4 * (r & 1)) = ru[i];
-    }
-    __syncthreads();
-    if (c + 1 < nchunks) load_regs(c + 1);
-    // ---- B^T d B for (tile m_t, channels 2q, 2q+1) ----
-    {
-      f32x2 d[4][4];
+  for (int i = 0; i < RAW_ITEMS; ++i) ld_raw(0, i);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 8; ++i) ld_u(0, i);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const f32x2*>(sRaw + (rp0 + i * PW + j) * RS + 2 * q);
-      f32x2 t[4][4];
+  for (int i = 0; i < RAW_ITEMS; ++i) st_raw(i);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        t[0][j] = d[0][j] - d[2][j];
-        t[1][j] = d[1][j] + d[2][j];
-        t[2][j] = d[2][j] - d[1][j];
-        t[3][j] = d[1][j] - d[3][j];
-      }
+  for (int i = 0; i < 8; ++i) st_u(sU, i);
+  __syncthreads();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const f32x2 v0 = t[i][0] - t[i][2], v1 = t[i][1] + t[i][2], v2 = t[i][2] - t[i][1], v3 = t[i][1] - t[i][3];
-        float* dst = sV + ((4 * i) * MT + m_t) * LDV + 2 * q;
-        *reinterpret_cast<f32x2*>(dst) = v0;
-        *reinterpret_cast<f32x2*>(dst + MT * LDV) = v1;
-        *reinterpret_cast<f32x2*>(dst + 2 * MT * LDV) = v2;
-        *reinterpret_cast<f32x2*>(dst + 3 * MT * LDV) = v3;
-      }
-    }
-    __syncthreads();
-    // ---- 16 frequencies x 4 k-steps ----
-    const float* pa = sV + (wm * 32 + li) * LDV + 4 * lh;
-    const float* pb = sU + (wn * 32 + li) * LDV + 4 * lh;
-    f32x4 fa = *reinterpret_cast<const f32x4*>(pa), fb = *reinterpret_cast<const f32x4*>(pb);
+  for (int i = 0; i < RAW_ITEMS; ++i) ld_raw(1, i);       // (chunk index beyond K only reads unused data: see below)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ld_u(1, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rd_patch(i);
+  tf_rows();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tf_store(sV, i);
+  __syncthreads();
+
+  // main loop: all chunks but the last.  Loads run two chunks ahead; past the last chunk they fetch neighbouring
+  // (in-bounds or zero-filled) data that is never stored.
+  for (int c = 0; c + 1 < nchunks; ++c) {
+    const int cur = c & 1;
+    const float* svc = sV + cur * BUF;
+    const float* suc = sU + cur * BUF;
+    float* svn = sV + (cur ^ 1) * BUF;
+    float* sun = sU + (cur ^ 1) * BUF;
+    rd_frag(svc, suc, 0);
+    fa = na; fb = nb;
+    WINO_FENCE();
+    // step 0
+    rd_frag(svc, suc, 1); st_raw(0); st_raw(1); st_u(sun, 0);
+    WINO_MFMA4(0); fa = na; fb = nb; WINO_FENCE();
+    // step 1
+    rd_frag(svc, suc, 2); st_raw(2); st_raw(3); st_u(sun, 1);
+    WINO_MFMA4(1); fa = na; fb = nb; WINO_FENCE();
+    // step 2
+    rd_frag(svc, suc, 3); st_raw(4); st_u(sun, 2); st_u(sun, 3); ld_raw(c + 2, 0); ld_raw(c + 2, 1);
+    WINO_MFMA4(2); fa = na; fb = nb; WINO_FENCE();
+    // step 3
+    rd_frag(svc, suc, 4); st_u(sun, 4); st_u(sun, 5); ld_raw(c + 2, 2); ld_raw(c + 2, 3); ld_u(c + 2, 0);
+    WINO_MFMA4(3); fa = na; fb = nb; WINO_FENCE();
+    // step 4
+    rd_frag(svc, suc, 5); st_u(sun, 6); st_u(sun, 7); ld_raw(c + 2, 4); ld_u(c + 2, 1); ld_u(c + 2, 2);
+    WINO_MFMA4(4); fa = na; fb = nb; WINO_FENCE();
+    // step 5
+    rd_frag(svc, suc, 6); ld_u(c + 2, 3); ld_u(c + 2, 4); ld_u(c + 2, 5);
+    WINO_MFMA4(5); fa = na; fb = nb; WINO_FENCE();
+    // step 6
+    rd_frag(svc, suc, 7); ld_u(c + 2, 6); ld_u(c + 2, 7);
+    WINO_MFMA4(6); fa = na; fb = nb; WINO_FENCE();
+    // step 7
+    rd_frag(svc, suc, 8);
+    WINO_MFMA4(7); fa = na; fb = nb; WINO_FENCE();
+    __syncthreads();                                 // raw pixels of chunk c+1 are visible
+    // step 8
+    rd_frag(svc, suc, 9); rd_patch(0); rd_patch(1);
+    WINO_MFMA4(8); fa = na; fb = nb; WINO_FENCE();
+    // step 9
+    rd_frag(svc, suc, 10); rd_patch(2); rd_patch(3);
+    WINO_MFMA4(9); fa = na; fb = nb; WINO_FENCE();
+    // step 10
+    rd_frag(svc, suc, 11);
+    WINO_MFMA4(10); fa = na; fb = nb; WINO_FENCE();
+    // step 11
+    rd_frag(svc, suc, 12); tf_rows();
+    WINO_MFMA4(11); fa = na; fb = nb; WINO_FENCE();
+    // step 12..15
+    rd_frag(svc, suc, 13); tf_store(svn, 0);
+    WINO_MFMA4(12); fa = na; fb = nb; WINO_FENCE();
+    rd_frag(svc, suc, 14); tf_store(svn, 1);
+    WINO_MFMA4(13); fa = na; fb = nb; WINO_FENCE();
+    rd_frag(svc, suc, 15); tf_store(svn, 2);
+    WINO_MFMA4(14); fa = na; fb = nb; WINO_FENCE();
+    tf_store(svn, 3);
+    WINO_MFMA4(15); WINO_FENCE();
+    __syncthreads();                                 // V/U of chunk c+1 complete, chunk c's buffers free
+  }
+  {                                                  // last chunk: MFMA only
+    const int cur = (nchunks - 1) & 1;
+    const float* svc = sV + cur * BUF;
+    const float* suc = sU + cur * BUF;
 #pragma unroll
     for (int f = 0; f < 16; ++f) {
-      f32x4 na = fa, nb = fb;
-      if (f + 1 < 16) {
-        na = *reinterpret_cast<const f32x4*>(pa + (f + 1) * MT * LDV);
-        nb = *reinterpret_cast<const f32x4*>(pb + (f + 1) * NT * LDV);
-      }
-#pragma unroll
-      for (int s = 0; s < 4; ++s) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s], acc[f], 0, 0, 0);
-      fa = na;
-      fb = nb;
+      fa = *reinterpret_cast<const f32x4*>(svc + f * FB + a_rd);
+      fb = *reinterpret_cast<const f32x4*>(suc + f * FB + b_rd);
+      WINO_MFMA4(f);
     }
   }
+#undef WINO_MFMA4
+#undef WINO_FENCE
 
   // ---- epilogue: A^T M A, lane-local ----
   const int col = nt * NT + wn * 32 + li;
@@ -514,7 +609,7 @@ int launch_wino_conv(const ConvGeom& g, const float* X, const float* Wp, const f
   a.by_n = (g.gH / 2) / bh; a.bx_n = (g.gW / 2) / bw;
   a.act = act;
   const int mtiles = nb > 1 ? ceil_div(g.B, nb) : g.B * a.by_n * a.bx_n;
-  const size_t smem = (size_t)(16 * MT * LDV + 16 * NT * LDV + NPMAX * RS) * 4 + MT * 4;
+  const size_t smem = (size_t)(2 * 16 * MT * 8 + 2 * 16 * NT * 8 + NPMAX * RS) * 4 + MT * 4;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
