@@ -354,10 +354,14 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
 // with the SAME B^T as the forward pass, G = [[1,0],[.5,.5],[.5,-.5],[0,1]], A'^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]].
 // The sixteen GEMMs now reduce over TILES: Mw[f][ci][co] = sum_t Vx[f][t][ci] * Vy[f][t][co].
 // workgroup = 64 ci x 64 co x one slice of the tile range (split over workgroups, slabs reduced by
-// reduce_partials_kernel like every other weight gradient); per chunk of 8 tiles (a 2 x 4 tile block, or two 2 x 2-tile
-// images): raw X pixels (+halo) and raw dY pixels -> LDS, both transforms LDS -> registers -> LDS as [f][channel][8],
-// 16 x 4 MFMA per wave; epilogue A'^T Mw A' lane-local -> slab[9][Ci][Co].
-constexpr int WG_XPIX = 72;    // raw X pixels per chunk: 6 x 10 (2x4 tiles + halo) or 2 x 6 x 6
+// reduce_partials_kernel like every other weight gradient).  Per chunk of 8 tiles (2 tile rows x 4 tile columns of one
+// image): raw X pixels (6 x 10 incl. halo) and raw dY pixels (8 x 4) -> LDS; waves 0,1 transform X, waves 2,3 dY:
+// thread = (channel, tile row), it reads its 4 x 10 strip once (the row pass of B^T d B is shared by the four tiles),
+// and writes V[f][channel][4 tiles] as ONE 16-byte LDS store per frequency; G's factors of 1/2 are applied to the
+// accumulators at the end instead of per tile.  16 x 4 MFMA per wave and chunk, all data movement slotted between MFMA
+// groups (see wino_conv_kernel); epilogue A'^T Mw A' lane-local -> slab[9][Ci][Co].
+constexpr int WG_XPIX = 60;    // raw X pixels per chunk: 6 rows x 10 columns
+constexpr int WG_XROWS = 64;   // rows allocated: the 4 x 256 staging items cover 64 pixel rows, the last 4 hold zeros
 constexpr int WG_YPIX = 32;    // raw dY pixels per chunk: 8 tiles x 4
 constexpr int RSW = 64;        // channels per raw pixel row
 
@@ -366,36 +370,121 @@ struct WinoWgArgs {
   const float* dY;     // [B][H][W][Co]
   float* part;         // [S][9][Ci][Co]
   int B, H, W, Ci, Co;
-  int ch, cw, nbk;     // chunk: nbk images x (ch x cw) tiles, nbk*ch*cw == 8
-  int cy_n, cx_n;      // chunks per image (TH/ch, TW/cw) when nbk == 1
+  int cy_n, cx_n;      // chunks per image: (H/4, W/8)
   int nchunks, chunks_per_split;
 };
 
 __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sVx = smem;                         // [16][64][LDV]
-  float* sVy = sVx + 16 * 64 * LDV;          // [16][64][LDV]
-  float* sRX = sVy + 16 * 64 * LDV;          // [WG_XPIX][RSW]
-  float* sRY = sRX + WG_XPIX * RSW;          // [WG_YPIX][RSW]
+  constexpr int FB = 64 * 8;                 // floats per frequency
+  constexpr int BUF = 16 * FB;               // floats per buffer
+  float* sVx = smem;                         // [2][16][64 ci][8 tiles]   (rows swizzled like wino_conv_kernel's)
+  float* sVy = sVx + 2 * BUF;                // [2][16][64 co][8 tiles]
+  float* sRX = sVy + 2 * BUF;                // [WG_XROWS][RSW]
+  float* sRY = sRX + WG_XROWS * RSW;         // [WG_YPIX][RSW]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
   const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, split = blockIdx.z;
-  const int PH = 2 * a.ch + 2, PW = 2 * a.cw + 2, NPX = a.nbk * PH * PW;
-  const int Ci = a.Ci, Co = a.Co;
-  const __amdgpu_buffer_rsrc_t rX = wrsrc(a.X, (long)a.B * a.H * a.W * Ci * 4);
-  const __amdgpu_buffer_rsrc_t rY = wrsrc(a.dY, (long)a.B * a.H * a.W * Co * 4);
+  const int Ci = a.Ci, Co = a.Co, H = a.H, W = a.W;
+  const __amdgpu_buffer_rsrc_t rX = wrsrc(a.X, (long)a.B * H * W * Ci * 4);
+  const __amdgpu_buffer_rsrc_t rY = wrsrc(a.dY, (long)a.B * H * W * Co * 4);
 
-  // raw-load roles.  X: item e = tid + 256*i -> pixel e>>4, float4 e&15 (NPX*16 <= 1152 items: 5 per thread)
-  //                  dY: item e -> pixel e>>4 (32 pixels: tile e>>6, 2x2 position (e>>4)&3), float4 e&15: 2 per thread
-  // transform roles: tile tt = tid>>5, channels q and q+32
-  const int tt = tid >> 5, q = tid & 31;
-  int xp0;   // raw X pixel of the patch origin of tile tt
-  {
-    const int per = a.ch * a.cw;
-    const int img = tt / per, r = tt - img * per, ty = r / a.cw, tx = r - ty * a.cw;
-    xp0 = (img * PH + 2 * ty) * PW + 2 * tx;
+  // raw-load items.  X: e = tid + 256*i (i < 4) -> pixel p = e>>4 (py = p/10, px = p%10), float4 e&15; p < 60
+  //                  dY: e = tid + 256*i (i < 2) -> pixel p = e>>4 = tile*4 + pos, float4 e&15
+  int x_py[4], x_px[4];
+  unsigned x_rel[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = tid + 256 * i, p = e >> 4;
+    x_py[i] = p < WG_XPIX ? p / 10 - 1 : -100000;          // relative to the chunk's first output row / column
+    x_px[i] = p % 10 - 1;
+    x_rel[i] = (unsigned)(((p / 10 - 1) * W + (p % 10 - 1)) * Ci + ci0 + 4 * (e & 15)) * 4u;
   }
+  unsigned y_rel[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + 256 * i, t = e >> 6, pos = (e >> 4) & 3;
+    const int y = 2 * (t >> 2) + (pos >> 1), x = 2 * (t & 3) + (pos & 1);
+    y_rel[i] = (unsigned)((y * W + x) * Co + co0 + 4 * (e & 15)) * 4u;
+  }
+  f32x4 rx[4], ry[2];
+  auto chunk_origin = [&](int c, int& pix0, int& y0, int& x0) {     // first output pixel of chunk c
+    const int per = a.cy_n * a.cx_n;
+    const int b = c / per, r = c - b * per;
+    y0 = (r / a.cx_n) * 4;
+    x0 = (r - (r / a.cx_n) * a.cx_n) * 8;
+    pix0 = (b * H + y0) * W + x0;
+  };
+  auto ld_x = [&](int pix0, int y0, int x0, bool live, int i) {
+    const bool ok = live && (unsigned)(y0 + x_py[i]) < (unsigned)H && (unsigned)(x0 + x_px[i]) < (unsigned)W;
+    rx[i] = wld4(rX, ok ? (unsigned)pix0 * (unsigned)Ci * 4u + x_rel[i] : kOOBw);
+  };
+  auto ld_y = [&](int pix0, bool live, int i) { ry[i] = wld4(rY, live ? (unsigned)pix0 * (unsigned)Co * 4u + y_rel[i] : kOOBw); };
+  auto st_x = [&](int i) {       // item 3 of the upper threads lies beyond pixel 59: zeros into the unused rows 60..63
+    const int e = tid + 256 * i;
+    *reinterpret_cast<f32x4*>(sRX + (e >> 4) * RSW + 4 * (e & 15)) = rx[i];
+  };
+  auto st_y = [&](int i) {
+    const int e = tid + 256 * i;
+    *reinterpret_cast<f32x4*>(sRY + (e >> 4) * RSW + 4 * (e & 15)) = ry[i];
+  };
+
+  // transform roles: waves 0,1 -> X, waves 2,3 -> dY; thread = (channel chn, tile row tq)
+  const int chn = tid & 63, tq = (tid >> 6) & 1;
+  const int v_st = chn * 8 + ((tq ^ ((chn >> 3) & 1)) << 2);
+  const int ma = wm * 32 + li, nbr = wn * 32 + li;
+  const int a_rd = ma * 8 + ((lh ^ ((ma >> 3) & 1)) << 2);
+  const int b_rd = nbr * 8 + ((lh ^ ((nbr >> 3) & 1)) << 2);
+
+  float sx[4][10];      // X role: strip rows 2tq..2tq+3, all 10 columns; afterwards the row-transformed strip
+  float ey[4][4];       // dY role: [tile][pos]
+  auto rd_x = [&](int r) {
+#pragma unroll
+    for (int x = 0; x < 10; ++x) sx[r][x] = sRX[((2 * tq + r) * 10 + x) * RSW + chn];
+  };
+  auto tf_x_rows = [&]() {
+#pragma unroll
+    for (int x = 0; x < 10; ++x) {
+      const float d0 = sx[0][x], d1 = sx[1][x], d2 = sx[2][x], d3 = sx[3][x];
+      sx[0][x] = d0 - d2; sx[1][x] = d1 + d2; sx[2][x] = d2 - d1; sx[3][x] = d1 - d3;
+    }
+  };
+  auto st_vx = [&](float* sv, int i) {      // frequencies 4i .. 4i+3, four tiles each
+    f32x4 v0, v1, v2, v3;
+#pragma unroll
+    for (int tx = 0; tx < 4; ++tx) {
+      const float t0 = sx[i][2 * tx], t1 = sx[i][2 * tx + 1], t2 = sx[i][2 * tx + 2], t3 = sx[i][2 * tx + 3];
+      v0[tx] = t0 - t2; v1[tx] = t1 + t2; v2[tx] = t2 - t1; v3[tx] = t1 - t3;
+    }
+    float* dst = sv + (4 * i) * FB + v_st;
+    *reinterpret_cast<f32x4*>(dst) = v0;
+    *reinterpret_cast<f32x4*>(dst + FB) = v1;
+    *reinterpret_cast<f32x4*>(dst + 2 * FB) = v2;
+    *reinterpret_cast<f32x4*>(dst + 3 * FB) = v3;
+  };
+  auto rd_y = [&](int tx) {
+#pragma unroll
+    for (int pos = 0; pos < 4; ++pos) ey[tx][pos] = sRY[((tq * 4 + tx) * 4 + pos) * RSW + chn];
+  };
+  auto st_vy = [&](float* sv, int i) {      // 2*G e (2G)^T without the factors: rows {e0, e0+e1, e0-e1, e1}, same for columns
+    f32x4 v0, v1, v2, v3;
+#pragma unroll
+    for (int tx = 0; tx < 4; ++tx) {
+      const float e00 = ey[tx][0], e01 = ey[tx][1], e10 = ey[tx][2], e11 = ey[tx][3];
+      float r0, r1;
+      if (i == 0) { r0 = e00; r1 = e01; }
+      else if (i == 1) { r0 = e00 + e10; r1 = e01 + e11; }
+      else if (i == 2) { r0 = e00 - e10; r1 = e01 - e11; }
+      else { r0 = e10; r1 = e11; }
+      v0[tx] = r0; v1[tx] = r0 + r1; v2[tx] = r0 - r1; v3[tx] = r1;
+    }
+    float* dst = sv + (4 * i) * FB + v_st;
+    *reinterpret_cast<f32x4*>(dst) = v0;
+    *reinterpret_cast<f32x4*>(dst + FB) = v1;
+    *reinterpret_cast<f32x4*>(dst + 2 * FB) = v2;
+    *reinterpret_cast<f32x4*>(dst + 3 * FB) = v3;
+  };
 
   f32x16 acc[16];
 #pragma unroll
@@ -403,135 +492,155 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
 
-  f32x4 rx[5], ry[2];
-  auto load_regs = [&](int c) {
-    int b0, y0, x0;
-    if (a.nbk > 1) { b0 = c * a.nbk; y0 = 0; x0 = 0; }
-    else {
-      const int per = a.cy_n * a.cx_n;
-      b0 = c / per;
-      const int r = c - b0 * per;
-      y0 = (r / a.cx_n) * 2 * a.ch;
-      x0 = (r - (r / a.cx_n) * a.cx_n) * 2 * a.cw;
-    }
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int e = tid + 256 * i, p = e >> 4;
-      unsigned off = kOOBw;
-      if (p < NPX) {
-        const int img = p / (PH * PW), r = p - img * (PH * PW), py = r / PW, px = r - py * PW;
-        const int b = b0 + img, y = y0 + py - 1, x = x0 + px - 1;
-        if (b < a.B && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
-          off = ((unsigned)((b * a.H + y) * a.W + x) * (unsigned)Ci + (unsigned)ci0 + 4u * (e & 15)) * 4u;
-      }
-      rx[i] = wld4(rX, off);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int e = tid + 256 * i, t = e >> 6, pos = (e >> 4) & 3;
-      const int per = a.ch * a.cw;
-      const int img = t / per, r = t - img * per, ty = r / a.cw, tx = r - ty * a.cw;
-      const int b = b0 + img, y = y0 + 2 * ty + (pos >> 1), x = x0 + 2 * tx + (pos & 1);
-      unsigned off = kOOBw;
-      if (b < a.B) off = ((unsigned)((b * a.H + y) * a.W + x) * (unsigned)Co + (unsigned)co0 + 4u * (e & 15)) * 4u;
-      ry[i] = wld4(rY, off);
-    }
+  f32x4 fa, fb, na, nb;
+  auto rd_frag = [&](const float* sx_, const float* sy_, int f) {
+    na = *reinterpret_cast<const f32x4*>(sx_ + f * FB + a_rd);
+    nb = *reinterpret_cast<const f32x4*>(sy_ + f * FB + b_rd);
   };
+#define WINO_MFMA4(f)                                                                                   \
+  _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_)                                                      \
+      acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s_], fb[s_], acc[f], 0, 0, 0)
+#define WINO_FENCE() __builtin_amdgcn_sched_barrier(0)
 
   const int c_begin = split * a.chunks_per_split;
   int c_end = c_begin + a.chunks_per_split;
   if (c_end > a.nchunks) c_end = a.nchunks;
-  if (c_begin < c_end) load_regs(c_begin);
-  for (int c = c_begin; c < c_end; ++c) {
-    __syncthreads();
+  const int n = c_end - c_begin;             // >= 1 by construction of the grid
+
+  // prologue: chunk 0 -> buffer 0, chunk 1 -> registers
+  int pix0, y0, x0;
+  chunk_origin(c_begin, pix0, y0, x0);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int e = tid + 256 * i;
-      if (e < NPX * 16) *reinterpret_cast<f32x4*>(sRX + (e >> 4) * RSW + 4 * (e & 15)) = rx[i];
+  for (int i = 0; i < 4; ++i) ld_x(pix0, y0, x0, true, i);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) ld_y(pix0, true, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) st_x(i);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) st_y(i);
+  __syncthreads();
+  {
+    const bool live = n > 1;
+    chunk_origin(live ? c_begin + 1 : c_begin, pix0, y0, x0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ld_x(pix0, y0, x0, live, i);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ld_y(pix0, live, i);
+  }
+  if (wave < 2) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rd_x(r);
+    tf_x_rows();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st_vx(sVx, i);
+  } else {
+#pragma unroll
+    for (int tx = 0; tx < 4; ++tx) rd_y(tx);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st_vy(sVy, i);
+  }
+  __syncthreads();
+
+  for (int cc = 0; cc + 1 < n; ++cc) {
+    const int cur = cc & 1;
+    const float* sxc = sVx + cur * BUF;
+    const float* syc = sVy + cur * BUF;
+    float* sxn = sVx + (cur ^ 1) * BUF;
+    float* syn = sVy + (cur ^ 1) * BUF;
+    const bool live = cc + 2 < n;                                   // is there a chunk two ahead?
+    chunk_origin(live ? c_begin + cc + 2 : c_begin, pix0, y0, x0);
+    rd_frag(sxc, syc, 0);
+    fa = na; fb = nb;
+    WINO_FENCE();
+    // steps 0..3: registers (chunk cc+1) -> raw LDS, then refill them with chunk cc+2
+    rd_frag(sxc, syc, 1); st_x(0); st_x(1);
+    WINO_MFMA4(0); fa = na; fb = nb; WINO_FENCE();
+    rd_frag(sxc, syc, 2); st_x(2); st_x(3); ld_x(pix0, y0, x0, live, 0);
+    WINO_MFMA4(1); fa = na; fb = nb; WINO_FENCE();
+    rd_frag(sxc, syc, 3); st_y(0); st_y(1); ld_x(pix0, y0, x0, live, 1);
+    WINO_MFMA4(2); fa = na; fb = nb; WINO_FENCE();
+    rd_frag(sxc, syc, 4); ld_x(pix0, y0, x0, live, 2); ld_x(pix0, y0, x0, live, 3);
+    WINO_MFMA4(3); fa = na; fb = nb; WINO_FENCE();
+    rd_frag(sxc, syc, 5); ld_y(pix0, live, 0); ld_y(pix0, live, 1);
+    WINO_MFMA4(4); fa = na; fb = nb; WINO_FENCE();
+    rd_frag(sxc, syc, 6);
+    WINO_MFMA4(5); fa = na; fb = nb; WINO_FENCE();
+    __syncthreads();                                 // raw pixels of chunk cc+1 are visible
+    if (wave < 2) {
+      rd_frag(sxc, syc, 7); rd_x(0); rd_x(1);
+      WINO_MFMA4(6); fa = na; fb = nb; WINO_FENCE();
+      rd_frag(sxc, syc, 8); rd_x(2); rd_x(3);
+      WINO_MFMA4(7); fa = na; fb = nb; WINO_FENCE();
+      rd_frag(sxc, syc, 9);
+      WINO_MFMA4(8); fa = na; fb = nb; WINO_FENCE();
+      rd_frag(sxc, syc, 10); tf_x_rows();
+      WINO_MFMA4(9); fa = na; fb = nb; WINO_FENCE();
+      rd_frag(sxc, syc, 11); st_vx(sxn, 0);
+      WINO_MFMA4(10); fa = na; fb = nb; WINO_FENCE();
+      rd_frag(sxc, syc, 12); st_vx(sxn, 1);
+      WINO_MFMA4(11); fa = na; fb = nb; WINO_FENCE();
+      rd_frag(sxc, syc, 13); st_vx(sxn, 2);
+      WINO_MFMA4(12); fa = na; fb = nb; WINO_FENCE();
+      rd_frag(sxc, syc, 14); st_vx(sxn, 3);
+      WINO_MFMA4(13); fa = na; fb = nb; WINO_FENCE();
+    } else {
+      rd_frag(sxc, syc, 7); rd_y(0); rd_y(1);
+      WINO_MFMA4(6); fa = na; fb = nb; WINO_FENCE();
+      rd_frag(sxc, syc, 8); rd_y(2); rd_y(3);
+      WINO_MFMA4(7); fa = na; fb = nb; WINO_FENCE();
+      rd_frag(sxc, syc, 9);
+      WINO_MFMA4(8); fa = na; fb = nb; WINO_FENCE();
+      rd_frag(sxc, syc, 10);
+      WINO_MFMA4(9); fa = na; fb = nb; WINO_FENCE();
+      rd_frag(sxc, syc, 11); st_vy(syn, 0);
+      WINO_MFMA4(10); fa = na; fb = nb; WINO_FENCE();
+      rd_frag(sxc, syc, 12); st_vy(syn, 1);
+      WINO_MFMA4(11); fa = na; fb = nb; WINO_FENCE();
+      rd_frag(sxc, syc, 13); st_vy(syn, 2);
+      WINO_MFMA4(12); fa = na; fb = nb; WINO_FENCE();
+      rd_frag(sxc, syc, 14); st_vy(syn, 3);
+      WINO_MFMA4(13); fa = na; fb = nb; WINO_FENCE();
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int e = tid + 256 * i;
-      *reinterpret_cast<f32x4*>(sRY + (e >> 4) * RSW + 4 * (e & 15)) = ry[i];
-    }
-    __syncthreads();
-    if (c + 1 < c_end) load_regs(c + 1);
-    // ---- X: B^T d B for (tile tt, channels q, q+32) -> sVx[f][channel][tt] ----
-#pragma unroll
-    for (int hsel = 0; hsel < 2; ++hsel) {
-      const int chn = q + 32 * hsel;
-      float d[4][4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) d[i][j] = sRX[(xp0 + i * PW + j) * RSW + chn];
-      float t[4][4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        t[0][j] = d[0][j] - d[2][j];
-        t[1][j] = d[1][j] + d[2][j];
-        t[2][j] = d[2][j] - d[1][j];
-        t[3][j] = d[1][j] - d[3][j];
-      }
-      float* dst = sVx + chn * LDV + tt;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        dst[(4 * i + 0) * 64 * LDV] = t[i][0] - t[i][2];
-        dst[(4 * i + 1) * 64 * LDV] = t[i][1] + t[i][2];
-        dst[(4 * i + 2) * 64 * LDV] = t[i][2] - t[i][1];
-        dst[(4 * i + 3) * 64 * LDV] = t[i][1] - t[i][3];
-      }
-    }
-    // ---- dY: G dy G^T for (tile tt, channels q, q+32) -> sVy[f][channel][tt] ----
-#pragma unroll
-    for (int hsel = 0; hsel < 2; ++hsel) {
-      const int chn = q + 32 * hsel;
-      const float e00 = sRY[(tt * 4 + 0) * RSW + chn], e01 = sRY[(tt * 4 + 1) * RSW + chn];
-      const float e10 = sRY[(tt * 4 + 2) * RSW + chn], e11 = sRY[(tt * 4 + 3) * RSW + chn];
-      // rows: G e  (4 x 2)
-      const float r0[2] = {e00, e01};
-      const float r1[2] = {0.5f * (e00 + e10), 0.5f * (e01 + e11)};
-      const float r2[2] = {0.5f * (e00 - e10), 0.5f * (e01 - e11)};
-      const float r3[2] = {e10, e11};
-      float* dst = sVy + chn * LDV + tt;
-      auto put = [&](int i, const float* r) {
-        dst[(4 * i + 0) * 64 * LDV] = r[0];
-        dst[(4 * i + 1) * 64 * LDV] = 0.5f * (r[0] + r[1]);
-        dst[(4 * i + 2) * 64 * LDV] = 0.5f * (r[0] - r[1]);
-        dst[(4 * i + 3) * 64 * LDV] = r[1];
-      };
-      put(0, r0); put(1, r1); put(2, r2); put(3, r3);
-    }
-    __syncthreads();
-    const float* pa = sVx + (wm * 32 + li) * LDV + 4 * lh;
-    const float* pb = sVy + (wn * 32 + li) * LDV + 4 * lh;
-    f32x4 fa = *reinterpret_cast<const f32x4*>(pa), fb = *reinterpret_cast<const f32x4*>(pb);
+    rd_frag(sxc, syc, 15);
+    WINO_MFMA4(14); fa = na; fb = nb; WINO_FENCE();
+    WINO_MFMA4(15); WINO_FENCE();
+    __syncthreads();                                 // V of chunk cc+1 complete, chunk cc's buffers free
+  }
+  {                                                  // last chunk: MFMA only
+    const int cur = (n - 1) & 1;
+    const float* sxc = sVx + cur * BUF;
+    const float* syc = sVy + cur * BUF;
 #pragma unroll
     for (int f = 0; f < 16; ++f) {
-      f32x4 na = fa, nb = fb;
-      if (f + 1 < 16) {
-        na = *reinterpret_cast<const f32x4*>(pa + (f + 1) * 64 * LDV);
-        nb = *reinterpret_cast<const f32x4*>(pb + (f + 1) * 64 * LDV);
-      }
-#pragma unroll
-      for (int s = 0; s < 4; ++s) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s], acc[f], 0, 0, 0);
-      fa = na;
-      fb = nb;
+      fa = *reinterpret_cast<const f32x4*>(sxc + f * FB + a_rd);
+      fb = *reinterpret_cast<const f32x4*>(syc + f * FB + b_rd);
+      WINO_MFMA4(f);
     }
   }
+#undef WINO_MFMA4
+#undef WINO_FENCE
 
-  // ---- epilogue: dW[ky][kx] = A'^T Mw A', A'^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]] ----
+  // ---- epilogue: G's halves (rows/columns 1,2 of the dY transform), then dW[ky][kx] = A'^T Mw A',
+  //      A'^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]] ----
   float* slab = a.part + (long)split * 9 * Ci * Co;
   const int col = co0 + wn * 32 + li;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = ci0 + wm * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+    float m[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float sc = ((i == 1 || i == 2) ? 0.5f : 1.f) * ((j == 1 || j == 2) ? 0.5f : 1.f);
+        m[i][j] = acc[4 * i + j][r] * sc;
+      }
     float t[3][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      t[0][j] = acc[j][r] + acc[4 + j][r] + acc[8 + j][r];
-      t[1][j] = acc[4 + j][r] - acc[8 + j][r];
-      t[2][j] = acc[4 + j][r] + acc[8 + j][r] - acc[12 + j][r];
+      t[0][j] = m[0][j] + m[1][j] + m[2][j];
+      t[1][j] = m[1][j] - m[2][j];
+      t[2][j] = m[1][j] + m[2][j] - m[3][j];
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -628,25 +737,20 @@ int launch_wino_conv(const ConvGeom& g, const float* X, const float* Wp, const f
 }
 
 
-static bool wino_wgrad_chunk(const ConvGeom& g, int& ch, int& cw, int& nbk) {
-  if (g.gH % 2 || g.gW % 2) return false;
-  const int TH = g.gH / 2, TW = g.gW / 2;
-  if (TW % 4 == 0 && TH % 2 == 0) { ch = 2; cw = 4; nbk = 1; return true; }
-  if (TW == 2 && TH == 2) { ch = 2; cw = 2; nbk = 2; return true; }
-  return false;
+static bool wino_wgrad_chunk(const ConvGeom& g) {      // chunks of 2 x 4 tiles = 4 x 8 output pixels
+  return g.gH % 4 == 0 && g.gW % 8 == 0;
 }
 
 // weight gradient of a 3x3 / stride 1 / same-padding conv, bias-free caller (geometry of kind 0)
 bool wino_wgrad_supported(const ConvGeom& g, size_t ws_floats, int* splits) {
   WTaps wt;
-  int ch, cw, nbk;
-  if (g.wT != 0 || !wino_taps(g, wt) || !wino_wgrad_chunk(g, ch, cw, nbk)) return false;
+  if (g.wT != 0 || !wino_taps(g, wt) || !wino_wgrad_chunk(g)) return false;
   for (int a = 0; a < 9; ++a)
     if (wt.t[a] != a) return false;                 // dW is written as [ky*3+kx][Ci][Co]
   if (g.gC % 64 || g.sC % 64) return false;
   if ((long)g.B * g.gH * g.gW * g.gC >= (1L << 29) || (long)g.B * g.sH * g.sW * g.sC >= (1L << 29)) return false;
   const int tiles = g.B * (g.gH / 2) * (g.gW / 2);
-  const int nchunks = nbk > 1 ? ceil_div(g.B, nbk) : tiles / 8;
+  const int nchunks = tiles / 8;
   const int out_tiles = (g.gC / 64) * (g.sC / 64);
   int S = ceil_div(256, out_tiles);                 // one workgroup per CU
   if (S > nchunks / 8) S = nchunks / 8;             // at least 8 chunks per workgroup
@@ -660,14 +764,13 @@ bool wino_wgrad_supported(const ConvGeom& g, size_t ws_floats, int* splits) {
 
 int launch_wino_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, size_t ws_floats, int* nparts,
                       hipStream_t st) {
-  int S = 0, ch, cw, nbk;
-  if (!wino_wgrad_supported(g, ws_floats, &S) || !wino_wgrad_chunk(g, ch, cw, nbk)) return kErrBadArg;
+  int S = 0;
+  if (!wino_wgrad_supported(g, ws_floats, &S)) return kErrBadArg;
   WinoWgArgs a{};
   a.X = X; a.dY = dY; a.part = ws;
   a.B = g.B; a.H = g.gH; a.W = g.gW; a.Ci = g.gC; a.Co = g.sC;
-  a.ch = ch; a.cw = cw; a.nbk = nbk;
-  a.cy_n = (g.gH / 2) / ch; a.cx_n = (g.gW / 2) / cw;
-  a.nchunks = nbk > 1 ? ceil_div(g.B, nbk) : g.B * a.cy_n * a.cx_n;
+  a.cy_n = g.gH / 4; a.cx_n = g.gW / 8;
+  a.nchunks = g.B * a.cy_n * a.cx_n;
   a.chunks_per_split = ceil_div(a.nchunks, S);
   S = ceil_div(a.nchunks, a.chunks_per_split);
   *nparts = S;
@@ -676,7 +779,7 @@ int launch_wino_wgrad(const ConvGeom& g, const float* X, const float* dY, float*
   if (prof_detailed()) snprintf(name, sizeof name, "wino_wgrad_kernel B=%d %dx%d Ci=%d Co=%d S=%d", g.B, g.gH, g.gW, a.Ci, a.Co, S);
   ProfScope ps(name, st, 2.0 * 9.0 * (double)g.B * g.gH * g.gW * a.Ci * a.Co,
                4.0 * ((double)g.B * g.gH * g.gW * (a.Ci + a.Co) + 9.0 * S * a.Ci * a.Co));
-  const size_t smem = (size_t)(2 * 16 * 64 * LDV + (WG_XPIX + WG_YPIX) * RSW) * 4;
+  const size_t smem = (size_t)(4 * 16 * 64 * 8 + (WG_XROWS + WG_YPIX) * RSW) * 4;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

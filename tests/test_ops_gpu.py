@@ -310,7 +310,7 @@ def test_winograd_conv3x3(K, case, with_bias):
     native.prof_enable(False)
     rep = native.prof_report()
     assert rep["wino_conv_kernel"]["count"] == 2, sorted(rep)          # forward + data gradient
-    assert ("wino_wgrad_kernel" in rep) == (not with_bias), sorted(rep)
+    assert ("wino_wgrad_kernel" in rep) == (not with_bias and H % 8 == 0), sorted(rep)   # chunks of 4 x 8 output pixels
     np.testing.assert_allclose(out.detach().cpu().permute(0, 3, 1, 2).numpy(), ya.detach().numpy(), atol=TOL, rtol=1e-4)
     sc = max(1.0, float(x.grad.abs().max()))
     np.testing.assert_allclose(xd.grad.cpu().permute(0, 3, 1, 2).numpy(), x.grad.numpy(), atol=TOL * sc, rtol=1e-4)
