@@ -8,6 +8,7 @@ namespace ctvae {
 int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
                    const float* mask, int mask_act, float* S, int act, float* bn_part, float* ws, size_t ws_floats,
                    hipStream_t st, const BnBwdFuse* bnb = nullptr, const InXform* xf = nullptr);
+int wino_set_enabled(int on);
 bool thin_forward_supported(const ConvGeom& g);
 bool thin_wgrad_supported(const ConvGeom& g);
 int tapgemm_bnb_rows(const ConvGeom& g, size_t ws_floats);
@@ -76,6 +77,8 @@ const char* ctvae_error_string(int code) {
   if (code > 0) return hipGetErrorString((hipError_t)code);
   return "ctvae: unknown error";
 }
+
+int ctvae_winograd_enable(int on) { return wino_set_enabled(on); }
 
 size_t ctvae_workspace_bytes(void) { return (size_t)256 << 20; }
 

@@ -627,10 +627,7 @@ bool wino_supported(const ConvGeom& g, size_t ws_floats);
 int launch_wino_conv(const ConvGeom& g, const float* X, const float* Wp, const float* bias, float* Y, int act, float* ws,
                      size_t ws_floats, hipStream_t st);
 
-static bool wino_enabled() {
-  static const bool on = [] { const char* e = getenv("CTVAE_NO_WINOGRAD"); return !(e != nullptr && e[0] == '1'); }();
-  return on;
-}
+bool wino_enabled();
 
 int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
                    const float* mask, int mask_act, float* S, int act, float* bn_part, float* ws, size_t ws_floats,

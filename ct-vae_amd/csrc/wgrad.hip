@@ -564,16 +564,13 @@ bool wino_wgrad_supported(const ConvGeom& g, size_t ws_floats, int* splits);
 int launch_wino_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, size_t ws_floats, int* nparts,
                       hipStream_t st);
 
-static bool wino_wgrad_enabled() {
-  static const bool on = [] { const char* e = getenv("CTVAE_NO_WINOGRAD"); return !(e != nullptr && e[0] == '1'); }();
-  return on;
-}
+bool wino_enabled();
 
 int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, float* dbias, float* ws,
                  size_t ws_bytes, int accumulate, hipStream_t st, const InXform* xf, const DyXform* dyx) {
   // bias-free 3x3 / stride 1 / same-padding layers: Winograd F(3x3,2x2), see wino.hip
   if (dbias == nullptr && (xf == nullptr || xf->scale == nullptr) && (dyx == nullptr || dyx->y == nullptr) &&
-      wino_wgrad_enabled() && wino_wgrad_supported(g, ws_bytes / sizeof(float), nullptr)) {
+      wino_enabled() && wino_wgrad_supported(g, ws_bytes / sizeof(float), nullptr)) {
     int np = 0;
     int rc = launch_wino_wgrad(g, X, dY, ws, ws_bytes / sizeof(float), &np, st);
     if (rc) return rc;

@@ -683,6 +683,21 @@ bool wino_block(const ConvGeom& g, int& bh, int& bw, int& nb) {
 
 }  // namespace
 
+// process-wide switch (ctvae_winograd_enable): on unless the environment says CTVAE_NO_WINOGRAD=1
+static int g_wino_on = -1;
+bool wino_enabled() {
+  if (g_wino_on < 0) {
+    const char* e = getenv("CTVAE_NO_WINOGRAD");
+    g_wino_on = (e != nullptr && e[0] == '1') ? 0 : 1;
+  }
+  return g_wino_on != 0;
+}
+int wino_set_enabled(int on) {
+  const int prev = wino_enabled() ? 1 : 0;
+  g_wino_on = on ? 1 : 0;
+  return prev;
+}
+
 size_t wino_ws_floats(const ConvGeom& g) { return (size_t)16 * g.gC * g.sC; }
 
 // Is this launch a Winograd candidate?  (the caller still decides on epilogue features)

@@ -53,6 +53,7 @@ _RESTYPES = {
     "ctvae_prof_calibrate": None,
     "ctvae_prof_report": _c.c_size_t,
     "ctvae_conv_dgrad_bn_rows": _c.c_int,
+    "ctvae_winograd_enable": _c.c_int,
     "ctvae_conv_input_transform_supported": _c.c_int,
     "ctvae_conv_wgrad_bn_apply_supported": _c.c_int,
 }
@@ -89,6 +90,7 @@ def load():
                        "ctvae_prof_calibrate": [_c.c_void_p, _c.c_int],
                        "ctvae_prof_report": [_c.c_char_p, _c.c_size_t],
                        "ctvae_conv_dgrad_bn_rows": [_c.c_int] * 10 + [_c.c_size_t],
+                       "ctvae_winograd_enable": [_c.c_int],
                        "ctvae_conv_input_transform_supported": [_c.c_int] * 10,
                        "ctvae_conv_wgrad_bn_apply_supported": [_c.c_int] * 10}.get(name, [])
     if lib.ctvae_arch() != b"gfx950":
@@ -131,6 +133,11 @@ def call(name: str, *args):
     """Launch entry point `name` on the current stream (the trailing stream argument is appended here)."""
     lib = load()
     check(getattr(lib, name)(*args, stream_ptr()), name)
+
+
+def winograd_enable(on: bool) -> bool:
+    """Select Winograd (default) or the direct tap-GEMM kernels for the 3x3 stride-1 layers; returns the old setting."""
+    return bool(load().ctvae_winograd_enable(1 if on else 0))
 
 
 def prof_enable(on, detailed: bool = False):
