@@ -7,7 +7,10 @@
 namespace ctvae {
 int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
                    const float* mask, int mask_act, float* S, int act, float* bn_part, float* ws, size_t ws_floats,
-                   hipStream_t st, const BnBwdFuse* bnb = nullptr, const InXform* xf = nullptr);
+                   hipStream_t st, const BnBwdFuse* bnb = nullptr, const InXform* xf = nullptr,
+                   const WinoFilters* wf = nullptr);
+bool wino_supported(const ConvGeom& g, size_t ws_floats);
+bool wino_enabled();
 int wino_set_enabled(int on);
 bool thin_forward_supported(const ConvGeom& g);
 bool thin_wgrad_supported(const ConvGeom& g);
@@ -84,14 +87,29 @@ size_t ctvae_workspace_bytes(void) { return (size_t)256 << 20; }
 
 int ctvae_conv_forward(int kind, const float* x, const float* w, const float* bias, const float* add, float* y, int B,
                        int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int act, const float* in_scale,
-                       const float* in_shift, int in_act, float* ws, size_t ws_bytes, void* stream) {
+                       const float* in_shift, int in_act, float* wino_dgrad_filters_out, float* ws, size_t ws_bytes,
+                       void* stream) {
   if (!x || !w || !y || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
   if ((in_scale != nullptr) != (in_shift != nullptr)) return kErrBadArg;
   ConvGeom g;
   if (build_geom(g, kind == CTVAE_CONV ? 0 : 1, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
+  if (wino_dgrad_filters_out != nullptr &&
+      !ctvae_conv_wino_filter_floats(kind, B, H, W, Ci, Co, k, stride, pad, out_pad, ws_bytes))
+    return kErrBadArg;
   const InXform xf{in_scale, in_shift, in_act};
+  const WinoFilters wf{nullptr, wino_dgrad_filters_out};
   return launch_tapgemm(g, x, w, bias, add, nullptr, 0, y, act, nullptr, ws, ws_bytes / sizeof(float), (hipStream_t)stream,
-                        nullptr, &xf);
+                        nullptr, &xf, &wf);
+}
+
+size_t ctvae_conv_wino_filter_floats(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
+                                     size_t ws_bytes) {
+  if (kind != CTVAE_CONV || !wino_enabled()) return 0;
+  ConvGeom gf, gb;
+  if (build_geom(gf, 0, B, H, W, Ci, Co, k, stride, pad, out_pad) || build_geom(gb, 2, B, H, W, Ci, Co, k, stride, pad, out_pad))
+    return 0;
+  const size_t wsf = ws_bytes / sizeof(float);
+  return (wino_supported(gf, wsf) && wino_supported(gb, wsf)) ? (size_t)16 * Ci * Co : 0;
 }
 
 int ctvae_conv_input_transform_supported(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad,
@@ -135,13 +153,16 @@ int ctvae_conv_bn_act_forward(int kind, const float* x, const float* w, const fl
 }
 
 int ctvae_conv_dgrad(int kind, const float* dy, const float* w, const float* add, const float* mask, int mask_act,
-                     float* dx, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, float* ws,
-                     size_t ws_bytes, void* stream) {
+                     float* dx, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
+                     const float* wino_filters, float* ws, size_t ws_bytes, void* stream) {
   if (!dy || !w || !dx || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
   ConvGeom g;
   if (build_geom(g, kind == CTVAE_CONV ? 2 : 3, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
+  if (wino_filters != nullptr && !ctvae_conv_wino_filter_floats(kind, B, H, W, Ci, Co, k, stride, pad, out_pad, ws_bytes))
+    return kErrBadArg;
+  const WinoFilters wf{wino_filters, nullptr};
   return launch_tapgemm(g, dy, w, nullptr, add, mask, mask_act, dx, ACT_NONE, nullptr, ws, ws_bytes / sizeof(float),
-                        (hipStream_t)stream);
+                        (hipStream_t)stream, nullptr, nullptr, &wf);
 }
 
 int ctvae_conv_dgrad_bn_rows(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,

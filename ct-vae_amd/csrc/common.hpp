@@ -78,6 +78,12 @@ struct DyXform {
   int act;
 };
 
+// Winograd filter hand-over between a layer's forward launch and its data-gradient launch (wino.hip)
+struct WinoFilters {
+  const float* ready;   // dgrad: the filter set the forward launch left behind (skip the transform)
+  float* bwd_out;       // forward: where to leave the data gradient's filter set
+};
+
 // BatchNorm(+activation) layer whose output gradient a dgrad launch produces (fused backward sums)
 struct BnBwdFuse {
   const float* y;

@@ -105,6 +105,64 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
   }
 }
 
+// Forward launch of a layer whose data gradient will also run Winograd: both filter sets in one launch.
+//   Uf[f][ci/8][co][ci%8] = (G g G^T)[f]                   (operand of the forward pass,   K = Ci, N = Co)
+//   Ub[f][co/8][ci][co%8] = (G g~ G^T)[f], g~ = g mirrored  (operand of the data gradient,  K = Co, N = Ci)
+// Mirroring the 3x3 taps only permutes the Winograd rows/columns (0 <-> 3), so Ub[(i,j)] = Uf[(p(i),p(j))], p = (3,1,2,0).
+// workgroup = a 32 ci x 32 co tile of W ([9][Ci][Co], tap = ky*3+kx): 128-byte coalesced tap loads, the 16 transformed
+// values of every (ci,co) go through LDS, and both layouts leave as 1-KB contiguous runs of 16-byte stores.
+constexpr int W2_LD = 33;
+__global__ __launch_bounds__(256) void wino_weight2_kernel(const float* __restrict__ Wp, float* __restrict__ Uf,
+                                                           float* __restrict__ Ub, int Ci, int Co) {
+  extern __shared__ __attribute__((aligned(16))) float sW2[];     // [16][32 ci][W2_LD]
+  const int tid = threadIdx.x;
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  {
+    const int co_l = tid & 31;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ci_l = (tid >> 5) + 8 * r;
+      float g[3][3];
+#pragma unroll
+      for (int a = 0; a < 9; ++a) g[a / 3][a % 3] = Wp[((long)a * Ci + ci0 + ci_l) * Co + co0 + co_l];
+      float t[4][3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        t[0][j] = g[0][j];
+        t[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
+        t[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
+        t[3][j] = g[2][j];
+      }
+      float* dst = sW2 + ci_l * W2_LD + co_l;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        dst[(4 * i + 0) * 32 * W2_LD] = t[i][0];
+        dst[(4 * i + 1) * 32 * W2_LD] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+        dst[(4 * i + 2) * 32 * W2_LD] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+        dst[(4 * i + 3) * 32 * W2_LD] = t[i][2];
+      }
+    }
+  }
+  __syncthreads();
+  const long fs = (long)Ci * Co;
+  const int o = (tid >> 6) & 3, x_l = (tid >> 1) & 31, half = tid & 1;
+#pragma unroll 4
+  for (int f = 0; f < 16; ++f) {
+    const float* src = sW2 + f * 32 * W2_LD;
+    // forward set: octet o of ci, row co = x_l, elements ci%8 = 4*half .. 4*half+3
+    f32x4 v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = src[(8 * o + 4 * half + k) * W2_LD + x_l];
+    *reinterpret_cast<f32x4*>(Uf + f * fs + ((long)(ci0 / 8 + o) * Co + co0 + x_l) * 8 + 4 * half) = v;
+    // data-gradient set: octet o of co, row ci = x_l, elements co%8 = 4*half .. 4*half+3, mirrored frequency
+    const int i = f >> 2, j = f & 3;
+    const int fo = ((i == 0 ? 3 : (i == 3 ? 0 : i)) << 2) | (j == 0 ? 3 : (j == 3 ? 0 : j));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = src[x_l * W2_LD + 8 * o + 4 * half + k];
+    *reinterpret_cast<f32x4*>(Ub + fo * fs + ((long)(co0 / 8 + o) * Ci + ci0 + x_l) * 8 + 4 * half) = v;
+  }
+}
+
 // ---- the GEMM --------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -714,20 +772,38 @@ bool wino_supported(const ConvGeom& g, size_t ws_floats) {
   return wino_ws_floats(g) <= ws_floats;
 }
 
+// filters_ready: this launch's transformed filters (what an earlier forward launch left in its bwd_out) -> no transform.
+// bwd_out (forward launches only): also write the data gradient's filter set there, in the same transform launch.
 int launch_wino_conv(const ConvGeom& g, const float* X, const float* Wp, const float* bias, float* Y, int act, float* ws,
-                     size_t ws_floats, hipStream_t st) {
+                     size_t ws_floats, hipStream_t st, const float* filters_ready, float* bwd_out) {
   WTaps wt;
   int bh, bw, nb;
   if (!wino_supported(g, ws_floats) || !wino_taps(g, wt) || !wino_block(g, bh, bw, nb)) return kErrBadArg;
   const int K = g.gC, N = g.sC;
-  {
+  const float* Ut = ws;
+  bool plain_fwd = g.wT == 0;
+  for (int a9 = 0; a9 < 9; ++a9) plain_fwd = plain_fwd && wt.t[a9] == a9;
+  if (filters_ready != nullptr) {
+    Ut = filters_ready;
+  } else if (bwd_out != nullptr && plain_fwd && K % 32 == 0 && N % 32 == 0) {
+    static bool attr2_set = false;
+    if (!attr2_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_weight2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
+      attr2_set = true;
+    }
+    ProfScope ps("wino_weight2_kernel", st, 0.0, 4.0 * (9.0 + 32.0) * K * N);
+    hipLaunchKernelGGL(wino_weight2_kernel, dim3(K / 32, N / 32), dim3(256), (size_t)16 * 32 * W2_LD * 4, st, Wp, ws, bwd_out, K,
+                       N);
+    CTVAE_LAUNCH_CHECK();
+  } else {
     ProfScope ps("wino_weight_kernel", st, 0.0, 4.0 * (9.0 + 16.0) * K * N);
     hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)(((long)K * N + 255) / 256)), dim3(256), 0, st, Wp, ws, K, N, g.wCi,
                        g.wCo, g.wT, wt);
     CTVAE_LAUNCH_CHECK();
   }
   WinoArgs a{};
-  a.X = X; a.Ut = ws; a.bias = bias; a.Y = Y;
+  a.X = X; a.Ut = Ut; a.bias = bias; a.Y = Y;
   a.B = g.B; a.H = g.gH; a.W = g.gW; a.K = K; a.N = N;
   a.bh = bh; a.bw = bw; a.nb = nb;
   a.by_n = (g.gH / 2) / bh; a.bx_n = (g.gW / 2) / bw;

@@ -66,8 +66,21 @@ def grad_target(p):
 # ---------------------------------------------------------------------------------------------------
 # low level launch helpers (no autograd)
 # ---------------------------------------------------------------------------------------------------
-def conv_forward_raw(x, w, b, spec: ConvSpec, add=None, act=None, in_coef=None, in_act=ACT_NONE):
-    """in_coef [2][Ci]: read act_in(x*scale+shift) instead of x (lazy BatchNorm apply, image-side layers only)."""
+_wino_floats_cache = {}
+
+
+def wino_filter_floats(spec: ConvSpec, B, H, W, ws_numel) -> int:
+    """Size of the Winograd filter hand-over buffer of this layer (0: its forward / data gradient are not both Winograd)."""
+    key = (spec.kind, B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, ws_numel, native.winograd_enabled())
+    n = _wino_floats_cache.get(key)
+    if n is None:
+        n = _wino_floats_cache[key] = int(native.load().ctvae_conv_wino_filter_floats(*key[:10], ws_numel * 4))
+    return n
+
+
+def conv_forward_raw(x, w, b, spec: ConvSpec, add=None, act=None, in_coef=None, in_act=ACT_NONE, wino_out=None):
+    """in_coef [2][Ci]: read act_in(x*scale+shift) instead of x (lazy BatchNorm apply, image-side layers only).
+    wino_out: buffer of wino_filter_floats() floats that receives the data gradient's Winograd filters."""
     B, H, W, _ = x.shape
     ho, wo = spec.out_hw(H, W)
     y = torch.empty((B, ho, wo, spec.co), dtype=torch.float32, device=x.device)
@@ -76,18 +89,20 @@ def conv_forward_raw(x, w, b, spec: ConvSpec, add=None, act=None, in_coef=None, 
     sh = in_coef.data_ptr() + 4 * spec.ci if in_coef is not None else None
     native.call("ctvae_conv_forward", spec.kind, x.data_ptr(), w.data_ptr(), native.ptr(b), native.ptr(add), y.data_ptr(),
                 B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, spec.act if act is None else act,
-                sc, sh, in_act, ws.data_ptr(), ws.numel() * 4)
+                sc, sh, in_act, native.ptr(wino_out), ws.data_ptr(), ws.numel() * 4)
     return y
 
 
-def conv_dgrad_raw(dy, w, spec: ConvSpec, in_hw, add=None, mask=None, mask_act=ACT_NONE):
+def conv_dgrad_raw(dy, w, spec: ConvSpec, in_hw, add=None, mask=None, mask_act=ACT_NONE, wino_filters=None):
     B = dy.shape[0]
     H, W = in_hw
     dx = torch.empty((B, H, W, spec.ci), dtype=torch.float32, device=dy.device)
     ws = native.workspace(dy.device)
+    if wino_filters is not None and wino_filter_floats(spec, B, H, W, ws.numel()) != wino_filters.numel():
+        wino_filters = None        # the switch was flipped between forward and backward
     native.call("ctvae_conv_dgrad", spec.kind, dy.data_ptr(), w.data_ptr(), native.ptr(add), native.ptr(mask), mask_act,
                 dx.data_ptr(), B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad,
-                ws.data_ptr(), ws.numel() * 4)
+                native.ptr(wino_filters), ws.data_ptr(), ws.numel() * 4)
     return dx
 
 
@@ -182,7 +197,7 @@ def conv_wgrad_raw(x, dy, w_param, b_param, spec: ConvSpec, in_coef=None, in_act
                 by, bc, bact, bgy, ws.data_ptr(), ws.numel() * 4)
 
 
-def wgrad_then_dgrad(x, g, w_param, b_param, spec, need_dgrad, link=None):
+def wgrad_then_dgrad(x, g, w_param, b_param, spec, need_dgrad, link=None, wino_filters=None):
     """Weight gradient (accumulated straight into ``.grad``) and data gradient of one layer, on the launch stream.
     Measured on MI355X: putting the wgrad kernels on a second HIP stream (joined right after dgrad, or once at the
     end of backward) is SLOWER than back-to-back launches (2.43 vs 2.32 ms/step) -- each GEMM launch already covers
@@ -194,7 +209,7 @@ def wgrad_then_dgrad(x, g, w_param, b_param, spec, need_dgrad, link=None):
         dx = conv_dgrad_bn_raw(g, w_param, spec, (x.shape[1], x.shape[2]), link)
         if dx is not None:
             return dx
-    return conv_dgrad_raw(g, w_param, spec, (x.shape[1], x.shape[2]))
+    return conv_dgrad_raw(g, w_param, spec, (x.shape[1], x.shape[2]), wino_filters=wino_filters)
 
 
 def act_backward_raw(g_out, out, act):
@@ -273,7 +288,12 @@ class ConvAct(Function):
         ctx.link_in = link_of(x)
         x = _c(x)
         add_c = _c(add) if add is not None else None
-        y = conv_forward_raw(x, w, b, spec, add_c)
+        ctx.wino_u = None
+        if add is None and ctx.needs_input_grad[0]:
+            n = wino_filter_floats(spec, x.shape[0], x.shape[1], x.shape[2], native.workspace(x.device).numel())
+            if n:
+                ctx.wino_u = torch.empty(n, dtype=torch.float32, device=x.device)
+        y = conv_forward_raw(x, w, b, spec, add_c, wino_out=ctx.wino_u)
         ctx.spec = spec
         ctx.w, ctx.b = w, b
         ctx.has_add = add is not None
@@ -286,7 +306,7 @@ class ConvAct(Function):
         x, y = ctx.saved_tensors
         g_y = _c(g_y)
         g_pre = act_backward_raw(g_y, y, spec.act) if spec.act != ACT_NONE else g_y
-        g_x = wgrad_then_dgrad(x, g_pre, ctx.w, ctx.b, spec, ctx.needs_input_grad[0], ctx.link_in)
+        g_x = wgrad_then_dgrad(x, g_pre, ctx.w, ctx.b, spec, ctx.needs_input_grad[0], ctx.link_in, ctx.wino_u)
         g_add = g_pre if (ctx.has_add and ctx.needs_input_grad[3]) else None
         return g_x, None, None, g_add, None
 

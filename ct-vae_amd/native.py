@@ -17,10 +17,10 @@ _fp, _vp, _i, _l, _f, _sz = _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_long, _c.c_
 
 # name -> argtypes (all return int unless listed in _RESTYPES)
 SIGNATURES = {
-    "ctvae_conv_forward": [_i, _fp, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _fp, _i, _fp, _sz, _vp],
+    "ctvae_conv_forward": [_i, _fp, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _fp, _i, _fp, _fp, _sz, _vp],
     "ctvae_conv_bn_act_forward": [_i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp] + [_i] * 9
                                  + [_fp, _sz, _vp],
-    "ctvae_conv_dgrad": [_i, _fp, _fp, _fp, _fp, _i, _fp] + [_i] * 9 + [_fp, _sz, _vp],
+    "ctvae_conv_dgrad": [_i, _fp, _fp, _fp, _fp, _i, _fp] + [_i] * 9 + [_fp, _fp, _sz, _vp],
     "ctvae_conv_wgrad": [_i, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _sz, _vp],
     "ctvae_bn_forward": [_fp, _i, _i, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _fp, _fp, _fp, _fp, _fp, _sz, _vp],
     "ctvae_bn_backward": [_fp, _fp, _fp, _i, _i, _fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _fp, _i, _fp, _fp, _sz, _vp],
@@ -54,6 +54,7 @@ _RESTYPES = {
     "ctvae_prof_report": _c.c_size_t,
     "ctvae_conv_dgrad_bn_rows": _c.c_int,
     "ctvae_winograd_enable": _c.c_int,
+    "ctvae_conv_wino_filter_floats": _c.c_size_t,
     "ctvae_conv_input_transform_supported": _c.c_int,
     "ctvae_conv_wgrad_bn_apply_supported": _c.c_int,
 }
@@ -91,6 +92,7 @@ def load():
                        "ctvae_prof_report": [_c.c_char_p, _c.c_size_t],
                        "ctvae_conv_dgrad_bn_rows": [_c.c_int] * 10 + [_c.c_size_t],
                        "ctvae_winograd_enable": [_c.c_int],
+                       "ctvae_conv_wino_filter_floats": [_c.c_int] * 10 + [_c.c_size_t],
                        "ctvae_conv_input_transform_supported": [_c.c_int] * 10,
                        "ctvae_conv_wgrad_bn_apply_supported": [_c.c_int] * 10}.get(name, [])
     if lib.ctvae_arch() != b"gfx950":
@@ -135,9 +137,24 @@ def call(name: str, *args):
     check(getattr(lib, name)(*args, stream_ptr()), name)
 
 
+_wino_on = None
+
+
 def winograd_enable(on: bool) -> bool:
     """Select Winograd (default) or the direct tap-GEMM kernels for the 3x3 stride-1 layers; returns the old setting."""
-    return bool(load().ctvae_winograd_enable(1 if on else 0))
+    global _wino_on
+    prev = bool(load().ctvae_winograd_enable(1 if on else 0))
+    _wino_on = bool(on)
+    return prev
+
+
+def winograd_enabled() -> bool:
+    global _wino_on
+    if _wino_on is None:
+        lib = load()
+        _wino_on = bool(lib.ctvae_winograd_enable(1))
+        lib.ctvae_winograd_enable(1 if _wino_on else 0)
+    return _wino_on
 
 
 def prof_enable(on, detailed: bool = False):

@@ -43,10 +43,17 @@ size_t ctvae_workspace_bytes(void); /* scratch size that is sufficient for every
  * in_scale/in_shift [Ci] (both or neither; NULL = plain x): the layer reads x' = act_in(x*scale[c] + shift[c]) instead
  * of x, i.e. the BatchNorm2d + LeakyReLU in front of it (vanilla_vae.py:71-74) is applied while loading and its
  * output never touches memory.  Only where ctvae_conv_input_transform_supported() says 1 (the 3-output-channel
- * image-side layers); kErrBadArg otherwise. */
+ * image-side layers); kErrBadArg otherwise.
+ * wino_dgrad_filters_out (may be NULL): for a layer whose forward AND data gradient run Winograd
+ * (ctvae_conv_wino_filter_floats() > 0, that many floats), the forward's filter-transform launch also leaves the data
+ * gradient's transformed filters there; hand them to ctvae_conv_dgrad of the same layer and weights (one transform
+ * launch per layer and step instead of two). */
 int ctvae_conv_forward(int kind, const float* x, const float* w, const float* bias, const float* add, float* y, int B,
                        int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int act, const float* in_scale,
-                       const float* in_shift, int in_act, float* ws, size_t ws_bytes, void* stream);
+                       const float* in_shift, int in_act, float* wino_dgrad_filters_out, float* ws, size_t ws_bytes,
+                       void* stream);
+size_t ctvae_conv_wino_filter_floats(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
+                                     size_t ws_bytes);
 int ctvae_conv_input_transform_supported(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad,
                                          int out_pad);
 
@@ -62,10 +69,11 @@ int ctvae_conv_bn_act_forward(int kind, const float* x, const float* w, const fl
                               int stride, int pad, int out_pad, float* ws, size_t ws_bytes, void* stream);
 
 /* dx = (dgrad(dy, w) + add) * act'(mask)      (autograd of the ops above)
- * add / mask (saved post-activation output of the PREVIOUS layer, layout of dx) may be NULL. */
+ * add / mask (saved post-activation output of the PREVIOUS layer, layout of dx) may be NULL.
+ * wino_filters: NULL, or what ctvae_conv_forward left in wino_dgrad_filters_out for these weights. */
 int ctvae_conv_dgrad(int kind, const float* dy, const float* w, const float* add, const float* mask, int mask_act,
-                     float* dx, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, float* ws,
-                     size_t ws_bytes, void* stream);
+                     float* dx, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
+                     const float* wino_filters, float* ws, size_t ws_bytes, void* stream);
 
 /* ctvae_conv_dgrad whose result dx is the gradient w.r.t. a = act(BN(y)), the output of a train-mode BatchNorm2d
  * (+activation) that fed this layer (autograd of vanilla_vae.py:28-31 chained into the next block).  The epilogue
