@@ -189,6 +189,65 @@ __global__ __launch_bounds__(256) void vq_bwd_codebook_kernel(const float* __res
   }
 }
 
+// Same result, organised by POSITIONS instead of by codes: workgroup = (slice of positions, codebook i); a half-wave owns
+// one position per step (lane = d < 32) and adds its latent row into ITS OWN table sAcc[wave][half][k][d] in LDS -- a
+// plain read-modify-write, no atomics: one owner per table, positions in a fixed order, so the sums are bit-reproducible.
+// The scan-for-my-code form above walks every index once per code and then gathers its hits one dependent 128-byte
+// load at a time (377 us for P = 16384, K = 64, C = 4); here every index and every latent element is read exactly once.
+// Requires Dc <= 32 and K <= 128 (8 tables of K x 32 floats + counts in LDS).  grid (S, C), part[z][C*K*Dc] as above.
+__global__ __launch_bounds__(256) void vq_bwd_codebook_pos_kernel(const float* __restrict__ gvq, const float* __restrict__ lat,
+                                                                  const float* __restrict__ cb,
+                                                                  const long long* __restrict__ inds, float* __restrict__ part,
+                                                                  int P, int D, int K, int Dc, int C, int HW, int Ps) {
+  extern __shared__ float vq_smem[];
+  float* sAcc = vq_smem;                               // [8][K][32]
+  float* sCnt = sAcc + 8 * K * 32;                     // [8][K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, d = lane & 31;
+  const int i = blockIdx.y;
+  for (int e = tid; e < 8 * K * 32 + 8 * K; e += 256) vq_smem[e] = 0.f;
+  __syncthreads();
+  float* tAcc = sAcc + (size_t)(wave * 2 + half) * K * 32;
+  float* tCnt = sCnt + (wave * 2 + half) * K;
+  const int p_lo = blockIdx.x * Ps;
+  const int p_hi = p_lo + Ps < P ? p_lo + Ps : P;
+  constexpr int U = 4;                                 // positions in flight per half-wave
+  for (int base = p_lo + wave * 2 + half; base < p_hi; base += 8 * U) {
+    int kk[U];
+    float vv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = base + 8 * u;
+      kk[u] = -1;
+      vv[u] = 0.f;
+      if (p < p_hi) {
+        const int b = p / HW, hw = p - b * HW;
+        kk[u] = (int)inds[((size_t)b * C + i) * HW + hw];
+        if (d < Dc) vv[u] = lat[(size_t)p * D + i + d];    // codebook i reads latent columns i .. i+Dc-1 (reference slicing)
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (kk[u] >= 0) {                                // uniform over the half-wave
+        tAcc[kk[u] * 32 + d] += vv[u];
+        if (d == 0) tCnt[kk[u]] += 1.f;
+      }
+    }
+  }
+  __syncthreads();
+  const float sc = (gvq != nullptr ? gvq[0] : 0.f) * 2.f / ((float)P * (float)Dc);
+  for (int e = tid; e < K * Dc; e += 256) {
+    const int k = e / Dc, dd = e - k * Dc;
+    float sx = 0.f, c = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      sx += sAcc[((size_t)t * K + k) * 32 + dd];
+      c += sCnt[t * K + k];
+    }
+    const size_t o = ((size_t)i * K + k) * Dc + dd;
+    part[(size_t)blockIdx.x * ((size_t)C * K * Dc) + o] = sc * (c * cb[o] - sx);
+  }
+}
+
 __global__ __launch_bounds__(256) void vq_cb_reduce_kernel(const float* __restrict__ part, float* __restrict__ dcb, int n, int S,
                                                           int accumulate) {
   const int o = blockIdx.x * 256 + threadIdx.x;
@@ -248,6 +307,32 @@ int launch_vq_backward(const float* gq, const float* gvq, const float* lat, cons
     CTVAE_LAUNCH_CHECK();
   }
   if (dcb != nullptr) {
+    const size_t n_all = (size_t)C * K * Dc;
+    if (Dc <= 32 && K <= 128 && ws != nullptr) {
+      // position-major kernel: ~256 positions per workgroup
+      int S = ceil_div(P, 256);
+      if (S > 512) S = 512;
+      while (S > 1 && (size_t)S * n_all > ws_bytes / sizeof(float)) --S;
+      if ((size_t)S * n_all <= ws_bytes / sizeof(float)) {
+        const int Ps = ceil_div(P, S);
+        S = ceil_div(P, Ps);
+        const size_t smem = ((size_t)8 * K * 32 + 8 * K) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vq_bwd_codebook_pos_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          attr_set = true;
+        }
+        ProfScope ps("vq_bwd_codebook_pos_kernel", st, 0.0, 4.0 * (double)P * D + 8.0 * (double)P * C + 4.0 * S * n_all);
+        hipLaunchKernelGGL(vq_bwd_codebook_pos_kernel, dim3(S, C), dim3(256), smem, st, gvq, lat, cb, inds, ws, P, D, K, Dc, C,
+                           HW, Ps);
+        CTVAE_LAUNCH_CHECK();
+        hipLaunchKernelGGL(vq_cb_reduce_kernel, dim3(ceil_div((int)n_all, 256)), dim3(256), 0, st, ws, dcb, (int)n_all, S,
+                           accumulate);
+        CTVAE_LAUNCH_CHECK();
+        return 0;
+      }
+    }
     // enough slices of the position range for ~1024 workgroups (each slice >= 512 positions), if scratch is available
     int S = 1024 / (K * C);
     if (S > P / 512) S = P / 512;
