@@ -135,6 +135,43 @@ class BNLink:
         return part, rows
 
 
+class ActLink:
+    """Hand-over between a ConvAct layer with a fused activation and the SOLE consumer of its output h (declared by the
+    model code, e.g. blocks.ResidualLayer where h never leaves forward()).  The consumer's data gradient multiplies by
+    act'(h) in its epilogue (the ``mask`` operand of ctvae_conv_dgrad), so the tensor that arrives at the producer's
+    backward is already the gradient w.r.t. its pre-activation and the separate activation-backward pass is skipped.
+    The producer checks that it received exactly that tensor; anything else cannot be repaired and raises."""
+    __slots__ = ("act", "g_ptr", "g_ver", "g_shape", "done")
+
+    def __init__(self, act):
+        self.act = act
+        self.done = False
+        self.g_ptr = self.g_ver = self.g_shape = None
+
+    def publish_done(self, g):
+        self.done = True
+        self.g_ptr, self.g_ver, self.g_shape = g.data_ptr(), g._version, tuple(g.shape)
+
+    def take(self, g):
+        """True when ``g`` already carries the activation derivative.  One use only."""
+        done, self.done = self.done, False
+        if not done:
+            return False
+        if g.data_ptr() != self.g_ptr or g._version != self.g_ver or tuple(g.shape) != self.g_shape:
+            raise RuntimeError("ActLink: the activation backward was folded into the consumer's data gradient (sole "
+                               "consumer promised), but a different gradient tensor arrived")
+        return True
+
+
+_last_act_link = None  # set by ConvAct.forward (fused activation), picked up by the caller of .apply right after
+
+
+def pop_act_link():
+    global _last_act_link
+    link, _last_act_link = _last_act_link, None
+    return link
+
+
 _last_link = None     # set by ConvBNAct.forward, picked up by the caller of .apply (models/blocks.py) right after
 
 
@@ -284,8 +321,11 @@ class ConvAct(Function):
 
     @staticmethod
     def forward(ctx, x, w, b, add, spec):
+        global _last_act_link
         _req_cuda(x, w)
         ctx.link_in = link_of(x)
+        ctx.act_in = getattr(x, "_ctvae_act_link", None) if x.is_contiguous() else None
+        ctx.act_out = _last_act_link = ActLink(spec.act) if spec.act != ACT_NONE else None
         x = _c(x)
         add_c = _c(add) if add is not None else None
         ctx.wino_u = None
@@ -305,8 +345,17 @@ class ConvAct(Function):
         spec = ctx.spec
         x, y = ctx.saved_tensors
         g_y = _c(g_y)
-        g_pre = act_backward_raw(g_y, y, spec.act) if spec.act != ACT_NONE else g_y
-        g_x = wgrad_then_dgrad(x, g_pre, ctx.w, ctx.b, spec, ctx.needs_input_grad[0], ctx.link_in, ctx.wino_u)
+        if spec.act == ACT_NONE or (ctx.act_out is not None and ctx.act_out.take(g_y)):
+            g_pre = g_y                                   # no activation, or its derivative is already in g_y
+        else:
+            g_pre = act_backward_raw(g_y, y, spec.act)
+        if ctx.act_in is not None and ctx.needs_input_grad[0] and ctx.link_in is None:
+            # x is the activated output of the producer and this layer is its only consumer: dgrad * act'(x) in one launch
+            conv_wgrad_raw(x, g_pre, ctx.w, ctx.b, spec)
+            g_x = conv_dgrad_raw(g_pre, ctx.w, spec, (x.shape[1], x.shape[2]), mask=x, mask_act=ctx.act_in.act)
+            ctx.act_in.publish_done(g_x)
+        else:
+            g_x = wgrad_then_dgrad(x, g_pre, ctx.w, ctx.b, spec, ctx.needs_input_grad[0], ctx.link_in, ctx.wino_u)
         g_add = g_pre if (ctx.has_add and ctx.needs_input_grad[3]) else None
         return g_x, None, None, g_add, None
 
