@@ -107,6 +107,25 @@ class _GraphTransitioner(nn.Module):
         return x
 
 
+class _ProdLastDim(torch.autograd.Function):
+    """x.prod(-1) with a backward that never leaves the device: d/dx_i = g * prod_{j != i} x_j from an exclusive prefix
+    and suffix product.  torch's own prod backward counts the zeros of x with .item() (a host sync, which also makes the
+    step impossible to capture into a hipGraph); this form is exact with zeros too."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return x.prod(-1)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        one = torch.ones_like(x[..., :1])
+        prefix = torch.cat([one, torch.cumprod(x, -1)[..., :-1]], -1)                               # prod_{j<i}
+        suffix = torch.cat([torch.cumprod(x.flip(-1), -1)[..., :-1].flip(-1), one], -1)             # prod_{j>i}
+        return g.unsqueeze(-1) * prefix * suffix
+
+
 def sample_bernoulli_st(p, noise=None):
     """Straight-through Bernoulli sample via 2-class Gumbel-softmax(tau=1, hard=True) of log(clamp([1-p, p], 1e-4))
     (ct_mcq_vae.py:177-183): HIP kernel, noise = two standard Gumbel draws per element (injectable)."""
@@ -256,7 +275,7 @@ class CausalTransition(nn.Module):
         return torch.linalg.matrix_norm(graph).mean()
 
     def positive_trial_loss(self, adj):
-        return torch.linalg.vector_norm((1 - adj).prod(-1), dim=-1).mean()
+        return torch.linalg.vector_norm(_ProdLastDim.apply(1 - adj), dim=-1).mean()
 
     def causal_accuracy(self, action_probas, action):
         return (torch.argmax(action_probas, dim=-1) == torch.argmax(action, dim=-1)).float().mean()
