@@ -407,6 +407,240 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
   }
 }
 
+// ---- the same GEMM for launches with fewer than 256 of the 64 x 64 workgroups ------------------------------------------
+// (CT-MCQ-VAE: 128 images per GPU and pass -> 128 workgroups for 256 CUs.)  Workgroup = 64 tiles x 32 output channels,
+// twice as many of them; the waves of a workgroup split the FREQUENCIES instead of the channels: wave (wm, fh) holds the
+// 8 accumulators f = 4i + 2fh + jj (all four rows i, columns j = 2fh + jj) of a 32 x 32 block.  The row pass of A^T M A
+// stays lane-local; the column pass needs both waves' columns, so each wave forms its partial outputs, hands the half
+// it does not store through LDS (8 KB per wave) and finishes the other half.  Staging of the input block and the
+// transform are those of wino_conv_kernel; the filter chunk is half as large (16 KB).
+__global__ __launch_bounds__(256) void wino_conv_fs_kernel(WinoArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NTs = 32;
+  constexpr int FBv = MT * 8, FBu = NTs * 8;          // floats per frequency
+  constexpr int BUFv = 16 * FBv, BUFu = 16 * FBu;     // floats per buffer
+  float* sV = smem;                          // [2][16][MT][8]
+  float* sU = sV + 2 * BUFv;                 // [2][16][NTs][8]
+  float* sRaw = sU + 2 * BUFu;               // [NPMAX][RS]
+  int* sOut = reinterpret_cast<int*>(sRaw + NPMAX * RS);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, fh = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int ntiles = a.N / NTs;
+  const int mt = blockIdx.x / ntiles, nt = blockIdx.x - mt * ntiles;
+  const int PH = 2 * a.bh + 2, PW = 2 * a.bw + 2, NP = a.nb * PH * PW;
+  const int K = a.K, N = a.N;
+
+  int b0, y0, x0;
+  if (a.nb > 1) { b0 = mt * a.nb; y0 = 0; x0 = 0; }
+  else {
+    const int per = a.by_n * a.bx_n;
+    b0 = mt / per;
+    const int r = mt - b0 * per;
+    y0 = (r / a.bx_n) * 2 * a.bh;
+    x0 = (r - (r / a.bx_n) * a.bx_n) * 2 * a.bw;
+  }
+  const __amdgpu_buffer_rsrc_t rX = wrsrc(a.X, (long)a.B * a.H * a.W * K * 4);
+  const __amdgpu_buffer_rsrc_t rU = wrsrc(a.Ut, (long)16 * K * N * 4);
+
+  unsigned roff[RAW_ITEMS];
+#pragma unroll
+  for (int i = 0; i < RAW_ITEMS; ++i) {
+    const int e = tid + 256 * i, p = e >> 1, half = e & 1;
+    unsigned off = kOOBw;
+    if (p < NP) {
+      const int img = p / (PH * PW), r = p - img * (PH * PW), py = r / PW, px = r - py * PW;
+      const int b = b0 + img, y = y0 + py - 1, x = x0 + px - 1;
+      if (b < a.B && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
+        off = ((unsigned)((b * a.H + y) * a.W + x) * (unsigned)K + 4u * half) * 4u;
+    }
+    roff[i] = off;
+  }
+  // U-load items: e = tid + 256*i (i < 4) -> f = e>>6, float4 r = e&63 of the 256-float row block of frequency f
+  const unsigned u_fs = (unsigned)(K >> 3) * (unsigned)N * 8u * 4u;
+  const unsigned u_base = ((unsigned)nt * NTs * 8u + 4u * (tid & 63)) * 4u + (unsigned)(tid >> 6) * u_fs;
+
+  const int m_t = tid >> 2, q = tid & 3;
+  int rp0;
+  {
+    const int per = a.bh * a.bw;
+    const int img = m_t / per, r = m_t - img * per, ty = r / a.bw, tx = r - ty * a.bw;
+    rp0 = (img * PH + 2 * ty) * PW + 2 * tx;
+    if (q == 0) {
+      const int b = b0 + img;
+      sOut[m_t] = b < a.B ? (b * a.H + y0 + 2 * ty) * a.W + x0 + 2 * tx : -1;
+    }
+  }
+
+  f32x16 acc[8];                                       // a8 = 2i + jj  <->  f = 4i + 2fh + jj
+#pragma unroll
+  for (int f = 0; f < 8; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+  f32x4 rr[RAW_ITEMS], ru[4];
+  const int nchunks = K / KC8;
+  const int swz_t = (m_t >> 3) & 1;
+  const int v_st = m_t * 8 + ((((q >> 1) ^ swz_t)) << 2) + (q & 1) * 2;
+  const int u_row = (tid & 63) >> 1;
+  const int u_st = u_row * 8 + ((((tid & 1) ^ ((u_row >> 3) & 1))) << 2);
+  const int ma = wm * 32 + li;
+  const int a_rd = ma * 8 + ((lh ^ ((ma >> 3) & 1)) << 2) + 2 * fh * FBv;      // + this wave's column offset
+  const int b_rd = li * 8 + ((lh ^ ((li >> 3) & 1)) << 2) + 2 * fh * FBu;
+
+  auto st_raw = [&](int i) {
+    const int e = tid + 256 * i;
+    *reinterpret_cast<f32x4*>(sRaw + (e >> 1) * RS + 4 * (e & 1)) = rr[i];
+  };
+  auto st_u = [&](float* su, int i) { *reinterpret_cast<f32x4*>(su + (4 * i + (tid >> 6)) * FBu + u_st) = ru[i]; };
+  auto ld_raw = [&](int c, int i) { rr[i] = wld4(rX, roff[i] == kOOBw ? kOOBw : roff[i] + (unsigned)c * 32u); };
+  auto ld_u = [&](int c, int i) { ru[i] = wld4(rU, u_base + (unsigned)c * (unsigned)N * 32u + (unsigned)(4 * i) * u_fs); };
+  f32x2 d[4][4], t[4][4];
+  auto rd_patch = [&](int i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const f32x2*>(sRaw + (rp0 + i * PW + j) * RS + 2 * q);
+  };
+  auto tf_rows = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      t[0][j] = d[0][j] - d[2][j];
+      t[1][j] = d[1][j] + d[2][j];
+      t[2][j] = d[2][j] - d[1][j];
+      t[3][j] = d[1][j] - d[3][j];
+    }
+  };
+  auto tf_store = [&](float* sv, int i) {
+    float* dst = sv + (4 * i) * FBv + v_st;
+    *reinterpret_cast<f32x2*>(dst) = t[i][0] - t[i][2];
+    *reinterpret_cast<f32x2*>(dst + FBv) = t[i][1] + t[i][2];
+    *reinterpret_cast<f32x2*>(dst + 2 * FBv) = t[i][2] - t[i][1];
+    *reinterpret_cast<f32x2*>(dst + 3 * FBv) = t[i][1] - t[i][3];
+  };
+  f32x4 fa, fb, na, nb;
+  auto rd_frag = [&](const float* sv, const float* su, int a8) {     // frequency 4*(a8>>1) + 2fh + (a8&1)
+    const int fl = 4 * (a8 >> 1) + (a8 & 1);
+    na = *reinterpret_cast<const f32x4*>(sv + fl * FBv + a_rd);
+    nb = *reinterpret_cast<const f32x4*>(su + fl * FBu + b_rd);
+  };
+#define WINO_MFMA4(f)                                                                                   \
+  _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_)                                                      \
+      acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s_], fb[s_], acc[f], 0, 0, 0)
+#define WINO_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+#pragma unroll
+  for (int i = 0; i < RAW_ITEMS; ++i) ld_raw(0, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ld_u(0, i);
+#pragma unroll
+  for (int i = 0; i < RAW_ITEMS; ++i) st_raw(i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) st_u(sU, i);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < RAW_ITEMS; ++i) ld_raw(1, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ld_u(1, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rd_patch(i);
+  tf_rows();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tf_store(sV, i);
+  __syncthreads();
+
+  for (int c = 0; c + 1 < nchunks; ++c) {
+    const int cur = c & 1;
+    const float* svc = sV + cur * BUFv;
+    const float* suc = sU + cur * BUFu;
+    float* svn = sV + (cur ^ 1) * BUFv;
+    float* sun = sU + (cur ^ 1) * BUFu;
+    rd_frag(svc, suc, 0);
+    fa = na; fb = nb;
+    WINO_FENCE();
+    rd_frag(svc, suc, 1); st_raw(0); st_raw(1); st_raw(2); st_u(sun, 0);
+    WINO_MFMA4(0); fa = na; fb = nb; WINO_FENCE();
+    rd_frag(svc, suc, 2); st_raw(3); st_raw(4); st_u(sun, 1); st_u(sun, 2); st_u(sun, 3);
+    ld_raw(c + 2, 0); ld_raw(c + 2, 1); ld_raw(c + 2, 2);
+    WINO_MFMA4(1); fa = na; fb = nb; WINO_FENCE();
+    rd_frag(svc, suc, 3); ld_raw(c + 2, 3); ld_raw(c + 2, 4); ld_u(c + 2, 0); ld_u(c + 2, 1);
+    WINO_MFMA4(2); fa = na; fb = nb; WINO_FENCE();
+    rd_frag(svc, suc, 4); ld_u(c + 2, 2); ld_u(c + 2, 3);
+    WINO_MFMA4(3); fa = na; fb = nb; WINO_FENCE();
+    __syncthreads();                                 // raw pixels of chunk c+1 are visible
+    rd_frag(svc, suc, 5); rd_patch(0); rd_patch(1); rd_patch(2); rd_patch(3);
+    WINO_MFMA4(4); fa = na; fb = nb; WINO_FENCE();
+    rd_frag(svc, suc, 6); tf_rows(); tf_store(svn, 0);
+    WINO_MFMA4(5); fa = na; fb = nb; WINO_FENCE();
+    rd_frag(svc, suc, 7); tf_store(svn, 1); tf_store(svn, 2);
+    WINO_MFMA4(6); fa = na; fb = nb; WINO_FENCE();
+    tf_store(svn, 3);
+    WINO_MFMA4(7); WINO_FENCE();
+    __syncthreads();                                 // V/U of chunk c+1 complete, chunk c's buffers free
+  }
+  {
+    const int cur = (nchunks - 1) & 1;
+    const float* svc = sV + cur * BUFv;
+    const float* suc = sU + cur * BUFu;
+#pragma unroll
+    for (int a8 = 0; a8 < 8; ++a8) {
+      rd_frag(svc, suc, a8);
+      fa = na; fb = nb;
+      WINO_MFMA4(a8);
+    }
+  }
+#undef WINO_MFMA4
+#undef WINO_FENCE
+  __syncthreads();                                   // every wave is done with sV: it becomes the exchange area
+
+  // ---- epilogue ----
+  float* sX = sV;                                    // [wave][8 rows][4 partials][64 lanes]
+  float keep[8][4];                                  // partial outputs of the rows this wave stores: r in [8fh, 8fh+8)
+#pragma unroll
+  for (int rl = 0; rl < 8; ++rl)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) keep[rl][v] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float t0[2], t1[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      t0[jj] = acc[jj][r] + acc[2 + jj][r] + acc[4 + jj][r];
+      t1[jj] = acc[2 + jj][r] - acc[4 + jj][r] - acc[6 + jj][r];
+    }
+    float pv[4];
+    // columns 0,1 (fh = 0):  y[.][0] += t[0] + t[1],  y[.][1] += t[1];   columns 2,3:  y[.][0] += t[2],  y[.][1] += -t[2] - t[3]
+    pv[0] = fh == 0 ? t0[0] + t0[1] : t0[0];
+    pv[1] = fh == 0 ? t0[1] : -t0[0] - t0[1];
+    pv[2] = fh == 0 ? t1[0] + t1[1] : t1[0];
+    pv[3] = fh == 0 ? t1[1] : -t1[0] - t1[1];
+    const bool mine = (r >> 3) == fh;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      if (!mine) sX[((wave * 8 + (r & 7)) * 4 + v) * 64 + lane] = pv[v];       // the other wave finishes this row
+      keep[r & 7][v] = mine ? pv[v] : keep[r & 7][v];
+    }
+  }
+  __syncthreads();
+  const int col = nt * NTs + li;
+  const float bv = a.bias != nullptr ? a.bias[col] : 0.f;
+  const int other = wave ^ 1;
+#pragma unroll
+  for (int rl = 0; rl < 8; ++rl) {
+    float y[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) y[v] = keep[rl][v] + sX[((other * 8 + rl) * 4 + v) * 64 + lane];
+    const int r = 8 * fh + rl;
+    const int row = wm * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+    const int op = sOut[row];
+    if (op >= 0) {
+      float* dst = a.Y + (long)op * N + col;
+      dst[0] = act_fwd(y[0] + bv, a.act);
+      dst[N] = act_fwd(y[1] + bv, a.act);
+      dst[(long)a.W * N] = act_fwd(y[2] + bv, a.act);
+      dst[(long)a.W * N + N] = act_fwd(y[3] + bv, a.act);
+    }
+  }
+}
+
 // ---- weight gradient: F(3x3, 2x2) ---------------------------------------------------------------------------------
 //     dW = sum_tiles A'^T [ (B^T d B) (.) (G dy G^T) ] A'     d = 4x4 input patch, dy = 2x2 output-gradient tile
 // with the SAME B^T as the forward pass, G = [[1,0],[.5,.5],[.5,-.5],[0,1]], A'^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]].
@@ -768,7 +1002,7 @@ bool wino_supported(const ConvGeom& g, size_t ws_floats) {
   if ((long)16 * g.gC * g.sC >= (1L << 29)) return false;
   const int tiles = g.B * (g.gH / 2) * (g.gW / 2);
   const long wgs = (long)ceil_div(tiles, MT) * (g.sC / NT);
-  if (wgs < 128) return false;                     // too few workgroups: the split-K direct kernel fills the chip better
+  if (wgs < 64) return false;                      // too few workgroups: the split-K direct kernel fills the chip better
   return wino_ws_floats(g) <= ws_floats;
 }
 
@@ -809,20 +1043,27 @@ int launch_wino_conv(const ConvGeom& g, const float* X, const float* Wp, const f
   a.by_n = (g.gH / 2) / bh; a.bx_n = (g.gW / 2) / bw;
   a.act = act;
   const int mtiles = nb > 1 ? ceil_div(g.B, nb) : g.B * a.by_n * a.bx_n;
-  const size_t smem = (size_t)(2 * 16 * MT * 8 + 2 * 16 * NT * 8 + NPMAX * RS) * 4 + MT * 4;
+  // fewer than 200 of the 64 x 64 workgroups: 64 x 32 workgroups whose waves split the frequencies (twice as many)
+  const bool fsplit = (long)mtiles * (N / NT) < 200;
+  const size_t smem = (size_t)(2 * 16 * MT * 8 + 2 * 16 * (fsplit ? 32 : NT) * 8 + NPMAX * RS) * 4 + MT * 4;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_fs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
     attr_set = true;
   }
   char name[128];
-  snprintf(name, sizeof name, "wino_conv_kernel");
-  if (prof_detailed()) snprintf(name, sizeof name, "wino_conv_kernel B=%d %dx%d K=%d N=%d wT=%d", g.B, g.gH, g.gW, K, N, g.wT);
+  snprintf(name, sizeof name, fsplit ? "wino_conv_fs_kernel" : "wino_conv_kernel");
+  if (prof_detailed())
+    snprintf(name, sizeof name, "%s B=%d %dx%d K=%d N=%d wT=%d", fsplit ? "wino_conv_fs_kernel" : "wino_conv_kernel", g.B, g.gH,
+             g.gW, K, N, g.wT);
   // flops are counted as the direct convolution's (what the layer computes), bytes as input + output + filters
   ProfScope ps(name, st, 2.0 * 9.0 * (double)g.B * g.gH * g.gW * K * N,
                4.0 * ((double)g.B * g.gH * g.gW * (K + N) + 16.0 * K * N));
-  hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)(mtiles * (N / NT))), dim3(256), smem, st, a);
+  if (fsplit) hipLaunchKernelGGL(wino_conv_fs_kernel, dim3((unsigned)(mtiles * (N / 32))), dim3(256), smem, st, a);
+  else hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)(mtiles * (N / NT))), dim3(256), smem, st, a);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }

@@ -273,8 +273,10 @@ def test_bn_backward_sums_fused_into_dgrad(K, transposed, B, H):
 
 
 WINO_CASES = [
-    # B, H, Ci, Co
-    (128, 8, 256, 256),    # the MCQ-VAE residual 3x3 at its bench batch / 2: four images per workgroup block
+    # B, H, Ci, Co     (fewer than 200 workgroups of 64 tiles x 64 channels -> the frequency-split kernel, 64 x 32)
+    (256, 8, 256, 256),    # the MCQ-VAE residual 3x3 at its bench batch: 256 workgroups, wino_conv_kernel
+    (100, 16, 64, 128),    # 200 workgroups, one image per block, wino_conv_kernel
+    (128, 8, 256, 256),    # the CT-MCQ-VAE per-GPU batch: 128 -> wino_conv_fs_kernel; four images per workgroup block
     (130, 8, 256, 256),    # batch not a multiple of the images per block
     (64, 16, 128, 128),    # one image per block
     (32, 32, 64, 64),      # 2 x 2 blocks of 8 x 8 tiles per image
@@ -309,10 +311,19 @@ def test_winograd_conv3x3(K, case, with_bias):
     torch.cuda.synchronize()
     native.prof_enable(False)
     rep = native.prof_report()
-    assert rep["wino_conv_kernel"]["count"] == 2, sorted(rep)          # forward + data gradient
+    nconv = sum(rep.get(k, {"count": 0})["count"] for k in ("wino_conv_kernel", "wino_conv_fs_kernel"))
+    assert nconv == 2, sorted(rep)                                     # forward + data gradient
+    fwd = "wino_conv_kernel" if (B * (H // 2) ** 2 + 63) // 64 * (Co // 64) >= 200 else "wino_conv_fs_kernel"
+    assert fwd in rep, sorted(rep)
     assert ("wino_wgrad_kernel" in rep) == (not with_bias and H % 8 == 0), sorted(rep)   # chunks of 4 x 8 output pixels
     np.testing.assert_allclose(out.detach().cpu().permute(0, 3, 1, 2).numpy(), ya.detach().numpy(), atol=TOL, rtol=1e-4)
+    # a pre-activation within rounding of 0 may land on the other side of the ReLU (one flip moves the 3x3 x Ci input
+    # gradients under it by O(1)): allow a vanishing fraction of outliers, as in the BatchNorm chain tests above
     sc = max(1.0, float(x.grad.abs().max()))
-    np.testing.assert_allclose(xd.grad.cpu().permute(0, 3, 1, 2).numpy(), x.grad.numpy(), atol=TOL * sc, rtol=1e-4)
+    got, ref = xd.grad.cpu().permute(0, 3, 1, 2).numpy(), x.grad.numpy()
+    bad = np.abs(got - ref) > TOL * sc + 1e-4 * np.abs(ref)
+    assert bad.mean() < 2e-3, f"{bad.sum()} of {bad.size} elements differ"
+    dw = (wp.grad.cpu() - w.grad).numpy()
     scale = max(1.0, float(w.grad.abs().max()))
-    np.testing.assert_allclose(wp.grad.cpu().numpy(), w.grad.numpy(), atol=TOL * scale, rtol=1e-4)
+    assert (np.abs(dw) > TOL * scale).mean() < 1e-2, "weight gradient differs beyond what a ReLU flip or two explain"
+    assert float(np.linalg.norm(dw) / w.grad.norm()) < 5e-3
