@@ -67,6 +67,61 @@ __global__ __launch_bounds__(256) void vq_inds_kernel(const float* __restrict__ 
   }
 }
 
+// Register-blocked form for Dc in {32, 64, 128} and K <= 64: lane k keeps ITS code row E[k][:] in registers (the generic
+// kernel re-reads it from LDS for every latent row: two LDS reads per multiply-add), the latent row is broadcast from LDS
+// four elements at a time.  Same arithmetic and summation order per (row, code) as the generic kernel.
+template <int DC>
+__global__ __launch_bounds__(256) void vq_inds_reg_kernel(const float* __restrict__ lat, const float* __restrict__ cb,
+                                                          long long* __restrict__ inds, int P, int D, int K, int C, int HW,
+                                                          int rows_per_block) {
+  __shared__ __attribute__((aligned(16))) float sX[4][DC];
+  const int cbi = blockIdx.y;
+  const float* E = cb + (size_t)cbi * K * DC;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float e[DC];
+  float ee = 0.f;
+  {
+    const float* row = E + (size_t)(lane < K ? lane : 0) * DC;
+#pragma unroll
+    for (int d = 0; d < DC; ++d) e[d] = row[d];          // (codebooks sit at 4-byte-aligned offsets of the flat buffer)
+#pragma unroll
+    for (int d = 0; d < DC; ++d) ee += e[d] * e[d];
+  }
+  float* myX = sX[wave];
+  const int r0 = blockIdx.x * rows_per_block;
+  int r1 = r0 + rows_per_block;
+  if (r1 > P) r1 = P;
+  for (int p = r0 + wave; p < r1; p += 4) {
+    const float* x = lat + (size_t)p * D + cbi;      // slice offset i, not i*Dc (reference quirk)
+    for (int d = lane; d < DC; d += 64) myX[d] = x[d];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float xx = 0.f, dot = 0.f;
+#pragma unroll
+    for (int d4 = 0; d4 < DC; d4 += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(myX + d4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xx += v[u] * v[u];
+        dot += v[u] * e[d4 + u];
+      }
+    }
+    float best = lane < K ? (xx + ee) - 2.f * dot : 3.4e38f;
+    int bestk = lane < K ? lane : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      float ob = __shfl_xor(best, o, 64);
+      int ok = __shfl_xor(bestk, o, 64);
+      if (ob < best || (ob == best && ok < bestk)) { best = ob; bestk = ok; }
+    }
+    if (lane == 0) {
+      int b = p / HW, hw = p - b * HW;
+      inds[((size_t)b * C + cbi) * HW + hw] = (long long)bestk;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // out[p][i*Dc+d] = x + (E_i[idx][d] - x),  x = lat[p][i+d];  part[blk][i] = sum (q-x)^2
 __global__ __launch_bounds__(256) void vq_lookup_kernel(const float* __restrict__ lat, const float* __restrict__ cb,
                                                         const long long* __restrict__ inds, float* __restrict__ out,
@@ -274,6 +329,18 @@ int launch_vq_inds(const float* lat, const float* cb, long long* inds, int B, in
     attr_set = true;
   }
   ProfScope ps("vq_inds_kernel", st, 2.0 * (double)P * K * D, 4.0 * (double)P * D + 8.0 * (double)P * C);
+  if (K <= 64 && (Dc == 32 || Dc == 64 || Dc == 128)) {
+    // more, smaller row blocks: nothing is staged per workgroup any more
+    int nb = ceil_div(P, 16);
+    if (nb > 2048) nb = 2048;
+    const int rp = ceil_div(P, nb);
+    nb = ceil_div(P, rp);
+    if (Dc == 32) hipLaunchKernelGGL(vq_inds_reg_kernel<32>, dim3(nb, C), dim3(256), 0, st, lat, cb, inds, P, D, K, C, HW, rp);
+    else if (Dc == 64) hipLaunchKernelGGL(vq_inds_reg_kernel<64>, dim3(nb, C), dim3(256), 0, st, lat, cb, inds, P, D, K, C, HW, rp);
+    else hipLaunchKernelGGL(vq_inds_reg_kernel<128>, dim3(nb, C), dim3(256), 0, st, lat, cb, inds, P, D, K, C, HW, rp);
+    CTVAE_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(vq_inds_kernel, dim3(blocks, C), dim3(256), smem, st, lat, cb, inds, P, D, K, Dc, C, HW, rpb);
   CTVAE_LAUNCH_CHECK();
   return 0;
