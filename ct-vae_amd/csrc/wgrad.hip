@@ -562,21 +562,23 @@ int launch_img_enc_wgrad(const ConvGeom& g, const float* X, const float* dY, flo
 
 bool wino_wgrad_supported(const ConvGeom& g, size_t ws_floats, int* splits);
 int launch_wino_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, size_t ws_floats, int* nparts,
-                      hipStream_t st);
+                      bool want_bias, float** pbias_out, hipStream_t st);
 
 bool wino_enabled();
 
 int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, float* dbias, float* ws,
                  size_t ws_bytes, int accumulate, hipStream_t st, const InXform* xf, const DyXform* dyx) {
-  // bias-free 3x3 / stride 1 / same-padding layers: Winograd F(3x3,2x2), see wino.hip
-  if (dbias == nullptr && (xf == nullptr || xf->scale == nullptr) && (dyx == nullptr || dyx->y == nullptr) &&
-      wino_enabled() && wino_wgrad_supported(g, ws_bytes / sizeof(float), nullptr)) {
+  // 3x3 / stride 1 / same-padding layers: Winograd F(3x3,2x2), see wino.hip
+  if ((xf == nullptr || xf->scale == nullptr) && (dyx == nullptr || dyx->y == nullptr) && wino_enabled() &&
+      wino_wgrad_supported(g, ws_bytes / sizeof(float), nullptr)) {
     int np = 0;
-    int rc = launch_wino_wgrad(g, X, dY, ws, ws_bytes / sizeof(float), &np, st);
+    float* pb = nullptr;
+    int rc = launch_wino_wgrad(g, X, dY, ws, ws_bytes / sizeof(float), &np, dbias != nullptr, &pb, st);
     if (rc) return rc;
     const long n = 9L * g.gC * g.sC;
     ProfScope ps("reduce_partials_kernel", st, 0.0, 4.0 * (double)(np + 1) * n);
-    launch_reduce(ws, dW, n, np, n, accumulate, st);
+    if (dbias) launch_reduce2(ws, dW, n, np, n, pb, dbias, (long)g.sC, np, (long)g.sC, accumulate, st);
+    else launch_reduce(ws, dW, n, np, n, accumulate, st);
     CTVAE_LAUNCH_CHECK();
     return 0;
   }

@@ -661,6 +661,7 @@ struct WinoWgArgs {
   const float* X;      // [B][H][W][Ci]
   const float* dY;     // [B][H][W][Co]
   float* part;         // [S][9][Ci][Co]
+  float* pbias;        // [S][Co] or null: sum of dY over this slice's pixels (written by the ci-block-0 workgroups)
   int B, H, W, Ci, Co;
   int cy_n, cx_n;      // chunks per image: (H/4, W/8)
   int nchunks, chunks_per_split;
@@ -755,9 +756,13 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
     *reinterpret_cast<f32x4*>(dst + 2 * FB) = v2;
     *reinterpret_cast<f32x4*>(dst + 3 * FB) = v3;
   };
+  float bsum = 0.f;     // dY role: running sum of this thread's (channel, tile row) pixels = its share of the bias gradient
   auto rd_y = [&](int tx) {
 #pragma unroll
-    for (int pos = 0; pos < 4; ++pos) ey[tx][pos] = sRY[((tq * 4 + tx) * 4 + pos) * RSW + chn];
+    for (int pos = 0; pos < 4; ++pos) {
+      ey[tx][pos] = sRY[((tq * 4 + tx) * 4 + pos) * RSW + chn];
+      bsum += ey[tx][pos];
+    }
   };
   auto st_vy = [&](float* sv, int i) {      // 2*G e (2G)^T without the factors: rows {e0, e0+e1, e0-e1, e1}, same for columns
     f32x4 v0, v1, v2, v3;
@@ -911,6 +916,13 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
   }
 #undef WINO_MFMA4
 #undef WINO_FENCE
+
+  if (a.pbias != nullptr && blockIdx.x == 0) {         // bias gradient: the two tile rows of a channel meet in LDS
+    __syncthreads();
+    if (wave == 3) sRY[chn] = bsum;
+    __syncthreads();
+    if (wave == 2) a.pbias[(long)split * Co + co0 + chn] = bsum + sRY[chn];
+  }
 
   // ---- epilogue: G's halves (rows/columns 1,2 of the dY transform), then dW[ky][kx] = A'^T Mw A',
   //      A'^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]] ----
@@ -1088,14 +1100,15 @@ bool wino_wgrad_supported(const ConvGeom& g, size_t ws_floats, int* splits) {
   if (S > nchunks / 8) S = nchunks / 8;             // at least 8 chunks per workgroup
   if (S < 1) return false;
   if ((long)S * out_tiles < 128) return false;
-  while (S > 1 && (size_t)S * 9 * g.gC * g.sC > ws_floats) --S;
-  if ((size_t)S * 9 * g.gC * g.sC > ws_floats) return false;
+  while (S > 1 && (size_t)S * (9 * g.gC + 1) * g.sC > ws_floats) --S;
+  if ((size_t)S * (9 * g.gC + 1) * g.sC > ws_floats) return false;
   if (splits != nullptr) *splits = S;
   return true;
 }
 
+// slabs at ws [nparts][9][Ci][Co]; with want_bias the dY sums follow at *pbias_out [nparts][Co]
 int launch_wino_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, size_t ws_floats, int* nparts,
-                      hipStream_t st) {
+                      bool want_bias, float** pbias_out, hipStream_t st) {
   int S = 0;
   if (!wino_wgrad_supported(g, ws_floats, &S)) return kErrBadArg;
   WinoWgArgs a{};
@@ -1106,6 +1119,8 @@ int launch_wino_wgrad(const ConvGeom& g, const float* X, const float* dY, float*
   a.chunks_per_split = ceil_div(a.nchunks, S);
   S = ceil_div(a.nchunks, a.chunks_per_split);
   *nparts = S;
+  a.pbias = want_bias ? ws + (size_t)S * 9 * a.Ci * a.Co : nullptr;
+  if (pbias_out != nullptr) *pbias_out = a.pbias;
   char name[128];
   snprintf(name, sizeof name, "wino_wgrad_kernel");
   if (prof_detailed()) snprintf(name, sizeof name, "wino_wgrad_kernel B=%d %dx%d Ci=%d Co=%d S=%d", g.B, g.gH, g.gW, a.Ci, a.Co, S);

@@ -193,7 +193,7 @@ int ctvae_adam_step(float* params, const float* grads, float* exp_avg, float* ex
                     float grad_scale, void* stream);
 
 /* 3x3 / stride-1 / pad-1 layers with at least 64 channels run Winograd F(2x2,3x3) (forward, data gradient) and
- * F(3x3,2x2) (weight gradient of bias-free layers) instead of the direct tap-GEMM (csrc/wino.hip): 2.25x fewer MFMA
+ * F(3x3,2x2) (weight and bias gradient) instead of the direct tap-GEMM (csrc/wino.hip): 2.25x fewer MFMA
  * operations, results within a few 1e-6 of the direct kernels.  This switch (default on; environment
  * CTVAE_NO_WINOGRAD=1 turns it off) selects the direct kernels for A/B parity checks.  Returns the previous setting. */
 int ctvae_winograd_enable(int on);
