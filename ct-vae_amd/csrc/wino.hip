@@ -803,6 +803,10 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
   int c_end = c_begin + a.chunks_per_split;
   if (c_end > a.nchunks) c_end = a.nchunks;
   const int n = c_end - c_begin;             // >= 1 by construction of the grid
+#ifdef CTVAE_PHASE_TIMING
+  long long tq_[6];
+  tq_[0] = clock64();
+#endif
 
   // prologue: chunk 0 -> buffer 0, chunk 1 -> registers
   int pix0, y0, x0;
@@ -838,6 +842,14 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
   }
   __syncthreads();
 
+#ifdef CTVAE_PHASE_TIMING
+  tq_[1] = clock64();
+  long long seg_[5] = {0, 0, 0, 0, 0};
+  long long tl_ = clock64();
+#define WSEG(i) do { const long long now_ = clock64(); seg_[i] += now_ - tl_; tl_ = now_; } while (0)
+#else
+#define WSEG(i) do {} while (0)
+#endif
   for (int cc = 0; cc + 1 < n; ++cc) {
     const int cur = cc & 1;
     const float* sxc = sVx + cur * BUF;
@@ -862,47 +874,47 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
     WINO_MFMA4(4); fa = na; fb = nb; WINO_FENCE();
     rd_frag(sxc, syc, 6);
     WINO_MFMA4(5); fa = na; fb = nb; WINO_FENCE();
+    WSEG(0);
     __syncthreads();                                 // raw pixels of chunk cc+1 are visible
-    if (wave < 2) {
-      rd_frag(sxc, syc, 7); rd_x(0); rd_x(1);
-      WINO_MFMA4(6); fa = na; fb = nb; WINO_FENCE();
-      rd_frag(sxc, syc, 8); rd_x(2); rd_x(3);
-      WINO_MFMA4(7); fa = na; fb = nb; WINO_FENCE();
-      rd_frag(sxc, syc, 9);
-      WINO_MFMA4(8); fa = na; fb = nb; WINO_FENCE();
-      rd_frag(sxc, syc, 10); tf_x_rows();
-      WINO_MFMA4(9); fa = na; fb = nb; WINO_FENCE();
-      rd_frag(sxc, syc, 11); st_vx(sxn, 0);
-      WINO_MFMA4(10); fa = na; fb = nb; WINO_FENCE();
-      rd_frag(sxc, syc, 12); st_vx(sxn, 1);
-      WINO_MFMA4(11); fa = na; fb = nb; WINO_FENCE();
-      rd_frag(sxc, syc, 13); st_vx(sxn, 2);
-      WINO_MFMA4(12); fa = na; fb = nb; WINO_FENCE();
-      rd_frag(sxc, syc, 14); st_vx(sxn, 3);
-      WINO_MFMA4(13); fa = na; fb = nb; WINO_FENCE();
-    } else {
-      rd_frag(sxc, syc, 7); rd_y(0); rd_y(1);
-      WINO_MFMA4(6); fa = na; fb = nb; WINO_FENCE();
-      rd_frag(sxc, syc, 8); rd_y(2); rd_y(3);
-      WINO_MFMA4(7); fa = na; fb = nb; WINO_FENCE();
-      rd_frag(sxc, syc, 9);
-      WINO_MFMA4(8); fa = na; fb = nb; WINO_FENCE();
-      rd_frag(sxc, syc, 10);
-      WINO_MFMA4(9); fa = na; fb = nb; WINO_FENCE();
-      rd_frag(sxc, syc, 11); st_vy(syn, 0);
-      WINO_MFMA4(10); fa = na; fb = nb; WINO_FENCE();
-      rd_frag(sxc, syc, 12); st_vy(syn, 1);
-      WINO_MFMA4(11); fa = na; fb = nb; WINO_FENCE();
-      rd_frag(sxc, syc, 13); st_vy(syn, 2);
-      WINO_MFMA4(12); fa = na; fb = nb; WINO_FENCE();
-      rd_frag(sxc, syc, 14); st_vy(syn, 3);
-      WINO_MFMA4(13); fa = na; fb = nb; WINO_FENCE();
-    }
+    WSEG(1);
+    // the MFMA groups stay in straight-line code: with the groups duplicated inside the two role branches the register
+    // allocator copied accumulator tiles between AGPRs/VGPRs at every join (~1000 v_accvgpr_* per chunk, measured
+    // 7600 cycles per chunk against 3700 for the MFMAs alone)
+    const bool xrole = wave < 2;
+    rd_frag(sxc, syc, 7);
+    if (xrole) { rd_x(0); rd_x(1); } else { rd_y(0); rd_y(1); }
+    WINO_MFMA4(6); fa = na; fb = nb; WINO_FENCE();
+    rd_frag(sxc, syc, 8);
+    if (xrole) { rd_x(2); rd_x(3); } else { rd_y(2); rd_y(3); }
+    WINO_MFMA4(7); fa = na; fb = nb; WINO_FENCE();
+    rd_frag(sxc, syc, 9);
+    WINO_MFMA4(8); fa = na; fb = nb; WINO_FENCE();
+    rd_frag(sxc, syc, 10);
+    if (xrole) tf_x_rows();
+    WINO_MFMA4(9); fa = na; fb = nb; WINO_FENCE();
+    rd_frag(sxc, syc, 11);
+    if (xrole) st_vx(sxn, 0); else st_vy(syn, 0);
+    WINO_MFMA4(10); fa = na; fb = nb; WINO_FENCE();
+    rd_frag(sxc, syc, 12);
+    if (xrole) st_vx(sxn, 1); else st_vy(syn, 1);
+    WINO_MFMA4(11); fa = na; fb = nb; WINO_FENCE();
+    rd_frag(sxc, syc, 13);
+    if (xrole) st_vx(sxn, 2); else st_vy(syn, 2);
+    WINO_MFMA4(12); fa = na; fb = nb; WINO_FENCE();
+    rd_frag(sxc, syc, 14);
+    if (xrole) st_vx(sxn, 3); else st_vy(syn, 3);
+    WINO_MFMA4(13); fa = na; fb = nb; WINO_FENCE();
+    WSEG(2);
     rd_frag(sxc, syc, 15);
     WINO_MFMA4(14); fa = na; fb = nb; WINO_FENCE();
     WINO_MFMA4(15); WINO_FENCE();
+    WSEG(3);
     __syncthreads();                                 // V of chunk cc+1 complete, chunk cc's buffers free
+    WSEG(4);
   }
+#ifdef CTVAE_PHASE_TIMING
+  tq_[2] = clock64();
+#endif
   {                                                  // last chunk: MFMA only
     const int cur = (n - 1) & 1;
     const float* sxc = sVx + cur * BUF;
@@ -917,6 +929,9 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
 #undef WINO_MFMA4
 #undef WINO_FENCE
 
+#ifdef CTVAE_PHASE_TIMING
+  tq_[3] = clock64();
+#endif
   if (a.pbias != nullptr && blockIdx.x == 0) {         // bias gradient: the two tile rows of a channel meet in LDS
     __syncthreads();
     if (wave == 3) sRY[chn] = bsum;
@@ -954,6 +969,17 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
       dst[2L * Ci * Co] = t[i][1] + t[i][2] - t[i][3];
     }
   }
+#ifdef CTVAE_PHASE_TIMING
+  __builtin_amdgcn_s_waitcnt(0);
+  tq_[4] = clock64();
+  if (lane == 0) {
+    const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (wg < 256) {
+      for (int i = 0; i < 5; ++i) g_wino_phase[(wg * 4 + wave) * 8 + i] = tq_[i] - tq_[0];
+      for (int i = 0; i < 5; ++i) g_wino_phase[8 * 1024 + (wg * 4 + wave) * 8 + i] = seg_[i];
+    }
+  }
+#endif
 }
 
 // 3x3, stride 1, "same" padding, one class: effective tap table (ky' = dy + 1, kx' = dx + 1) or false
