@@ -685,14 +685,15 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
 
   // raw-load items.  X: e = tid + 256*i (i < 4) -> pixel p = e>>4 (py = p/10, px = p%10), float4 e&15; p < 60
   //                  dY: e = tid + 256*i (i < 2) -> pixel p = e>>4 = tile*4 + pos, float4 e&15
-  int x_py[4], x_px[4];
+  // halo flags of an item: 1 row above the chunk, 2 row below, 4 column left, 8 column right, 16 not a pixel of the block.
+  // A chunk at the image border turns the matching flags into "outside": no per-chunk coordinate arithmetic per item.
+  int x_flag[4];
   unsigned x_rel[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int e = tid + 256 * i, p = e >> 4;
-    x_py[i] = p < WG_XPIX ? p / 10 - 1 : -100000;          // relative to the chunk's first output row / column
-    x_px[i] = p % 10 - 1;
-    x_rel[i] = (unsigned)(((p / 10 - 1) * W + (p % 10 - 1)) * Ci + ci0 + 4 * (e & 15)) * 4u;
+    const int e = tid + 256 * i, p = e >> 4, py = p / 10 - 1, px = p % 10 - 1;
+    x_flag[i] = (py == -1 ? 1 : 0) | (py == 4 ? 2 : 0) | (px == -1 ? 4 : 0) | (px == 8 ? 8 : 0) | (p < WG_XPIX ? 0 : 16);
+    x_rel[i] = (unsigned)((py * W + px) * Ci + ci0 + 4 * (e & 15)) * 4u;
   }
   unsigned y_rel[2];
 #pragma unroll
@@ -702,18 +703,28 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
     y_rel[i] = (unsigned)((y * W + x) * Co + co0 + 4 * (e & 15)) * 4u;
   }
   f32x4 rx[4], ry[2];
-  auto chunk_origin = [&](int c, int& pix0, int& y0, int& x0) {     // first output pixel of chunk c
+  // position of the next chunk to load (uniform): image lb, chunk row lcy, chunk column lcx; stepped, never divided
+  int lb, lcy, lcx;
+  {
     const int per = a.cy_n * a.cx_n;
-    const int b = c / per, r = c - b * per;
-    y0 = (r / a.cx_n) * 4;
-    x0 = (r - (r / a.cx_n) * a.cx_n) * 8;
-    pix0 = (b * H + y0) * W + x0;
+    const int c = split * a.chunks_per_split;
+    lb = c / per;
+    const int r = c - lb * per;
+    lcy = r / a.cx_n;
+    lcx = r - lcy * a.cx_n;
+  }
+  int pix0 = 0, cflag = 16;                          // first output pixel of that chunk, its border flags (| 16)
+  auto chunk_here = [&](bool live) {
+    pix0 = (lb * H + 4 * lcy) * W + 8 * lcx;
+    cflag = live ? ((lcy == 0 ? 1 : 0) | (lcy == a.cy_n - 1 ? 2 : 0) | (lcx == 0 ? 4 : 0) | (lcx == a.cx_n - 1 ? 8 : 0) | 16) : 31;
   };
-  auto ld_x = [&](int pix0, int y0, int x0, bool live, int i) {
-    const bool ok = live && (unsigned)(y0 + x_py[i]) < (unsigned)H && (unsigned)(x0 + x_px[i]) < (unsigned)W;
-    rx[i] = wld4(rX, ok ? (unsigned)pix0 * (unsigned)Ci * 4u + x_rel[i] : kOOBw);
+  auto chunk_step = [&]() {
+    if (++lcx == a.cx_n) { lcx = 0; if (++lcy == a.cy_n) { lcy = 0; ++lb; } }
   };
-  auto ld_y = [&](int pix0, bool live, int i) { ry[i] = wld4(rY, live ? (unsigned)pix0 * (unsigned)Co * 4u + y_rel[i] : kOOBw); };
+  auto ld_x = [&](int i) {
+    rx[i] = wld4(rX, (x_flag[i] & cflag) ? kOOBw : (unsigned)pix0 * (unsigned)Ci * 4u + x_rel[i]);
+  };
+  auto ld_y = [&](bool live, int i) { ry[i] = wld4(rY, live ? (unsigned)pix0 * (unsigned)Co * 4u + y_rel[i] : kOOBw); };
   auto st_x = [&](int i) {       // item 3 of the upper threads lies beyond pixel 59: zeros into the unused rows 60..63
     const int e = tid + 256 * i;
     *reinterpret_cast<f32x4*>(sRX + (e >> 4) * RSW + 4 * (e & 15)) = rx[i];
@@ -809,12 +820,11 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
 #endif
 
   // prologue: chunk 0 -> buffer 0, chunk 1 -> registers
-  int pix0, y0, x0;
-  chunk_origin(c_begin, pix0, y0, x0);
+  chunk_here(true);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) ld_x(pix0, y0, x0, true, i);
+  for (int i = 0; i < 4; ++i) ld_x(i);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) ld_y(pix0, true, i);
+  for (int i = 0; i < 2; ++i) ld_y(true, i);
 #pragma unroll
   for (int i = 0; i < 4; ++i) st_x(i);
 #pragma unroll
@@ -822,11 +832,12 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
   __syncthreads();
   {
     const bool live = n > 1;
-    chunk_origin(live ? c_begin + 1 : c_begin, pix0, y0, x0);
+    chunk_step();
+    chunk_here(live);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ld_x(pix0, y0, x0, live, i);
+    for (int i = 0; i < 4; ++i) ld_x(i);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) ld_y(pix0, live, i);
+    for (int i = 0; i < 2; ++i) ld_y(live, i);
   }
   if (wave < 2) {
 #pragma unroll
@@ -857,20 +868,21 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
     float* sxn = sVx + (cur ^ 1) * BUF;
     float* syn = sVy + (cur ^ 1) * BUF;
     const bool live = cc + 2 < n;                                   // is there a chunk two ahead?
-    chunk_origin(live ? c_begin + cc + 2 : c_begin, pix0, y0, x0);
     rd_frag(sxc, syc, 0);
+    chunk_step();
+    chunk_here(live);
     fa = na; fb = nb;
     WINO_FENCE();
     // steps 0..3: registers (chunk cc+1) -> raw LDS, then refill them with chunk cc+2
     rd_frag(sxc, syc, 1); st_x(0); st_x(1);
     WINO_MFMA4(0); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(sxc, syc, 2); st_x(2); st_x(3); ld_x(pix0, y0, x0, live, 0);
+    rd_frag(sxc, syc, 2); st_x(2); st_x(3); ld_x(0);
     WINO_MFMA4(1); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(sxc, syc, 3); st_y(0); st_y(1); ld_x(pix0, y0, x0, live, 1);
+    rd_frag(sxc, syc, 3); st_y(0); st_y(1); ld_x(1);
     WINO_MFMA4(2); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(sxc, syc, 4); ld_x(pix0, y0, x0, live, 2); ld_x(pix0, y0, x0, live, 3);
+    rd_frag(sxc, syc, 4); ld_x(2); ld_x(3);
     WINO_MFMA4(3); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(sxc, syc, 5); ld_y(pix0, live, 0); ld_y(pix0, live, 1);
+    rd_frag(sxc, syc, 5); ld_y(live, 0); ld_y(live, 1);
     WINO_MFMA4(4); fa = na; fb = nb; WINO_FENCE();
     rd_frag(sxc, syc, 6);
     WINO_MFMA4(5); fa = na; fb = nb; WINO_FENCE();
