@@ -718,8 +718,14 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
     pix0 = (lb * H + 4 * lcy) * W + 8 * lcx;
     cflag = live ? ((lcy == 0 ? 1 : 0) | (lcy == a.cy_n - 1 ? 2 : 0) | (lcx == 0 ? 4 : 0) | (lcx == a.cx_n - 1 ? 8 : 0) | 16) : 31;
   };
-  auto chunk_step = [&]() {
-    if (++lcx == a.cx_n) { lcx = 0; if (++lcy == a.cy_n) { lcy = 0; ++lb; } }
+  auto chunk_step = [&]() {                          // branch-free (selects): no control flow inside the MFMA loop
+    const int nx = lcx + 1;
+    const bool wx = nx == a.cx_n;
+    lcx = wx ? 0 : nx;
+    const int ny = lcy + (wx ? 1 : 0);
+    const bool wy = ny == a.cy_n;
+    lcy = wy ? 0 : ny;
+    lb += wy ? 1 : 0;
   };
   auto ld_x = [&](int i) {
     rx[i] = wld4(rX, (x_flag[i] & cflag) ? kOOBw : (unsigned)pix0 * (unsigned)Ci * 4u + x_rel[i]);
@@ -734,51 +740,53 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
     *reinterpret_cast<f32x4*>(sRY + (e >> 4) * RSW + 4 * (e & 15)) = ry[i];
   };
 
-  // transform roles: waves 0,1 -> X, waves 2,3 -> dY; thread = (channel chn, tile row tq)
-  const int chn = tid & 63, tq = (tid >> 6) & 1;
-  const int v_st = chn * 8 + ((tq ^ ((chn >> 3) & 1)) << 2);
+  // transform roles: EVERY thread = (channel chn, tile row tq, tile half th) and does the same work: the two tiles
+  // 2th, 2th+1 of the X strip (columns 4th .. 4th+5) and the same two tiles of dY.  (Role branches -- some waves X,
+  // others dY -- cost ~150 register moves per chunk at the joins, and left the X waves with twice the VALU work.)
+  const int chn = tid & 63, tq = (tid >> 6) & 1, th = tid >> 7;
+  const int v_st = chn * 8 + ((tq ^ ((chn >> 3) & 1)) << 2) + 2 * th;
   const int ma = wm * 32 + li, nbr = wn * 32 + li;
   const int a_rd = ma * 8 + ((lh ^ ((ma >> 3) & 1)) << 2);
   const int b_rd = nbr * 8 + ((lh ^ ((nbr >> 3) & 1)) << 2);
 
-  float sx[4][10];      // X role: strip rows 2tq..2tq+3, all 10 columns; afterwards the row-transformed strip
-  float ey[4][4];       // dY role: [tile][pos]
+  float sx[4][6];       // strip rows 2tq..2tq+3, columns 4th..4th+5; afterwards the row-transformed strip
+  float ey[2][4];       // dY [tile][pos]
   auto rd_x = [&](int r) {
 #pragma unroll
-    for (int x = 0; x < 10; ++x) sx[r][x] = sRX[((2 * tq + r) * 10 + x) * RSW + chn];
+    for (int x = 0; x < 6; ++x) sx[r][x] = sRX[((2 * tq + r) * 10 + 4 * th + x) * RSW + chn];
   };
   auto tf_x_rows = [&]() {
 #pragma unroll
-    for (int x = 0; x < 10; ++x) {
+    for (int x = 0; x < 6; ++x) {
       const float d0 = sx[0][x], d1 = sx[1][x], d2 = sx[2][x], d3 = sx[3][x];
       sx[0][x] = d0 - d2; sx[1][x] = d1 + d2; sx[2][x] = d2 - d1; sx[3][x] = d1 - d3;
     }
   };
-  auto st_vx = [&](float* sv, int i) {      // frequencies 4i .. 4i+3, four tiles each
-    f32x4 v0, v1, v2, v3;
+  auto st_vx = [&](float* sv, int i) {      // frequencies 4i .. 4i+3, two tiles each
+    f32x2 v0, v1, v2, v3;
 #pragma unroll
-    for (int tx = 0; tx < 4; ++tx) {
+    for (int tx = 0; tx < 2; ++tx) {
       const float t0 = sx[i][2 * tx], t1 = sx[i][2 * tx + 1], t2 = sx[i][2 * tx + 2], t3 = sx[i][2 * tx + 3];
       v0[tx] = t0 - t2; v1[tx] = t1 + t2; v2[tx] = t2 - t1; v3[tx] = t1 - t3;
     }
     float* dst = sv + (4 * i) * FB + v_st;
-    *reinterpret_cast<f32x4*>(dst) = v0;
-    *reinterpret_cast<f32x4*>(dst + FB) = v1;
-    *reinterpret_cast<f32x4*>(dst + 2 * FB) = v2;
-    *reinterpret_cast<f32x4*>(dst + 3 * FB) = v3;
+    *reinterpret_cast<f32x2*>(dst) = v0;
+    *reinterpret_cast<f32x2*>(dst + FB) = v1;
+    *reinterpret_cast<f32x2*>(dst + 2 * FB) = v2;
+    *reinterpret_cast<f32x2*>(dst + 3 * FB) = v3;
   };
-  float bsum = 0.f;     // dY role: running sum of this thread's (channel, tile row) pixels = its share of the bias gradient
+  float bsum = 0.f;     // running sum of this thread's dY pixels = its share of the bias gradient
   auto rd_y = [&](int tx) {
 #pragma unroll
     for (int pos = 0; pos < 4; ++pos) {
-      ey[tx][pos] = sRY[((tq * 4 + tx) * 4 + pos) * RSW + chn];
+      ey[tx][pos] = sRY[((tq * 4 + 2 * th + tx) * 4 + pos) * RSW + chn];
       bsum += ey[tx][pos];
     }
   };
   auto st_vy = [&](float* sv, int i) {      // 2*G e (2G)^T without the factors: rows {e0, e0+e1, e0-e1, e1}, same for columns
-    f32x4 v0, v1, v2, v3;
+    f32x2 v0, v1, v2, v3;
 #pragma unroll
-    for (int tx = 0; tx < 4; ++tx) {
+    for (int tx = 0; tx < 2; ++tx) {
       const float e00 = ey[tx][0], e01 = ey[tx][1], e10 = ey[tx][2], e11 = ey[tx][3];
       float r0, r1;
       if (i == 0) { r0 = e00; r1 = e01; }
@@ -788,10 +796,10 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
       v0[tx] = r0; v1[tx] = r0 + r1; v2[tx] = r0 - r1; v3[tx] = r1;
     }
     float* dst = sv + (4 * i) * FB + v_st;
-    *reinterpret_cast<f32x4*>(dst) = v0;
-    *reinterpret_cast<f32x4*>(dst + FB) = v1;
-    *reinterpret_cast<f32x4*>(dst + 2 * FB) = v2;
-    *reinterpret_cast<f32x4*>(dst + 3 * FB) = v3;
+    *reinterpret_cast<f32x2*>(dst) = v0;
+    *reinterpret_cast<f32x2*>(dst + FB) = v1;
+    *reinterpret_cast<f32x2*>(dst + 2 * FB) = v2;
+    *reinterpret_cast<f32x2*>(dst + 3 * FB) = v3;
   };
 
   f32x16 acc[16];
@@ -839,18 +847,12 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) ld_y(live, i);
   }
-  if (wave < 2) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) rd_x(r);
-    tf_x_rows();
+  for (int r = 0; r < 4; ++r) rd_x(r);
+  rd_y(0); rd_y(1);
+  tf_x_rows();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) st_vx(sVx, i);
-  } else {
-#pragma unroll
-    for (int tx = 0; tx < 4; ++tx) rd_y(tx);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) st_vy(sVy, i);
-  }
+  for (int i = 0; i < 4; ++i) { st_vx(sVx, i); st_vy(sVy, i); }
   __syncthreads();
 
 #ifdef CTVAE_PHASE_TIMING
@@ -889,32 +891,21 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
     WSEG(0);
     __syncthreads();                                 // raw pixels of chunk cc+1 are visible
     WSEG(1);
-    // the MFMA groups stay in straight-line code: with the groups duplicated inside the two role branches the register
-    // allocator copied accumulator tiles between AGPRs/VGPRs at every join (~1000 v_accvgpr_* per chunk, measured
-    // 7600 cycles per chunk against 3700 for the MFMAs alone)
-    const bool xrole = wave < 2;
-    rd_frag(sxc, syc, 7);
-    if (xrole) { rd_x(0); rd_x(1); } else { rd_y(0); rd_y(1); }
+    rd_frag(sxc, syc, 7); rd_x(0); rd_x(1);
     WINO_MFMA4(6); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(sxc, syc, 8);
-    if (xrole) { rd_x(2); rd_x(3); } else { rd_y(2); rd_y(3); }
+    rd_frag(sxc, syc, 8); rd_x(2); rd_x(3);
     WINO_MFMA4(7); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(sxc, syc, 9);
+    rd_frag(sxc, syc, 9); rd_y(0); rd_y(1);
     WINO_MFMA4(8); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(sxc, syc, 10);
-    if (xrole) tf_x_rows();
+    rd_frag(sxc, syc, 10); tf_x_rows();
     WINO_MFMA4(9); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(sxc, syc, 11);
-    if (xrole) st_vx(sxn, 0); else st_vy(syn, 0);
+    rd_frag(sxc, syc, 11); st_vx(sxn, 0); st_vy(syn, 0);
     WINO_MFMA4(10); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(sxc, syc, 12);
-    if (xrole) st_vx(sxn, 1); else st_vy(syn, 1);
+    rd_frag(sxc, syc, 12); st_vx(sxn, 1); st_vy(syn, 1);
     WINO_MFMA4(11); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(sxc, syc, 13);
-    if (xrole) st_vx(sxn, 2); else st_vy(syn, 2);
+    rd_frag(sxc, syc, 13); st_vx(sxn, 2); st_vy(syn, 2);
     WINO_MFMA4(12); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(sxc, syc, 14);
-    if (xrole) st_vx(sxn, 3); else st_vy(syn, 3);
+    rd_frag(sxc, syc, 14); st_vx(sxn, 3); st_vy(syn, 3);
     WINO_MFMA4(13); fa = na; fb = nb; WINO_FENCE();
     WSEG(2);
     rd_frag(sxc, syc, 15);
@@ -946,9 +937,9 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
 #endif
   if (a.pbias != nullptr && blockIdx.x == 0) {         // bias gradient: the two tile rows of a channel meet in LDS
     __syncthreads();
-    if (wave == 3) sRY[chn] = bsum;
+    if (wave > 0) sRY[(wave - 1) * 64 + chn] = bsum;            // the four (tile row, tile half) shares of a channel
     __syncthreads();
-    if (wave == 2) a.pbias[(long)split * Co + co0 + chn] = bsum + sRY[chn];
+    if (wave == 0) a.pbias[(long)split * Co + co0 + chn] = ((bsum + sRY[chn]) + sRY[64 + chn]) + sRY[128 + chn];
   }
 
   // ---- epilogue: G's halves (rows/columns 1,2 of the dY transform), then dW[ky][kx] = A'^T Mw A',
