@@ -21,13 +21,13 @@ namespace {
 constexpr int PMAX = 17;    // (r,c) pairs per thread: N*N <= 17*256 -> N <= 65 (64 latent nodes + the action node)
 constexpr int NB = 68;      // backward: rows padded to a multiple of 4 (b128 broadcast reads)
 
-template <int MODE>
+template <int MODE, int NPC>   // NPC: compile-time row length N|1 (65 for the model's 64 + 1 nodes) or 0 = runtime
 __global__ __launch_bounds__(256) void gat_score_kernel(const float* __restrict__ xl, const float* __restrict__ xr,
                                                        const float* __restrict__ attr, const float* __restrict__ we,
                                                        const float* __restrict__ att, float* __restrict__ out, int N, int H,
                                                        int C, float slope) {
   extern __shared__ float smem[];
-  const int NP = N | 1;                 // odd row length: conflict-free for consecutive c, broadcast for equal r
+  const int NP = NPC ? NPC : (N | 1);   // odd row length: conflict-free for consecutive c, broadcast for equal r
   float* sL = smem;                     // [C][NP]
   float* sR = smem + C * NP;            // [C][NP]
   float* sWe = sR + C * NP;             // [C]
@@ -43,34 +43,56 @@ __global__ __launch_bounds__(256) void gat_score_kernel(const float* __restrict_
     sWe[k] = we[h * C + k];
     sAt[k] = att[h * C + k];
   }
-  int rr[PMAX], cc[PMAX];
-  float at[PMAX], acc[PMAX];
+  // pairs are processed two at a time in packed f32x2 registers (v_pk_add/fma/mul_f32: two lanes of arithmetic per
+  // instruction; only the max has no packed form) -- this loop is pure VALU work
+  constexpr int PH = (PMAX + 1) / 2;
+  int rr[2 * PH], cc[2 * PH];
+  f32x2 at[PH], acc[PH];
 #pragma unroll
-  for (int q = 0; q < PMAX; ++q) {
+  for (int q = 0; q < 2 * PH; ++q) {
     const int p = tid + 256 * q;
-    const bool ok = p < N * N;
+    const bool ok = q < PMAX && p < N * N;
     const int r = ok ? p / N : 0, c = ok ? p - r * N : 0;
     rr[q] = r;
     cc[q] = c;
-    at[q] = ok ? attr[((long)b * N + r) * N + c] : 0.f;
-    acc[q] = 0.f;
+    at[q >> 1][q & 1] = ok ? attr[((long)b * N + r) * N + c] : 0.f;
+    acc[q >> 1][q & 1] = 0.f;
   }
   __syncthreads();
-  for (int k = 0; k < C; ++k) {
-    const float wk = sWe[k], ak = sAt[k];
-    const float* l = sL + k * NP;
-    const float* r_ = sR + k * NP;
+  // per-pair LDS addresses advance by one row (NP floats) per k: kept in registers and bumped once per 4 k (the row
+  // stride of the 4 unrolled steps is an immediate offset when N = 65, the model's 64 latent nodes + 1 action node)
+  for (int k0 = 0; k0 < C; k0 += 4) {
 #pragma unroll
-    for (int q = 0; q < PMAX; ++q) {
-      const float m = l[rr[q]] + r_[cc[q]] + at[q] * wk;
-      if (MODE == 0) acc[q] += ak * fmaxf(m, m * slope);   // slope < 1
-      else acc[q] += (ak * wk) * (m > 0.f ? 1.f : slope);
+   for (int kk = 0; kk < 4; ++kk) {
+    const int k = k0 + kk;
+    if (k < C) {
+    const float wk = sWe[k], ak = sAt[k];
+    const int ro = kk * NP;                       // an immediate LDS offset when NPC is given
+    const f32x2 wk2 = {wk, wk}, sl2 = {slope, slope};
+    const f32x2 ak2 = MODE == 0 ? f32x2{ak, ak} : f32x2{ak * wk, ak * wk};
+#pragma unroll
+    for (int h = 0; h < PH; ++h) {
+      const f32x2 lv = {sL[rr[2 * h] + ro], sL[rr[2 * h + 1] + ro]};
+      const f32x2 rv = {sR[cc[2 * h] + ro], sR[cc[2 * h + 1] + ro]};
+      const f32x2 m = (lv + rv) + at[h] * wk2;
+      if (MODE == 0) {
+        const f32x2 ms = m * sl2;
+        const f32x2 lr = {fmaxf(m[0], ms[0]), fmaxf(m[1], ms[1])};       // slope < 1
+        acc[h] += ak2 * lr;
+      } else {
+        const f32x2 d = {m[0] > 0.f ? 1.f : slope, m[1] > 0.f ? 1.f : slope};
+        acc[h] += ak2 * d;
+      }
     }
+    }
+   }
+#pragma unroll
+    for (int q = 0; q < 2 * PH; ++q) { rr[q] += 4 * NP; cc[q] += 4 * NP; }     // row index -> running LDS element index
   }
 #pragma unroll
   for (int q = 0; q < PMAX; ++q) {
     const int p = tid + 256 * q;
-    if (p < N * N) out[(((long)b * H + h) * N) * N + p] = acc[q];
+    if (p < N * N) out[(((long)b * H + h) * N) * N + p] = acc[q >> 1][q & 1];
   }
 }
 
@@ -155,14 +177,19 @@ int launch_gat_score(int mode, const float* xl, const float* xr, const float* at
   if (smem > 160 * 1024) return kErrBadArg;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_score_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_score_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_score_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_score_kernel<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_score_kernel<0, 65>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_score_kernel<1, 65>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   ProfScope ps(mode == 0 ? "gat_score_kernel<0>" : "gat_score_kernel<1>", st, 4.0 * B * H * (double)N * N * C,
                4.0 * B * H * (2.0 * N * C + (double)N * N));
-  if (mode == 0) hipLaunchKernelGGL(gat_score_kernel<0>, dim3(H, B), dim3(256), smem, st, xl, xr, attr, we, att, out, N, H, C, slope);
-  else hipLaunchKernelGGL(gat_score_kernel<1>, dim3(H, B), dim3(256), smem, st, xl, xr, attr, we, att, out, N, H, C, slope);
+  const bool n65 = (N | 1) == 65;
+  if (mode == 0 && n65) hipLaunchKernelGGL((gat_score_kernel<0, 65>), dim3(H, B), dim3(256), smem, st, xl, xr, attr, we, att, out, N, H, C, slope);
+  else if (mode == 0) hipLaunchKernelGGL((gat_score_kernel<0, 0>), dim3(H, B), dim3(256), smem, st, xl, xr, attr, we, att, out, N, H, C, slope);
+  else if (n65) hipLaunchKernelGGL((gat_score_kernel<1, 65>), dim3(H, B), dim3(256), smem, st, xl, xr, attr, we, att, out, N, H, C, slope);
+  else hipLaunchKernelGGL((gat_score_kernel<1, 0>), dim3(H, B), dim3(256), smem, st, xl, xr, attr, we, att, out, N, H, C, slope);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }

@@ -311,6 +311,14 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
 
   // main loop: all chunks but the last.  Loads run two chunks ahead; past the last chunk they fetch neighbouring
   // (in-bounds or zero-filled) data that is never stored.
+#ifdef CTVAE_PHASE_TIMING
+  long long cseg_[5] = {0, 0, 0, 0, 0};
+  long long ctl_ = clock64();
+  const long long cts_ = ctl_;
+#define CSEG(i) do { const long long now_ = clock64(); cseg_[i] += now_ - ctl_; ctl_ = now_; } while (0)
+#else
+#define CSEG(i) do {} while (0)
+#endif
   for (int c = 0; c + 1 < nchunks; ++c) {
     const int cur = c & 1;
     const float* svc = sV + cur * BUF;
@@ -344,7 +352,9 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
     // step 7
     rd_frag(svc, suc, 8);
     WINO_MFMA4(7); fa = na; fb = nb; WINO_FENCE();
+    CSEG(0);
     __syncthreads();                                 // raw pixels of chunk c+1 are visible
+    CSEG(1);
     // step 8
     rd_frag(svc, suc, 9); rd_patch(0); rd_patch(1);
     WINO_MFMA4(8); fa = na; fb = nb; WINO_FENCE();
@@ -366,8 +376,16 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
     WINO_MFMA4(14); fa = na; fb = nb; WINO_FENCE();
     tf_store(svn, 3);
     WINO_MFMA4(15); WINO_FENCE();
+    CSEG(2);
     __syncthreads();                                 // V/U of chunk c+1 complete, chunk c's buffers free
+    CSEG(3);
   }
+#ifdef CTVAE_PHASE_TIMING
+  if (lane == 0 && blockIdx.x < 256) {
+    cseg_[4] = clock64() - cts_;
+    for (int i = 0; i < 5; ++i) g_wino_phase[(blockIdx.x * 4 + wave) * 8 + i] = cseg_[i];
+  }
+#endif
   {                                                  // last chunk: MFMA only
     const int cur = (nchunks - 1) & 1;
     const float* svc = sV + cur * BUF;

@@ -27,8 +27,8 @@ torch.cuda.synchronize()
 buf = np.zeros(8 * 4096, dtype=np.int64)
 lib.ctvae_debug_wino_phase_read(buf.ctypes.data, buf.size)
 t = buf.reshape(-1, 8)[:1024]
-names = ["store raw+U", "issue global loads", "mfma f0-7", "barrier 1", "patch read + mfma f8-11", "transform + mfma f12-15",
-         "barrier 2", "whole loop"]
+names = ["steps 0-7 (8 MFMA groups + 13 LDS stores + 13 global loads)", "barrier 1",
+         "steps 8-15 (8 groups + patch reads + transform + V stores)", "barrier 2", "whole loop"]
 print(f"event-timed launches (weight transform + conv): {e0.elapsed_time(e1) * 1e3:.1f} us")
 for i, n in enumerate(names):
-    print(f"  {n:28s} mean {t[:, i].mean():10.0f} cycles  (min {t[:, i].min():8d} max {t[:, i].max():8d})   per chunk {t[:, i].mean() / 32:7.0f}")
+    print(f"  {n:62s} mean {t[:, i].mean():10.0f} cycles   per chunk {t[:, i].mean() / 31:7.0f}")
