@@ -122,45 +122,48 @@ __global__ __launch_bounds__(256, 2) void gat_score_bwd_kernel(const float* __re
     sG[c][r] = gv;
     sA[c][r] = av;
   }
-  float xlr[NH], dl[NH];
+  // sources are processed two at a time in packed f32x2 registers (NH = 34 is even): v_pk_add/mul/fma_f32
+  f32x2 xlr[NH / 2], dl[NH / 2];
 #pragma unroll
   for (int i = 0; i < NH; ++i) {
     const int r = r0 + i;
-    xlr[i] = (kok && r < N) ? xl[(((long)b * N + r) * H + h) * C + k] : 0.f;
-    dl[i] = 0.f;
+    xlr[i >> 1][i & 1] = (kok && r < N) ? xl[(((long)b * N + r) * H + h) * C + k] : 0.f;
+    dl[i >> 1][i & 1] = 0.f;
   }
   const float wk = kok ? we[h * C + k] : 0.f, ak = kok ? att[h * C + k] : 0.f;
-  float datt = 0.f, dwe = 0.f;
+  const f32x2 wk2 = {wk, wk}, ak2 = {ak, ak};
+  f32x2 datt2 = {0.f, 0.f}, dwe2 = {0.f, 0.f};
   __syncthreads();
+  float xr_next = kok ? xr[(((long)b * N) * H + h) * C + k] : 0.f;        // one target ahead: the load is off the chain
   for (int c = 0; c < N; ++c) {
-    const float xrc = kok ? xr[(((long)b * N + c) * H + h) * C + k] : 0.f;
-    float dr = 0.f;
+    const float xrc = xr_next;
+    if (c + 1 < N) xr_next = kok ? xr[(((long)b * N + c + 1) * H + h) * C + k] : 0.f;
+    const f32x2 xrc2 = {xrc, xrc};
+    f32x2 dr2 = {0.f, 0.f};
 #pragma unroll
-    for (int i2 = 0; i2 < NH; i2 += 2) {
-      const float2 g2 = *reinterpret_cast<const float2*>(&sG[c][r0 + i2]);   // two addresses per wave: broadcast reads
-      const float2 a2 = *reinterpret_cast<const float2*>(&sA[c][r0 + i2]);
-      const float gq[2] = {g2.x, g2.y}, aq[2] = {a2.x, a2.y};
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const float m = xlr[i2 + q] + xrc + aq[q] * wk;
-        const float sl = m > 0.f ? 1.f : slope;
-        const float gs = gq[q] * sl;        // g * lrelu'(m)
-        datt += gs * m;                     // g * lrelu(m)
-        const float gd = gs * ak;           // d m
-        dl[i2 + q] += gd;
-        dr += gd;
-        dwe += gd * aq[q];
-      }
+    for (int i2 = 0; i2 < NH / 2; ++i2) {
+      const f32x2 g2 = *reinterpret_cast<const f32x2*>(&sG[c][r0 + 2 * i2]);   // two addresses per wave: broadcast reads
+      const f32x2 a2 = *reinterpret_cast<const f32x2*>(&sA[c][r0 + 2 * i2]);
+      const f32x2 m = (xlr[i2] + xrc2) + a2 * wk2;
+      const f32x2 sl = {m[0] > 0.f ? 1.f : slope, m[1] > 0.f ? 1.f : slope};
+      const f32x2 gs = g2 * sl;            // g * lrelu'(m)
+      datt2 += gs * m;                     // g * lrelu(m)
+      const f32x2 gd = gs * ak2;           // d m
+      dl[i2] += gd;
+      dr2 += gd;
+      dwe2 += gd * a2;
     }
+    float dr = dr2[0] + dr2[1];
     dr += __shfl_xor(dr, 1, 64);
     if (kok && half == 0) dxr[(((long)b * N + c) * H + h) * C + k] = dr;
   }
+  float datt = datt2[0] + datt2[1], dwe = dwe2[0] + dwe2[1];
   datt += __shfl_xor(datt, 1, 64);
   dwe += __shfl_xor(dwe, 1, 64);
   if (kok) {
 #pragma unroll
     for (int i = 0; i < NH; ++i)
-      if (r0 + i < N) dxl[(((long)b * N + r0 + i) * H + h) * C + k] = dl[i];
+      if (r0 + i < N) dxl[(((long)b * N + r0 + i) * H + h) * C + k] = dl[i >> 1][i & 1];
     if (half == 0) {
       datt_part[((long)b * H + h) * C + k] = datt;
       dwe_part[((long)b * H + h) * C + k] = dwe;
