@@ -29,8 +29,8 @@ __global__ __launch_bounds__(256) void pair_mlp_fwd_kernel(const float* __restri
                                                           float* __restrict__ out, int N, int H, float slope, int w2_bs,
                                                           int b2_bs) {
   __shared__ float sV[HC][JT + 1];
-  __shared__ float sU[IT][HC];
-  __shared__ float sW[HC];
+  __shared__ __attribute__((aligned(8))) float sU[IT][HC];
+  __shared__ __attribute__((aligned(8))) float sW[HC];
   const int tid = threadIdx.x, j_l = tid & (JT - 1), i_l = tid / JT;
   const int b = blockIdx.y, i = blockIdx.x * IT + i_l;
   const float* ub = u + (long)b * N * H;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void pair_mlp_fwd_kernel(const float* __restri
   const float bias = b2 != nullptr ? b2[(long)b * b2_bs] : 0.f;
   w2 += (long)b * w2_bs;               // per-sample scorer (w2_bs = H) or one shared scorer (0)
   for (int j0 = 0; j0 < N; j0 += JT) {
-    float acc = 0.f;
+    f32x2 acc2 = {0.f, 0.f};
     for (int h0 = 0; h0 < H; h0 += HC) {
       __syncthreads();
       // stage v[b, j0:j0+64, h0:h0+32] transposed (reads coalesced along h), u rows and w2
@@ -55,12 +55,17 @@ __global__ __launch_bounds__(256) void pair_mlp_fwd_kernel(const float* __restri
       if (tid < HC) sW[tid] = (h0 + tid < H) ? w2[h0 + tid] : 0.f;   // zero weight masks the h tail
       __syncthreads();
 #pragma unroll
-      for (int hh = 0; hh < HC; ++hh) {
-        const float t = sU[i_l][hh] + sV[hh][j_l];
-        acc += sW[hh] * fmaxf(t, t * slope);
+      for (int hh = 0; hh < HC; hh += 2) {       // two h per step in packed f32x2 registers
+        const f32x2 uu = *reinterpret_cast<const f32x2*>(&sU[i_l][hh]);
+        const f32x2 ww = *reinterpret_cast<const f32x2*>(&sW[hh]);
+        const f32x2 vv = {sV[hh][j_l], sV[hh + 1][j_l]};
+        const f32x2 t = uu + vv;
+        const f32x2 ts = t * f32x2{slope, slope};
+        acc2 += ww * f32x2{fmaxf(t[0], ts[0]), fmaxf(t[1], ts[1])};
       }
     }
     const int j = j0 + j_l;
+    const float acc = acc2[0] + acc2[1];
     if (i < N && j < N) out[((long)b * N + i) * N + j] = 1.f / (1.f + __expf(-(acc + bias)));
   }
 }
@@ -90,36 +95,42 @@ __global__ __launch_bounds__(256) void pair_mlp_bwd_kernel(const float* __restri
   gsum = block_sum_256(gsum, sRed);   // contains the barrier that publishes sG
   if (tid == 0 && blockIdx.x == 0) db2_part[b] = gsum;
 
-  float ur[NMAX], du[NMAX];
+  // rows i are processed two at a time in packed f32x2 registers; v[b,j,h] is fetched one j ahead
+  f32x2 ur[NMAX / 2], du[NMAX / 2];
 #pragma unroll
   for (int i = 0; i < NMAX; ++i) {
-    ur[i] = (hok && i < N) ? u[bo + (long)i * H + h] : 0.f;
-    du[i] = 0.f;
+    ur[i >> 1][i & 1] = (hok && i < N) ? u[bo + (long)i * H + h] : 0.f;
+    du[i >> 1][i & 1] = 0.f;
   }
   const float wh = hok ? w2[(long)b * w2_bs + h] : 0.f;
-  float dw = 0.f;
+  f32x2 dw2 = {0.f, 0.f};
+  float v_next = hok ? v[bo + h] : 0.f;
   for (int j = 0; j < N; ++j) {
-    const float vj = hok ? v[bo + (long)j * H + h] : 0.f;
-    float dvj = 0.f;
+    const float vj = v_next;
+    if (j + 1 < N) v_next = hok ? v[bo + (long)(j + 1) * H + h] : 0.f;
+    const f32x2 vj2 = {vj, vj};
+    f32x2 dvj2 = {0.f, 0.f};
 #pragma unroll
     for (int i4 = 0; i4 < NMAX; i4 += 4) {
       const f32x4 g4 = *reinterpret_cast<const f32x4*>(&sG[j][i4]);   // same address in every lane: broadcast
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float t = ur[i4 + q] + vj;
-        const float sl = t > 0.f ? 1.f : slope;
-        const float gd = g4[q] * sl;
-        du[i4 + q] += gd;
-        dvj += gd;
-        dw += gd * t;                 // g * lrelu(t) = g * sl * t
+      for (int q = 0; q < 2; ++q) {
+        const f32x2 g2 = {g4[2 * q], g4[2 * q + 1]};
+        const f32x2 t = ur[(i4 >> 1) + q] + vj2;
+        const f32x2 sl = {t[0] > 0.f ? 1.f : slope, t[1] > 0.f ? 1.f : slope};
+        const f32x2 gd = g2 * sl;
+        du[(i4 >> 1) + q] += gd;
+        dvj2 += gd;
+        dw2 += gd * t;                // g * lrelu(t) = g * sl * t
       }
     }
-    if (hok) dV[bo + (long)j * H + h] = wh * dvj;
+    if (hok) dV[bo + (long)j * H + h] = wh * (dvj2[0] + dvj2[1]);
   }
+  const float dw = dw2[0] + dw2[1];
   if (hok) {
 #pragma unroll
     for (int i = 0; i < NMAX; ++i)
-      if (i < N) dU[bo + (long)i * H + h] = wh * du[i];
+      if (i < N) dU[bo + (long)i * H + h] = wh * du[i >> 1][i & 1];
     dw2_part[(long)b * H + h] = dw;
   }
 }
