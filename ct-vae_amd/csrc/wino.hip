@@ -174,7 +174,20 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
   const int ntiles = a.N / NT;
-  const int mt = blockIdx.x / ntiles, nt = blockIdx.x - mt * ntiles;
+  // XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2); the ntiles
+  // workgroups that read the same input block are given ids with the same id % 8, so the block is fetched once per XCD
+  int mt, nt;
+  {
+    const int mtiles = gridDim.x / ntiles;
+    if ((mtiles & 7) == 0) {
+      const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+      mt = (slot / ntiles) * 8 + xcd;
+      nt = slot - (slot / ntiles) * ntiles;
+    } else {
+      mt = blockIdx.x / ntiles;
+      nt = blockIdx.x - mt * ntiles;
+    }
+  }
   const int PH = 2 * a.bh + 2, PW = 2 * a.bw + 2, NP = a.nb * PH * PW;
   const int K = a.K, N = a.N;
 
@@ -445,7 +458,18 @@ __global__ __launch_bounds__(256) void wino_conv_fs_kernel(WinoArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, fh = wave & 1, li = lane & 31, lh = lane >> 5;
   const int ntiles = a.N / NTs;
-  const int mt = blockIdx.x / ntiles, nt = blockIdx.x - mt * ntiles;
+  int mt, nt;                                // XCD-aware order, see wino_conv_kernel
+  {
+    const int mtiles = gridDim.x / ntiles;
+    if ((mtiles & 7) == 0) {
+      const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+      mt = (slot / ntiles) * 8 + xcd;
+      nt = slot - (slot / ntiles) * ntiles;
+    } else {
+      mt = blockIdx.x / ntiles;
+      nt = blockIdx.x - mt * ntiles;
+    }
+  }
   const int PH = 2 * a.bh + 2, PW = 2 * a.bw + 2, NP = a.nb * PH * PW;
   const int K = a.K, N = a.N;
 
@@ -696,7 +720,18 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
-  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, split = blockIdx.z;
+  // XCD-aware order: all (ci block, co block) workgroups of one slice of the tile range read the same X and dY pixels
+  // (about 1 MB each); workgroup ids go round-robin over the 8 XCDs, so the slices are dealt out per XCD
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if ((gridDim.z & 7) == 0) {
+    const int nt = gridDim.x * gridDim.y;
+    const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int slot = L >> 3, t = slot % nt;
+    bz = (slot / nt) * 8 + (L & 7);
+    bx = t % gridDim.x;
+    by = t / gridDim.x;
+  }
+  const int ci0 = bx * 64, co0 = by * 64, split = bz;
   const int Ci = a.Ci, Co = a.Co, H = a.H, W = a.W;
   const __amdgpu_buffer_rsrc_t rX = wrsrc(a.X, (long)a.B * H * W * Ci * 4);
   const __amdgpu_buffer_rsrc_t rY = wrsrc(a.dY, (long)a.B * H * W * Co * 4);
@@ -953,7 +988,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
 #ifdef CTVAE_PHASE_TIMING
   tq_[3] = clock64();
 #endif
-  if (a.pbias != nullptr && blockIdx.x == 0) {         // bias gradient: the two tile rows of a channel meet in LDS
+  if (a.pbias != nullptr && bx == 0) {                 // bias gradient: the two tile rows of a channel meet in LDS
     __syncthreads();
     if (wave > 0) sRY[(wave - 1) * 64 + chn] = bsum;            // the four (tile row, tile half) shares of a channel
     __syncthreads();
