@@ -322,7 +322,8 @@ def main():
                         "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
                         "avg_launch_us": round(top["ms"] / top["count"] * 1e3, 2),
                         "launches_per_step": top["count"] / nprof}
-        if args.model == "VanillaVAE" and B == 256:   # the PMC passes were taken on this workload
+        # the PMC passes were taken on VanillaVAE bs=256 and, for the Winograd kernels (names unique to it), on MCQVAE bs=256
+        if B == 256 and (args.model == "VanillaVAE" or (args.model == "MCQVAE" and name.startswith("wino_"))):
             roofline["traffic"], src = pmc_traffic(name)
             if src:
                 roofline["traffic_source"] = src + " (bytes per launch; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"
