@@ -587,7 +587,13 @@ void tapgemm_plan(const ConvGeom& g, size_t ws_floats, TapGemmPlan& p) {
   p.BM = 128; p.BN = 32; p.splitk = 1;
   if (!(N <= 32 || !avec || !bvec)) {
     const long tiles128 = (long)ceil_div(Mc, 128) * ceil_div(N, 64) * g.ncls;
-    p.BM = tiles128 >= 512 ? 128 : 64;
+    // 128-row tiles only for long reductions: with <= 72 K-chunks per workgroup the launch is dominated by its prologue /
+    // epilogue phases and twice as many 64-row workgroups hide them better (measured, MI355X: VanillaVAE bs=256 step
+    // 1.913 -> 1.879 ms, MCQVAE 8.15 -> 7.93 ms; CTVAE_SHORT_K overrides the threshold for experiments)
+    static const int short_k = [] { const char* e = getenv("CTVAE_SHORT_K"); return e ? atoi(e) : 72; }();
+    int kch = 1 << 30;
+    for (int c = 0; c < g.ncls; ++c) kch = g.ntaps[c] * g.gC / KC < kch ? g.ntaps[c] * g.gC / KC : kch;
+    p.BM = (tiles128 >= 512 && kch > short_k) ? 128 : 64;
     p.BN = 64;
   }
   p.mtiles = ceil_div(Mc, p.BM);
@@ -598,8 +604,10 @@ void tapgemm_plan(const ConvGeom& g, size_t ws_floats, TapGemmPlan& p) {
     const int nch = avec ? g.ntaps[c] * g.gC / KC : ceil_div(g.ntaps[c] * g.gC, KC);
     if (nch < nch_min) nch_min = nch;
   }
-  if (avec && bvec && (N % 4) == 0 && wgs < 384 && nch_min >= 8) {
-    int sk = (int)((768 + wgs - 1) / wgs);
+  static const int sk_target = [] { const char* e = getenv("CTVAE_SK_TARGET"); return e ? atoi(e) : 768; }();   // diagnostic
+  static const int sk_maxwgs = [] { const char* e = getenv("CTVAE_SK_MAXWGS"); return e ? atoi(e) : 384; }();   // diagnostic
+  if (avec && bvec && (N % 4) == 0 && wgs < sk_maxwgs && nch_min >= 8) {
+    int sk = (int)((sk_target + wgs - 1) / wgs);
     if (sk > nch_min / 4) sk = nch_min / 4;
     if (sk > 16) sk = 16;
     const size_t per = (size_t)g.B * g.sH * g.sW * N;
@@ -694,7 +702,8 @@ int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const floa
     rc = launch_masked(a, wt, avec, bvec, st);
   } else {
     // few workgroups per CU -> latency must be hidden inside the workgroup (double-buffered LDS); many -> by occupancy
-    const bool db = (long)plan.mtiles * plan.ntiles * g.ncls * plan.splitk <= 1024;
+    static const long pf_wgs = [] { const char* e = getenv("CTVAE_PF_WGS"); return e ? atol(e) : 1024L; }();   // diagnostic
+    const bool db = (long)plan.mtiles * plan.ntiles * g.ncls * plan.splitk <= pf_wgs;
     // measured (bench.py, VanillaVAE bs=256): pipelined double-buffer loop 2.35 ms vs 2.37 (plain double buffer) vs 2.42
     // when the large grids use it too (LDS doubling costs them occupancy)
     rc = launch_tapgemm_fast(a, plan, db ? 3 : 0, st);
