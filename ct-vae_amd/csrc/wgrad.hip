@@ -637,7 +637,8 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
   const bool xvec = (g.gC % 4) == 0, dvec = (a.N % 4) == 0;
   const bool narrow = a.N <= 32;
   // 128x128 tiles for wide layers whose pixel range still leaves >= 8 chunks per workgroup at ~1024 workgroups
-  bool big = xvec && dvec && (a.N % 128) == 0 && a.Mc >= 8192;
+  static const int no_big = [] { const char* e = getenv("CTVAE_WGRAD_NO_BIG"); return e ? atoi(e) : 0; }();   // diagnostic
+  bool big = !no_big && xvec && dvec && (a.N % 128) == 0 && a.Mc >= 8192;
   for (int c = 0; c < g.ncls && big; ++c) big = (g.ntaps[c] * g.gC) % 128 == 0;
   if (big) {
     int tiles128 = 0;
