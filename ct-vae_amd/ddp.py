@@ -46,6 +46,8 @@ class GradBucketAllReduce:
         collectives on its own stream behind the current one; with async_op the current stream waits only in wait()."""
         if not self.active:
             return []
+        if hasattr(self.model, "gather_torch_grads"):
+            self.model.gather_torch_grads()            # autograd-produced gradients into the flat buffer first
         if not async_op:   # stream-ordered, no work objects: measured 0.09 ms per step cheaper than async + wait
             for b in self.buckets():
                 dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.pg)
@@ -57,6 +59,8 @@ class GradBucketAllReduce:
         current stream.  Returns the work handles for wait()."""
         if not self.active or hi <= lo:
             return []
+        if hasattr(self.model, "gather_torch_grads"):
+            self.model.gather_torch_grads()
         g = self.model.flat_grads
         parts, off = [], lo
         while off < hi:

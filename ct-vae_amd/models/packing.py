@@ -135,10 +135,12 @@ class FlatParamMixin:
         for _, views in blocks:
             for p, *_ in views:
                 claimed.add(id(p))
+        self._torch_param_ids = set()
         for name, p in self.named_parameters():
             if id(p) not in claimed:   # any other parameter (e.g. torch-level sub-modules): contiguous block
                 pc = p.detach().contiguous()
                 blocks.append((p.numel(), [(p, 0, tuple(p.shape), tuple(pc.stride()))]))
+                self._torch_param_ids.add(id(p))     # its gradient comes from autograd, not from a HIP wgrad kernel
         return blocks
 
     def flatten_parameters(self):
@@ -164,6 +166,7 @@ class FlatParamMixin:
                     self._grad_views.append((p, g))
                 off += n
         self._flat_params, self._flat_grads = flat, gflat
+        self._torch_grad_views = [(p, g) for p, g in self._grad_views if id(p) in self._torch_param_ids]
         return flat, gflat
 
     def attach_grads(self):
@@ -173,6 +176,8 @@ class FlatParamMixin:
             self.flatten_parameters()
             return
         for p, g in self._grad_views:
+            if id(p) in self._torch_param_ids:
+                continue        # autograd-managed: stays detached until gather_torch_grads() (see zero_grad)
             if p.grad is not g:
                 with torch.no_grad():
                     if p.grad is None:
@@ -202,8 +207,10 @@ class FlatParamMixin:
 
     @property
     def flat_grads(self):
+        """The flat gradient buffer, complete: autograd-produced gradients of torch-level parameters are moved in first."""
         if getattr(self, "_flat_grads", None) is None:
             self.flatten_parameters()
+        self.gather_torch_grads()
         return self._flat_grads
 
     def _apply(self, fn, *args, **kwargs):
@@ -214,8 +221,25 @@ class FlatParamMixin:
         return out
 
     def zero_grad(self, set_to_none: bool = False):
-        """Gradients live in the flat buffer: zero it in one memset instead of dropping the views."""
+        """Gradients live in the flat buffer: zero it in one memset instead of dropping the views.
+
+        Parameters of torch-level sub-modules (CausalTransition) get their gradient from autograd: with ``.grad``
+        attached, AccumulateGrad adds into it with one tiny launch per parameter (62 per CT-MCQ-VAE step); detached,
+        autograd just hands the tensor over and gather_torch_grads() moves all of them into the flat buffer with one
+        multi-tensor copy."""
         if getattr(self, "_flat_grads", None) is not None:
             self._flat_grads.zero_()
+            for p, _ in getattr(self, "_torch_grad_views", ()):
+                p.grad = None
         else:
             super().zero_grad(set_to_none=set_to_none)
+
+    def gather_torch_grads(self):
+        """Move autograd-produced gradients of torch-level parameters into their views of the flat gradient buffer and
+        re-attach the views (call before the optimizer step / gradient exchange)."""
+        pairs = [(p, g) for p, g in getattr(self, "_torch_grad_views", ()) if p.grad is not None and p.grad is not g]
+        if pairs:
+            with torch.no_grad():
+                torch._foreach_copy_([g for _, g in pairs], [p.grad for p, _ in pairs])
+        for p, g in getattr(self, "_torch_grad_views", ()):
+            p.grad = g

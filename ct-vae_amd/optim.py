@@ -27,6 +27,7 @@ class FlatAdam:
         self.state[1:2].fill_(lr)
 
     def step(self, grad_scale=1.0):
+        self.model.gather_torch_grads()
         K.adam_step(self.model.flat_params[self.slice], self.model.flat_grads[self.slice], self.exp_avg, self.exp_avg_sq,
                     self.state, grad_scale)
 
