@@ -594,6 +594,8 @@ void tapgemm_plan(const ConvGeom& g, size_t ws_floats, TapGemmPlan& p) {
     int kch = 1 << 30;
     for (int c = 0; c < g.ncls; ++c) kch = g.ntaps[c] * g.gC / KC < kch ? g.ntaps[c] * g.gC / KC : kch;
     p.BM = (tiles128 >= 512 && kch > short_k) ? 128 : 64;
+    static const int force_bm = [] { const char* e = getenv("CTVAE_FORCE_BM"); return e ? atoi(e) : 0; }();   // diagnostic
+    if (force_bm == 64 || force_bm == 128) p.BM = force_bm;
     p.BN = 64;
   }
   p.mtiles = ceil_div(Mc, p.BM);
@@ -703,7 +705,10 @@ int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const floa
   } else {
     // few workgroups per CU -> latency must be hidden inside the workgroup (double-buffered LDS); many -> by occupancy
     static const long pf_wgs = [] { const char* e = getenv("CTVAE_PF_WGS"); return e ? atol(e) : 1024L; }();   // diagnostic
-    const bool db = (long)plan.mtiles * plan.ntiles * g.ncls * plan.splitk <= pf_wgs;
+    static const int force_pf = [] { const char* e = getenv("CTVAE_FORCE_PF"); return e ? atoi(e) : -1; }();   // diagnostic
+    bool db = (long)plan.mtiles * plan.ntiles * g.ncls * plan.splitk <= pf_wgs;
+    if (force_pf == 0) db = false;
+    if (force_pf == 3) db = true;
     // measured (bench.py, VanillaVAE bs=256): pipelined double-buffer loop 2.35 ms vs 2.37 (plain double buffer) vs 2.42
     // when the large grids use it too (LDS doubling costs them occupancy)
     rc = launch_tapgemm_fast(a, plan, db ? 3 : 0, st);
