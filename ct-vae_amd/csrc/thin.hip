@@ -287,11 +287,17 @@ int launch_img_forward(const ConvGeom& g, const float* X, const float* W, const 
 int launch_img_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, float** part_out, float** pbias_out,
                      int* nparts, bool want_bias, const InXform* xf, hipStream_t st);
 
+bool upimg_supported(const ConvGeom& g);
+int launch_upimg_forward(const ConvGeom& g, const float* X, const float* Wp, const float* bias, float* Y, int act,
+                         hipStream_t st);
+
 int launch_thin_forward(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
                         const float* mask, int mask_act, float* S, int act, float* bn_part, hipStream_t st,
                         const InXform* xf) {
   if (add != nullptr || mask != nullptr || bn_part != nullptr) return kErrBadArg;
   if (img_conv_supported(g)) return launch_img_forward(g, G, W, bias, S, act, xf, st);   // 3x3 s1, 32 -> 3: MFMA form (image.hip)
+  if (upimg_supported(g) && (xf == nullptr || xf->scale == nullptr))                     // ConvT k4 s2, 64 -> 3: MFMA form (upimg.hip)
+    return launch_upimg_forward(g, G, W, bias, S, act, st);
   ThinArgs a{};
   a.g = g; a.G = G; a.W = W; a.bias = bias; a.S = S; a.act = act;
   if (xf != nullptr && xf->scale != nullptr) { a.in_scale = xf->scale; a.in_shift = xf->shift; a.in_act = xf->act; }
