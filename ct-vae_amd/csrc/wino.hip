@@ -341,54 +341,48 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
     rd_frag(svc, suc, 0);
     fa = na; fb = nb;
     WINO_FENCE();
-    // step 0
-    rd_frag(svc, suc, 1); st_raw(0); st_raw(1); st_u(sun, 0);
-    WINO_MFMA4(0); fa = na; fb = nb; WINO_FENCE();
-    // step 1
-    rd_frag(svc, suc, 2); st_raw(2); st_raw(3); st_u(sun, 1);
-    WINO_MFMA4(1); fa = na; fb = nb; WINO_FENCE();
-    // step 2
-    rd_frag(svc, suc, 3); st_raw(4); st_u(sun, 2); st_u(sun, 3); ld_raw(c + 2, 0); ld_raw(c + 2, 1);
-    WINO_MFMA4(2); fa = na; fb = nb; WINO_FENCE();
-    // step 3
-    rd_frag(svc, suc, 4); st_u(sun, 4); st_u(sun, 5); ld_raw(c + 2, 2); ld_raw(c + 2, 3); ld_u(c + 2, 0);
-    WINO_MFMA4(3); fa = na; fb = nb; WINO_FENCE();
-    // step 4
-    rd_frag(svc, suc, 5); st_u(sun, 6); st_u(sun, 7); ld_raw(c + 2, 4); ld_u(c + 2, 1); ld_u(c + 2, 2);
-    WINO_MFMA4(4); fa = na; fb = nb; WINO_FENCE();
-    // step 5
-    rd_frag(svc, suc, 6); ld_u(c + 2, 3); ld_u(c + 2, 4); ld_u(c + 2, 5);
-    WINO_MFMA4(5); fa = na; fb = nb; WINO_FENCE();
-    // step 6
-    rd_frag(svc, suc, 7); ld_u(c + 2, 6); ld_u(c + 2, 7);
-    WINO_MFMA4(6); fa = na; fb = nb; WINO_FENCE();
-    // step 7
-    rd_frag(svc, suc, 8);
+    // steps 0..7: one data-movement instruction (or two) behind each single MFMA, so that an LDS / texture queue that
+    // is momentarily full stalls the wave while an MFMA is executing, not between two of them
+#define WINO_M1(f, s_) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s_], fb[s_], acc[f], 0, 0, 0); WINO_FENCE()
+    rd_frag(svc, suc, 1);
+    WINO_M1(0, 0); st_raw(0); WINO_M1(0, 1); st_raw(1); WINO_M1(0, 2); st_u(sun, 0); WINO_M1(0, 3);
+    fa = na; fb = nb; rd_frag(svc, suc, 2);
+    WINO_M1(1, 0); st_raw(2); WINO_M1(1, 1); st_raw(3); WINO_M1(1, 2); st_u(sun, 1); WINO_M1(1, 3);
+    fa = na; fb = nb; rd_frag(svc, suc, 3);
+    WINO_M1(2, 0); st_raw(4); st_u(sun, 2); WINO_M1(2, 1); st_u(sun, 3); WINO_M1(2, 2); ld_raw(c + 2, 0); WINO_M1(2, 3); ld_raw(c + 2, 1);
+    fa = na; fb = nb; rd_frag(svc, suc, 4);
+    WINO_M1(3, 0); st_u(sun, 4); WINO_M1(3, 1); st_u(sun, 5); ld_raw(c + 2, 2); WINO_M1(3, 2); ld_raw(c + 2, 3); WINO_M1(3, 3); ld_u(c + 2, 0);
+    fa = na; fb = nb; rd_frag(svc, suc, 5);
+    WINO_M1(4, 0); st_u(sun, 6); WINO_M1(4, 1); st_u(sun, 7); ld_raw(c + 2, 4); WINO_M1(4, 2); ld_u(c + 2, 1); WINO_M1(4, 3); ld_u(c + 2, 2);
+    fa = na; fb = nb; rd_frag(svc, suc, 6);
+    WINO_M1(5, 0); ld_u(c + 2, 3); WINO_M1(5, 1); ld_u(c + 2, 4); WINO_M1(5, 2); ld_u(c + 2, 5); WINO_M1(5, 3);
+    fa = na; fb = nb; rd_frag(svc, suc, 7);
+    WINO_M1(6, 0); ld_u(c + 2, 6); WINO_M1(6, 1); ld_u(c + 2, 7); WINO_M1(6, 2); WINO_M1(6, 3);
+    fa = na; fb = nb; rd_frag(svc, suc, 8);
     WINO_MFMA4(7); fa = na; fb = nb; WINO_FENCE();
+#undef WINO_M1
     CSEG(0);
     __syncthreads();                                 // raw pixels of chunk c+1 are visible
     CSEG(1);
-    // step 8
-    rd_frag(svc, suc, 9); rd_patch(0); rd_patch(1);
-    WINO_MFMA4(8); fa = na; fb = nb; WINO_FENCE();
-    // step 9
-    rd_frag(svc, suc, 10); rd_patch(2); rd_patch(3);
-    WINO_MFMA4(9); fa = na; fb = nb; WINO_FENCE();
-    // step 10
-    rd_frag(svc, suc, 11);
+    // steps 8..15: patch reads, transform and V stores, again behind single MFMAs
+#define WINO_M1(f, s_) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s_], fb[s_], acc[f], 0, 0, 0); WINO_FENCE()
+    rd_frag(svc, suc, 9);
+    WINO_M1(8, 0); rd_patch(0); WINO_M1(8, 1); rd_patch(1); WINO_M1(8, 2); WINO_M1(8, 3);
+    fa = na; fb = nb; rd_frag(svc, suc, 10);
+    WINO_M1(9, 0); rd_patch(2); WINO_M1(9, 1); rd_patch(3); WINO_M1(9, 2); WINO_M1(9, 3);
+    fa = na; fb = nb; rd_frag(svc, suc, 11);
     WINO_MFMA4(10); fa = na; fb = nb; WINO_FENCE();
-    // step 11
     rd_frag(svc, suc, 12); tf_rows();
     WINO_MFMA4(11); fa = na; fb = nb; WINO_FENCE();
-    // step 12..15
-    rd_frag(svc, suc, 13); tf_store(svn, 0);
-    WINO_MFMA4(12); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(svc, suc, 14); tf_store(svn, 1);
-    WINO_MFMA4(13); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(svc, suc, 15); tf_store(svn, 2);
-    WINO_MFMA4(14); fa = na; fb = nb; WINO_FENCE();
-    tf_store(svn, 3);
-    WINO_MFMA4(15); WINO_FENCE();
+    rd_frag(svc, suc, 13);
+    WINO_M1(12, 0); tf_store(svn, 0); WINO_M1(12, 1); WINO_M1(12, 2); WINO_M1(12, 3);
+    fa = na; fb = nb; rd_frag(svc, suc, 14);
+    WINO_M1(13, 0); tf_store(svn, 1); WINO_M1(13, 1); WINO_M1(13, 2); WINO_M1(13, 3);
+    fa = na; fb = nb; rd_frag(svc, suc, 15);
+    WINO_M1(14, 0); tf_store(svn, 2); WINO_M1(14, 1); WINO_M1(14, 2); WINO_M1(14, 3);
+    fa = na; fb = nb;
+    WINO_M1(15, 0); tf_store(svn, 3); WINO_M1(15, 1); WINO_M1(15, 2); WINO_M1(15, 3);
+#undef WINO_M1
     CSEG(2);
     __syncthreads();                                 // V/U of chunk c+1 complete, chunk c's buffers free
     CSEG(3);
