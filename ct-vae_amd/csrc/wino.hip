@@ -40,6 +40,11 @@ constexpr unsigned kOOBw = 0x80000000u;
 __device__ __forceinline__ f32x4 wld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
 }
+// voff: per-lane byte offset (kOOBw = outside -> 0), soff: wave-uniform byte offset added by the instruction (SGPR operand:
+// the per-chunk part of an address costs no VALU instruction)
+__device__ __forceinline__ f32x4 wld4s(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wrsrc(const void* p, long bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
@@ -266,10 +271,11 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
     *reinterpret_cast<f32x4*>(sRaw + (e >> 1) * RS + 4 * (e & 1)) = rr[i];
   };
   auto st_u = [&](float* su, int i) { *reinterpret_cast<f32x4*>(su + (2 * i + (tid >> 7)) * FB + u_st) = ru[i]; };
-  auto ld_raw = [&](int c, int i) {
-    rr[i] = wld4(rX, roff[i] == kOOBw ? kOOBw : roff[i] + (unsigned)c * 32u);
-  };
-  auto ld_u = [&](int c, int i) { ru[i] = wld4(rU, u_base + (unsigned)c * (unsigned)N * 32u + (unsigned)(2 * i) * u_fs); };
+  unsigned uoff[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) uoff[i] = u_base + (unsigned)(2 * i) * u_fs;
+  auto ld_raw = [&](int c, int i) { rr[i] = wld4s(rX, roff[i], (unsigned)c * 32u); };
+  auto ld_u = [&](int c, int i) { ru[i] = wld4s(rU, uoff[i], (unsigned)c * (unsigned)N * 32u); };
   f32x2 d[4][4], t[4][4];
   auto rd_patch = [&](int i) {
 #pragma unroll
@@ -529,8 +535,11 @@ __global__ __launch_bounds__(256) void wino_conv_fs_kernel(WinoArgs a) {
     *reinterpret_cast<f32x4*>(sRaw + (e >> 1) * RS + 4 * (e & 1)) = rr[i];
   };
   auto st_u = [&](float* su, int i) { *reinterpret_cast<f32x4*>(su + (4 * i + (tid >> 6)) * FBu + u_st) = ru[i]; };
-  auto ld_raw = [&](int c, int i) { rr[i] = wld4(rX, roff[i] == kOOBw ? kOOBw : roff[i] + (unsigned)c * 32u); };
-  auto ld_u = [&](int c, int i) { ru[i] = wld4(rU, u_base + (unsigned)c * (unsigned)N * 32u + (unsigned)(4 * i) * u_fs); };
+  unsigned uoff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) uoff[i] = u_base + (unsigned)(4 * i) * u_fs;
+  auto ld_raw = [&](int c, int i) { rr[i] = wld4s(rX, roff[i], (unsigned)c * 32u); };
+  auto ld_u = [&](int c, int i) { ru[i] = wld4s(rU, uoff[i], (unsigned)c * (unsigned)N * 32u); };
   f32x2 d[4][4], t[4][4];
   auto rd_patch = [&](int i) {
 #pragma unroll
@@ -774,10 +783,12 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
     lcy = wy ? 0 : ny;
     lb += wy ? 1 : 0;
   };
+  // (x_rel is negative for the halo row / column above-left of the chunk: it must be added to the chunk base BEFORE the
+  //  buffer's range check sees it, so this one stays a VALU add)
   auto ld_x = [&](int i) {
     rx[i] = wld4(rX, (x_flag[i] & cflag) ? kOOBw : (unsigned)pix0 * (unsigned)Ci * 4u + x_rel[i]);
   };
-  auto ld_y = [&](bool live, int i) { ry[i] = wld4(rY, live ? (unsigned)pix0 * (unsigned)Co * 4u + y_rel[i] : kOOBw); };
+  auto ld_y = [&](bool live, int i) { ry[i] = wld4s(rY, live ? y_rel[i] : kOOBw, (unsigned)pix0 * (unsigned)Co * 4u); };
   auto st_x = [&](int i) {       // item 3 of the upper threads lies beyond pixel 59: zeros into the unused rows 60..63
     const int e = tid + 256 * i;
     *reinterpret_cast<f32x4*>(sRX + (e >> 4) * RSW + 4 * (e & 15)) = rx[i];
