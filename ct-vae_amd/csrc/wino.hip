@@ -60,6 +60,13 @@ extern "C" int ctvae_debug_wino_phase_read(long long* out, int n) {
 #define WPH(i) do {} while (0)
 #endif
 
+// a - b on both halves in one instruction (the compiler packs f32x2 additions but splits subtractions in two)
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
 struct WinoArgs {
   const float* X;      // [B][H][W][K]
   const float* Ut;     // [16][K/8][N][8]
@@ -284,18 +291,18 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
   auto tf_rows = [&]() {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      t[0][j] = d[0][j] - d[2][j];
+      t[0][j] = pk_sub(d[0][j], d[2][j]);
       t[1][j] = d[1][j] + d[2][j];
-      t[2][j] = d[2][j] - d[1][j];
-      t[3][j] = d[1][j] - d[3][j];
+      t[2][j] = pk_sub(d[2][j], d[1][j]);
+      t[3][j] = pk_sub(d[1][j], d[3][j]);
     }
   };
   auto tf_store = [&](float* sv, int i) {
     float* dst = sv + (4 * i) * FB + v_st;
-    *reinterpret_cast<f32x2*>(dst) = t[i][0] - t[i][2];
+    *reinterpret_cast<f32x2*>(dst) = pk_sub(t[i][0], t[i][2]);
     *reinterpret_cast<f32x2*>(dst + FB) = t[i][1] + t[i][2];
-    *reinterpret_cast<f32x2*>(dst + 2 * FB) = t[i][2] - t[i][1];
-    *reinterpret_cast<f32x2*>(dst + 3 * FB) = t[i][1] - t[i][3];
+    *reinterpret_cast<f32x2*>(dst + 2 * FB) = pk_sub(t[i][2], t[i][1]);
+    *reinterpret_cast<f32x2*>(dst + 3 * FB) = pk_sub(t[i][1], t[i][3]);
   };
   f32x4 fa, fb, na, nb;
   auto rd_frag = [&](const float* sv, const float* su, int f) {
@@ -548,18 +555,18 @@ __global__ __launch_bounds__(256) void wino_conv_fs_kernel(WinoArgs a) {
   auto tf_rows = [&]() {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      t[0][j] = d[0][j] - d[2][j];
+      t[0][j] = pk_sub(d[0][j], d[2][j]);
       t[1][j] = d[1][j] + d[2][j];
-      t[2][j] = d[2][j] - d[1][j];
-      t[3][j] = d[1][j] - d[3][j];
+      t[2][j] = pk_sub(d[2][j], d[1][j]);
+      t[3][j] = pk_sub(d[1][j], d[3][j]);
     }
   };
   auto tf_store = [&](float* sv, int i) {
     float* dst = sv + (4 * i) * FBv + v_st;
-    *reinterpret_cast<f32x2*>(dst) = t[i][0] - t[i][2];
+    *reinterpret_cast<f32x2*>(dst) = pk_sub(t[i][0], t[i][2]);
     *reinterpret_cast<f32x2*>(dst + FBv) = t[i][1] + t[i][2];
-    *reinterpret_cast<f32x2*>(dst + 2 * FBv) = t[i][2] - t[i][1];
-    *reinterpret_cast<f32x2*>(dst + 3 * FBv) = t[i][1] - t[i][3];
+    *reinterpret_cast<f32x2*>(dst + 2 * FBv) = pk_sub(t[i][2], t[i][1]);
+    *reinterpret_cast<f32x2*>(dst + 3 * FBv) = pk_sub(t[i][1], t[i][3]);
   };
   f32x4 fa, fb, na, nb;
   auto rd_frag = [&](const float* sv, const float* su, int a8) {     // frequency 4*(a8>>1) + 2fh + (a8&1)
