@@ -608,24 +608,27 @@ __global__ __launch_bounds__(256) void wino_conv_fs_kernel(WinoArgs a) {
     rd_frag(svc, suc, 0);
     fa = na; fb = nb;
     WINO_FENCE();
-    rd_frag(svc, suc, 1); st_raw(0); st_raw(1); st_raw(2); st_u(sun, 0);
-    WINO_MFMA4(0); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(svc, suc, 2); st_raw(3); st_raw(4); st_u(sun, 1); st_u(sun, 2); st_u(sun, 3);
-    ld_raw(c + 2, 0); ld_raw(c + 2, 1); ld_raw(c + 2, 2);
-    WINO_MFMA4(1); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(svc, suc, 3); ld_raw(c + 2, 3); ld_raw(c + 2, 4); ld_u(c + 2, 0); ld_u(c + 2, 1);
-    WINO_MFMA4(2); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(svc, suc, 4); ld_u(c + 2, 2); ld_u(c + 2, 3);
-    WINO_MFMA4(3); fa = na; fb = nb; WINO_FENCE();
+#define WINO_M1(f, s_) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s_], fb[s_], acc[f], 0, 0, 0); WINO_FENCE()
+    rd_frag(svc, suc, 1);
+    WINO_M1(0, 0); st_raw(0); WINO_M1(0, 1); st_raw(1); WINO_M1(0, 2); st_raw(2); WINO_M1(0, 3); st_u(sun, 0);
+    fa = na; fb = nb; rd_frag(svc, suc, 2);
+    WINO_M1(1, 0); st_raw(3); st_raw(4); WINO_M1(1, 1); st_u(sun, 1); st_u(sun, 2); WINO_M1(1, 2); st_u(sun, 3); ld_raw(c + 2, 0);
+    WINO_M1(1, 3); ld_raw(c + 2, 1); ld_raw(c + 2, 2);
+    fa = na; fb = nb; rd_frag(svc, suc, 3);
+    WINO_M1(2, 0); ld_raw(c + 2, 3); WINO_M1(2, 1); ld_raw(c + 2, 4); WINO_M1(2, 2); ld_u(c + 2, 0); WINO_M1(2, 3); ld_u(c + 2, 1);
+    fa = na; fb = nb; rd_frag(svc, suc, 4);
+    WINO_M1(3, 0); ld_u(c + 2, 2); WINO_M1(3, 1); ld_u(c + 2, 3); WINO_M1(3, 2); WINO_M1(3, 3);
+    fa = na; fb = nb;
     __syncthreads();                                 // raw pixels of chunk c+1 are visible
-    rd_frag(svc, suc, 5); rd_patch(0); rd_patch(1); rd_patch(2); rd_patch(3);
-    WINO_MFMA4(4); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(svc, suc, 6); tf_rows(); tf_store(svn, 0);
-    WINO_MFMA4(5); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(svc, suc, 7); tf_store(svn, 1); tf_store(svn, 2);
-    WINO_MFMA4(6); fa = na; fb = nb; WINO_FENCE();
-    tf_store(svn, 3);
-    WINO_MFMA4(7); WINO_FENCE();
+    rd_frag(svc, suc, 5);
+    WINO_M1(4, 0); rd_patch(0); WINO_M1(4, 1); rd_patch(1); WINO_M1(4, 2); rd_patch(2); WINO_M1(4, 3); rd_patch(3);
+    fa = na; fb = nb; rd_frag(svc, suc, 6); tf_rows();
+    WINO_M1(5, 0); tf_store(svn, 0); WINO_M1(5, 1); WINO_M1(5, 2); WINO_M1(5, 3);
+    fa = na; fb = nb; rd_frag(svc, suc, 7);
+    WINO_M1(6, 0); tf_store(svn, 1); WINO_M1(6, 1); WINO_M1(6, 2); tf_store(svn, 2); WINO_M1(6, 3);
+    fa = na; fb = nb;
+    WINO_M1(7, 0); tf_store(svn, 3); WINO_M1(7, 1); WINO_M1(7, 2); WINO_M1(7, 3);
+#undef WINO_M1
     __syncthreads();                                 // V/U of chunk c+1 complete, chunk c's buffers free
   }
   {
