@@ -943,38 +943,41 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
     chunk_here(live);
     fa = na; fb = nb;
     WINO_FENCE();
-    // steps 0..3: registers (chunk cc+1) -> raw LDS, then refill them with chunk cc+2
-    rd_frag(sxc, syc, 1); st_x(0); st_x(1);
-    WINO_MFMA4(0); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(sxc, syc, 2); st_x(2); st_x(3); ld_x(0);
-    WINO_MFMA4(1); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(sxc, syc, 3); st_y(0); st_y(1); ld_x(1);
-    WINO_MFMA4(2); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(sxc, syc, 4); ld_x(2); ld_x(3);
+    // steps 0..5: registers (chunk cc+1) -> raw LDS, then refill them with chunk cc+2; one instruction behind each MFMA
+#define WINO_M1(f, s_) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s_], fb[s_], acc[f], 0, 0, 0); WINO_FENCE()
+    rd_frag(sxc, syc, 1);
+    WINO_M1(0, 0); st_x(0); WINO_M1(0, 1); st_x(1); WINO_M1(0, 2); st_x(2); WINO_M1(0, 3); st_x(3);
+    fa = na; fb = nb; rd_frag(sxc, syc, 2);
+    WINO_M1(1, 0); st_y(0); WINO_M1(1, 1); st_y(1); WINO_M1(1, 2); ld_x(0); WINO_M1(1, 3); ld_x(1);
+    fa = na; fb = nb; rd_frag(sxc, syc, 3);
+    WINO_M1(2, 0); ld_x(2); WINO_M1(2, 1); ld_x(3); WINO_M1(2, 2); ld_y(live, 0); WINO_M1(2, 3); ld_y(live, 1);
+    fa = na; fb = nb; rd_frag(sxc, syc, 4);
     WINO_MFMA4(3); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(sxc, syc, 5); ld_y(live, 0); ld_y(live, 1);
+    rd_frag(sxc, syc, 5);
     WINO_MFMA4(4); fa = na; fb = nb; WINO_FENCE();
     rd_frag(sxc, syc, 6);
     WINO_MFMA4(5); fa = na; fb = nb; WINO_FENCE();
     WSEG(0);
     __syncthreads();                                 // raw pixels of chunk cc+1 are visible
     WSEG(1);
-    rd_frag(sxc, syc, 7); rd_x(0); rd_x(1);
-    WINO_MFMA4(6); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(sxc, syc, 8); rd_x(2); rd_x(3);
-    WINO_MFMA4(7); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(sxc, syc, 9); rd_y(0); rd_y(1);
+    rd_frag(sxc, syc, 7);
+    WINO_M1(6, 0); rd_x(0); WINO_M1(6, 1); rd_x(1); WINO_M1(6, 2); rd_x(2); WINO_M1(6, 3); rd_x(3);
+    fa = na; fb = nb; rd_frag(sxc, syc, 8);
+    WINO_M1(7, 0); rd_y(0); WINO_M1(7, 1); rd_y(1); WINO_M1(7, 2); WINO_M1(7, 3);
+    fa = na; fb = nb; rd_frag(sxc, syc, 9);
     WINO_MFMA4(8); fa = na; fb = nb; WINO_FENCE();
     rd_frag(sxc, syc, 10); tf_x_rows();
     WINO_MFMA4(9); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(sxc, syc, 11); st_vx(sxn, 0); st_vy(syn, 0);
-    WINO_MFMA4(10); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(sxc, syc, 12); st_vx(sxn, 1); st_vy(syn, 1);
-    WINO_MFMA4(11); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(sxc, syc, 13); st_vx(sxn, 2); st_vy(syn, 2);
-    WINO_MFMA4(12); fa = na; fb = nb; WINO_FENCE();
-    rd_frag(sxc, syc, 14); st_vx(sxn, 3); st_vy(syn, 3);
-    WINO_MFMA4(13); fa = na; fb = nb; WINO_FENCE();
+    rd_frag(sxc, syc, 11);
+    WINO_M1(10, 0); st_vx(sxn, 0); WINO_M1(10, 1); st_vy(syn, 0); WINO_M1(10, 2); WINO_M1(10, 3);
+    fa = na; fb = nb; rd_frag(sxc, syc, 12);
+    WINO_M1(11, 0); st_vx(sxn, 1); WINO_M1(11, 1); st_vy(syn, 1); WINO_M1(11, 2); WINO_M1(11, 3);
+    fa = na; fb = nb; rd_frag(sxc, syc, 13);
+    WINO_M1(12, 0); st_vx(sxn, 2); WINO_M1(12, 1); st_vy(syn, 2); WINO_M1(12, 2); WINO_M1(12, 3);
+    fa = na; fb = nb; rd_frag(sxc, syc, 14);
+    WINO_M1(13, 0); st_vx(sxn, 3); WINO_M1(13, 1); st_vy(syn, 3); WINO_M1(13, 2); WINO_M1(13, 3);
+    fa = na; fb = nb;
+#undef WINO_M1
     WSEG(2);
     rd_frag(sxc, syc, 15);
     WINO_MFMA4(14); fa = na; fb = nb; WINO_FENCE();
