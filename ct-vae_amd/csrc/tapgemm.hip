@@ -670,7 +670,10 @@ int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const floa
   a.N = g.sC;
   if (a.Mc <= 0 || a.N <= 0) return kErrBadArg;
   // buffer resources take 31-bit byte counts: every tensor bound here must stay below 2 GiB
-  if ((long)g.B * g.sH * g.sW * g.sC >= (1L << 29) || (long)g.B * g.gH * g.gW * g.gC >= (1L << 29)) return kErrBadArg;
+  // (the fast kernel binds the gathered tensor with a bias of (3*gW+3)*gC elements in front of it: keep that inside 2 GiB too)
+  if ((long)g.B * g.sH * g.sW * g.sC >= (1L << 29) ||
+      (long)g.B * g.gH * g.gW * g.gC + (long)(3 * g.gW + 3) * g.gC >= (1L << 29))
+    return kErrBadArg;
   for (int c = 0; c < g.ncls; ++c)
     for (int t = 0; t < g.ntaps[c]; ++t) {
       const Tap& tp = g.taps[c][t];

@@ -83,7 +83,12 @@ __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) 
   const int nch = ntaps * gC / KC;
   const bool dense = (g.os == 1);   // scatter index == m
 
-  const __amdgpu_buffer_rsrc_t rG = make_rsrc(a.G, (long)g.B * g.gH * g.gW * gC * 4);
+  // The gathered operand is addressed as  (G - BIAS) + a_off[row] + (tap offset + BIAS + channel offset):  the second
+  // term is the per-lane VGPR offset, the third is wave-uniform and rides in the load's scalar-offset operand -- no VALU
+  // add per row and chunk.  BIAS (>= the most negative tap offset) keeps the scalar part non-negative.
+  const unsigned gbias = (unsigned)((3 * g.gW + 3) * gC) * 4u;
+  const __amdgpu_buffer_rsrc_t rG = make_rsrc(reinterpret_cast<const char*>(a.G) - gbias,
+                                              (long)g.B * g.gH * g.gW * gC * 4 + gbias);
   long wtaps = 0;
   for (int c = 0; c < g.ncls; ++c) wtaps += g.ntaps[c];
   const __amdgpu_buffer_rsrc_t rW = make_rsrc(a.W, wtaps * g.wCi * g.wCo * 4);
@@ -215,16 +220,25 @@ __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) 
     tv_sh = (unsigned)(tp.dy + 3) | ((unsigned)(tp.dx + 11) << 8);
     tv_w = WT ? (unsigned)(tp.wtap * g.wCi * g.wCo) * 4u : (unsigned)(tp.wtap * g.wCi * g.wCo) * 4u;
   }
-  int lt = (c0 * KC) / gC, lci = c0 * KC - lt * gC;    // tap / channel offset of the next chunk to load
-  auto load_next = [&]() {
-    const unsigned tapoff = (unsigned)__builtin_amdgcn_readlane((int)tv_off, lt) + (unsigned)lci * 4u;
-    const unsigned sh = (unsigned)__builtin_amdgcn_readlane((int)tv_sh, lt);
-    const unsigned wsoff = (unsigned)__builtin_amdgcn_readlane((int)tv_w, lt) + (WT ? (unsigned)lci * 4u : (unsigned)(lci * g.wCo) * 4u);
+  // per row: bit t = tap t reads inside the image (<= 16 taps); one bit-field extract per row and chunk then decides
+  // between the row offset and the out-of-range offset (top bit set) -- no compare, no select, no add in the loop
+  unsigned a_tm[A_V];
+#pragma unroll
+  for (int j = 0; j < A_V; ++j) a_tm[j] = 0;
+  for (int t = 0; t < ntaps; ++t) {
+    const unsigned sh = (unsigned)__builtin_amdgcn_readlane((int)tv_sh, t);
     const unsigned sy = sh & 0xff, sx = sh >> 8;
 #pragma unroll
+    for (int j = 0; j < A_V; ++j) a_tm[j] |= ((a_ok[j] >> sy) & (a_ok[j] >> sx) & 1u) << t;
+  }
+  int lt = (c0 * KC) / gC, lci = c0 * KC - lt * gC;    // tap / channel offset of the next chunk to load
+  auto load_next = [&]() {
+    const unsigned tapoff = (unsigned)__builtin_amdgcn_readlane((int)tv_off, lt) + gbias + (unsigned)lci * 4u;
+    const unsigned wsoff = (unsigned)__builtin_amdgcn_readlane((int)tv_w, lt) + (WT ? (unsigned)lci * 4u : (unsigned)(lci * g.wCo) * 4u);
+#pragma unroll
     for (int j = 0; j < A_V; ++j) {
-      const bool ok = ((a_ok[j] >> sy) & (a_ok[j] >> sx) & 1u) != 0;
-      ra[0][j] = buf_load4(rG, ok ? a_off[j] + tapoff : kOOB, 0);
+      const unsigned out = ((a_tm[j] >> lt) & 1u) ^ 1u;            // 1 = this tap falls outside for this row
+      ra[0][j] = buf_load4(rG, a_off[j] | (out << 31), tapoff);
     }
 #pragma unroll
     for (int j = 0; j < B_V; ++j) rb[0][j] = buf_load4(rW, b_off[j], wsoff);
