@@ -12,6 +12,8 @@ int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const floa
 bool wino_supported(const ConvGeom& g, size_t ws_floats);
 bool wino_enabled();
 int wino_set_enabled(int on);
+int launch_crop_resize_u8(const unsigned char* img, const long long* rows, float* out, int B, int N, int H, int W, int crop,
+                          int S, hipStream_t st);
 bool thin_forward_supported(const ConvGeom& g);
 bool thin_wgrad_supported(const ConvGeom& g);
 int tapgemm_bnb_rows(const ConvGeom& g, size_t ws_floats);
@@ -79,6 +81,12 @@ const char* ctvae_error_string(int code) {
   if (code == kErrWorkspace) return "ctvae: workspace too small";
   if (code > 0) return hipGetErrorString((hipError_t)code);
   return "ctvae: unknown error";
+}
+
+int ctvae_crop_resize_u8(const uint8_t* images, const int64_t* rows, float* out, int B, int N, int H, int W, int crop, int size,
+                         void* stream) {
+  if (!images || !rows || !out) return kErrBadArg;
+  return launch_crop_resize_u8(images, (const long long*)rows, out, B, N, H, W, crop, size, (hipStream_t)stream);
 }
 
 int ctvae_winograd_enable(int on) { return wino_set_enabled(on); }

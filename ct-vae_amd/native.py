@@ -26,6 +26,7 @@ SIGNATURES = {
     "ctvae_bn_backward": [_fp, _fp, _fp, _i, _i, _fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _fp, _i, _fp, _fp, _sz, _vp],
     "ctvae_conv_dgrad_bn": [_i, _fp, _fp, _fp, _fp, _i, _fp] + [_i] * 9 + [_fp, _fp, _fp, _fp, _fp, _i, _fp, _i, _fp, _sz, _vp],
     "ctvae_permute": [_fp, _fp, _i, _i, _i, _i, _vp],
+    "ctvae_crop_resize_u8": [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _vp],
     "ctvae_gat_score": [_i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _f, _vp],
     "ctvae_gat_score_backward": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _f, _vp],
     "ctvae_pair_mlp_forward": [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _f, _i, _vp],

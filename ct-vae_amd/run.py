@@ -54,6 +54,78 @@ class SyntheticData:
         return self._batches(self.p["val_batch_size"], self.seed + 1_000_003)
 
 
+class HbmData:
+    """Real data, resident in HBM (ctvae_amd.data): ``data_params.hbm_images`` names a ``.npy`` uint8 array [N,H,W,3] (the
+    decoded dataset, converted once); ``hbm_names`` optionally a text file with one item name per row (default: the row
+    number, which is what the disent datasets use, disent_dataset.py:56).  Splits come from
+    ``<data_path>/<folder>/list_eval_partition.txt`` (row id, item index, split code; disent_dataset.py:70-80) when it
+    exists.  ``T*`` datasets read ``<data_path>/<folder>/variation_attrs_<V>.txt`` (transition.py:111-125) with
+    V = action_dim / 2 and yield mode-pure (x, labels, options) batches; others yield (x, labels).  Train batches are
+    shuffled and sharded over the ranks; validation uses split ``test`` like dataset.py:88-93."""
+
+    FOLDERS = {"TCeleba": "celeba", "TShapes3D": "3dshapes", "TCars3D": "cars3d", "TDSprites": "dsprites",
+               "TSmallNORB": "smallnorb", "TSprites": "sprites"}
+
+    def __init__(self, data_params, model_params, device, rank=0, world=1, seed=0):
+        import numpy as np
+        from . import data as D
+        self.D, self.p, self.dev, self.rank, self.world, self.seed = D, data_params, device, rank, world, seed
+        name = data_params.get("dataset_name", "")
+        self.transition = name.startswith("T")
+        self.folder = os.path.join(data_params.get("data_path", "."), self.FOLDERS.get(name, name.lower().lstrip("t")))
+        imgs = torch.from_numpy(np.load(data_params["hbm_images"], mmap_mode="c", allow_pickle=False))
+        self.store = D.HbmImageStore(imgs, device, crop=data_params.get("crop_size", 148), size=data_params.get("patch_size", 64))
+        if data_params.get("hbm_names"):
+            all_names = [l.strip() for l in open(data_params["hbm_names"]) if l.strip()]
+        else:
+            all_names = [str(i) for i in range(len(self.store))]
+        part = os.path.join(self.folder, "list_eval_partition.txt")
+        self.split_rows = {}
+        if os.path.exists(part):
+            import csv
+            rows = list(csv.reader(open(part)))[1:]
+            for code, split in ((0, "train"), (1, "valid"), (2, "test")):
+                self.split_rows[split] = [int(r[1]) for r in rows if int(r[2]) == code]
+        else:
+            self.split_rows = {s: list(range(len(all_names))) for s in ("train", "valid", "test")}
+        self.all_names = all_names
+        self.V = int(model_params.get("action_dim", 12)) // 2
+        self.epoch = 0
+
+    def _loader(self, split, batch_size, shuffle):
+        D = self.D
+        rows = torch.tensor(self.split_rows[split], dtype=torch.int64)
+        names = [self.all_names[i] for i in self.split_rows[split]]
+        store = self.store
+        if self.transition:
+            table = D.TransitionTable(os.path.join(self.folder, f"variation_attrs_{self.V}.txt"), names, self.V, split)
+            sampler = D.TransitionBatchSampler(table, batch_size, shuffle=shuffle, drop_last=True, limit=self.p.get("limit"),
+                                               rank=self.rank, world=self.world, seed=self.seed)
+            sampler.set_epoch(self.epoch)
+            rows_dev = rows.to(self.dev)
+            for batch in sampler:
+                mode, xr, yr, act = table.resolve_batch(batch)
+                x = store.fetch(rows_dev[xr.to(self.dev)])
+                opts = {"mode": [mode] * len(batch)}
+                if mode != "base":
+                    opts.update({"input_y": store.fetch(rows_dev[yr.to(self.dev)]), "action": act.to(self.dev)})
+                yield x, torch.zeros(len(batch), device=self.dev), opts
+        else:
+            g = torch.Generator().manual_seed(self.seed + 7919 * (self.epoch + 1))
+            order = rows[torch.randperm(len(rows), generator=g)] if shuffle else rows
+            order = order[self.rank::self.world]
+            for i in range(0, len(order), batch_size):
+                r = order[i:i + batch_size]
+                yield store.fetch(r), torch.zeros(len(r), device=self.dev)
+
+    def train(self):
+        self.epoch += 1
+        return self._loader("train", self.p["train_batch_size"], True)
+
+    def val(self):
+        return self._loader("test", self.p["val_batch_size"], False)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description='MI355X runner for the ct-vae models')
     ap.add_argument('--config', '-c', dest="filename", metavar='FILE', default='configs/vae.yaml')
@@ -89,7 +161,10 @@ def main(argv=None):
     os.makedirs(os.path.join(log_dir, "checkpoints"), exist_ok=True)
     log_file = open(os.path.join(log_dir, f"metrics_rank{rank}.jsonl"), "a") if rank == 0 else None
     exp = VAEXperiment(model, config['exp_params'], ddp=ddp, log_file=log_file)
-    data = SyntheticData(config['data_params'], mp, dev, rank, world, args.steps_per_epoch, seed)
+    if config['data_params'].get('hbm_images'):
+        data = HbmData(config['data_params'], mp, dev, rank, world, seed)
+    else:
+        data = SyntheticData(config['data_params'], mp, dev, rank, world, args.steps_per_epoch, seed)
 
     best = []
 

@@ -192,6 +192,13 @@ int ctvae_gumbel_st_backward(const float* g_sample, const float* p, const float*
 int ctvae_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* state, long n,
                     float grad_scale, void* stream);
 
+/* Input side: the reference's per-sample pipeline ToTensor -> CenterCrop(crop) -> Resize(size)
+ * (dataset.py:72-80; bilinear, align_corners=False, no antialias -- what transforms.Resize does to a tensor; images smaller
+ * than the crop are zero-padded as torchvision's center_crop does) for a batch of rows of a uint8 dataset
+ * images[N][H][W][3] resident in HBM.  rows[B] int64 (out-of-range rows give zeros); out[B][size][size][3] fp32 NHWC. */
+int ctvae_crop_resize_u8(const uint8_t* images, const int64_t* rows, float* out, int B, int N, int H, int W, int crop, int size,
+                         void* stream);
+
 /* 3x3 / stride-1 / pad-1 layers with at least 64 channels run Winograd F(2x2,3x3) (forward, data gradient) and
  * F(3x3,2x2) (weight and bias gradient) instead of the direct tap-GEMM (csrc/wino.hip): 2.25x fewer MFMA
  * operations, results within a few 1e-6 of the direct kernels.  This switch (default on; environment
