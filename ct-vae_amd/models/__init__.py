@@ -4,6 +4,7 @@ from .base import BaseVAE
 from .blocks import ResidualLayer
 from .mcq_vae import MCQVAE, MultipleCodebookVectorQuantizer, VectorQuantizerMS
 from .vanilla_vae import VanillaVAE
+from .beta_vae import BetaVAE
 
 # Aliases (models/__init__.py:29-32)
 VAE = VanillaVAE
@@ -14,6 +15,7 @@ vae_models = {
     'VAE': VanillaVAE,
     'GaussianVAE': VanillaVAE,
     'MCQVAE': MCQVAE,
+    'BetaVAE': BetaVAE,       # same network as VanillaVAE, beta / capacity objectives (beta_vae.py)
 }
 
 try:  # CTMCQVAE needs nothing beyond torch, but keep the registry usable if it is being developed

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/beta_{B,H}_b2.npz from the REFERENCE's own ``models/beta_vae.py``.  TEST INFRASTRUCTURE ONLY.
+
+Same method as gen_golden.py (the module is exec'd where it lies under a synthetic ``models`` package; weights from the
+build's deterministic filler, noise injected).  Records, for both objectives (configs/bhvae.yaml type 'H',
+configs/bbvae.yaml type 'B'): mu / log_var, the loss dict of TWO consecutive loss_function calls (type 'B' depends on
+the call counter), and gradient checksums of every parameter after backward of the first.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_beta_golden.py
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("CTVAE_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+CONFIGS = {   # model_params of configs/bhvae.yaml / configs/bbvae.yaml (facts, not files)
+    "H": dict(in_channels=3, latent_dim=128, loss_type='H', beta=10.0),
+    "B": dict(in_channels=3, latent_dim=128, loss_type='B', gamma=10.0, max_capacity=25, Capacity_max_iter=10000),
+}
+
+
+def load_beta():
+    pkg = types.ModuleType("models")
+    pkg.__path__ = [os.path.join(REF, "models")]
+    sys.modules["models"] = pkg
+
+    def run(name):
+        spec = importlib.util.spec_from_file_location(f"models.{name}", os.path.join(REF, "models", f"{name}.py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[f"models.{name}"] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    run("types_")
+    pkg.BaseVAE = run("base").BaseVAE
+    return run("beta_vae").BetaVAE
+
+
+def cks(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()], dtype=np.float64)
+
+
+def main():
+    from ctvae_amd import filler
+    BetaVAE = load_beta()
+    seed, B, M_N = 1265, 2, 0.00025
+    for tag, cfg in CONFIGS.items():
+        torch.manual_seed(0)
+        model = BetaVAE(**cfg)
+        model.load_state_dict(filler.fill_state(filler.specs_of(model), seed + 1))
+        model.train()
+        x, eps = filler.synthetic_batch(seed, B)
+        orig = torch.randn_like
+        torch.randn_like = lambda t, **kw: eps.clone()
+        try:
+            out = {"seed": np.int64(seed), "B": np.int64(B), "M_N": np.float64(M_N)}
+            recons, inp, mu, log_var = model(x)
+            l1 = model.loss_function(recons, inp, mu, log_var, M_N=M_N)
+            l1["loss"].backward()
+            out["mu"], out["log_var"] = mu.detach().numpy().copy(), log_var.detach().numpy().copy()
+            out["recons_cks"] = cks(recons)
+            for k in ("loss", "Reconstruction_Loss", "KLD"):
+                out["call1." + k] = np.float64(l1[k].item())
+            for k, p in model.named_parameters():
+                out["gradcks." + k] = cks(p.grad)
+            with torch.no_grad():
+                l2 = model.loss_function(recons, inp, mu, log_var, M_N=M_N)
+            for k in ("loss", "Reconstruction_Loss", "KLD"):
+                out["call2." + k] = np.float64(l2[k].item())
+        finally:
+            torch.randn_like = orig
+        np.savez_compressed(os.path.join(OUT, f"beta_{tag}_b{B}.npz"), **out)
+        print(tag, {k: float(out["call1." + k]) for k in ("loss", "Reconstruction_Loss", "KLD")}, float(out["call2.loss"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -88,6 +88,21 @@ def vanilla_loss(recons, x, mu, log_var, M_N):
 # --------------------------------------------------------------------------------------------
 # Vector quantisers  (models/mcq_vae.py:7-137)
 # --------------------------------------------------------------------------------------------
+def beta_loss(recons, x, mu, log_var, M_N, loss_type, num_iter, beta=4, gamma=1000.0, max_capacity=25, capacity_max_iter=1e5):
+    """BetaVAE.loss_function (beta_vae.py:132-153); num_iter = value of the call counter AFTER its increment."""
+    mse = F.mse_loss(recons, x)
+    kld = torch.mean(-0.5 * torch.sum(1 + log_var - mu ** 2 - log_var.exp(), dim=1), dim=0)
+    if loss_type == 'H':
+        loss = mse + beta * M_N * kld
+    elif loss_type == 'B':
+        c_max = torch.tensor([float(max_capacity)])
+        C = torch.clamp(c_max / capacity_max_iter * num_iter, 0, c_max[0])
+        loss = mse + gamma * M_N * (kld - C).abs()
+    else:
+        raise ValueError('Undefined loss type.')
+    return {'loss': loss, 'Reconstruction_Loss': mse, 'KLD': kld}
+
+
 def vq_compute_inds(codebook, latents):
     """mcq_vae.py:26-39: expanded-form distances, first-min argmin.  latents [B,Dc,H,W] -> [B,H,W] i64."""
     lat = latents.permute(0, 2, 3, 1).contiguous()

@@ -295,3 +295,29 @@ def test_mcq_winograd_matches_direct_kernels(dev):
         a, b = p.grad.cpu().numpy(), gd[k].cpu().numpy()
         sc = max(1.0, float(np.abs(b).max()))
         np.testing.assert_allclose(a, b, atol=TOL * sc, rtol=2e-3, err_msg=k)
+
+
+@pytest.mark.parametrize("tag,cfg", [("H", dict(loss_type="H", beta=10.0)),
+                                     ("B", dict(loss_type="B", gamma=10.0, max_capacity=25, Capacity_max_iter=10000))])
+def test_beta_vae_vs_golden(dev, golden, tag, cfg):
+    """BetaVAE (VanillaVAE's network, beta / capacity objectives) against the reference's own beta_vae.py fixture: two
+    consecutive loss calls (type 'B' depends on the call counter) and every parameter gradient of the first."""
+    from ctvae_amd.models import vae_models
+    g = golden(f"beta_{tag}_b2")
+    seed = int(g["seed"])
+    m = vae_models["BetaVAE"](in_channels=3, latent_dim=128, **cfg)
+    m.load_state_dict(filler.fill_state(H.vanilla_specs(), seed + 1))
+    m = m.to(dev).train()
+    x, eps = filler.synthetic_batch(seed, 2)
+    out = m(x.to(dev), eps=eps.to(dev))
+    np.testing.assert_allclose(out[2].detach().cpu().numpy(), g["mu"], atol=TOL, rtol=0)
+    l1 = m.loss_function(*out, M_N=float(g["M_N"]))
+    l1["loss"].backward()
+    with torch.no_grad():
+        l2 = m.loss_function(*out, M_N=float(g["M_N"]))
+    for call, l in (("call1", l1), ("call2", l2)):
+        for k in ("loss", "Reconstruction_Loss", "KLD"):
+            want = float(g[f"{call}.{k}"])
+            assert abs(float(l[k].detach()) - want) <= TOL * max(1.0, abs(want)), (call, k, float(l[k].detach()), want)
+    for k, p in m.named_parameters():
+        H.assert_cks_close(H.cks(p.grad), g["gradcks." + k], rtol=2e-3, atol=2e-5, what=k)

@@ -91,3 +91,28 @@ def test_vanilla_adam_steps(golden):
             cur[k] = v
         got.append(l["loss"].item())
     np.testing.assert_allclose(got, g["adam_losses"], rtol=2e-3, atol=1e-4)
+
+
+BETA_CFG = {"H": dict(loss_type="H", beta=10.0), "B": dict(loss_type="B", gamma=10.0, max_capacity=25, capacity_max_iter=10000)}
+
+
+@pytest.mark.parametrize("tag", ["H", "B"])
+def test_beta_vae_losses(golden, tag):
+    """BetaVAE = VanillaVAE's network + beta / capacity objective: oracle against the reference's beta_vae.py fixture
+    (two consecutive loss calls: type 'B' depends on the call counter)."""
+    g = golden(f"beta_{tag}_b2")
+    sd = O.leafify(filler.fill_state(H.vanilla_specs(), int(g["seed"]) + 1))
+    x, eps = filler.synthetic_batch(int(g["seed"]), 2)
+    recons, inp, mu, log_var = O.vanilla_forward(sd, x, eps, True, {})
+    np.testing.assert_allclose(mu.detach().numpy(), g["mu"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(H.cks(recons), g["recons_cks"], rtol=1e-4)
+    l1 = O.beta_loss(recons, inp, mu, log_var, float(g["M_N"]), num_iter=1, **BETA_CFG[tag])
+    l2 = O.beta_loss(recons, inp, mu, log_var, float(g["M_N"]), num_iter=2, **BETA_CFG[tag])
+    for call, l in (("call1", l1), ("call2", l2)):
+        for k in ("loss", "Reconstruction_Loss", "KLD"):
+            want = float(g[f"{call}.{k}"])
+            assert abs(l[k].item() - want) <= TOL * max(1.0, abs(want)), (call, k)
+    l1["loss"].backward()
+    for k, v in sd.items():
+        if v.requires_grad:
+            H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
