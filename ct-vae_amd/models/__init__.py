@@ -5,6 +5,7 @@ from .blocks import ResidualLayer
 from .mcq_vae import MCQVAE, MultipleCodebookVectorQuantizer, VectorQuantizerMS
 from .vanilla_vae import VanillaVAE
 from .beta_vae import BetaVAE
+from .vq_vae import VQVAE
 
 # Aliases (models/__init__.py:29-32)
 VAE = VanillaVAE
@@ -16,6 +17,7 @@ vae_models = {
     'GaussianVAE': VanillaVAE,
     'MCQVAE': MCQVAE,
     'BetaVAE': BetaVAE,       # same network as VanillaVAE, beta / capacity objectives (beta_vae.py)
+    'VQVAE': VQVAE,           # MCQ-VAE's conv stacks around one codebook (vq_vae.py)
 }
 
 try:  # CTMCQVAE needs nothing beyond torch, but keep the registry usable if it is being developed

@@ -82,5 +82,41 @@ def main():
         print(tag, {k: float(out["call1." + k]) for k in ("loss", "Reconstruction_Loss", "KLD")}, float(out["call2.loss"]))
 
 
+def gen_vqvae():
+    """tests/golden/vqvae_b2.npz from the reference's models/vq_vae.py (configs/vq_vae.yaml: D 64, K 512, beta 0.25)."""
+    from ctvae_amd import filler
+    pkg = sys.modules["models"]
+    spec = importlib.util.spec_from_file_location("models.vq_vae", os.path.join(REF, "models", "vq_vae.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["models.vq_vae"] = mod
+    spec.loader.exec_module(mod)
+    seed, B = 1265, 2
+    torch.manual_seed(0)
+    model = mod.VQVAE(in_channels=3, embedding_dim=64, num_embeddings=512, img_size=64, beta=0.25)
+    model.load_state_dict(filler.fill_state(filler.specs_of(model), seed + 1))
+    model.train()
+    x, _ = filler.synthetic_batch(seed, B)
+    lat = model.encode(x)[0]
+    flat = lat.permute(0, 2, 3, 1).reshape(-1, 64).double()
+    e = model.vq_layer.embedding.weight.double()
+    d = (flat ** 2).sum(1, keepdim=True) + (e ** 2).sum(1) - 2 * flat @ e.t()
+    top2 = torch.topk(d, 2, dim=1, largest=False)
+    q, vq_loss = model.vq_layer(lat)
+    recons = model.decode(q)
+    losses = model.loss_function(recons, x, vq_loss)
+    losses["loss"].backward()
+    out = {"seed": np.int64(seed), "B": np.int64(B), "latents": lat.detach().numpy().copy(), "recons_cks": cks(recons),
+           "inds": top2.indices[:, 0].view(B, 16, 16).numpy().copy(),
+           "margin": (top2.values[:, 1] - top2.values[:, 0]).detach().view(B, 16, 16).float().numpy().copy()}
+    for k in ("loss", "Reconstruction_Loss", "VQ_Loss"):
+        out["loss." + k] = np.float64(losses[k].item())
+    for k, p in model.named_parameters():
+        out["gradcks." + k] = cks(p.grad)
+    np.savez_compressed(os.path.join(OUT, f"vqvae_b{B}.npz"), **out)
+    print("vqvae", {k: float(out["loss." + k]) for k in ("loss", "Reconstruction_Loss", "VQ_Loss")},
+          "min margin", float(out["margin"].min()))
+
+
 if __name__ == "__main__":
     main()
+    gen_vqvae()

@@ -68,6 +68,15 @@ def mcq_specs(cfg):
     return s
 
 
+VQVAE_CFG = dict(in_channels=3, embedding_dim=64, num_embeddings=512, hidden_dims=[128, 256], img_size=64, codebooks=1,
+                 beta=0.25)      # configs/vq_vae.yaml (hidden_dims = the class default, vq_vae.py:92)
+
+
+def vqvae_specs():
+    """state_dict keys/shapes of VQVAE (vq_vae.py:73-166): MCQVAE's with the single embedding directly under vq_layer."""
+    return [(k.replace("vq_layer.quantizers.0.embedding", "vq_layer.embedding"), sh, dt) for k, sh, dt in mcq_specs(VQVAE_CFG)]
+
+
 def cks(t):
     t = t.detach().double().cpu()
     return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()], dtype=np.float64)

@@ -321,3 +321,31 @@ def test_beta_vae_vs_golden(dev, golden, tag, cfg):
             assert abs(float(l[k].detach()) - want) <= TOL * max(1.0, abs(want)), (call, k, float(l[k].detach()), want)
     for k, p in m.named_parameters():
         H.assert_cks_close(H.cks(p.grad), g["gradcks." + k], rtol=2e-3, atol=2e-5, what=k)
+
+
+def test_vqvae_vs_golden(dev, golden):
+    """VQVAE (vq_vae.py: MCQ-VAE's conv stacks around one 512-entry codebook) against the reference's own fixture."""
+    from ctvae_amd.models import vae_models
+    g = golden("vqvae_b2")
+    seed = int(g["seed"])
+    cfg = {**H.VQVAE_CFG, "hidden_dims": list(H.VQVAE_CFG["hidden_dims"])}
+    cfg.pop("codebooks")
+    m = vae_models["VQVAE"](**cfg)
+    m.load_state_dict(filler.fill_state(H.vqvae_specs(), seed + 1))
+    m = m.to(dev).train()
+    x, _ = filler.synthetic_batch(seed, 2)
+    xd = x.to(dev)
+    lat = m.encode(xd)[0]
+    inds = m.vq_layer.compute_inds(lat)
+    assert not ((inds.cpu().numpy() != g["inds"]) & (g["margin"] > 1e-5)).any()
+    out = m(xd)
+    losses = m.loss_function(*out)
+    losses["loss"].backward()
+    np.testing.assert_allclose(lat.detach().cpu().numpy(), g["latents"], atol=TOL, rtol=0)
+    H.assert_cks_close(H.cks(out[0]), g["recons_cks"], rtol=1e-4, atol=1e-5, what="recons")
+    for k in ("loss", "Reconstruction_Loss", "VQ_Loss"):
+        assert abs(float(losses[k].detach()) - float(g["loss." + k])) <= TOL, k
+    for k, p in m.named_parameters():
+        H.assert_cks_close(H.cks(p.grad), g["gradcks." + k], rtol=2e-3, atol=2e-5, what=k)
+    with pytest.raises(Warning):
+        m.sample(2, dev)

@@ -116,3 +116,23 @@ def test_beta_vae_losses(golden, tag):
     for k, v in sd.items():
         if v.requires_grad:
             H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
+
+
+def test_vqvae_forward_loss_grads(golden):
+    """VQVAE = MCQ-VAE's stacks around ONE codebook: oracle (single-codebook path of the MCQ restatement) against the
+    reference's own vq_vae.py fixture."""
+    g = golden("vqvae_b2")
+    cfg = H.VQVAE_CFG
+    sd = filler.fill_state(H.vqvae_specs(), int(g["seed"]) + 1)
+    sd = type(sd)((k.replace("vq_layer.embedding", "vq_layer.quantizers.0.embedding"), v) for k, v in sd.items())
+    x, _ = filler.synthetic_batch(int(g["seed"]), 2)
+    losses, grads, aux = O.mcq_step(sd, x, 1, cfg["beta"], len(cfg["hidden_dims"]))
+    inds = aux["inds"].numpy()[:, 0]
+    assert not ((inds != g["inds"]) & (g["margin"] > 1e-5)).any()
+    np.testing.assert_allclose(aux["latents"].numpy(), g["latents"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(H.cks(aux["recons"]), g["recons_cks"], rtol=1e-4)
+    for k in ("loss", "Reconstruction_Loss", "VQ_Loss"):
+        assert abs(losses[k].item() - float(g["loss." + k])) <= TOL
+    for k, gr in grads.items():
+        H.assert_cks_close(H.cks(gr), g["gradcks." + k.replace("vq_layer.quantizers.0.embedding", "vq_layer.embedding")],
+                           rtol=1e-3, atol=1e-5, what=k)
