@@ -55,6 +55,11 @@ int launch_reparam_bwd(const float* gz, const float* lv, long lv_rs, const float
 int launch_adam(float* p, const float* g, float* m, float* v, float* state, long n, float grad_scale, hipStream_t st);
 int launch_gumbel_fwd(const float* p, const float* noise, float* out, float* soft, long n, hipStream_t st);
 int launch_gumbel_bwd(const float* go, const float* p, const float* soft, float* gp, long n, hipStream_t st);
+int launch_gumbel_softmax_fwd(const float* z, const float* u, float* s, long rows, int Q, float temp, float eps, hipStream_t st);
+int launch_gumbel_softmax_bwd(const float* gs, const float* s, float* gz, long rows, int Q, float temp, hipStream_t st);
+int launch_cat_kl_fwd(const float* logits, long rows, int Q, int B, float eps, float c, float* out, float* ws, size_t ws_bytes,
+                      hipStream_t st);
+int launch_cat_kl_bwd(const float* logits, const float* go, float* gq, long rows, int Q, int B, float eps, float c, hipStream_t st);
 int launch_loss_forward(const float* r, const float* x, long n, const float* mu, long mu_rs, const float* lv, long lv_rs,
                         int B, int L, float M_N, const float* extra, float* out3, float* ws, size_t ws_bytes, hipStream_t st);
 int launch_mse_backward(const float* r, const float* x, const float* go, float* gr, long n, hipStream_t st);
@@ -345,6 +350,30 @@ int ctvae_gumbel_st_forward(const float* p, const float* gumbel_noise, float* sa
 int ctvae_gumbel_st_backward(const float* g_sample, const float* p, const float* soft, float* g_p, long n, void* stream) {
   if (!g_sample || !p || !soft || !g_p || n <= 0) return kErrBadArg;
   return launch_gumbel_bwd(g_sample, p, soft, g_p, n, (hipStream_t)stream);
+}
+
+int ctvae_gumbel_softmax_forward(const float* logits, const float* uniform, float* sample, long rows, int Q, float temperature,
+                                 float eps, void* stream) {
+  if (!logits || !uniform || !sample || rows <= 0 || Q <= 0 || !(temperature > 0.f)) return kErrBadArg;
+  return launch_gumbel_softmax_fwd(logits, uniform, sample, rows, Q, temperature, eps, (hipStream_t)stream);
+}
+
+int ctvae_gumbel_softmax_backward(const float* g_sample, const float* sample, float* g_logits, long rows, int Q,
+                                  float temperature, void* stream) {
+  if (!g_sample || !sample || !g_logits || rows <= 0 || Q <= 0 || !(temperature > 0.f)) return kErrBadArg;
+  return launch_gumbel_softmax_bwd(g_sample, sample, g_logits, rows, Q, temperature, (hipStream_t)stream);
+}
+
+int ctvae_cat_kl_forward(const float* logits, long rows, int Q, int B, float eps, float log_prior, float* kld, float* ws,
+                         size_t ws_bytes, void* stream) {
+  if (!logits || !kld || !ws || rows <= 0 || Q <= 0 || B <= 0) return kErrBadArg;
+  return launch_cat_kl_fwd(logits, rows, Q, B, eps, log_prior, kld, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int ctvae_cat_kl_backward(const float* logits, const float* g_kld, float* g_logits, long rows, int Q, int B, float eps,
+                          float log_prior, void* stream) {
+  if (!logits || !g_kld || !g_logits || rows <= 0 || Q <= 0 || B <= 0) return kErrBadArg;
+  return launch_cat_kl_bwd(logits, g_kld, g_logits, rows, Q, B, eps, log_prior, (hipStream_t)stream);
 }
 
 int ctvae_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* state, long n,

@@ -11,9 +11,9 @@ Conventions
   DDP hooks on parameters do not fire -- use ``ctvae_amd.ddp.GradBucketAllReduce``.
 * No op here has a PyTorch/CPU fallback: a missing library or a CPU tensor raises.
 """
-from dataclasses import dataclass
-
+import math
 import os
+from dataclasses import dataclass
 
 import torch
 from torch.autograd import Function
@@ -624,6 +624,60 @@ class VAELoss(Function):
                         g_lv.data_ptr(), B, L, M_N)
         g_extra = g_loss.reshape(()) if (has_extra and ctx.needs_input_grad[4]) else None
         return g_r, None, g_mu, g_lv, g_extra, None
+
+
+class GumbelSoftmax(Function):
+    """s = softmax((z + g)/temp, dim=-1), g = -log(-log(u + eps) + eps): CategoricalVAE.reparameterize
+    (cat_vae.py:118-132) with the uniform draws injectable.  z, u: [..., Q]."""
+
+    @staticmethod
+    def forward(ctx, z, u, temp, eps):
+        _req_cuda(z, u)
+        if z.shape != u.shape:
+            raise RuntimeError("gumbel_softmax: logits / uniform shape mismatch")
+        z, u = _c(z), _c(u)
+        Q = z.shape[-1]
+        s = torch.empty_like(z)
+        native.call("ctvae_gumbel_softmax_forward", z.data_ptr(), u.data_ptr(), s.data_ptr(), z.numel() // Q, Q, float(temp), float(eps))
+        ctx.save_for_backward(s)
+        ctx.temp = float(temp)
+        return s
+
+    @staticmethod
+    def backward(ctx, g_s):
+        (s,) = ctx.saved_tensors
+        g_s = _c(g_s)
+        Q = s.shape[-1]
+        g_z = torch.empty_like(s)
+        native.call("ctvae_gumbel_softmax_backward", g_s.data_ptr(), s.data_ptr(), g_z.data_ptr(), s.numel() // Q, Q, ctx.temp)
+        return g_z, None, None, None
+
+
+class CatKL(Function):
+    """kld = mean_b sum_{d,q} p (log(p + eps) - log(1/Q + eps)), p = softmax(q, -1) (cat_vae.py:147,160-167).  q: [B,D,Q]."""
+
+    @staticmethod
+    def forward(ctx, q, eps):
+        _req_cuda(q)
+        q = _c(q)
+        B, Q = q.shape[0], q.shape[-1]
+        log_prior = math.log(1.0 / Q + eps)
+        out = torch.empty(1, dtype=torch.float32, device=q.device)
+        ws = native.workspace(q.device)
+        native.call("ctvae_cat_kl_forward", q.data_ptr(), q.numel() // Q, Q, B, float(eps), log_prior, out.data_ptr(),
+                    ws.data_ptr(), ws.numel() * 4)
+        ctx.save_for_backward(q)
+        ctx.meta = (B, Q, float(eps), log_prior)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (q,) = ctx.saved_tensors
+        B, Q, eps, log_prior = ctx.meta
+        g = _c(g.reshape(1))
+        g_q = torch.empty_like(q)
+        native.call("ctvae_cat_kl_backward", q.data_ptr(), g.data_ptr(), g_q.data_ptr(), q.numel() // Q, Q, B, eps, log_prior)
+        return g_q, None
 
 
 class PairMLP(Function):

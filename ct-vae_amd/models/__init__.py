@@ -6,10 +6,12 @@ from .mcq_vae import MCQVAE, MultipleCodebookVectorQuantizer, VectorQuantizerMS
 from .vanilla_vae import VanillaVAE
 from .beta_vae import BetaVAE
 from .vq_vae import VQVAE
+from .cat_vae import CategoricalVAE
 
 # Aliases (models/__init__.py:29-32)
 VAE = VanillaVAE
 GaussianVAE = VanillaVAE
+GumbelVAE = CategoricalVAE
 
 vae_models = {
     'VanillaVAE': VanillaVAE,
@@ -18,6 +20,7 @@ vae_models = {
     'MCQVAE': MCQVAE,
     'BetaVAE': BetaVAE,       # same network as VanillaVAE, beta / capacity objectives (beta_vae.py)
     'VQVAE': VQVAE,           # MCQ-VAE's conv stacks around one codebook (vq_vae.py)
+    'CategoricalVAE': CategoricalVAE,   # VanillaVAE's stacks around a Gumbel-softmax categorical latent (cat_vae.py)
 }
 
 try:  # CTMCQVAE needs nothing beyond torch, but keep the registry usable if it is being developed

@@ -43,6 +43,10 @@ SIGNATURES = {
     "ctvae_vq_backward": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _f, _i, _i, _i, _i, _i, _fp, _sz, _vp],
     "ctvae_gumbel_st_forward": [_fp, _fp, _fp, _fp, _l, _vp],
     "ctvae_gumbel_st_backward": [_fp, _fp, _fp, _fp, _l, _vp],
+    "ctvae_gumbel_softmax_forward": [_fp, _fp, _fp, _l, _i, _f, _f, _vp],
+    "ctvae_gumbel_softmax_backward": [_fp, _fp, _fp, _l, _i, _f, _vp],
+    "ctvae_cat_kl_forward": [_fp, _l, _i, _i, _f, _f, _fp, _fp, _sz, _vp],
+    "ctvae_cat_kl_backward": [_fp, _fp, _fp, _l, _i, _i, _f, _f, _vp],
     "ctvae_adam_step": [_fp, _fp, _fp, _fp, _fp, _l, _f, _vp],
 }
 _RESTYPES = {

@@ -187,6 +187,22 @@ int ctvae_vq_backward(const float* g_quantized, const float* g_vq_loss, const fl
 int ctvae_gumbel_st_forward(const float* p, const float* gumbel_noise, float* sample, float* soft, long n, void* stream);
 int ctvae_gumbel_st_backward(const float* g_sample, const float* p, const float* soft, float* g_p, long n, void* stream);
 
+/* Categorical latent of CategoricalVAE (models/cat_vae.py).  rows = B * latent_dim, Q = categorical_dim (<= 256).
+ * Gumbel-softmax reparameterisation (cat_vae.py:118-132): sample = softmax((logits + g) / temperature) along Q with
+ * g = -log(-log(uniform + eps) + eps); `uniform` [rows][Q] are the U[0,1) draws (injectable).
+ * Backward: g_logits = sample * (g_sample - sum_Q g_sample * sample) / temperature. */
+int ctvae_gumbel_softmax_forward(const float* logits, const float* uniform, float* sample, long rows, int Q, float temperature,
+                                 float eps, void* stream);
+int ctvae_gumbel_softmax_backward(const float* g_sample, const float* sample, float* g_logits, long rows, int Q,
+                                  float temperature, void* stream);
+/* KL between softmax(logits) and the uniform categorical prior (cat_vae.py:147,160-167):
+ * kld[0] = 1/B * sum_rows sum_Q p * (log(p + eps) - log_prior), log_prior = log(1/Q + eps) (computed by the caller in
+ * double like the reference's np.log).  ws: >= 4 KiB of scratch.  Backward writes g_logits = g_kld[0] * d kld / d logits. */
+int ctvae_cat_kl_forward(const float* logits, long rows, int Q, int B, float eps, float log_prior, float* kld, float* ws,
+                         size_t ws_bytes, void* stream);
+int ctvae_cat_kl_backward(const float* logits, const float* g_kld, float* g_logits, long rows, int Q, int B, float eps,
+                          float log_prior, void* stream);
+
 /* torch.optim.Adam step over one flat buffer (experiment.py:158-160).  state (device, 8 floats):
  * {step, lr, beta1, beta2, eps, weight_decay, beta1^step, beta2^step}; the call advances step. */
 int ctvae_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* state, long n,

@@ -85,6 +85,29 @@ def vanilla_loss(recons, x, mu, log_var, M_N):
     return {"loss": recons_loss + M_N * kld, "Reconstruction_Loss": recons_loss.detach(), "KLD": -kld.detach()}
 
 
+def categorical_forward(sd, x, u, latent_dim, categorical_dim, temp, training=True, new_buffers=None, eps=1e-7):
+    """CategoricalVAE.forward (cat_vae.py:90-138) with the uniform draws injected: -> [recons, input, q]."""
+    h = x
+    for i in range(5):
+        h = F.conv2d(h, sd[f"encoder.{i}.0.weight"], sd[f"encoder.{i}.0.bias"], stride=2, padding=1)
+        h = _bn_lrelu(sd, f"encoder.{i}.1", h, training, new_buffers)
+    q = F.linear(torch.flatten(h, start_dim=1), sd["fc_z.weight"], sd["fc_z.bias"]).view(-1, latent_dim, categorical_dim)
+    g = -torch.log(-torch.log(u + eps) + eps)
+    s = F.softmax((q + g) / temp, dim=-1).view(-1, latent_dim * categorical_dim)
+    return [vanilla_decode(sd, s, training, new_buffers), x, q]
+
+
+def categorical_loss(recons, x, q, M_N, alpha, eps=1e-7):
+    """cat_vae.py:140-169 (temperature annealing is host state of the model, not part of the arithmetic)."""
+    import math
+    q_p = F.softmax(q, dim=-1)
+    recons_loss = F.mse_loss(recons, x)
+    h1 = q_p * torch.log(q_p + eps)
+    h2 = q_p * math.log(1.0 / q.shape[-1] + eps)
+    kld = torch.mean(torch.sum(h1 - h2, dim=(1, 2)), dim=0)
+    return {"loss": alpha * recons_loss + M_N * kld, "Reconstruction_Loss": recons_loss, "KLD": -kld}
+
+
 # --------------------------------------------------------------------------------------------
 # Vector quantisers  (models/mcq_vae.py:7-137)
 # --------------------------------------------------------------------------------------------

@@ -77,6 +77,27 @@ def vqvae_specs():
     return [(k.replace("vq_layer.quantizers.0.embedding", "vq_layer.embedding"), sh, dt) for k, sh, dt in mcq_specs(VQVAE_CFG)]
 
 
+def cat_specs(latent_dim, categorical_dim):
+    """state_dict keys/shapes of CategoricalVAE (cat_vae.py:11-87): VanillaVAE's with the two Gaussian heads replaced by
+    fc_z and decoder_input widened to latent_dim * categorical_dim."""
+    n = latent_dim * categorical_dim
+    out = []
+    for k, sh, dt in vanilla_specs():
+        if k.startswith("fc_var."):
+            continue
+        if k.startswith("fc_mu."):
+            k, sh = k.replace("fc_mu", "fc_z"), ((n, 2048) if k.endswith("weight") else (n,))
+        elif k == "decoder_input.weight":
+            sh = (2048, n)
+        out.append((k, sh, dt))
+    return out
+
+
+def cat_uniform(seed, B, latent_dim, categorical_dim):
+    """The injected U[0,1) draws of the Gumbel-softmax reparameterisation (same rule as oracle/gen_cat_golden.py)."""
+    return torch.rand(B, latent_dim, categorical_dim, generator=torch.Generator().manual_seed(seed + 2))
+
+
 def cks(t):
     t = t.detach().double().cpu()
     return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()], dtype=np.float64)

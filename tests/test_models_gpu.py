@@ -323,6 +323,36 @@ def test_beta_vae_vs_golden(dev, golden, tag, cfg):
         H.assert_cks_close(H.cks(p.grad), g["gradcks." + k], rtol=2e-3, atol=2e-5, what=k)
 
 
+def test_categorical_vae_vs_golden(dev, golden):
+    """CategoricalVAE (cat_vae.py: VanillaVAE's stacks around a Gumbel-softmax categorical latent) against the reference's
+    own fixture: logits, reconstruction, loss dict, temperature annealing, every parameter gradient."""
+    from ctvae_amd.models import vae_models
+    g = golden("cat_b2")
+    seed = int(g["seed"])
+    D, Q = 64, 40
+    m = vae_models["CategoricalVAE"](in_channels=3, latent_dim=D, categorical_dim=Q, temperature=0.5, anneal_rate=0.00003,
+                                     anneal_interval=100, alpha=1.0)
+    m.load_state_dict(filler.fill_state(H.cat_specs(D, Q), seed + 1))
+    m = m.to(dev).train()
+    x, _ = filler.synthetic_batch(seed, 2)
+    out = m(x.to(dev), u=H.cat_uniform(seed, 2, D, Q).to(dev))
+    np.testing.assert_allclose(out[2].detach().cpu().numpy(), g["q"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(out[0].detach()[:, :, ::8, ::8].cpu().numpy(), g["recons_slice"], atol=TOL, rtol=0)
+    l1 = m.loss_function(*out, M_N=float(g["M_N"]), batch_idx=0)
+    l1["loss"].backward()
+    with torch.no_grad():
+        l2 = m.loss_function(*out, M_N=float(g["M_N"]), batch_idx=100)
+    assert float(m.temp) == float(g["temp_after"])
+    for call, l in (("call1", l1), ("call2", l2)):
+        for k in ("loss", "Reconstruction_Loss", "KLD"):
+            want = float(g[f"{call}.{k}"])
+            assert abs(float(l[k].detach()) - want) <= TOL * max(1.0, abs(want)), (call, k, float(l[k].detach()), want)
+    np.testing.assert_allclose(m.fc_z.bias.grad.cpu().numpy(), g["grad.fc_z.bias"], atol=TOL, rtol=2e-3)
+    for k, p in m.named_parameters():
+        H.assert_cks_close(H.cks(p.grad), g["gradcks." + k], rtol=2e-3, atol=2e-5, what=k)
+    assert m.sample(3, dev).shape == (3, 3, 64, 64)
+
+
 def test_vqvae_vs_golden(dev, golden):
     """VQVAE (vq_vae.py: MCQ-VAE's conv stacks around one 512-entry codebook) against the reference's own fixture."""
     from ctvae_amd.models import vae_models

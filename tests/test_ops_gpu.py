@@ -155,6 +155,31 @@ def test_reparam_and_loss(K):
     np.testing.assert_allclose(ld.grad.cpu().numpy(), lv.grad.numpy(), atol=1e-7, rtol=1e-4)
 
 
+@pytest.mark.parametrize("rows,Q", [(2 * 64, 40), (33, 10), (7, 1), (19, 64), (5, 100), (3, 200), (4096 * 3 + 5, 40)])
+def test_gumbel_softmax_and_categorical_kl(K, rows, Q):
+    """CategoricalVAE's latent kernels (catlatent.hip) against the torch expressions of cat_vae.py:125-130,147,160-167:
+    group sizes 1..64 lanes, 1/2/4 categories per lane, ragged row counts, grid-stride tail."""
+    g = torch.Generator().manual_seed(rows * 1000 + Q)
+    B = 3 if rows % 3 == 0 else 1
+    z = (2.0 * torch.randn(rows, Q, generator=g)).view(B, rows // B, Q).requires_grad_(True)
+    u = torch.rand(B, rows // B, Q, generator=g)
+    wgt = torch.randn(B, rows // B, Q, generator=g)
+    temp, eps = 0.5, 1e-7
+    gum = -torch.log(-torch.log(u + eps) + eps)
+    s = F.softmax((z + gum) / temp, dim=-1)
+    q_p = F.softmax(z, dim=-1)
+    kld = torch.mean(torch.sum(q_p * torch.log(q_p + eps) - q_p * np.log(1.0 / Q + eps), dim=(1, 2)), dim=0)
+    ((s * wgt).sum() + 0.7 * kld).backward()
+    zd = z.detach().cuda().requires_grad_(True)
+    sd = K.GumbelSoftmax.apply(zd, u.cuda(), temp, eps)
+    kd = K.CatKL.apply(zd, eps)
+    ((sd * wgt.cuda()).sum() + 0.7 * kd).backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(sd.detach().cpu().numpy(), s.detach().numpy(), atol=2e-6, rtol=1e-5)
+    assert abs(kd.item() - kld.item()) <= 1e-5 * max(1.0, abs(kld.item()))
+    np.testing.assert_allclose(zd.grad.cpu().numpy(), z.grad.numpy(), atol=2e-6, rtol=1e-4)
+
+
 def test_permute_roundtrip(K):
     x = torch.randn(3, 5, 6, 7)
     xd = x.cuda()

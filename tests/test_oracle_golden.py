@@ -118,6 +118,33 @@ def test_beta_vae_losses(golden, tag):
             H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
 
 
+CAT_CFG = dict(in_channels=3, latent_dim=64, categorical_dim=40, temperature=0.5, anneal_rate=0.00003, anneal_interval=100, alpha=1.0)
+
+
+def test_categorical_vae_forward_loss_grads(golden):
+    """CategoricalVAE (Gumbel-softmax latent): oracle restatement against the reference's own cat_vae.py fixture
+    (oracle/gen_cat_golden.py), uniform draws injected."""
+    g = golden("cat_b2")
+    seed = int(g["seed"])
+    sd = O.leafify(filler.fill_state(H.cat_specs(CAT_CFG["latent_dim"], CAT_CFG["categorical_dim"]), seed + 1))
+    x, _ = filler.synthetic_batch(seed, 2)
+    u = H.cat_uniform(seed, 2, CAT_CFG["latent_dim"], CAT_CFG["categorical_dim"])
+    recons, inp, q = O.categorical_forward(sd, x, u, CAT_CFG["latent_dim"], CAT_CFG["categorical_dim"], CAT_CFG["temperature"], True, {})
+    np.testing.assert_allclose(q.detach().numpy(), g["q"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(recons.detach()[:, :, ::8, ::8].numpy(), g["recons_slice"], atol=TOL, rtol=0)
+    l = O.categorical_loss(recons, inp, q, float(g["M_N"]), CAT_CFG["alpha"])
+    for k in ("loss", "Reconstruction_Loss", "KLD"):
+        want = float(g["call1." + k])
+        assert abs(l[k].item() - want) <= TOL * max(1.0, abs(want)), k
+        assert abs(float(g["call2." + k]) - want) <= 1e-7       # annealing never drops below the initial temperature
+    assert float(g["temp_after"]) == CAT_CFG["temperature"]
+    l["loss"].backward()
+    np.testing.assert_allclose(sd["fc_z.bias"].grad.numpy(), g["grad.fc_z.bias"], atol=TOL, rtol=1e-3)
+    for k, v in sd.items():
+        if v.requires_grad:
+            H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
+
+
 def test_vqvae_forward_loss_grads(golden):
     """VQVAE = MCQ-VAE's stacks around ONE codebook: oracle (single-codebook path of the MCQ restatement) against the
     reference's own vq_vae.py fixture."""
