@@ -60,6 +60,11 @@ int launch_gumbel_softmax_bwd(const float* gs, const float* s, float* gz, long r
 int launch_cat_kl_fwd(const float* logits, long rows, int Q, int B, float eps, float c, float* out, float* ws, size_t ws_bytes,
                       hipStream_t st);
 int launch_cat_kl_bwd(const float* logits, const float* go, float* gq, long rows, int Q, int B, float eps, float c, hipStream_t st);
+int launch_iw_loss_forward(const float* recons, const float* x, long n, int R, int rep, const float* mu, const float* lv, int L,
+                           int S, float M_N, float* lp, float* kld, float* coef, float* out4, hipStream_t st);
+int launch_iw_loss_backward(const float* recons, const float* x, long n, int R, int rep, const float* mu, const float* lv, int L,
+                            float M_N, const float* coef, const float* go, float* g_recons, float* g_mu, float* g_lv,
+                            hipStream_t st);
 int launch_loss_forward(const float* r, const float* x, long n, const float* mu, long mu_rs, const float* lv, long lv_rs,
                         int B, int L, float M_N, const float* extra, float* out3, float* ws, size_t ws_bytes, hipStream_t st);
 int launch_mse_backward(const float* r, const float* x, const float* go, float* gr, long n, hipStream_t st);
@@ -374,6 +379,22 @@ int ctvae_cat_kl_backward(const float* logits, const float* g_kld, float* g_logi
                           float log_prior, void* stream) {
   if (!logits || !g_kld || !g_logits || rows <= 0 || Q <= 0 || B <= 0) return kErrBadArg;
   return launch_cat_kl_bwd(logits, g_kld, g_logits, rows, Q, B, eps, log_prior, (hipStream_t)stream);
+}
+
+int ctvae_iw_loss_forward(const float* recons, const float* x, long n, int R, int rep, const float* mu, const float* logvar,
+                          int L, int S, float M_N, float* lp, float* kld, float* coef, float* out4, void* stream) {
+  if (!recons || !x || !mu || !logvar || !lp || !kld || !coef || !out4) return kErrBadArg;
+  if (n <= 0 || (n & 3) || R <= 0 || rep <= 0 || R % rep || S <= 0 || R % S || L <= 0) return kErrBadArg;
+  return launch_iw_loss_forward(recons, x, n, R, rep, mu, logvar, L, S, M_N, lp, kld, coef, out4, (hipStream_t)stream);
+}
+
+int ctvae_iw_loss_backward(const float* recons, const float* x, long n, int R, int rep, const float* mu, const float* logvar,
+                           int L, float M_N, const float* coef, const float* g_loss, float* g_recons, float* g_mu,
+                           float* g_logvar, void* stream) {
+  if (!recons || !x || !mu || !logvar || !coef || !g_loss || (g_mu == nullptr) != (g_logvar == nullptr)) return kErrBadArg;
+  if (n <= 0 || (n & 3) || R <= 0 || rep <= 0 || R % rep || L <= 0) return kErrBadArg;
+  return launch_iw_loss_backward(recons, x, n, R, rep, mu, logvar, L, M_N, coef, g_loss, g_recons, g_mu, g_logvar,
+                                 (hipStream_t)stream);
 }
 
 int ctvae_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* state, long n,

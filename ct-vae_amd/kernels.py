@@ -680,6 +680,43 @@ class CatKL(Function):
         return g_q, None
 
 
+class IWLoss(Function):
+    """out = [loss, mean lp, mean kld, -mean kld] of the importance-weighted objective (iwae.py:126-155, miwae.py:130-163):
+    recons [R,...] (R = B*M*S rows, same per-image layout as x [B,...]), mu / logvar [R,L], S samples per group.
+    Only out[0] carries gradient (through both the softmax weights and the log-weights, as in the reference)."""
+
+    @staticmethod
+    def forward(ctx, recons, x, mu, logvar, S, M_N):
+        _req_cuda(recons, x, mu, logvar)
+        recons, x, mu, logvar = _c(recons), _c(x), _c(mu), _c(logvar)
+        R, B = recons.shape[0], x.shape[0]
+        n = recons.numel() // R
+        if R % B or x.numel() != B * n or mu.shape[0] != R or mu.shape != logvar.shape:
+            raise RuntimeError("iw_loss: shape mismatch")
+        L = mu.numel() // R
+        dev = recons.device
+        rows = torch.empty(3, R, dtype=torch.float32, device=dev)      # lp, kld, coef
+        out = torch.empty(4, dtype=torch.float32, device=dev)
+        native.call("ctvae_iw_loss_forward", recons.data_ptr(), x.data_ptr(), n, R, R // B, mu.data_ptr(), logvar.data_ptr(), L,
+                    int(S), float(M_N), rows[0].data_ptr(), rows[1].data_ptr(), rows[2].data_ptr(), out.data_ptr())
+        ctx.save_for_backward(recons, x, mu, logvar, rows)
+        ctx.meta = (n, R, R // B, L, float(M_N))
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        recons, x, mu, logvar, rows = ctx.saved_tensors
+        n, R, rep, L, M_N = ctx.meta
+        g_loss = _c(g_out[0:1])
+        g_r = torch.empty_like(recons) if ctx.needs_input_grad[0] else None
+        g_mu = g_lv = None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            g_mu, g_lv = torch.empty_like(mu), torch.empty_like(logvar)
+        native.call("ctvae_iw_loss_backward", recons.data_ptr(), x.data_ptr(), n, R, rep, mu.data_ptr(), logvar.data_ptr(), L, M_N,
+                    rows[2].data_ptr(), g_loss.data_ptr(), native.ptr(g_r), native.ptr(g_mu), native.ptr(g_lv))
+        return g_r, None, g_mu, g_lv, None, None
+
+
 class PairMLP(Function):
     """out[b,i,j] = sigmoid(b2 + sum_h w2[h] * leaky_relu(u[b,i,h] + v[b,j,h])): the all-pairs tail of
     ``CausalTransition.graph_discovers[k]`` (ct_mcq_vae.py:86-95,147-151) without the [B,N,N,H] intermediates.

@@ -7,6 +7,7 @@ from .vanilla_vae import VanillaVAE
 from .beta_vae import BetaVAE
 from .vq_vae import VQVAE
 from .cat_vae import CategoricalVAE
+from .iwae import IWAE, MIWAE
 
 # Aliases (models/__init__.py:29-32)
 VAE = VanillaVAE
@@ -20,6 +21,8 @@ vae_models = {
     'MCQVAE': MCQVAE,
     'BetaVAE': BetaVAE,       # same network as VanillaVAE, beta / capacity objectives (beta_vae.py)
     'VQVAE': VQVAE,           # MCQ-VAE's conv stacks around one codebook (vq_vae.py)
+    'IWAE': IWAE,             # VanillaVAE's network, importance-weighted bound over S samples (iwae.py)
+    'MIWAE': MIWAE,           # ... over M estimates x S samples (miwae.py)
     'CategoricalVAE': CategoricalVAE,   # VanillaVAE's stacks around a Gumbel-softmax categorical latent (cat_vae.py)
 }
 

@@ -203,6 +203,19 @@ int ctvae_cat_kl_forward(const float* logits, long rows, int Q, int B, float eps
 int ctvae_cat_kl_backward(const float* logits, const float* g_kld, float* g_logits, long rows, int Q, int B, float eps,
                           float log_prior, void* stream);
 
+/* Importance-weighted objective of IWAE / MIWAE (models/iwae.py:126-155, models/miwae.py:130-163).  recons [R][n] are the
+ * reconstructions of the R = B*M*S latent samples, row r belongs to image r / rep of x [R/rep][n] (rep = M*S; same
+ * per-image layout as recons, n % 4 == 0); mu / logvar [R][L] are the (repeated) posterior parameters of each row.
+ *   lp[r] = mean_n (recons - x)^2, kld[r] = -0.5 sum_d (1 + lv - mu^2 - e^lv), lw = lp + M_N*kld, w = softmax over the S
+ *   consecutive rows of a group, out4 = {loss = mean_groups sum_s w*lw, mean lp, mean kld, -mean kld};
+ *   coef[r] = d loss / d lw[r] (weights NOT detached, like the reference) is kept for the backward call, which writes
+ *   g_recons (may be NULL) and g_mu / g_logvar (both or neither) scaled by g_loss[0]. */
+int ctvae_iw_loss_forward(const float* recons, const float* x, long n, int R, int rep, const float* mu, const float* logvar,
+                          int L, int S, float M_N, float* lp, float* kld, float* coef, float* out4, void* stream);
+int ctvae_iw_loss_backward(const float* recons, const float* x, long n, int R, int rep, const float* mu, const float* logvar,
+                           int L, float M_N, const float* coef, const float* g_loss, float* g_recons, float* g_mu,
+                           float* g_logvar, void* stream);
+
 /* torch.optim.Adam step over one flat buffer (experiment.py:158-160).  state (device, 8 floats):
  * {step, lr, beta1, beta2, eps, weight_decay, beta1^step, beta2^step}; the call advances step. */
 int ctvae_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* state, long n,

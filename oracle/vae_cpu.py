@@ -85,6 +85,31 @@ def vanilla_loss(recons, x, mu, log_var, M_N):
     return {"loss": recons_loss + M_N * kld, "Reconstruction_Loss": recons_loss.detach(), "KLD": -kld.detach()}
 
 
+def miwae_forward(sd, x, eps, training=True, new_buffers=None):
+    """IWAE.forward (iwae.py:119-124) / MIWAE.forward (miwae.py:124-130) with the noise injected: eps [B,S,D] or
+    [B,M,S,D] fixes the sample dimensions -> [recons [B,(M,)S,C,H,W], input, mu, log_var, z, eps_out]."""
+    mu, log_var = vanilla_encode(sd, x, training, new_buffers)
+    lead, L = tuple(eps.shape[:-1]), eps.shape[-1]
+    shape = (lead[0],) + (1,) * (len(lead) - 1) + (L,)
+    mu = mu.view(shape).expand(lead + (L,))
+    log_var = log_var.view(shape).expand(lead + (L,))
+    z = eps * torch.exp(0.5 * log_var) + mu
+    r = vanilla_decode(sd, z.reshape(-1, L), training, new_buffers)
+    return [r.view(lead + tuple(r.shape[1:])), x, mu, log_var, z, (z - mu) / log_var]
+
+
+def iw_loss(recons, x, mu, log_var, M_N):
+    """iwae.py:126-160 / miwae.py:130-163: softmax over the LAST sample dimension, mean over everything in front."""
+    lead = tuple(recons.shape[:-3])
+    xin = x.view((x.shape[0],) + (1,) * (len(lead) - 1) + tuple(x.shape[1:])).expand(lead + tuple(x.shape[1:]))
+    log_p_x_z = ((recons - xin) ** 2).flatten(len(lead)).mean(-1)
+    kld = -0.5 * torch.sum(1 + log_var - mu ** 2 - log_var.exp(), dim=-1)
+    log_weight = log_p_x_z + M_N * kld
+    weight = F.softmax(log_weight, dim=-1)
+    loss = torch.sum(weight * log_weight, dim=-1).mean()
+    return {"loss": loss, "Reconstruction_Loss": log_p_x_z.mean(), "KLD": -kld.mean()}
+
+
 def categorical_forward(sd, x, u, latent_dim, categorical_dim, temp, training=True, new_buffers=None, eps=1e-7):
     """CategoricalVAE.forward (cat_vae.py:90-138) with the uniform draws injected: -> [recons, input, q]."""
     h = x

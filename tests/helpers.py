@@ -98,6 +98,15 @@ def cat_uniform(seed, B, latent_dim, categorical_dim):
     return torch.rand(B, latent_dim, categorical_dim, generator=torch.Generator().manual_seed(seed + 2))
 
 
+def iw_noise(seed, lead, L=128):
+    """The injected N(0,1) draws of IWAE / MIWAE (same rule as oracle/gen_iw_golden.py)."""
+    return torch.randn(*lead, L, generator=torch.Generator().manual_seed(seed + 3))
+
+
+IW_CASES = {"iwae": ("IWAE", dict(in_channels=3, latent_dim=128, num_samples=5), (5,)),
+            "miwae": ("MIWAE", dict(in_channels=3, latent_dim=128, num_samples=5, num_estimates=3), (3, 5))}
+
+
 def cks(t):
     t = t.detach().double().cpu()
     return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()], dtype=np.float64)

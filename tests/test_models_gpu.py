@@ -353,6 +353,35 @@ def test_categorical_vae_vs_golden(dev, golden):
     assert m.sample(3, dev).shape == (3, 3, 64, 64)
 
 
+@pytest.mark.parametrize("tag", ["iwae", "miwae"])
+def test_iwae_miwae_vs_golden(dev, golden, tag):
+    """IWAE / MIWAE against the reference's own fixtures: repeated posterior parameters, reconstructions of all samples,
+    the importance-weighted loss dict and every parameter gradient (weights not detached)."""
+    from ctvae_amd.models import vae_models
+    g = golden(f"{tag}_b2")
+    seed = int(g["seed"])
+    name, cfg, lead = H.IW_CASES[tag]
+    m = vae_models[name](**cfg)
+    m.load_state_dict(filler.fill_state(H.vanilla_specs(), seed + 1))
+    m = m.to(dev).train()
+    x, _ = filler.synthetic_batch(seed, 2)
+    out = m(x.to(dev), eps=H.iw_noise(seed, (2,) + lead).to(dev))
+    assert tuple(out[0].shape) == tuple(g["recons_shape"]) and tuple(out[2].shape) == g["mu"].shape
+    np.testing.assert_allclose(out[2].detach().cpu().numpy(), g["mu"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(out[0].detach()[..., ::16, ::16].cpu().numpy(), g["recons_slice"], atol=TOL, rtol=0)
+    H.assert_cks_close(H.cks(out[4]), g["z_cks"], rtol=1e-5, atol=1e-5, what="z")
+    losses = m.loss_function(*out, M_N=float(g["M_N"]))
+    losses["loss"].backward()
+    for k in ("loss", "Reconstruction_Loss", "KLD"):
+        want = float(g["loss." + k])
+        assert abs(float(losses[k].detach()) - want) <= TOL * max(1.0, abs(want)), (k, float(losses[k].detach()), want)
+    for k in ("fc_mu.bias", "fc_var.bias"):
+        np.testing.assert_allclose(getattr(m, k.split(".")[0]).bias.grad.cpu().numpy(), g["grad." + k], atol=1e-6, rtol=2e-3)
+    for k, p in m.named_parameters():
+        H.assert_cks_close(H.cks(p.grad), g["gradcks." + k], rtol=2e-3, atol=2e-5, what=k)
+    assert m.sample(3, dev).shape == (3, 3, 64, 64) and m.generate(x.to(dev)).shape == (2, 3, 64, 64)
+
+
 def test_vqvae_vs_golden(dev, golden):
     """VQVAE (vq_vae.py: MCQ-VAE's conv stacks around one 512-entry codebook) against the reference's own fixture."""
     from ctvae_amd.models import vae_models

@@ -180,6 +180,29 @@ def test_gumbel_softmax_and_categorical_kl(K, rows, Q):
     np.testing.assert_allclose(zd.grad.cpu().numpy(), z.grad.numpy(), atol=2e-6, rtol=1e-4)
 
 
+@pytest.mark.parametrize("B,lead,n,L", [(3, (4,), 1024, 16), (2, (3, 5), 12288, 128), (5, (1,), 64, 300), (1, (2, 7), 256, 1)])
+def test_importance_weighted_loss(K, B, lead, n, L):
+    """csrc/iwloss.hip against the torch expressions of iwae.py:139-160 / miwae.py:146-163 (weights not detached)."""
+    from oracle import vae_cpu as O
+    g = torch.Generator().manual_seed(B * 100 + n)
+    R = B * int(np.prod(lead))
+    r = torch.rand((B,) + lead + (n // 4, 2, 2), generator=g).requires_grad_(True)
+    x = torch.rand(B, n // 4, 2, 2, generator=g)
+    mu = torch.randn((B,) + lead + (L,), generator=g).requires_grad_(True)
+    lv = (0.3 * torch.randn((B,) + lead + (L,), generator=g)).requires_grad_(True)
+    want = O.iw_loss(r, x, mu, lv, 0.01)
+    want["loss"].backward()
+    rd, md, ld = (t.detach().cuda().requires_grad_(True) for t in (r, mu, lv))
+    out = K.IWLoss.apply(rd.reshape(R, -1), x.cuda().reshape(B, -1), md.reshape(R, L), ld.reshape(R, L), lead[-1], 0.01)
+    out[0].backward()
+    torch.cuda.synchronize()
+    for i, k in ((0, "loss"), (1, "Reconstruction_Loss"), (3, "KLD")):
+        assert abs(out[i].item() - want[k].item()) <= 1e-5 * max(1.0, abs(want[k].item())), k
+    np.testing.assert_allclose(rd.grad.cpu().numpy(), r.grad.numpy(), atol=1e-9, rtol=1e-3)
+    np.testing.assert_allclose(md.grad.cpu().numpy(), mu.grad.numpy(), atol=1e-8, rtol=1e-3)
+    np.testing.assert_allclose(ld.grad.cpu().numpy(), lv.grad.numpy(), atol=1e-8, rtol=1e-3)
+
+
 def test_permute_roundtrip(K):
     x = torch.randn(3, 5, 6, 7)
     xd = x.cuda()

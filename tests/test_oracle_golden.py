@@ -145,6 +145,31 @@ def test_categorical_vae_forward_loss_grads(golden):
             H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
 
 
+@pytest.mark.parametrize("tag", ["iwae", "miwae"])
+def test_iwae_miwae_forward_loss_grads(golden, tag):
+    """IWAE / MIWAE (VanillaVAE's network, importance-weighted bound): oracle restatement against the reference's own
+    iwae.py / miwae.py fixtures (oracle/gen_iw_golden.py), noise injected."""
+    g = golden(f"{tag}_b2")
+    seed = int(g["seed"])
+    sd = O.leafify(filler.fill_state(H.vanilla_specs(), seed + 1))
+    x, _ = filler.synthetic_batch(seed, 2)
+    eps = H.iw_noise(seed, (2,) + H.IW_CASES[tag][2])
+    res = O.miwae_forward(sd, x, eps, True, {})
+    assert tuple(res[0].shape) == tuple(g["recons_shape"])
+    np.testing.assert_allclose(res[2].detach().numpy(), g["mu"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(res[0].detach()[..., ::16, ::16].numpy(), g["recons_slice"], atol=TOL, rtol=0)
+    l = O.iw_loss(res[0], res[1], res[2], res[3], float(g["M_N"]))
+    for k in ("loss", "Reconstruction_Loss", "KLD"):
+        want = float(g["loss." + k])
+        assert abs(l[k].item() - want) <= TOL * max(1.0, abs(want)), k
+    l["loss"].backward()
+    for k in ("fc_mu.bias", "fc_var.bias"):
+        np.testing.assert_allclose(sd[k].grad.numpy(), g["grad." + k], atol=1e-6, rtol=1e-3)
+    for k, v in sd.items():
+        if v.requires_grad:
+            H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
+
+
 def test_vqvae_forward_loss_grads(golden):
     """VQVAE = MCQ-VAE's stacks around ONE codebook: oracle (single-codebook path of the MCQ restatement) against the
     reference's own vq_vae.py fixture."""
