@@ -66,8 +66,9 @@ int launch_iw_loss_backward(const float* recons, const float* x, long n, int R, 
                             float M_N, const float* coef, const float* go, float* g_recons, float* g_mu, float* g_lv,
                             hipStream_t st);
 int launch_loss_forward(const float* r, const float* x, long n, const float* mu, long mu_rs, const float* lv, long lv_rs,
-                        int B, int L, float M_N, const float* extra, float* out3, float* ws, size_t ws_bytes, hipStream_t st);
-int launch_mse_backward(const float* r, const float* x, const float* go, float* gr, long n, hipStream_t st);
+                        int B, int L, float M_N, const float* extra, float* out3, float* ws, size_t ws_bytes, hipStream_t st,
+                        float logcosh_alpha);
+int launch_mse_backward(const float* r, const float* x, const float* go, float* gr, long n, hipStream_t st, float logcosh_alpha);
 int launch_kl_backward(const float* mu, long mu_rs, const float* lv, long lv_rs, const float* go, float* gmu, float* glv,
                        int B, int L, float M_N, hipStream_t st);
 int launch_vq_inds(const float* lat, const float* cb, long long* inds, int B, int HW, int D, int K, int C, hipStream_t st);
@@ -312,12 +313,27 @@ int ctvae_loss_forward(const float* recons, const float* x, long n, const float*
   if (!recons || !x || !out4 || !ws || n <= 0) return kErrBadArg;
   if ((mu == nullptr) != (logvar == nullptr)) return kErrBadArg;
   return launch_loss_forward(recons, x, n, mu, mu_rs, logvar, lv_rs, B, L, M_N, extra, out4, ws, ws_bytes,
-                             (hipStream_t)stream);
+                             (hipStream_t)stream, 0.f);
 }
 
 int ctvae_mse_backward(const float* recons, const float* x, const float* g_loss, float* g_recons, long n, void* stream) {
   if (!recons || !x || !g_loss || !g_recons || n <= 0) return kErrBadArg;
-  return launch_mse_backward(recons, x, g_loss, g_recons, n, (hipStream_t)stream);
+  return launch_mse_backward(recons, x, g_loss, g_recons, n, (hipStream_t)stream, 0.f);
+}
+
+int ctvae_logcosh_loss_forward(const float* recons, const float* x, long n, float alpha, const float* mu, long mu_rs,
+                               const float* logvar, long lv_rs, int B, int L, float M_N, float* out4, float* ws,
+                               size_t ws_bytes, void* stream) {
+  if (!recons || !x || !out4 || !ws || n <= 0 || !(alpha > 0.f)) return kErrBadArg;
+  if ((mu == nullptr) != (logvar == nullptr)) return kErrBadArg;
+  return launch_loss_forward(recons, x, n, mu, mu_rs, logvar, lv_rs, B, L, M_N, nullptr, out4, ws, ws_bytes,
+                             (hipStream_t)stream, alpha);
+}
+
+int ctvae_logcosh_backward(const float* recons, const float* x, const float* g_loss, float* g_recons, long n, float alpha,
+                           void* stream) {
+  if (!recons || !x || !g_loss || !g_recons || n <= 0 || !(alpha > 0.f)) return kErrBadArg;
+  return launch_mse_backward(recons, x, g_loss, g_recons, n, (hipStream_t)stream, alpha);
 }
 
 int ctvae_kl_backward(const float* mu, long mu_rs, const float* logvar, long lv_rs, const float* g_loss, float* g_mu,

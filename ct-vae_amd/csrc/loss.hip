@@ -10,10 +10,29 @@ namespace ctvae {
 
 constexpr int kLossBlocks = 1024;
 
+// per-element reconstruction term: MODE 0 (t = r - x): t^2;  MODE 1 (LogCoshVAE, logcosh_vae.py:141-148, written the way the
+// reference writes it): alpha t + log(1 + exp(-2 alpha t))   (the constant -log 2 and the factor 1/alpha are applied once, in
+// loss_finish_kernel)
+template <int MODE>
+__device__ __forceinline__ float recon_term(float d, float alpha) {
+  if constexpr (MODE == 0) return d * d;
+  else return alpha * d + logf(1.f + expf(-2.f * alpha * d));
+}
+// its derivative: 2 t  resp.  alpha (1 - e) / (1 + e), e = exp(-2 alpha t)   (= alpha tanh(alpha t))
+template <int MODE>
+__device__ __forceinline__ float recon_term_grad(float d, float alpha) {
+  if constexpr (MODE == 0) return 2.f * d;
+  else {
+    const float e = expf(-2.f * alpha * d);
+    return e < 3.0e38f ? alpha * (1.f - e) / (1.f + e) : -alpha;
+  }
+}
+
+template <int MODE>
 __global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ r, const float* __restrict__ x,
                                                           float* __restrict__ part, long n4, long n,
                                                           const float* __restrict__ mu, long mu_rs,
-                                                          const float* __restrict__ lv, long lv_rs, int B, int L) {
+                                                          const float* __restrict__ lv, long lv_rs, int B, int L, float alpha) {
   __shared__ float sm[4];
   float s = 0.f;
   const long stride = (long)gridDim.x * 256;
@@ -21,16 +40,10 @@ __global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restric
     f32x4 a = reinterpret_cast<const f32x4*>(r)[i];
     f32x4 b = reinterpret_cast<const f32x4*>(x)[i];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float d = a[k] - b[k];
-      s += d * d;
-    }
+    for (int k = 0; k < 4; ++k) s += recon_term<MODE>(a[k] - b[k], alpha);
   }
   if (blockIdx.x == 0) {  // tail (n % 4)
-    for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) {
-      float d = r[i] - x[i];
-      s += d * d;
-    }
+    for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) s += recon_term<MODE>(r[i] - x[i], alpha);
   }
   float k = 0.f;          // KL terms 1 + lv - mu^2 - e^lv, spread over the same grid
   if (mu != nullptr) {
@@ -51,7 +64,7 @@ __global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restric
 // out[0] = loss = mse + M_N*kld (+ extra[0] if given), out[1] = mse, out[2] = kld, out[3] = -kld ('KLD' key, vanilla_vae.py:146)
 __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ part, int nparts, double inv_n, int has_kl,
                                                           int B, float M_N, const float* __restrict__ extra,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, float post_sub, float post_scale) {
   __shared__ double smd[8];
   double s = 0.0, k = 0.0;
   for (int i = threadIdx.x; i < nparts; i += 256) {
@@ -66,7 +79,7 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
   if (threadIdx.x == 0) {
     const double st = smd[0] + smd[1] + smd[2] + smd[3];
     const double kt = smd[4] + smd[5] + smd[6] + smd[7];
-    float mse = (float)(st * inv_n);
+    float mse = ((float)(st * inv_n) - post_sub) * post_scale;   // (0, 1) for the MSE; (log 2, 1/alpha) for log-cosh
     float kld = has_kl ? (float)(-0.5 * kt / (double)B) : 0.f;
     float loss = mse + M_N * kld;
     if (extra != nullptr) loss += extra[0];
@@ -77,22 +90,23 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
   }
 }
 
-// g_r = go * 2 (r - x) / n
+// g_r = go * term'(r - x) * scale      (MSE: 2 (r - x) / n;  log-cosh: tanh(alpha (r - x)) / n)
+template <int MODE>
 __global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ r, const float* __restrict__ x,
                                                       const float* __restrict__ go, float* __restrict__ gr, long n4, long n,
-                                                      float two_over_n) {
-  const float sc = go[0] * two_over_n;
+                                                      float scale, float alpha) {
+  const float sc = go[0] * scale;
   const long stride = (long)gridDim.x * 256;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     f32x4 a = reinterpret_cast<const f32x4*>(r)[i];
     f32x4 b = reinterpret_cast<const f32x4*>(x)[i];
     f32x4 o;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = sc * (a[k] - b[k]);
+    for (int k = 0; k < 4; ++k) o[k] = sc * recon_term_grad<MODE>(a[k] - b[k], alpha);
     reinterpret_cast<f32x4*>(gr)[i] = o;
   }
   if (blockIdx.x == 0)
-    for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) gr[i] = sc * (r[i] - x[i]);
+    for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) gr[i] = sc * recon_term_grad<MODE>(r[i] - x[i], alpha);
 }
 
 // g_mu = go*M_N*mu/B ; g_lv = go*M_N*0.5*(e^lv - 1)/B     (dense [B][L] outputs)
@@ -111,7 +125,7 @@ size_t loss_workspace_floats() { return 2 * kLossBlocks; }
 
 int launch_loss_forward(const float* r, const float* x, long n, const float* mu, long mu_rs, const float* lv, long lv_rs,
                         int B, int L, float M_N, const float* extra, float* out4, float* ws, size_t ws_bytes,
-                        hipStream_t st) {
+                        hipStream_t st, float logcosh_alpha) {
   if (ws_bytes / sizeof(float) < loss_workspace_floats() || n <= 0) return kErrWorkspace;
   const long n4 = n / 4;
   long blocks = (n4 + 255) / 256;
@@ -119,23 +133,30 @@ int launch_loss_forward(const float* r, const float* x, long n, const float* mu,
   if (blocks < 1) blocks = 1;
   {
   ProfScope ps("mse_partial_kernel", st, 0.0, 8.0 * (double)n);
-  hipLaunchKernelGGL(mse_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, st, r, x, ws, n4, n, mu, mu_rs, lv, lv_rs, B, L);
+  if (logcosh_alpha > 0.f)
+    hipLaunchKernelGGL(mse_partial_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, r, x, ws, n4, n, mu, mu_rs, lv, lv_rs, B, L, logcosh_alpha);
+  else
+    hipLaunchKernelGGL(mse_partial_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, r, x, ws, n4, n, mu, mu_rs, lv, lv_rs, B, L, 0.f);
   }
   CTVAE_LAUNCH_CHECK();
   ProfScope ps2("loss_finish_kernel", st, 0.0, 8.0 * (double)B * L);
   hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, ws, (int)blocks, 1.0 / (double)n, mu != nullptr ? 1 : 0,
-                     B, M_N, extra, out4);
+                     B, M_N, extra, out4, logcosh_alpha > 0.f ? 0.69314718f : 0.f, logcosh_alpha > 0.f ? 1.f / logcosh_alpha : 1.f);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }
 
-int launch_mse_backward(const float* r, const float* x, const float* go, float* gr, long n, hipStream_t st) {
+int launch_mse_backward(const float* r, const float* x, const float* go, float* gr, long n, hipStream_t st, float logcosh_alpha) {
   const long n4 = n / 4;
   long blocks = (n4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   ProfScope ps("mse_bwd_kernel", st, 0.0, 12.0 * (double)n);
-  hipLaunchKernelGGL(mse_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, r, x, go, gr, n4, n, (float)(2.0 / (double)n));
+  if (logcosh_alpha > 0.f)   // d/dt of (alpha t + log(1 + e^{-2 alpha t}) - log 2) / alpha = tanh(alpha t)
+    hipLaunchKernelGGL(mse_bwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, r, x, go, gr, n4, n,
+                       (float)(1.0 / ((double)n * logcosh_alpha)), logcosh_alpha);
+  else
+    hipLaunchKernelGGL(mse_bwd_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, r, x, go, gr, n4, n, (float)(1.0 / (double)n), 0.f);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }

@@ -588,7 +588,8 @@ class VAELoss(Function):
     recons/x are same-layout contiguous tensors.  Only out[0] carries gradient."""
 
     @staticmethod
-    def forward(ctx, recons, x, mu, logvar, extra, M_N):
+    def forward(ctx, recons, x, mu, logvar, extra, M_N, logcosh_alpha=0.0):
+        """logcosh_alpha > 0: the reconstruction term is LogCoshVAE's (logcosh_vae.py:141-150) instead of the MSE."""
         _req_cuda(recons, x)
         recons, x = _c(recons), _c(x)
         if recons.shape != x.shape:
@@ -601,10 +602,17 @@ class VAELoss(Function):
             B, L = mu.shape
         else:
             mu_, lv_, mrs, lrs, B, L = None, None, 0, 0, 0, 0
-        native.call("ctvae_loss_forward", recons.data_ptr(), x.data_ptr(), recons.numel(), native.ptr(mu_), mrs, native.ptr(lv_),
-                    lrs, B, L, float(M_N), native.ptr(extra), out.data_ptr(), ws.data_ptr(), ws.numel() * 4)
+        if logcosh_alpha > 0.0:
+            if extra is not None:
+                raise RuntimeError("log-cosh loss: no extra term")
+            native.call("ctvae_logcosh_loss_forward", recons.data_ptr(), x.data_ptr(), recons.numel(), float(logcosh_alpha),
+                        native.ptr(mu_), mrs, native.ptr(lv_), lrs, B, L, float(M_N), out.data_ptr(), ws.data_ptr(), ws.numel() * 4)
+        else:
+            native.call("ctvae_loss_forward", recons.data_ptr(), x.data_ptr(), recons.numel(), native.ptr(mu_), mrs, native.ptr(lv_),
+                        lrs, B, L, float(M_N), native.ptr(extra), out.data_ptr(), ws.data_ptr(), ws.numel() * 4)
         ctx.save_for_backward(recons, x, mu_, lv_)
         ctx.meta = (mrs, lrs, B, L, float(M_N), extra is not None)
+        ctx.logcosh_alpha = float(logcosh_alpha)
         return out
 
     @staticmethod
@@ -615,7 +623,11 @@ class VAELoss(Function):
         g_r = None
         if ctx.needs_input_grad[0]:
             g_r = torch.empty_like(recons)
-            native.call("ctvae_mse_backward", recons.data_ptr(), x.data_ptr(), g_loss.data_ptr(), g_r.data_ptr(), recons.numel())
+            if ctx.logcosh_alpha > 0.0:
+                native.call("ctvae_logcosh_backward", recons.data_ptr(), x.data_ptr(), g_loss.data_ptr(), g_r.data_ptr(),
+                            recons.numel(), ctx.logcosh_alpha)
+            else:
+                native.call("ctvae_mse_backward", recons.data_ptr(), x.data_ptr(), g_loss.data_ptr(), g_r.data_ptr(), recons.numel())
         g_mu = g_lv = None
         if mu_ is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
             g_mu = torch.empty((B, L), dtype=torch.float32, device=recons.device)
@@ -623,7 +635,7 @@ class VAELoss(Function):
             native.call("ctvae_kl_backward", mu_.data_ptr(), mrs, lv_.data_ptr(), lrs, g_loss.data_ptr(), g_mu.data_ptr(),
                         g_lv.data_ptr(), B, L, M_N)
         g_extra = g_loss.reshape(()) if (has_extra and ctx.needs_input_grad[4]) else None
-        return g_r, None, g_mu, g_lv, g_extra, None
+        return g_r, None, g_mu, g_lv, g_extra, None, None
 
 
 class GumbelSoftmax(Function):

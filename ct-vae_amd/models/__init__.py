@@ -8,6 +8,7 @@ from .beta_vae import BetaVAE
 from .vq_vae import VQVAE
 from .cat_vae import CategoricalVAE
 from .iwae import IWAE, MIWAE
+from .logcosh_vae import LogCoshVAE
 
 # Aliases (models/__init__.py:29-32)
 VAE = VanillaVAE
@@ -23,6 +24,7 @@ vae_models = {
     'VQVAE': VQVAE,           # MCQ-VAE's conv stacks around one codebook (vq_vae.py)
     'IWAE': IWAE,             # VanillaVAE's network, importance-weighted bound over S samples (iwae.py)
     'MIWAE': MIWAE,           # ... over M estimates x S samples (miwae.py)
+    'LogCoshVAE': LogCoshVAE, # VanillaVAE's network, log-cosh reconstruction term (logcosh_vae.py)
     'CategoricalVAE': CategoricalVAE,   # VanillaVAE's stacks around a Gumbel-softmax categorical latent (cat_vae.py)
 }
 

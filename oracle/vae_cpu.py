@@ -85,6 +85,15 @@ def vanilla_loss(recons, x, mu, log_var, M_N):
     return {"loss": recons_loss + M_N * kld, "Reconstruction_Loss": recons_loss.detach(), "KLD": -kld.detach()}
 
 
+def logcosh_loss(recons, x, mu, log_var, M_N, alpha, beta):
+    """LogCoshVAE.loss_function (logcosh_vae.py:135-155), written as the reference writes it."""
+    t = recons - x
+    rl = alpha * t + torch.log(1. + torch.exp(-2 * alpha * t)) - torch.log(torch.tensor(2.0))
+    rl = (1. / alpha) * rl.mean()
+    kld = torch.mean(-0.5 * torch.sum(1 + log_var - mu ** 2 - log_var.exp(), dim=1), dim=0)
+    return {"loss": rl + beta * M_N * kld, "Reconstruction_Loss": rl, "KLD": -kld}
+
+
 def miwae_forward(sd, x, eps, training=True, new_buffers=None):
     """IWAE.forward (iwae.py:119-124) / MIWAE.forward (miwae.py:124-130) with the noise injected: eps [B,S,D] or
     [B,M,S,D] fixes the sample dimensions -> [recons [B,(M,)S,C,H,W], input, mu, log_var, z, eps_out]."""

@@ -382,6 +382,28 @@ def test_iwae_miwae_vs_golden(dev, golden, tag):
     assert m.sample(3, dev).shape == (3, 3, 64, 64) and m.generate(x.to(dev)).shape == (2, 3, 64, 64)
 
 
+def test_logcosh_vae_vs_golden(dev, golden):
+    """LogCoshVAE against the reference's own logcosh_vae.py fixture: loss dict and every parameter gradient."""
+    from ctvae_amd.models import vae_models
+    g = golden("logcosh_b2")
+    seed = int(g["seed"])
+    m = vae_models["LogCoshVAE"](in_channels=3, latent_dim=128, alpha=10.0, beta=1.0)
+    m.load_state_dict(filler.fill_state(H.vanilla_specs(), seed + 1))
+    m = m.to(dev).train()
+    x, eps = filler.synthetic_batch(seed, 2)
+    out = m(x.to(dev), eps=eps.to(dev))
+    np.testing.assert_allclose(out[2].detach().cpu().numpy(), g["mu"], atol=TOL, rtol=0)
+    losses = m.loss_function(*out, M_N=float(g["M_N"]))
+    losses["loss"].backward()
+    for k in ("loss", "Reconstruction_Loss", "KLD"):
+        want = float(g["loss." + k])
+        assert abs(float(losses[k].detach()) - want) <= TOL * max(1.0, abs(want)), (k, float(losses[k].detach()), want)
+    np.testing.assert_allclose(m.fc_mu.bias.grad.cpu().numpy(), g["grad.fc_mu.bias"], atol=1e-5, rtol=2e-3)
+    np.testing.assert_allclose(m.final_layer._modules["3"].weight.grad.cpu().numpy(), g["grad.final_layer.3.weight"], atol=1e-5, rtol=2e-3)
+    for k, p in m.named_parameters():
+        H.assert_cks_close(H.cks(p.grad), g["gradcks." + k], rtol=2e-3, atol=2e-5, what=k)
+
+
 def test_vqvae_vs_golden(dev, golden):
     """VQVAE (vq_vae.py: MCQ-VAE's conv stacks around one 512-entry codebook) against the reference's own fixture."""
     from ctvae_amd.models import vae_models

@@ -170,6 +170,26 @@ def test_iwae_miwae_forward_loss_grads(golden, tag):
             H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
 
 
+def test_logcosh_vae_loss_grads(golden):
+    """LogCoshVAE (VanillaVAE's network, log-cosh reconstruction term): oracle against the reference's logcosh_vae.py fixture."""
+    g = golden("logcosh_b2")
+    seed = int(g["seed"])
+    sd = O.leafify(filler.fill_state(H.vanilla_specs(), seed + 1))
+    x, eps = filler.synthetic_batch(seed, 2)
+    recons, inp, mu, log_var = O.vanilla_forward(sd, x, eps, True, {})
+    np.testing.assert_allclose(mu.detach().numpy(), g["mu"], atol=TOL, rtol=0)
+    l = O.logcosh_loss(recons, inp, mu, log_var, float(g["M_N"]), 10.0, 1.0)
+    for k in ("loss", "Reconstruction_Loss", "KLD"):
+        want = float(g["loss." + k])
+        assert abs(l[k].item() - want) <= TOL * max(1.0, abs(want)), k
+    l["loss"].backward()
+    for k in ("fc_mu.bias", "final_layer.3.weight"):
+        np.testing.assert_allclose(sd[k].grad.numpy(), g["grad." + k], atol=1e-5, rtol=1e-3)
+    for k, v in sd.items():
+        if v.requires_grad:
+            H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
+
+
 def test_vqvae_forward_loss_grads(golden):
     """VQVAE = MCQ-VAE's stacks around ONE codebook: oracle (single-codebook path of the MCQ restatement) against the
     reference's own vq_vae.py fixture."""
