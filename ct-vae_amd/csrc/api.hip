@@ -65,6 +65,8 @@ int launch_iw_loss_forward(const float* recons, const float* x, long n, int R, i
 int launch_iw_loss_backward(const float* recons, const float* x, long n, int R, int rep, const float* mu, const float* lv, int L,
                             float M_N, const float* coef, const float* go, float* g_recons, float* g_mu, float* g_lv,
                             hipStream_t st);
+int launch_mmd_forward(const float* z, const float* p, int N, int D, int kind, float c, float eps, float w_pp, float w_zz,
+                       float w_pz, float* out4, float* grad, float* ws, size_t ws_bytes, hipStream_t st);
 int launch_loss_forward(const float* r, const float* x, long n, const float* mu, long mu_rs, const float* lv, long lv_rs,
                         int B, int L, float M_N, const float* extra, float* out3, float* ws, size_t ws_bytes, hipStream_t st,
                         float logcosh_alpha);
@@ -411,6 +413,12 @@ int ctvae_iw_loss_backward(const float* recons, const float* x, long n, int R, i
   if (n <= 0 || (n & 3) || R <= 0 || rep <= 0 || R % rep || L <= 0) return kErrBadArg;
   return launch_iw_loss_backward(recons, x, n, R, rep, mu, logvar, L, M_N, coef, g_loss, g_recons, g_mu, g_logvar,
                                  (hipStream_t)stream);
+}
+
+int ctvae_mmd_forward(const float* z, const float* prior, int N, int D, int kind, float c, float eps, float w_pp, float w_zz,
+                      float w_pz, float* out4, float* grad_z, float* ws, size_t ws_bytes, void* stream) {
+  if (!z || !prior || !out4 || !grad_z || !ws || N <= 0 || D <= 0 || (kind != 0 && kind != 1) || !(c > 0.f)) return kErrBadArg;
+  return launch_mmd_forward(z, prior, N, D, kind, c, eps, w_pp, w_zz, w_pz, out4, grad_z, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int ctvae_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* state, long n,

@@ -611,7 +611,7 @@ class VAELoss(Function):
             native.call("ctvae_loss_forward", recons.data_ptr(), x.data_ptr(), recons.numel(), native.ptr(mu_), mrs, native.ptr(lv_),
                         lrs, B, L, float(M_N), native.ptr(extra), out.data_ptr(), ws.data_ptr(), ws.numel() * 4)
         ctx.save_for_backward(recons, x, mu_, lv_)
-        ctx.meta = (mrs, lrs, B, L, float(M_N), extra is not None)
+        ctx.meta = (mrs, lrs, B, L, float(M_N), tuple(extra.shape) if extra is not None else None)
         ctx.logcosh_alpha = float(logcosh_alpha)
         return out
 
@@ -634,7 +634,7 @@ class VAELoss(Function):
             g_lv = torch.empty((B, L), dtype=torch.float32, device=recons.device)
             native.call("ctvae_kl_backward", mu_.data_ptr(), mrs, lv_.data_ptr(), lrs, g_loss.data_ptr(), g_mu.data_ptr(),
                         g_lv.data_ptr(), B, L, M_N)
-        g_extra = g_loss.reshape(()) if (has_extra and ctx.needs_input_grad[4]) else None
+        g_extra = g_loss.reshape(has_extra) if (has_extra is not None and ctx.needs_input_grad[4]) else None
         return g_r, None, g_mu, g_lv, g_extra, None, None
 
 
@@ -727,6 +727,33 @@ class IWLoss(Function):
         native.call("ctvae_iw_loss_backward", recons.data_ptr(), x.data_ptr(), n, R, rep, mu.data_ptr(), logvar.data_ptr(), L, M_N,
                     rows[2].data_ptr(), g_loss.data_ptr(), native.ptr(g_r), native.ptr(g_mu), native.ptr(g_lv))
         return g_r, None, g_mu, g_lv, None, None
+
+
+class MMD(Function):
+    """out = [mmd, K(p,p), K(z,z), K(p,z)] of WAE_MMD / InfoVAE (wae_mmd.py:120-203): z, prior [N,D]; kind 'imq' | 'rbf';
+    c = 2*D*latent_var.  Only out[0] carries gradient, and only towards z (the prior draws are constants)."""
+
+    @staticmethod
+    def forward(ctx, z, prior, kind, c, w_pp, w_zz, w_pz):
+        _req_cuda(z, prior)
+        z, prior = _c(z), _c(prior)
+        if z.dim() != 2 or z.shape != prior.shape:
+            raise RuntimeError("mmd: z / prior must be [N,D] of one shape")
+        if kind not in ("imq", "rbf"):
+            raise ValueError('Undefined kernel type.')
+        N, D = z.shape
+        out = torch.empty(4, dtype=torch.float32, device=z.device)
+        grad = torch.empty_like(z)
+        ws = native.workspace(z.device)
+        native.call("ctvae_mmd_forward", z.data_ptr(), prior.data_ptr(), N, D, 0 if kind == "imq" else 1, float(c), 1e-7,
+                    float(w_pp), float(w_zz), float(w_pz), out.data_ptr(), grad.data_ptr(), ws.data_ptr(), ws.numel() * 4)
+        ctx.save_for_backward(grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (grad,) = ctx.saved_tensors
+        return grad * g_out[0], None, None, None, None, None, None
 
 
 class PairMLP(Function):

@@ -9,6 +9,7 @@ from .vq_vae import VQVAE
 from .cat_vae import CategoricalVAE
 from .iwae import IWAE, MIWAE
 from .logcosh_vae import LogCoshVAE
+from .wae_mmd import WAE_MMD, InfoVAE
 
 # Aliases (models/__init__.py:29-32)
 VAE = VanillaVAE
@@ -25,6 +26,8 @@ vae_models = {
     'IWAE': IWAE,             # VanillaVAE's network, importance-weighted bound over S samples (iwae.py)
     'MIWAE': MIWAE,           # ... over M estimates x S samples (miwae.py)
     'LogCoshVAE': LogCoshVAE, # VanillaVAE's network, log-cosh reconstruction term (logcosh_vae.py)
+    'WAE_MMD': WAE_MMD,       # VanillaVAE's stacks, one deterministic head, mse + MMD (wae_mmd.py)
+    'InfoVAE': InfoVAE,       # VanillaVAE's network, beta*mse + (1-alpha)*KL + MMD (info_vae.py)
     'CategoricalVAE': CategoricalVAE,   # VanillaVAE's stacks around a Gumbel-softmax categorical latent (cat_vae.py)
 }
 

@@ -51,6 +51,7 @@ SIGNATURES = {
     "ctvae_cat_kl_backward": [_fp, _fp, _fp, _l, _i, _i, _f, _f, _vp],
     "ctvae_iw_loss_forward": [_fp, _fp, _l, _i, _i, _fp, _fp, _i, _i, _f, _fp, _fp, _fp, _fp, _vp],
     "ctvae_iw_loss_backward": [_fp, _fp, _l, _i, _i, _fp, _fp, _i, _f, _fp, _fp, _fp, _fp, _fp, _vp],
+    "ctvae_mmd_forward": [_fp, _fp, _i, _i, _i, _f, _f, _f, _f, _f, _fp, _fp, _fp, _sz, _vp],
     "ctvae_adam_step": [_fp, _fp, _fp, _fp, _fp, _l, _f, _vp],
 }
 _RESTYPES = {

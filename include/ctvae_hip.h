@@ -225,6 +225,14 @@ int ctvae_iw_loss_backward(const float* recons, const float* x, long n, int R, i
                            int L, float M_N, const float* coef, const float* g_loss, float* g_recons, float* g_mu,
                            float* g_logvar, void* stream);
 
+/* Maximum-mean-discrepancy regulariser of WAE_MMD / InfoVAE (wae_mmd.py:120-203, info_vae.py:150-229) between the latent
+ * codes z [N][D] and prior draws [N][D] (D <= 512):  out4 = {mmd, K(p,p), K(z,z), K(p,z)},
+ * mmd = w_pp*K(p,p) + w_zz*K(z,z) - 2*w_pz*K(p,z);  kind 0 (imq): K(a,b) = sum_{i != j} c / (eps + c + |a_i - b_j|^2),
+ * kind 1 (rbf): K(a,b) = mean_{i,j} exp(-mean_d (a_i - b_j)^2 / c);  c = 2 * D * latent_var is passed by the caller.
+ * grad_z [N][D] receives d mmd / d z (the backward pass scales it by the incoming gradient).  ws: >= 12*N bytes. */
+int ctvae_mmd_forward(const float* z, const float* prior, int N, int D, int kind, float c, float eps, float w_pp, float w_zz,
+                      float w_pz, float* out4, float* grad_z, float* ws, size_t ws_bytes, void* stream);
+
 /* torch.optim.Adam step over one flat buffer (experiment.py:158-160).  state (device, 8 floats):
  * {step, lr, beta1, beta2, eps, weight_decay, beta1^step, beta2^step}; the call advances step. */
 int ctvae_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* state, long n,

@@ -85,6 +85,52 @@ def vanilla_loss(recons, x, mu, log_var, M_N):
     return {"loss": recons_loss + M_N * kld, "Reconstruction_Loss": recons_loss.detach(), "KLD": -kld.detach()}
 
 
+def mmd_terms(z, prior_z, kernel_type, z_var, eps=1e-7):
+    """compute_kernel on (p,p), (z,z), (p,z) (wae_mmd.py:120-198 == info_vae.py:150-216): imq sums every off-diagonal pair
+    (the cross term's diagonal is removed too), rbf is the full [N,N] matrix, reduced by .mean() in compute_mmd."""
+    def kern(a, b):
+        d2 = (a.unsqueeze(-2) - b.unsqueeze(-3)).pow(2)
+        c = 2. * a.size(1) * z_var
+        if kernel_type == 'rbf':
+            return torch.exp(-(d2.mean(-1) / c)).mean()
+        if kernel_type == 'imq':
+            k = c / (eps + c + d2.sum(dim=-1))
+            return k.sum() - k.diag().sum()
+        raise ValueError('Undefined kernel type.')
+    return kern(prior_z, prior_z), kern(z, z), kern(prior_z, z)
+
+
+def wae_forward(sd, x, training=True, new_buffers=None):
+    """WAE_MMD.forward (wae_mmd.py:81-103): deterministic encoder with one head fc_z -> [recons, input, z]."""
+    h = x
+    for i in range(5):
+        h = F.conv2d(h, sd[f"encoder.{i}.0.weight"], sd[f"encoder.{i}.0.bias"], stride=2, padding=1)
+        h = _bn_lrelu(sd, f"encoder.{i}.1", h, training, new_buffers)
+    z = F.linear(torch.flatten(h, start_dim=1), sd["fc_z.weight"], sd["fc_z.bias"])
+    return [vanilla_decode(sd, z, training, new_buffers), x, z]
+
+
+def wae_loss(recons, x, z, prior_z, reg_weight, kernel_type, z_var=2.0):
+    """wae_mmd.py:105-118,192-203."""
+    B = x.size(0)
+    w = reg_weight / (B * (B - 1))
+    pp, zz, pz = mmd_terms(z, prior_z, kernel_type, z_var)
+    mmd = w * pp + w * zz - 2 * w * pz
+    rl = F.mse_loss(recons, x)
+    return {"loss": rl + mmd, "Reconstruction_Loss": rl, "MMD": mmd}
+
+
+def infovae_loss(recons, x, z, mu, log_var, prior_z, M_N, alpha, beta, reg_weight, kernel_type, z_var=2.0):
+    """info_vae.py:128-148,218-229."""
+    B = x.size(0)
+    pp, zz, pz = mmd_terms(z, prior_z, kernel_type, z_var)
+    mmd = pp + zz - 2 * pz
+    rl = F.mse_loss(recons, x)
+    kld = torch.mean(-0.5 * torch.sum(1 + log_var - mu ** 2 - log_var.exp(), dim=1), dim=0)
+    loss = beta * rl + (1. - alpha) * M_N * kld + (alpha + reg_weight - 1.) / (B * (B - 1)) * mmd
+    return {"loss": loss, "Reconstruction_Loss": rl, "MMD": mmd, "KLD": -kld}
+
+
 def logcosh_loss(recons, x, mu, log_var, M_N, alpha, beta):
     """LogCoshVAE.loss_function (logcosh_vae.py:135-155), written as the reference writes it."""
     t = recons - x

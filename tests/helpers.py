@@ -107,6 +107,26 @@ IW_CASES = {"iwae": ("IWAE", dict(in_channels=3, latent_dim=128, num_samples=5),
             "miwae": ("MIWAE", dict(in_channels=3, latent_dim=128, num_samples=5, num_estimates=3), (3, 5))}
 
 
+def mmd_prior(seed, B, L=128):
+    """The injected prior samples of compute_mmd (same rule as oracle/gen_mmd_golden.py)."""
+    return torch.randn(B, L, generator=torch.Generator().manual_seed(seed + 4))
+
+
+def wae_specs():
+    """state_dict keys/shapes of WAE_MMD(in_channels=3, latent_dim=128): VanillaVAE's with the one head fc_z."""
+    out = []
+    for k, sh, dt in vanilla_specs():
+        if k.startswith("fc_var."):
+            continue
+        out.append((k.replace("fc_mu", "fc_z"), sh, dt))
+    return out
+
+
+MMD_CASES = {"wae_imq": ("WAE_MMD", dict(in_channels=3, latent_dim=128, reg_weight=100, kernel_type='imq')),
+             "wae_rbf": ("WAE_MMD", dict(in_channels=3, latent_dim=128, reg_weight=5000, kernel_type='rbf')),
+             "infovae": ("InfoVAE", dict(in_channels=3, latent_dim=128, reg_weight=110, kernel_type='imq', alpha=-9.0, beta=10.5))}
+
+
 def cks(t):
     t = t.detach().double().cpu()
     return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()], dtype=np.float64)

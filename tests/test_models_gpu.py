@@ -404,6 +404,32 @@ def test_logcosh_vae_vs_golden(dev, golden):
         H.assert_cks_close(H.cks(p.grad), g["gradcks." + k], rtol=2e-3, atol=2e-5, what=k)
 
 
+@pytest.mark.parametrize("tag", ["wae_imq", "wae_rbf", "infovae"])
+def test_mmd_models_vs_golden(dev, golden, tag):
+    """WAE_MMD (imq / rbf) and InfoVAE against the reference's own fixtures: latent codes, loss dict (incl. the MMD term),
+    every parameter gradient."""
+    from ctvae_amd.models import vae_models
+    g = golden(f"{tag}_b4")
+    seed, B = int(g["seed"]), 4
+    name, cfg = H.MMD_CASES[tag]
+    gaussian = name == "InfoVAE"
+    m = vae_models[name](**cfg)
+    m.load_state_dict(filler.fill_state(H.vanilla_specs() if gaussian else H.wae_specs(), seed + 1))
+    m = m.to(dev).train()
+    x, eps = filler.synthetic_batch(seed, B)
+    out = m(x.to(dev), eps=eps.to(dev)) if gaussian else m(x.to(dev))
+    np.testing.assert_allclose(out[2].detach().cpu().numpy(), g["z"], atol=TOL, rtol=0)
+    losses = m.loss_function(*out, M_N=float(g["M_N"]), prior_z=H.mmd_prior(seed, B).to(dev))
+    losses["loss"].backward()
+    for k, v in losses.items():
+        want = float(g["loss." + k])
+        assert abs(float(v.detach()) - want) <= TOL * max(1.0, abs(want)), (k, float(v.detach()), want)
+    head = "fc_mu" if gaussian else "fc_z"
+    np.testing.assert_allclose(getattr(m, head).bias.grad.cpu().numpy(), g[f"grad.{head}.bias"], atol=1e-5, rtol=2e-3)
+    for k, p in m.named_parameters():
+        H.assert_cks_close(H.cks(p.grad), g["gradcks." + k], rtol=2e-3, atol=2e-5, what=k)
+
+
 def test_vqvae_vs_golden(dev, golden):
     """VQVAE (vq_vae.py: MCQ-VAE's conv stacks around one 512-entry codebook) against the reference's own fixture."""
     from ctvae_amd.models import vae_models

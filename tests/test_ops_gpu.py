@@ -203,6 +203,25 @@ def test_importance_weighted_loss(K, B, lead, n, L):
     np.testing.assert_allclose(ld.grad.cpu().numpy(), lv.grad.numpy(), atol=1e-8, rtol=1e-3)
 
 
+@pytest.mark.parametrize("N,D,kind", [(4, 128, "imq"), (37, 128, "rbf"), (256, 128, "imq"), (9, 20, "imq"), (5, 300, "rbf"), (2, 512, "imq")])
+def test_mmd_kernel(K, N, D, kind):
+    """csrc/mmd.hip against the torch expressions of wae_mmd.py:120-203: all three kernel sums, mmd and d mmd / d z."""
+    from oracle import vae_cpu as O
+    g = torch.Generator().manual_seed(N * 7 + D)
+    z = (1.5 * torch.randn(N, D, generator=g)).requires_grad_(True)
+    p = torch.randn(N, D, generator=g)
+    w = (0.3, 0.7, 1.1)
+    pp, zz, pz = O.mmd_terms(z, p, kind, 2.0)
+    (w[0] * pp + w[1] * zz - 2 * w[2] * pz).backward()
+    zd = z.detach().cuda().requires_grad_(True)
+    out = K.MMD.apply(zd, p.cuda(), kind, 2.0 * D * 2.0, *w)
+    (out[0] * 1.0).backward()
+    torch.cuda.synchronize()
+    for got, want in zip(out[1:].tolist(), (pp.item(), zz.item(), pz.item())):
+        assert abs(got - want) <= 2e-5 * max(1.0, abs(want)), (got, want)
+    np.testing.assert_allclose(zd.grad.cpu().numpy(), z.grad.numpy(), atol=1e-7, rtol=2e-4)
+
+
 def test_permute_roundtrip(K):
     x = torch.randn(3, 5, 6, 7)
     xd = x.cuda()

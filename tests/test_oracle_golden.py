@@ -190,6 +190,36 @@ def test_logcosh_vae_loss_grads(golden):
             H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
 
 
+@pytest.mark.parametrize("tag", ["wae_imq", "wae_rbf", "infovae"])
+def test_mmd_models_forward_loss_grads(golden, tag):
+    """WAE_MMD (imq / rbf) and InfoVAE: oracle restatement against the reference's own wae_mmd.py / info_vae.py fixtures
+    (oracle/gen_mmd_golden.py), prior samples injected."""
+    g = golden(f"{tag}_b4")
+    seed, B = int(g["seed"]), 4
+    name, cfg = H.MMD_CASES[tag]
+    gaussian = name == "InfoVAE"
+    sd = O.leafify(filler.fill_state(H.vanilla_specs() if gaussian else H.wae_specs(), seed + 1))
+    x, eps = filler.synthetic_batch(seed, B)
+    prior = H.mmd_prior(seed, B)
+    if gaussian:
+        recons, inp, mu, log_var = O.vanilla_forward(sd, x, eps, True, {})
+        z = O.vanilla_reparameterize(mu, log_var, eps)
+        l = O.infovae_loss(recons, inp, z, mu, log_var, prior, float(g["M_N"]), cfg["alpha"], cfg["beta"], cfg["reg_weight"], cfg["kernel_type"])
+    else:
+        recons, inp, z = O.wae_forward(sd, x, True, {})
+        l = O.wae_loss(recons, inp, z, prior, cfg["reg_weight"], cfg["kernel_type"])
+    np.testing.assert_allclose(z.detach().numpy(), g["z"], atol=TOL, rtol=0)
+    for k, v in l.items():
+        want = float(g["loss." + k])
+        assert abs(v.item() - want) <= TOL * max(1.0, abs(want)), k
+    l["loss"].backward()
+    head = "fc_mu" if gaussian else "fc_z"
+    np.testing.assert_allclose(sd[head + ".bias"].grad.numpy(), g[f"grad.{head}.bias"], atol=1e-5, rtol=1e-3)
+    for k, v in sd.items():
+        if v.requires_grad:
+            H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
+
+
 def test_vqvae_forward_loss_grads(golden):
     """VQVAE = MCQ-VAE's stacks around ONE codebook: oracle (single-codebook path of the MCQ restatement) against the
     reference's own vq_vae.py fixture."""
