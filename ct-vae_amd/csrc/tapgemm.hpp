@@ -33,6 +33,9 @@ struct TapGemmArgs {
   int N;       // sC
   int mtiles;  // per class
   int ntiles;
+  // fast kernel only: parity class of workgroup row blockIdx.y (+ blockIdx.z when cls_rot) -- see launch_fast_cfg
+  int cls_order[kMaxCls];
+  int cls_rot;
 };
 
 constexpr int KC = 32;

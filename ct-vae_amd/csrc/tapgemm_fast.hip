@@ -67,11 +67,17 @@ __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) 
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
-  const int cls = blockIdx.y;
+  int cls_i = a.cls_rot == 1 ? ((blockIdx.y + blockIdx.z) & 3) : blockIdx.y, bx = blockIdx.x;
+  if (a.cls_rot == 2) {   // classes interleaved in groups of 8 workgroups (one per XCD): L = ((t_hi * 4 + class) * 8 + t_lo)
+    const int L = blockIdx.y * gridDim.x + blockIdx.x;
+    cls_i = (L >> 3) & 3;
+    bx = ((L >> 5) << 3) | (L & 7);
+  }
+  const int cls = a.cls_order[cls_i];
   // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so the n-tiles of one
   // m-tile (same gathered pixels) would land in 8 different L2s.  Remap so that each XCD walks a contiguous range of
   // the (m-tile, n-tile) space; the remainder (grid.x % 8) keeps its place.
-  int tile = blockIdx.x;
+  int tile = bx;
   {
     const int per = gridDim.x >> 3;
     if (tile < per * 8) tile = (tile & 7) * per + (tile >> 3);
@@ -553,6 +559,32 @@ static int launch_fast_cfg(const TapGemmArgs& a, int pf, hipStream_t st) {
   args.ntiles = ceil_div(a.N, BN);
   const bool wt = a.g.wT != 0;
   dim3 grid(args.mtiles * args.ntiles, a.g.ncls, a.splitk > 1 ? a.splitk : 1), block(256);
+  // Parity classes of a stride-2 3x3 layer reduce over 1, 2, 2 and 4 taps: workgroups of one class are 4x longer than those
+  // of another.  Workgroups are dealt to the CUs in linear order (x, then y = class row, then z = K slice), so with the
+  // plain order the CUs that got the 4-tap rows finish last while the others idle (resident grids), or the longest
+  // workgroups start last (larger grids).  Resident grids (<= 1024 workgroups): class rows in the order
+  // [fewest, middle, most, middle] taps, so that the rows 256 workgroups apart -- which share CUs when a class row is half
+  // a round -- pair up as (1 + 4) and (2 + 2), and rotated by the K slice when the launch is split (a CU then sees three
+  // different classes instead of three times the same).  VanillaVAE bs=256: 1.882 -> 1.849 ms per step (M=4x1024 sk=3 launches
+  // 43 -> 33 us, M=4x4096 42 -> 38 us).  Larger grids keep the plain order: longest classes first 1.853 ms, classes
+  // interleaved in groups of 8 workgroups 1.880 ms against 1.849 / 1.857 ms (same box).
+  for (int c = 0; c < kMaxCls; ++c) args.cls_order[c] = c;
+  args.cls_rot = 0;
+  static const int no_cls_order = [] { const char* e = getenv("CTVAE_NO_CLS_ORDER"); return e ? atoi(e) : 0; }();   // diagnostic
+  if (a.g.ncls == 4 && !no_cls_order) {
+    int idx[4] = {0, 1, 2, 3};
+    for (int i = 1; i < 4; ++i)
+      for (int j = i; j > 0 && a.g.ntaps[idx[j]] < a.g.ntaps[idx[j - 1]]; --j) { const int t = idx[j]; idx[j] = idx[j - 1]; idx[j - 1] = t; }
+    const long total = (long)grid.x * grid.y * grid.z;
+    if (total <= 1024) {
+      args.cls_order[0] = idx[0]; args.cls_order[1] = idx[1]; args.cls_order[2] = idx[3]; args.cls_order[3] = idx[2];
+      args.cls_rot = grid.z > 1 ? 1 : 0;
+    } else {
+      static const int big = [] { const char* e = getenv("CTVAE_CLS_BIG"); return e ? atoi(e) : 0; }();   // diagnostic: 1 longest first, 2 interleaved -- both measured slower (below)
+      if (big == 1) for (int c = 0; c < 4; ++c) args.cls_order[c] = idx[3 - c];
+      if (big == 2 && grid.x % 8 == 0 && grid.z == 1) args.cls_rot = 2;
+    }
+  }
   char name[160];
   snprintf(name, sizeof name, "tapgemm_fast_kernel<%d,%d,%d,%d,%s,%d>", WM, WN, TM, TN, wt ? "true" : "false", pf);
   double macs = 0;
