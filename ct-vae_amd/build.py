@@ -32,7 +32,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "ctvae_hip.h"))
     hdr_m = max(os.path.getmtime(h) for h in hdrs)
 

@@ -3,6 +3,7 @@
 #include "../../include/ctvae_hip.h"
 
 #include "common.hpp"
+#include "pair.hpp"
 
 namespace ctvae {
 int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
@@ -223,6 +224,44 @@ int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float
   const InXform xf{in_scale, in_shift, in_act};
   const DyXform dyx{dy_bn_y, dy_bn_coef, gy_out, dy_bn_act};
   return launch_wgrad(g, x, dy, dw, dbias, ws, ws_bytes, accumulate, (hipStream_t)stream, &xf, &dyx);
+}
+
+int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* w, float* dw, float* dbias, float* dx, int B,
+                        int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int accumulate, const float* mask,
+                        int mask_act, const float* wino_filters, const float* bn_y, const float* bn_mean,
+                        const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int bn_act, float* bn_part,
+                        int bn_part_rows, float* ws, size_t ws_bytes, void* stream) {
+  if (!x || !dy || !w || !dw || !dx || !ws || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
+  const bool bn = bn_part != nullptr;
+  if (bn && (!bn_y || !bn_mean || !bn_invstd || !bn_gamma || !bn_beta)) return kErrBadArg;
+  ConvGeom gw, gd;
+  if (build_geom(gw, kind == CTVAE_CONV ? 0 : 1, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
+  if (build_geom(gd, kind == CTVAE_CONV ? 2 : 3, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
+  // the two GEMMs run concurrently: each gets its own half of the workspace
+  const size_t half_bytes = (ws_bytes / 2) & ~(size_t)255, half_floats = half_bytes / sizeof(float);
+  float* ws_d = ws + half_floats;
+  if (wino_filters != nullptr && !ctvae_conv_wino_filter_floats(kind, B, H, W, Ci, Co, k, stride, pad, out_pad, half_bytes))
+    return kErrBadArg;
+  if (bn) {
+    const int rows = tapgemm_bnb_rows(gd, half_floats);
+    if (rows <= 0 || rows != bn_part_rows) return kErrBadArg;
+    if (img_dgrad_supported(gd) && mask != nullptr) return kErrBadArg;
+  }
+  const hipStream_t st = (hipStream_t)stream;
+  PairCtx ctx;
+  pair_ctx() = &ctx;
+  const InXform xf{nullptr, nullptr, 0};
+  const DyXform dyx{nullptr, nullptr, nullptr, 0};
+  int rc = launch_wgrad(gw, x, dy, dw, dbias, ws, half_bytes, accumulate, st, &xf, &dyx);
+  if (!rc) {
+    const WinoFilters wf{wino_filters, nullptr};
+    const BnBwdFuse f{bn_y, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_act, bn_part};
+    rc = launch_tapgemm(gd, dy, w, nullptr, nullptr, mask, mask_act, dx, ACT_NONE, nullptr, ws_d, half_floats, st, bn ? &f : nullptr,
+                        nullptr, &wf);
+  }
+  pair_ctx() = nullptr;
+  if (rc) return rc;
+  return pair_flush(ctx, st);
 }
 
 int ctvae_conv_wgrad_bn_apply_supported(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad) {

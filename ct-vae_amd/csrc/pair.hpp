@@ -1,0 +1,32 @@
+// Paired backward launch (ctvae_conv_backward): while a PairCtx is installed for the calling thread, the data-gradient
+// launcher (tapgemm_fast.hip, 64x64 pipelined tile kernel) and the weight-gradient launcher (wgrad.hip, lean 64x64 kernel)
+// RECORD their main launch instead of issuing it, and every finishing launch behind them (split-K finish, slab
+// reduction) is queued; pair_flush() then issues ONE conv_bwd_pair_kernel for both GEMMs (or the single recorded kernel,
+// if only one side took its pairable path) followed by the queued launches in order.  Launches of any other path are
+// issued immediately as usual -- the two GEMMs are independent and work in disjoint halves of the workspace.
+#pragma once
+#include <functional>
+#include <vector>
+
+#include "tapgemm.hpp"
+#include "wgrad_fast.hpp"
+
+namespace ctvae {
+
+struct PairCtx {
+  bool haveA = false, haveB = false;
+  TapGemmArgs A;
+  unsigned gxA = 0, gyA = 0, gzA = 0;
+  double flopsA = 0, bytesA = 0;
+  WgradArgs B;
+  int lgQw = -1, lgQhw = -1, lgC = -1;
+  unsigned gxB = 0, gyB = 0;
+  double flopsB = 0, bytesB = 0;
+  std::vector<std::function<int()>> later;
+};
+
+PairCtx*& pair_ctx();                                    // tapgemm_fast.hip (thread-local, null = not pairing)
+int pair_flush(PairCtx& c, hipStream_t st);              // tapgemm_fast.hip
+int launch_wgrad_fast_recorded(const PairCtx& c, hipStream_t st);   // wgrad.hip: the recorded weight-gradient kernel on its own
+
+}  // namespace ctvae

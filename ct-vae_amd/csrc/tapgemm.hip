@@ -18,6 +18,7 @@
 // residual add, forward activation, or the multiplication by the previous layer's activation
 // derivative (backward).
 #include "prof.hpp"
+#include "pair.hpp"
 #include "tapgemm.hpp"
 
 namespace ctvae {
@@ -720,11 +721,19 @@ int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const floa
   const long n = (long)g.B * g.sH * g.sW * a.N, n4 = n / 4;
   long blocks = (n4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  ProfScope ps("splitk_finish_kernel", st, 0.0, 4.0 * (double)(plan.splitk + 1) * n);
-  hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ws, plan.splitk, n, bias, add, mask,
-                     mask_act, act, S, n4, a.N);
-  CTVAE_LAUNCH_CHECK();
-  return 0;
+  const int splitk = plan.splitk, N_ = a.N;
+  auto finish = [=]() -> int {
+    ProfScope ps("splitk_finish_kernel", st, 0.0, 4.0 * (double)(splitk + 1) * n);
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ws, splitk, n, bias, add, mask, mask_act, act,
+                       S, n4, N_);
+    CTVAE_LAUNCH_CHECK();
+    return 0;
+  };
+  if (PairCtx* pc = pair_ctx()) {   // ctvae_conv_backward: behind the paired main launch
+    pc->later.push_back(finish);
+    return 0;
+  }
+  return finish();
 }
 
 }  // namespace ctvae

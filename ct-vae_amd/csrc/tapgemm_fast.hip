@@ -17,7 +17,9 @@
 #include <type_traits>
 
 #include "prof.hpp"
+#include "pair.hpp"
 #include "tapgemm.hpp"
+#include "wgrad_fast.hpp"
 
 namespace ctvae {
 
@@ -50,505 +52,38 @@ extern "C" int ctvae_debug_phase_read(unsigned long long* out, int n) {
 
 template <int WM, int WN, int TM, int TN, bool WT, int PF>
 __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) {
-  static_assert(PF == 0 || PF == 3, "PF: 0 single LDS buffer, 3 double buffer + explicit software pipeline");
-  constexpr bool DB = PF == 3;
-  constexpr int NSET = 1;
-  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  static_assert(WM * WN == 4, "4 waves per workgroup");
-  constexpr int SA = BM * LDK, SB = WT ? BN * LDK : KC * BN;
-  constexpr int NBUF = DB ? 2 : 1;
-  __shared__ __attribute__((aligned(16))) float sAbuf[NBUF * SA];
-  __shared__ __attribute__((aligned(16))) float sBbuf[NBUF * SB];
-  __shared__ __attribute__((aligned(16))) int sOut[BM];
+  __shared__ __attribute__((aligned(16))) float sAbuf[(PF == 3 ? 2 : 1) * (WM * TM * 32) * LDK];
+  __shared__ __attribute__((aligned(16))) float sBbuf[(PF == 3 ? 2 : 1) * (WT ? (WN * TN * 32) * LDK : KC * (WN * TN * 32))];
+  __shared__ __attribute__((aligned(16))) int sOut[WM * TM * 32];
+  const int vbx = blockIdx.x, vby = blockIdx.y, vbz = blockIdx.z, vgx = gridDim.x;
+#include "tapgemm_fast_body.inc"
+}
 
-  PHASE(0);
-  const ConvGeom& g = a.g;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int li = lane & 31, lh = lane >> 5;
-  int cls_i = a.cls_rot == 1 ? ((blockIdx.y + blockIdx.z) & 3) : blockIdx.y, bx = blockIdx.x;
-  if (a.cls_rot == 2) {   // classes interleaved in groups of 8 workgroups (one per XCD): L = ((t_hi * 4 + class) * 8 + t_lo)
-    const int L = blockIdx.y * gridDim.x + blockIdx.x;
-    cls_i = (L >> 3) & 3;
-    bx = ((L >> 5) << 3) | (L & 7);
-  }
-  const int cls = a.cls_order[cls_i];
-  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so the n-tiles of one
-  // m-tile (same gathered pixels) would land in 8 different L2s.  Remap so that each XCD walks a contiguous range of
-  // the (m-tile, n-tile) space; the remainder (grid.x % 8) keeps its place.
-  int tile = bx;
-  {
-    const int per = gridDim.x >> 3;
-    if (tile < per * 8) tile = (tile & 7) * per + (tile >> 3);
-  }
-  const int mt = tile / a.ntiles, nt = tile - mt * a.ntiles;
-  const int m0 = mt * BM, n0 = nt * BN;
-  const int ntaps = g.ntaps[cls];
-  const int gC = g.gC, N = a.N;
-  const int nch = ntaps * gC / KC;
-  const bool dense = (g.os == 1);   // scatter index == m
-
-  // The gathered operand is addressed as  (G - BIAS) + a_off[row] + (tap offset + BIAS + channel offset):  the second
-  // term is the per-lane VGPR offset, the third is wave-uniform and rides in the load's scalar-offset operand -- no VALU
-  // add per row and chunk.  BIAS (>= the most negative tap offset) keeps the scalar part non-negative.
-  const unsigned gbias = (unsigned)((3 * g.gW + 3) * gC) * 4u;
-  const __amdgpu_buffer_rsrc_t rG = make_rsrc(reinterpret_cast<const char*>(a.G) - gbias,
-                                              (long)g.B * g.gH * g.gW * gC * 4 + gbias);
-  long wtaps = 0;
-  for (int c = 0; c < g.ncls; ++c) wtaps += g.ntaps[c];
-  const __amdgpu_buffer_rsrc_t rW = make_rsrc(a.W, wtaps * g.wCi * g.wCo * 4);
-
-  // ---- per-thread constants of the tile ---------------------------------------------------------------
-  constexpr int A_V = BM / 32;  // 16-B loads per thread and chunk (gathered operand)
-  constexpr int B_V = BN / 32;  // 16-B loads per thread and chunk (weights)
-  unsigned a_off[A_V], a_ok[A_V];
-#pragma unroll
-  for (int j = 0; j < A_V; ++j) {
-    const int m = m0 + (tid >> 3) + 32 * j;
-    unsigned msk = 0;
-    int pix = 0;
-    if (m < a.Mc) {
-      int b, qy, qx;
-      decode_m_fast(a, m, b, qy, qx);
-      const int iy0 = qy * g.is, ix0 = qx * g.is;
-      pix = (b * g.gH + iy0) * g.gW + ix0;
-#pragma unroll
-      for (int d = -3; d <= 4; ++d) {  // bit (d+3): dy = d allowed; bit (d+11): dx = d allowed
-        if ((unsigned)(iy0 + d) < (unsigned)g.gH) msk |= 1u << (d + 3);
-        if ((unsigned)(ix0 + d) < (unsigned)g.gW) msk |= 1u << (d + 11);
-      }
-    }
-    a_ok[j] = msk;
-    a_off[j] = (unsigned)(pix * gC + 4 * (tid & 7)) * 4u;
-  }
-  unsigned b_off[B_V];
-#pragma unroll
-  for (int j = 0; j < B_V; ++j) {
-    if constexpr (!WT) {   // Wmat[t][c][n] = W[t][c][n]: rows k, 16 B along n
-      const int f = tid + 256 * j;
-      const int kr = f / (BN / 4), nq = f - kr * (BN / 4);
-      const int n = n0 + 4 * nq;
-      b_off[j] = n < N ? (unsigned)(kr * g.wCo + n) * 4u : kOOB;
-    } else {               // Wmat[t][c][n] = W[t][n][c]: rows n, 16 B along c
-      const int n = n0 + (tid >> 3) + 32 * j;
-      b_off[j] = n < N ? (unsigned)(n * g.wCo + 4 * (tid & 7)) * 4u : kOOB;
-    }
-  }
-  if (!dense) {
-    for (int r = tid; r < BM; r += 256) {
-      const int m = m0 + r;
-      int sp = -1;
-      if (m < a.Mc) {
-        int b, qy, qx;
-        decode_m_fast(a, m, b, qy, qx);
-        sp = scatter_pix(g, cls, b, qy, qx);
-      }
-      sOut[r] = sp;
-    }
-  }
-
-  f32x4 ra[NSET][A_V], rb[NSET][B_V];
-  auto store_chunk = [&](int buf, auto set_c) {
-    constexpr int set = decltype(set_c)::value;
-    float* sA = sAbuf + buf * SA;
-    float* sB = sBbuf + buf * SB;
-#pragma unroll
-    for (int j = 0; j < A_V; ++j) *reinterpret_cast<f32x4*>(&sA[((tid >> 3) + 32 * j) * LDK + 4 * (tid & 7)]) = ra[set][j];
-#pragma unroll
-    for (int j = 0; j < B_V; ++j) {
-      if constexpr (!WT) {
-        const int f = tid + 256 * j;
-        const int kr = f / (BN / 4), nq = f - kr * (BN / 4);
-        *reinterpret_cast<f32x4*>(&sB[kr * BN + 4 * nq]) = rb[set][j];
-      } else {
-        *reinterpret_cast<f32x4*>(&sB[((tid >> 3) + 32 * j) * LDK + 4 * (tid & 7)]) = rb[set][j];
-      }
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // split-K: this workgroup owns chunks [c0, c1) of the class's K range
-  int c0 = 0, c1 = nch;
-  if (a.splitk > 1) {
-    const int cps = (nch + a.splitk - 1) / a.splitk;
-    c0 = blockIdx.z * cps;
-    c1 = c0 + cps < nch ? c0 + cps : nch;
-  }
-  using S0 = std::integral_constant<int, 0>;
-  auto compute_chunk = [&](int cur) {
-    const float* sA = sAbuf + cur * SA;
-    const float* sB = sBbuf + cur * SB;
-    f32x4 af[2][TM];
-    float bf[2][TN][4];
-    auto read_frags = [&](int kg, int slot) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        af[slot][i] = *reinterpret_cast<const f32x4*>(&sA[((wm * TM + i) * 32 + li) * LDK + kg * 8 + 4 * lh]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        if constexpr (WT) {
-          const f32x4 t4 = *reinterpret_cast<const f32x4*>(&sB[((wn * TN + j) * 32 + li) * LDK + kg * 8 + 4 * lh]);
-          bf[slot][j][0] = t4[0]; bf[slot][j][1] = t4[1]; bf[slot][j][2] = t4[2]; bf[slot][j][3] = t4[3];
-        } else {
-#pragma unroll
-          for (int s = 0; s < 4; ++s) bf[slot][j][s] = sB[(kg * 8 + 4 * lh + s) * BN + (wn * TN + j) * 32 + li];
-        }
-      }
-    };
-    read_frags(0, 0);
-#pragma unroll
-    for (int kg = 0; kg < 4; ++kg) {
-      if (kg + 1 < 4) read_frags(kg + 1, (kg + 1) & 1);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kg & 1][i][s], bf[kg & 1][j][s], acc[i][j], 0, 0, 0);
-    }
-  };
-
-  // Tap constants live in lanes (lane t = tap t) and are fetched with v_readlane: no scalar loads in the loop (an
-  // s_load forces an lgkmcnt(0) drain that also waits for every LDS read in flight) and no integer division.
-  unsigned tv_off = 0, tv_sh = 0, tv_w = 0;
-  if (lane < ntaps) {
-    const Tap tp = g.taps[cls][lane];
-    tv_off = (unsigned)(((tp.dy * g.gW + tp.dx) * gC) * 4);
-    tv_sh = (unsigned)(tp.dy + 3) | ((unsigned)(tp.dx + 11) << 8);
-    tv_w = WT ? (unsigned)(tp.wtap * g.wCi * g.wCo) * 4u : (unsigned)(tp.wtap * g.wCi * g.wCo) * 4u;
-  }
-  // per row: bit t = tap t reads inside the image (<= 16 taps); one bit-field extract per row and chunk then decides
-  // between the row offset and the out-of-range offset (top bit set) -- no compare, no select, no add in the loop
-  unsigned a_tm[A_V];
-#pragma unroll
-  for (int j = 0; j < A_V; ++j) a_tm[j] = 0;
-  for (int t = 0; t < ntaps; ++t) {
-    const unsigned sh = (unsigned)__builtin_amdgcn_readlane((int)tv_sh, t);
-    const unsigned sy = sh & 0xff, sx = sh >> 8;
-#pragma unroll
-    for (int j = 0; j < A_V; ++j) a_tm[j] |= ((a_ok[j] >> sy) & (a_ok[j] >> sx) & 1u) << t;
-  }
-  int lt = (c0 * KC) / gC, lci = c0 * KC - lt * gC;    // tap / channel offset of the next chunk to load
-  auto load_next = [&]() {
-    const unsigned tapoff = (unsigned)__builtin_amdgcn_readlane((int)tv_off, lt) + gbias + (unsigned)lci * 4u;
-    const unsigned wsoff = (unsigned)__builtin_amdgcn_readlane((int)tv_w, lt) + (WT ? (unsigned)lci * 4u : (unsigned)(lci * g.wCo) * 4u);
-#pragma unroll
-    for (int j = 0; j < A_V; ++j) {
-      const unsigned out = ((a_tm[j] >> lt) & 1u) ^ 1u;            // 1 = this tap falls outside for this row
-      ra[0][j] = buf_load4(rG, a_off[j] | (out << 31), tapoff);
-    }
-#pragma unroll
-    for (int j = 0; j < B_V; ++j) rb[0][j] = buf_load4(rW, b_off[j], wsoff);
-    lci += KC;
-    if (lci == gC) { lci = 0; ++lt; }
-  };
-  if constexpr (PF == 3) {
-    // ---- software-pipelined loop: one barrier per chunk, no exposed latency ---------------------------------
-    // iteration c:  A) chunk c+1 registers -> other LDS buffer, global loads of chunk c+2, LDS reads of k-groups
-    //                  2,3 of chunk c, MFMAs of k-groups 0,1 (fragments read during the previous iteration)
-    //               B) barrier: chunk c+1 is complete in LDS, nobody reads this buffer's k-groups any more
-    //               C) LDS reads of k-groups 0,1 of chunk c+1, MFMAs of k-groups 2,3 of chunk c
-    // sched_barrier keeps the compiler from sinking the reads next to their uses (it otherwise serialises
-    // read -> wait -> MFMA and leaves the matrix pipe idle for an LDS latency 6x per chunk).
-    // Tap constants live in lanes (lane t = tap t) and are fetched with v_readlane: no scalar loads, hence no
-    // lgkmcnt(0) drains, and no integer division in the loop.
-    f32x4 af[4][TM];
-    float bf[4][TN][4];
-    auto read_kg = [&](int buf, auto kg_c) {
-      constexpr int kg = decltype(kg_c)::value;
-      const float* sA = sAbuf + buf * SA;
-      const float* sB = sBbuf + buf * SB;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        af[kg][i] = *reinterpret_cast<const f32x4*>(&sA[((wm * TM + i) * 32 + li) * LDK + kg * 8 + 4 * lh]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        if constexpr (WT) {
-          const f32x4 t4 = *reinterpret_cast<const f32x4*>(&sB[((wn * TN + j) * 32 + li) * LDK + kg * 8 + 4 * lh]);
-          bf[kg][j][0] = t4[0]; bf[kg][j][1] = t4[1]; bf[kg][j][2] = t4[2]; bf[kg][j][3] = t4[3];
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) bf[kg][j][q] = sB[(kg * 8 + 4 * lh + q) * BN + (wn * TN + j) * 32 + li];
-        }
-      }
-    };
-    auto mfma_kg = [&](auto kg_c) {
-      constexpr int kg = decltype(kg_c)::value;
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kg][i][q], bf[kg][j][q], acc[i][j], 0, 0, 0);
-    };
-    using K0 = std::integral_constant<int, 0>;
-    using K1 = std::integral_constant<int, 1>;
-    using K2 = std::integral_constant<int, 2>;
-    using K3 = std::integral_constant<int, 3>;
-    PHASE(1);
-    if (c0 < c1) {
-      load_next();
-      store_chunk(0, S0{});
-    }
-    __syncthreads();
-    PHASE(2);
-    if (c0 < c1) {
-      read_kg(0, K0{});
-      read_kg(0, K1{});
-      if (c0 + 1 < c1) load_next();
-    }
-    for (int c = c0; c < c1; ++c) {
-      const int cur = (c - c0) & 1;
-      const bool more = c + 1 < c1;
-      if (more) store_chunk(cur ^ 1, S0{});
-      if (c + 2 < c1) load_next();
-      read_kg(cur, K2{});
-      read_kg(cur, K3{});
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_kg(K0{});
-      mfma_kg(K1{});
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
-      __builtin_amdgcn_sched_barrier(0);
-      if (more) {
-        read_kg(cur ^ 1, K0{});
-        read_kg(cur ^ 1, K1{});
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_kg(K2{});
-      mfma_kg(K3{});
-      __builtin_amdgcn_sched_barrier(0);
-    }
+// One launch for the two independent GEMMs of a layer's backward pass: workgroups [0, nA) run the data-gradient tile kernel
+// (64 x 64 tiles, pipelined loop), the others the weight-gradient kernel (64 x 64 tiles of dW per pixel slice).  Both
+// launches on their own are one lock-step round of workgroups that pays the kernel boundary (previous kernel's L2
+// write-back, launch gap, prologue, store burst: ~6.5 us) for ~20 us of MFMA work; sharing a launch
+// pays it once and lets the weight-gradient workgroups start while the data-gradient's stores drain.
+__global__ __launch_bounds__(256) void conv_bwd_pair_kernel(const TapGemmArgs a, const WgradArgs w, int lgQw, int lgQhw, int lgC,
+                                                            int nA, int gxA, int gyA, int gxB, int gyB) {
+  // the data-gradient kernel's arrays; the weight-gradient workgroups use the first 8 KB of each for their X / dY chunks
+  __shared__ __attribute__((aligned(16))) float sAbuf[2 * 64 * LDK];
+  __shared__ __attribute__((aligned(16))) float sBbuf[2 * 64 * LDK];
+  __shared__ __attribute__((aligned(16))) int sOut[64];
+  __shared__ unsigned sPix[2][MC];
+  __shared__ unsigned sMsk[2][MC];
+  __shared__ unsigned sOutB[2][MC];
+  static_assert(2 * 64 * LDK >= MC * 64, "chunk buffers of the weight-gradient kernel fit");
+  const int L = blockIdx.x;
+  if (L < nA) {
+    constexpr int WM = 2, WN = 2, TM = 1, TN = 1, PF = 3;
+    constexpr bool WT = true;
+    const int vbx = L % gxA, vr = L / gxA, vby = vr % gyA, vbz = vr / gyA, vgx = gxA;
+#include "tapgemm_fast_body.inc"
   } else {
-    // single LDS buffer: grids with many workgroups per CU hide the latency by occupancy (a second buffer would cost it)
-    if (c0 < c1) {
-      load_next();
-      store_chunk(0, S0{});
-    }
-    __syncthreads();
-    for (int c = c0; c < c1; ++c) {
-      if (c + 1 < c1) load_next();
-      compute_chunk(0);
-      __syncthreads();
-      if (c + 1 < c1) {
-        store_chunk(0, S0{});
-        __syncthreads();
-      }
-    }
-  }   // PF != 3
-
-  // ---- epilogue -----------------------------------------------------------------------------------------
-  PHASE(3);
-  const long sbytes = (long)g.B * g.sH * g.sW * N * 4;
-  if (a.splitk > 1) {  // raw partial sums; bias / activation happen in splitk_finish_kernel
-    const __amdgpu_buffer_rsrc_t rP = make_rsrc(a.part + (long)blockIdx.z * (sbytes / 4), sbytes);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + (wn * TN + j) * 32 + li;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const int row0 = (wm * TM + i) * 32 + 8 * q4 + 4 * lh;
-          int sp4[4];
-          if (dense) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) sp4[q] = (m0 + row0 + q < a.Mc) ? m0 + row0 + q : -1;
-          } else {
-            const int4 t = *reinterpret_cast<const int4*>(&sOut[row0]);
-            sp4[0] = t.x; sp4[1] = t.y; sp4[2] = t.z; sp4[3] = t.w;
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            buf_store1(rP, (sp4[q] >= 0 && col < N) ? ((unsigned)sp4[q] * (unsigned)N + (unsigned)col) * 4u : kOOB,
-                       acc[i][j][4 * q4 + q]);
-        }
-    }
-    return;
+    const int Lb = L - nA;
+    wgrad_fast_body<2, 2, 1, 1>(w, lgQw, lgQhw, lgC, sAbuf, sBbuf, sPix, sMsk, sOutB, Lb % gxB, Lb / gxB, gxB, gyB);
   }
-
-  const __amdgpu_buffer_rsrc_t rS = make_rsrc(a.S, sbytes);
-  const __amdgpu_buffer_rsrc_t rAdd = make_rsrc(a.add, a.add != nullptr ? sbytes : 0);
-  const __amdgpu_buffer_rsrc_t rMask = make_rsrc(a.mask, a.mask != nullptr ? sbytes : 0);
-  const bool bnb = a.bnb_part != nullptr;
-  const __amdgpu_buffer_rsrc_t rY = make_rsrc(a.bnb_y, bnb ? sbytes : 0);
-  const bool full_m = (m0 + BM <= a.Mc);
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + (wn * TN + j) * 32 + li;
-    const bool cok = col < N;
-    const float bv = (a.bias != nullptr && cok) ? a.bias[col] : 0.f;
-    float cnt = 0.f, s1 = 0.f;     // BN statistics of this lane's column (valid rows only)
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const int row0 = (wm * TM + i) * 32 + 8 * q4 + 4 * lh;
-        unsigned voff[4];
-        if (dense) {
-          const unsigned base = ((unsigned)(m0 + row0) * (unsigned)N + (unsigned)col) * 4u;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const bool ok = cok && (full_m || m0 + row0 + q < a.Mc);
-            voff[q] = ok ? base + (unsigned)(q * N) * 4u : kOOB;
-          }
-        } else {
-          const int4 t = *reinterpret_cast<const int4*>(&sOut[row0]);
-          const int sp4[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            voff[q] = (cok && sp4[q] >= 0) ? ((unsigned)sp4[q] * (unsigned)N + (unsigned)col) * 4u : kOOB;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v = acc[i][j][4 * q4 + q] + bv;
-          acc[i][j][4 * q4 + q] = v;                      // kept for the variance pass
-          if (a.bn_part != nullptr && voff[q] != kOOB) { cnt += 1.f; s1 += v; }
-          if (a.add != nullptr) v += buf_load1(rAdd, voff[q]);
-          if (a.act == ACT_LRELU) v = fmaxf(v, v * kLeaky);
-          else if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
-          else if (a.act == ACT_TANH) v = act_fwd(v, ACT_TANH);
-          if (a.mask != nullptr) {
-            const float mk = buf_load1(rMask, voff[q]);
-            if (a.mask_act == ACT_LRELU) v = mk > 0.f ? v : v * kLeaky;
-            else if (a.mask_act == ACT_RELU) v = mk > 0.f ? v : 0.f;
-            else if (a.mask_act == ACT_TANH) v *= 1.f - mk * mk;
-          }
-          buf_store1(rS, voff[q], v);
-          if (bnb) acc[i][j][4 * q4 + q] = v;            // the stored gradient, for the BN-backward sums below
-        }
-      }
-    }
-    // ---- fused BatchNorm-backward sums: S is d/d(act(BN(y))) of the producing layer -------------------------
-    if (bnb) {
-      float yv[TM][16];
-      bool okv[TM][16];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const int row0 = (wm * TM + i) * 32 + 8 * q4 + 4 * lh;
-          unsigned voff[4];
-          if (dense) {
-            const unsigned base = ((unsigned)(m0 + row0) * (unsigned)N + (unsigned)col) * 4u;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) voff[q] = (cok && (full_m || m0 + row0 + q < a.Mc)) ? base + (unsigned)(q * N) * 4u : kOOB;
-          } else {
-            const int4 t = *reinterpret_cast<const int4*>(&sOut[row0]);
-            const int sp4[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              voff[q] = (cok && sp4[q] >= 0) ? ((unsigned)sp4[q] * (unsigned)N + (unsigned)col) * 4u : kOOB;
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            yv[i][4 * q4 + q] = buf_load1(rY, voff[q]);
-            okv[i][4 * q4 + q] = voff[q] != kOOB;
-          }
-        }
-      const float bmean = cok ? a.bnb_mean[col] : 0.f, binv = cok ? a.bnb_invstd[col] : 0.f;
-      const float bgm = cok ? a.bnb_gamma[col] : 0.f, bbt = cok ? a.bnb_beta[col] : 0.f;
-      float s1b = 0.f, s2b = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float xh = (yv[i][r] - bmean) * binv;
-          const float gp = okv[i][r] ? acc[i][j][r] * act_bwd_from_out(act_fwd(bgm * xh + bbt, a.bnb_act), a.bnb_act) : 0.f;
-          s1b += gp;
-          s2b += gp * xh;
-        }
-      s1b += __shfl_xor(s1b, 32, 64);
-      s2b += __shfl_xor(s2b, 32, 64);
-      if (lh == 0) {  // the A buffer is free after the main loop
-        float* st = &sAbuf[(wm * BN + (wn * TN + j) * 32 + li) * 2];
-        st[0] = s1b; st[1] = s2b;
-      }
-    }
-    // ---- fused BatchNorm statistics of this tile (train-mode BN follows the conv: vanilla_vae.py:28-31) ----
-    if (a.bn_part != nullptr) {
-      const float mean0 = cnt > 0.f ? s1 / cnt : 0.f;
-      float m2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const int row0 = (wm * TM + i) * 32 + 8 * q4 + 4 * lh;
-          bool ok4[4];
-          if (dense) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ok4[q] = cok && (full_m || m0 + row0 + q < a.Mc);
-          } else {
-            const int4 t = *reinterpret_cast<const int4*>(&sOut[row0]);
-            ok4[0] = cok && t.x >= 0; ok4[1] = cok && t.y >= 0; ok4[2] = cok && t.z >= 0; ok4[3] = cok && t.w >= 0;
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float d = acc[i][j][4 * q4 + q] - mean0;
-            m2 += ok4[q] ? d * d : 0.f;
-          }
-        }
-      // merge the two lane halves (Chan et al.)
-      float mean = mean0;
-      const float ocnt = __shfl_xor(cnt, 32, 64), omean = __shfl_xor(mean, 32, 64), om2 = __shfl_xor(m2, 32, 64);
-      const float ntot = cnt + ocnt;
-      if (ntot > 0.f) {
-        const float d = omean - mean;
-        m2 = m2 + om2 + d * d * (cnt * ocnt / ntot);
-        mean = mean + d * (ocnt / ntot);
-      }
-      if (lh == 0) {  // the A buffer is free after the main loop (its last iteration ended with a barrier)
-        float* st = &sAbuf[(wm * BN + (wn * TN + j) * 32 + li) * 3];
-        st[0] = ntot; st[1] = mean; st[2] = m2;
-      }
-    }
-  }
-  if (a.bn_part != nullptr) {
-    __syncthreads();
-    if (tid < BN && n0 + tid < N) {
-      float n = 0.f, mean = 0.f, m2 = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) {
-        const float nb = sAbuf[(w * BN + tid) * 3], mb = sAbuf[(w * BN + tid) * 3 + 1], qb = sAbuf[(w * BN + tid) * 3 + 2];
-        if (nb > 0.f) {
-          const float nt2 = n + nb, d = mb - mean;
-          mean += d * (nb / nt2);
-          m2 += qb + d * d * (n * nb / nt2);
-          n = nt2;
-        }
-      }
-      float* p = a.bn_part + ((long)(cls * a.mtiles + mt) * N + n0 + tid) * 3;
-      p[0] = n; p[1] = mean; p[2] = m2;
-    }
-  }
-  if (bnb) {
-    __syncthreads();
-    if (tid < BN && n0 + tid < N) {
-      float s1b = 0.f, s2b = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) {   // fixed order -> deterministic
-        s1b += sAbuf[(w * BN + tid) * 2];
-        s2b += sAbuf[(w * BN + tid) * 2 + 1];
-      }
-      float* p = a.bnb_part + ((long)(cls * a.mtiles + mt) * N + n0 + tid) * 2;
-      p[0] = s1b; p[1] = s2b;
-    }
-  }
-#ifdef CTVAE_PHASE_TIMING
-  PHASE(4);
-  __builtin_amdgcn_s_waitcnt(0);   // all counters zero: the stores have retired
-  PHASE(5);
-#endif
 }
 
 template <int WM, int WN, int TM, int TN>
@@ -589,6 +124,17 @@ static int launch_fast_cfg(const TapGemmArgs& a, int pf, hipStream_t st) {
   snprintf(name, sizeof name, "tapgemm_fast_kernel<%d,%d,%d,%d,%s,%d>", WM, WN, TM, TN, wt ? "true" : "false", pf);
   double macs = 0;
   for (int c = 0; c < a.g.ncls; ++c) macs += (double)a.Mc * a.N * a.g.ntaps[c] * a.g.gC;
+  if constexpr (WM == 2 && WN == 2 && TM == 1 && TN == 1) {
+    PairCtx* pc = pair_ctx();
+    if (pc != nullptr && wt && pf == 3 && !pc->haveA) {   // ctvae_conv_backward: issued by pair_flush()
+      pc->haveA = true;
+      pc->A = args;
+      pc->gxA = grid.x; pc->gyA = grid.y; pc->gzA = grid.z;
+      pc->flopsA = 2.0 * macs;
+      pc->bytesA = 4.0 * ((double)a.g.B * a.g.gH * a.g.gW * a.g.gC + (double)a.g.B * a.g.sH * a.g.sW * a.g.sC);
+      return 0;
+    }
+  }
   if (prof_detailed()) {
     size_t l = strlen(name);
     snprintf(name + l, sizeof name - l, " M=%dx%d N=%d C=%d taps=%d sk=%d", a.g.ncls, a.Mc, a.N, a.g.gC, a.g.ntaps[a.g.ncls - 1],
@@ -605,6 +151,33 @@ static int launch_fast_cfg(const TapGemmArgs& a, int pf, hipStream_t st) {
     else hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, true, 0>), grid, block, 0, st, args);
   }
   CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+PairCtx*& pair_ctx() {
+  static thread_local PairCtx* ctx = nullptr;
+  return ctx;
+}
+
+int pair_flush(PairCtx& c, hipStream_t st) {
+  if (c.haveA && c.haveB) {
+    const unsigned nA = c.gxA * c.gyA * c.gzA, nB = c.gxB * c.gyB;
+    ProfScope ps("conv_bwd_pair_kernel", st, c.flopsA + c.flopsB, c.bytesA + c.bytesB);
+    hipLaunchKernelGGL(conv_bwd_pair_kernel, dim3(nA + nB), dim3(256), 0, st, c.A, c.B, c.lgQw, c.lgQhw, c.lgC, (int)nA, (int)c.gxA,
+                       (int)c.gyA, (int)c.gxB, (int)c.gyB);
+    CTVAE_LAUNCH_CHECK();
+  } else if (c.haveA) {
+    ProfScope ps("tapgemm_fast_kernel<2,2,1,1,true,3>", st, c.flopsA, c.bytesA);
+    hipLaunchKernelGGL((tapgemm_fast_kernel<2, 2, 1, 1, true, 3>), dim3(c.gxA, c.gyA, c.gzA), dim3(256), 0, st, c.A);
+    CTVAE_LAUNCH_CHECK();
+  } else if (c.haveB) {
+    const int rc = launch_wgrad_fast_recorded(c, st);
+    if (rc) return rc;
+  }
+  for (auto& f : c.later) {
+    const int rc = f();
+    if (rc) return rc;
+  }
   return 0;
 }
 

@@ -10,22 +10,11 @@
 // bitwise reproducible, and atomics would be bound at ~1.3 TB/s on gfx950).
 #include "common.hpp"
 #include "prof.hpp"
+#include "pair.hpp"
+#include "wgrad_fast.hpp"
 
 namespace ctvae {
 
-struct WgradArgs {
-  ConvGeom g;
-  const float* X;
-  const float* dY;
-  float* part;   // [S][rows_total][N]
-  float* pbias;  // [S*ncls][N] or null
-  int Mc, N, S, chunks_per_split;
-  int rows_total;          // taps_total * gC
-  int ktile_start[kMaxCls + 1];
-  int ntiles;
-};
-
-constexpr int MC = 32;
 
 template <int WK, int WN, bool XVEC, bool DVEC>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
@@ -236,198 +225,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   if (do_bias && n0 + tid < N) a.pbias[(long)(split * g.ncls + cls) * N + n0 + tid] = bsum;
 }
 
-// ---- lean variant (gC % 4 == 0, N % 4 == 0): same tiling, minimal VALU around the MFMAs ---------------------
-// f32 MFMA and VALU share the SIMD's vector datapath on gfx950 (tools/mfma_probe.hip), so address arithmetic is
-// hoisted: a thread's tap / channel offset is constant for the launch, the per-pixel part (byte offset, y/x validity
-// masks, scatter offset) is decoded once per 32-pixel chunk by 32 lanes with shifts, loads go through buffer
-// resources (32-bit offsets, out-of-range -> 0, no zero-fill selects).
-typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
-constexpr unsigned kOOBw = 0x80000000u;
-
-// TK x TN: 32x32 MFMA tiles per wave.  <2,2,1,1> = 64x64 output tile; <2,2,2,2> = 128x128 for the wide layers of
-// MCQ / CT-MCQ-VAE (rows and N multiples of 128): per MFMA half the LDS reads and half the L2->LDS bytes per FLOP
-// (a 64x64 tile streams 1/16 B/FLOP, i.e. ~6 TB/s of L2 traffic at 95 TFLOP/s -- that, not the MFMA pipe, capped it).
+// ---- lean variant: body in wgrad_fast.hpp (shared with the paired backward launch of tapgemm_fast.hip) --------
 template <int WK, int WN, int TK, int TN>
 __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradArgs a, int lgQw, int lgQhw, int lgC) {
   constexpr int KT = WK * TK * 32, NT = WN * TN * 32;
-  static_assert(WK * WN == 4, "4 waves");
   __shared__ __attribute__((aligned(16))) float sX[MC * KT];
   __shared__ __attribute__((aligned(16))) float sD[MC * NT];
   __shared__ unsigned sPix[2][MC];   // byte offset of the pixel base in X, or kOOBw
   __shared__ unsigned sMsk[2][MC];   // y/x validity bits (see tapgemm_fast.hip)
   __shared__ unsigned sOutB[2][MC];  // byte offset of the scatter pixel in dY, or kOOBw
-
-  const ConvGeom& g = a.g;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wk = wave / WN, wn = wave % WN;
-  const int li = lane & 31, lh = lane >> 5;
-  // XCD-aware order: every output tile of one pixel slice reads the same X / dY rows, and workgroups are dealt
-  // round-robin to the 8 XCDs (one L2 each) in linear order -> give each group of 8 slices one XCD per slice, so a
-  // slice's rows are filled into ONE L2 instead of eight.  The last (gridDim.y % 8) slices keep the plain order.
-  int split = blockIdx.y, xtile = blockIdx.x;
-  {
-    const int T = gridDim.x, L = blockIdx.y * T + blockIdx.x, full = (gridDim.y >> 3) * 8 * T;
-    if (L < full) {
-      const int grp = L / (8 * T), r = L - grp * 8 * T;
-      split = grp * 8 + (r & 7);
-      xtile = r >> 3;
-    }
-  }
-  const int ktg = xtile / a.ntiles, nt = xtile - ktg * a.ntiles;
-  int cls = 0;
-#pragma unroll
-  for (int c = 1; c < kMaxCls; ++c)
-    if (c < g.ncls && ktg >= a.ktile_start[c]) cls = c;
-  const int kt0 = (ktg - a.ktile_start[cls]) * KT;
-  const int n0 = nt * NT;
-  const int gC = g.gC, N = a.N;
-  const int Ktot = g.ntaps[cls] * gC;
-  const int cbeg = split * a.chunks_per_split;
-  const int nchunks_all = (a.Mc + MC - 1) / MC;
-  int cend = cbeg + a.chunks_per_split;
-  if (cend > nchunks_all) cend = nchunks_all;
-  const int nch = cend - cbeg;
-
-  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)((long)g.B * g.gH * g.gW * gC * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dY), 0, (int)((long)g.B * g.sH * g.sW * N * 4), 0x00020000);
-
-  auto rowinfo = [&](int c, int buf) {
-    if (tid < MC) {
-      const int m = (cbeg + c) * MC + tid;
-      unsigned pixb = kOOBw, msk = 0, outb = kOOBw;
-      if (m < a.Mc) {
-        int b, qy, qx;
-        if (lgQw >= 0) {
-          b = m >> lgQhw;
-          const int rr = m & ((1 << lgQhw) - 1);
-          qy = rr >> lgQw;
-          qx = rr & ((1 << lgQw) - 1);
-        } else {
-          decode_m(g, m, b, qy, qx);
-        }
-        const int iy0 = qy * g.is, ix0 = qx * g.is;
-        pixb = (unsigned)(((b * g.gH + iy0) * g.gW + ix0) * gC) * 4u;
-#pragma unroll
-        for (int d = -3; d <= 4; ++d) {
-          if ((unsigned)(iy0 + d) < (unsigned)g.gH) msk |= 1u << (d + 3);
-          if ((unsigned)(ix0 + d) < (unsigned)g.gW) msk |= 1u << (d + 11);
-        }
-        outb = (unsigned)(scatter_pix(g, cls, b, qy, qx) * N) * 4u;
-      }
-      sPix[buf][tid] = pixb; sMsk[buf][tid] = msk; sOutB[buf][tid] = outb;
-    }
-  };
-
-  constexpr int XQ = KT / 4, X_V = (MC * XQ) / 256;
-  constexpr int DQ = NT / 4, D_V = (MC * DQ) / 256;
-  // this thread's fixed k column: tap and channel
-  unsigned x_const = 0;
-  int x_sy = 0, x_sx = 0;
-  bool x_kok;
-  {
-    const int k = kt0 + 4 * (tid % XQ);
-    x_kok = k < Ktot;
-    int t = 0, c = 0;
-    if (x_kok) {
-      t = lgC >= 0 ? (k >> lgC) : (k / gC);
-      c = k - t * gC;
-    }
-    const Tap tp = g.taps[cls][t];
-    x_const = (unsigned)(((tp.dy * g.gW + tp.dx) * gC + c) * 4);
-    x_sy = tp.dy + 3;
-    x_sx = tp.dx + 11;
-  }
-  const unsigned d_const = (n0 + 4 * (tid % DQ) < N) ? (unsigned)(n0 + 4 * (tid % DQ)) * 4u : kOOBw;
-
-  f32x4 rx[X_V], rd[D_V];
-  auto load_chunk = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < X_V; ++j) {
-      const int r = tid / XQ + (256 / XQ) * j;
-      const unsigned msk = sMsk[buf][r];
-      const bool ok = x_kok && ((msk >> x_sy) & (msk >> x_sx) & 1u) != 0;
-      rx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, (int)(ok ? sPix[buf][r] + x_const : kOOBw), 0, 0));
-    }
-#pragma unroll
-    for (int j = 0; j < D_V; ++j) {
-      const int r = tid / DQ + (256 / DQ) * j;
-      const unsigned ob = sOutB[buf][r];
-      rd[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rD, (int)((ob | d_const) >= kOOBw ? kOOBw : ob + d_const), 0, 0));
-    }
-  };
-  auto store_chunk = [&]() {
-#pragma unroll
-    for (int j = 0; j < X_V; ++j) *reinterpret_cast<f32x4*>(&sX[(tid / XQ + (256 / XQ) * j) * KT + 4 * (tid % XQ)]) = rx[j];
-#pragma unroll
-    for (int j = 0; j < D_V; ++j) *reinterpret_cast<f32x4*>(&sD[(tid / DQ + (256 / DQ) * j) * NT + 4 * (tid % DQ)]) = rd[j];
-  };
-
-  f32x16 acc[TK][TN];
-#pragma unroll
-  for (int i = 0; i < TK; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float bsum = 0.f;
-  const bool do_bias = (a.pbias != nullptr) && (kt0 == 0) && (tid < NT);
-
-  if (nch > 0) {
-    rowinfo(0, 0);
-    __syncthreads();
-    load_chunk(0);
-    if (nch > 1) rowinfo(1, 1);
-    store_chunk();
-    __syncthreads();
-    for (int c = 0; c < nch; ++c) {
-      if (c + 1 < nch) load_chunk((c + 1) & 1);
-      if (c + 2 < nch) rowinfo(c + 2, c & 1);
-#pragma unroll
-      for (int s = 0; s < MC / 2; ++s) {
-        float av[TK], bv[TN];
-#pragma unroll
-        for (int i = 0; i < TK; ++i) av[i] = sX[(2 * s + lh) * KT + (wk * TK + i) * 32 + li];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bv[j] = sD[(2 * s + lh) * NT + (wn * TN + j) * 32 + li];
-#pragma unroll
-        for (int i = 0; i < TK; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-      }
-      if (do_bias) {
-        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-#pragma unroll
-        for (int r = 0; r < MC; r += 4) {
-          t0 += sD[r * NT + tid]; t1 += sD[(r + 1) * NT + tid]; t2 += sD[(r + 2) * NT + tid]; t3 += sD[(r + 3) * NT + tid];
-        }
-        bsum += (t0 + t1) + (t2 + t3);
-      }
-      __syncthreads();
-      if (c + 1 < nch) {
-        store_chunk();
-        __syncthreads();
-      }
-    }
-  }
-
-#pragma unroll
-  for (int i = 0; i < TK; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + (wn * TN + j) * 32 + li;
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const int k0 = kt0 + (wk * TK + i) * 32 + 8 * q4 + 4 * lh;      // 4 consecutive k rows: same tap when gC % 4 == 0
-        if (k0 < Ktot && col < N) {
-          const int t = lgC >= 0 ? (k0 >> lgC) : (k0 / gC);
-          const int wrow0 = g.taps[cls][t].wtap * gC + (k0 - t * gC);
-          float* dst = a.part + ((long)split * a.rows_total + wrow0) * N + col;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) dst[(long)q * N] = acc[i][j][4 * q4 + q];
-        }
-      }
-    }
-  if (do_bias && n0 + tid < N) a.pbias[(long)(split * g.ncls + cls) * N + n0 + tid] = bsum;
+  wgrad_fast_body<WK, WN, TK, TN>(a, lgQw, lgQhw, lgC, sX, sD, sPix, sMsk, sOutB, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
 }
 
 // dst[i] = (accumulate ? dst[i] : 0) + sum_s part[s*stride + i], for up to two jobs (weights, bias) in ONE launch:
@@ -666,7 +473,22 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
   a.ktile_start[g.ncls] = kt;
   a.ntiles = ceil_div(a.N, NT);
   dim3 grid(kt * a.ntiles, S), block(256);
-  {
+  bool recorded = false;
+  if (PairCtx* pc = pair_ctx(); pc != nullptr && !pc->haveB && xvec && dvec && !narrow && !big) {
+    // ctvae_conv_backward: the lean 64x64 kernel shares a launch with the data-gradient kernel (pair_flush())
+    auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+    const int lw = lg2(g.Qw), lh2 = lg2(g.Qh);
+    pc->haveB = true;
+    pc->B = a;
+    pc->lgQw = (lw >= 0 && lh2 >= 0) ? lw : -1;
+    pc->lgQhw = (lw >= 0 && lh2 >= 0) ? lw + lh2 : -1;
+    pc->lgC = lg2(g.gC);
+    pc->gxB = grid.x; pc->gyB = grid.y;
+    pc->flopsB = 2.0 * (double)a.Mc * a.N * a.rows_total;
+    pc->bytesB = 4.0 * ((double)g.B * g.gH * g.gW * g.gC + (double)g.B * g.sH * g.sW * g.sC);
+    recorded = true;
+  }
+  if (!recorded) {
   char name[160];
   if (big) snprintf(name, sizeof name, "wgrad_fast_kernel<2,2,2,2>");
   else if (xvec && dvec && !narrow) snprintf(name, sizeof name, "wgrad_fast_kernel<%d,%d,1,1>", narrow ? 4 : 2, narrow ? 1 : 2);
@@ -699,12 +521,29 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
   }
   CTVAE_LAUNCH_CHECK();
   const long n = (long)a.rows_total * a.N;
-  char rname[96];
-  snprintf(rname, sizeof rname, "reduce_partials_kernel");
-  if (prof_detailed()) snprintf(rname, sizeof rname, "reduce_partials_kernel n=%ld S=%d", n, S);
-  ProfScope ps2(rname, st, 0.0, 4.0 * (double)(S + 1) * n);
-  if (dbias) launch_reduce2(a.part, dW, n, S, (long)a.rows_total * a.N, a.pbias, dbias, (long)a.N, S * g.ncls, (long)a.N, accumulate, st);
-  else launch_reduce(a.part, dW, n, S, (long)a.rows_total * a.N, accumulate, st);
+  const float* part = a.part;
+  const float* pbias = a.pbias;
+  const int ncls = g.ncls, N_ = a.N;
+  auto reduce = [=]() -> int {
+    char rname[96];
+    snprintf(rname, sizeof rname, "reduce_partials_kernel");
+    if (prof_detailed()) snprintf(rname, sizeof rname, "reduce_partials_kernel n=%ld S=%d", n, S);
+    ProfScope ps2(rname, st, 0.0, 4.0 * (double)(S + 1) * n);
+    if (dbias) launch_reduce2(part, dW, n, S, n, pbias, dbias, (long)N_, S * ncls, (long)N_, accumulate, st);
+    else launch_reduce(part, dW, n, S, n, accumulate, st);
+    CTVAE_LAUNCH_CHECK();
+    return 0;
+  };
+  if (PairCtx* pc = pair_ctx()) {   // ctvae_conv_backward: behind the paired main launch
+    pc->later.push_back(reduce);
+    return 0;
+  }
+  return reduce();
+}
+
+int launch_wgrad_fast_recorded(const PairCtx& c, hipStream_t st) {
+  ProfScope ps("wgrad_fast_kernel<2,2,1,1>", st, c.flopsB, c.bytesB);
+  hipLaunchKernelGGL((wgrad_fast_kernel<2, 2, 1, 1>), dim3(c.gxB, c.gyB), dim3(256), 0, st, c.B, c.lgQw, c.lgQhw, c.lgC);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }

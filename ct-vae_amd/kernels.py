@@ -234,11 +234,52 @@ def conv_wgrad_raw(x, dy, w_param, b_param, spec: ConvSpec, in_coef=None, in_act
                 by, bc, bact, bgy, ws.data_ptr(), ws.numel() * 4)
 
 
+_PAIR = os.environ.get("CTVAE_NO_PAIR", "0") != "1"     # diagnostic: separate wgrad / dgrad launches
+
+
+def conv_backward_raw(x, dy, w_param, b_param, spec: ConvSpec, link=None, mask=None, mask_act=ACT_NONE, wino_filters=None):
+    """ctvae_conv_backward: weight (+bias) gradient into ``.grad`` and the data gradient of one layer in one call (the
+    two GEMMs share a launch when both run their 64x64 tile kernels).  ``link``: BNLink of the layer that produced x."""
+    B, H, W, _ = x.shape
+    ws = native.workspace(x.device)
+    gw, acc = grad_target(w_param)
+    gb = None
+    if b_param is not None:
+        gb, accb = grad_target(b_param)
+        if accb != acc:
+            (gw if acc == 0 else gb).zero_()
+            acc = 1
+    dx = torch.empty((B, H, W, spec.ci), dtype=torch.float32, device=dy.device)
+    part, rows = None, 0
+    if link is not None and tuple(link.y.shape) == (B, H, W, spec.ci):
+        key = (spec.kind, B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, ws.numel() // 2)
+        rows = _bn_rows_cache.get(key)
+        if rows is None:
+            rows = _bn_rows_cache[key] = native.load().ctvae_conv_dgrad_bn_rows(*key[:-1], (ws.numel() * 4) // 2)
+        if rows > 0:
+            part = torch.empty(rows * spec.ci * 2, dtype=torch.float32, device=dy.device)
+        else:
+            rows = 0
+    bn = link if part is not None else None
+    native.call("ctvae_conv_backward", spec.kind, x.data_ptr(), dy.data_ptr(), w_param.data_ptr(), gw.data_ptr(), native.ptr(gb),
+                dx.data_ptr(), B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, acc,
+                native.ptr(mask), mask_act, native.ptr(wino_filters),
+                native.ptr(bn.y if bn else None), native.ptr(bn.mean if bn else None), native.ptr(bn.invstd if bn else None),
+                native.ptr(bn.gamma if bn else None), native.ptr(bn.beta if bn else None), bn.act if bn else 0,
+                native.ptr(part), rows, ws.data_ptr(), ws.numel() * 4)
+    if bn is not None:
+        bn.publish(dx, part, rows)
+    return dx
+
+
 def wgrad_then_dgrad(x, g, w_param, b_param, spec, need_dgrad, link=None, wino_filters=None):
     """Weight gradient (accumulated straight into ``.grad``) and data gradient of one layer, on the launch stream.
     Measured on MI355X: putting the wgrad kernels on a second HIP stream (joined right after dgrad, or once at the
     end of backward) is SLOWER than back-to-back launches (2.43 vs 2.32 ms/step) -- each GEMM launch already covers
-    every CU, and the fork/join edges cost more than the overlap of prologue/epilogue phases returns."""
+    every CU, and the fork/join edges cost more than the overlap of prologue/epilogue phases returns.  What does pay is
+    ONE launch for both GEMMs (ctvae_conv_backward / conv_bwd_pair_kernel)."""
+    if need_dgrad and _PAIR:
+        return conv_backward_raw(x, g, w_param, b_param, spec, link=link, wino_filters=wino_filters)
     conv_wgrad_raw(x, g, w_param, b_param, spec)
     if not need_dgrad:
         return None
@@ -351,8 +392,11 @@ class ConvAct(Function):
             g_pre = act_backward_raw(g_y, y, spec.act)
         if ctx.act_in is not None and ctx.needs_input_grad[0] and ctx.link_in is None:
             # x is the activated output of the producer and this layer is its only consumer: dgrad * act'(x) in one launch
-            conv_wgrad_raw(x, g_pre, ctx.w, ctx.b, spec)
-            g_x = conv_dgrad_raw(g_pre, ctx.w, spec, (x.shape[1], x.shape[2]), mask=x, mask_act=ctx.act_in.act)
+            if _PAIR:
+                g_x = conv_backward_raw(x, g_pre, ctx.w, ctx.b, spec, mask=x, mask_act=ctx.act_in.act)
+            else:
+                conv_wgrad_raw(x, g_pre, ctx.w, ctx.b, spec)
+                g_x = conv_dgrad_raw(g_pre, ctx.w, spec, (x.shape[1], x.shape[2]), mask=x, mask_act=ctx.act_in.act)
             ctx.act_in.publish_done(g_x)
         else:
             g_x = wgrad_then_dgrad(x, g_pre, ctx.w, ctx.b, spec, ctx.needs_input_grad[0], ctx.link_in, ctx.wino_u)

@@ -95,6 +95,18 @@ int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float
                      int Co, int k, int stride, int pad, int out_pad, int accumulate, const float* in_scale,
                      const float* in_shift, int in_act, const float* dy_bn_y, const float* dy_bn_coef, int dy_bn_act,
                      float* gy_out, float* ws, size_t ws_bytes, void* stream);
+/* A layer's whole backward pass in one call: weight (+ bias) gradient as ctvae_conv_wgrad(x, dy -> dw, dbias) and data
+ * gradient as ctvae_conv_dgrad / ctvae_conv_dgrad_bn(dy, w -> dx; optional mask, Winograd filters, fused BatchNorm-backward
+ * sums).  The two GEMMs are independent; when both take their 64x64 tile kernels they are issued as ONE launch
+ * (conv_bwd_pair_kernel: one kernel boundary instead of two, the weight-gradient workgroups start while the data
+ * gradient's stores drain), otherwise as the separate launches of those entry points.  Each GEMM uses one half of ws:
+ * query bn_part_rows with ctvae_conv_dgrad_bn_rows(..., ws_bytes / 2).  bn_part == NULL: no BatchNorm fusion. */
+int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* w, float* dw, float* dbias, float* dx, int B,
+                        int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int accumulate, const float* mask,
+                        int mask_act, const float* wino_filters, const float* bn_y, const float* bn_mean,
+                        const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int bn_act, float* bn_part,
+                        int bn_part_rows, float* ws, size_t ws_bytes, void* stream);
+
 /* dy_bn_y / dy_bn_coef / gy_out (all or none): `dy` is then g_a, the gradient w.r.t. the output of the BatchNorm +
  * activation that follows this layer; the kernel forms g_y = k1*g_a*act'(y*scale+shift) + k2*y + k3 while loading
  * (coef = [5][Co]: k1,k2,k3,scale,shift as written by ctvae_bn_backward coef_out), uses it for dw/dbias and writes it to
