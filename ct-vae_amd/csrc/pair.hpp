@@ -8,6 +8,7 @@
 #include <functional>
 #include <vector>
 
+#include "finish.hpp"
 #include "tapgemm.hpp"
 #include "wgrad_fast.hpp"
 
@@ -22,11 +23,19 @@ struct PairCtx {
   int lgQw = -1, lgQhw = -1, lgC = -1;
   unsigned gxB = 0, gyB = 0;
   double flopsB = 0, bytesB = 0;
+  // finishing passes: the data gradient's split-K sum and the weight gradient's slab reduction share a launch when both exist
+  bool haveSK = false, haveRed = false;
+  SplitKJob sk;
+  ReduceJob j1, j2;
+  int nb1 = 0, nb2 = 0, accumulate = 0;
+  double bytesSK = 0, bytesRed = 0;
   std::vector<std::function<int()>> later;
 };
 
 PairCtx*& pair_ctx();                                    // tapgemm_fast.hip (thread-local, null = not pairing)
 int pair_flush(PairCtx& c, hipStream_t st);              // tapgemm_fast.hip
 int launch_wgrad_fast_recorded(const PairCtx& c, hipStream_t st);   // wgrad.hip: the recorded weight-gradient kernel on its own
+int launch_finish_recorded(const PairCtx& c, hipStream_t st);       // wgrad.hip: recorded reduction (+ split-K finish) in one launch
+int launch_splitk_recorded(const PairCtx& c, hipStream_t st);       // tapgemm.hip: recorded split-K finish on its own
 
 }  // namespace ctvae

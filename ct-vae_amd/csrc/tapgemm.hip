@@ -489,32 +489,8 @@ __global__ __launch_bounds__(256) void tapgemm_masked_kernel(const TapGemmArgs a
   }
 }
 
-// S[i] = epi(sum_z part[z][i]) for the split-K path (N % 4 == 0)
-__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ part, int splitk, long stride,
-                                                            const float* __restrict__ bias, const float* __restrict__ add,
-                                                            const float* __restrict__ mask, int mask_act, int act,
-                                                            float* __restrict__ S, long n4, int N) {
-  const long gs = (long)gridDim.x * 256;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += gs) {
-    f32x4 v = reinterpret_cast<const f32x4*>(part)[i];
-    for (int z = 1; z < splitk; ++z) {
-      f32x4 t = reinterpret_cast<const f32x4*>(part + z * stride)[i];
-      v += t;
-    }
-    const int col = (int)((i * 4) % N);
-    if (bias != nullptr) v += *reinterpret_cast<const f32x4*>(bias + col);
-    if (add != nullptr) v += reinterpret_cast<const f32x4*>(add)[i];
-    f32x4 o;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = act_fwd(v[k], act);
-    if (mask != nullptr) {
-      f32x4 m = reinterpret_cast<const f32x4*>(mask)[i];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) o[k] *= act_bwd_from_out(m[k], mask_act);
-    }
-    reinterpret_cast<f32x4*>(S)[i] = o;
-  }
-}
+// split-K finish: body in finish.hpp (shared with the paired backward's combined finishing launch in wgrad.hip)
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const SplitKJob k) { splitk_finish_body(k, blockIdx.x); }
 
 // ---- host side --------------------------------------------------------------------------------
 // masked variants: one tile shape (128 x 32), single-buffered
@@ -721,19 +697,24 @@ int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const floa
   const long n = (long)g.B * g.sH * g.sW * a.N, n4 = n / 4;
   long blocks = (n4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  const int splitk = plan.splitk, N_ = a.N;
-  auto finish = [=]() -> int {
-    ProfScope ps("splitk_finish_kernel", st, 0.0, 4.0 * (double)(splitk + 1) * n);
-    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ws, splitk, n, bias, add, mask, mask_act, act,
-                       S, n4, N_);
-    CTVAE_LAUNCH_CHECK();
-    return 0;
-  };
-  if (PairCtx* pc = pair_ctx()) {   // ctvae_conv_backward: behind the paired main launch
-    pc->later.push_back(finish);
+  const SplitKJob job{ws, plan.splitk, n, bias, add, mask, mask_act, act, S, n4, a.N, (int)blocks};
+  if (PairCtx* pc = pair_ctx()) {   // ctvae_conv_backward: behind the paired main launch (pair_flush)
+    pc->haveSK = true;
+    pc->sk = job;
+    pc->bytesSK = 4.0 * (double)(plan.splitk + 1) * n;
     return 0;
   }
-  return finish();
+  ProfScope ps("splitk_finish_kernel", st, 0.0, 4.0 * (double)(plan.splitk + 1) * n);
+  hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, st, job);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_splitk_recorded(const PairCtx& c, hipStream_t st) {
+  ProfScope ps("splitk_finish_kernel", st, 0.0, c.bytesSK);
+  hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)c.sk.nblk), dim3(256), 0, st, c.sk);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
 }
 
 }  // namespace ctvae

@@ -174,6 +174,13 @@ int pair_flush(PairCtx& c, hipStream_t st) {
     const int rc = launch_wgrad_fast_recorded(c, st);
     if (rc) return rc;
   }
+  if (c.haveRed) {            // slab reduction, with the data gradient's split-K finish as extra blocks of the same launch
+    const int rc = launch_finish_recorded(c, st);
+    if (rc) return rc;
+  } else if (c.haveSK) {
+    const int rc = launch_splitk_recorded(c, st);
+    if (rc) return rc;
+  }
   for (auto& f : c.later) {
     const int rc = f();
     if (rc) return rc;

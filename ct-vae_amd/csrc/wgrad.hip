@@ -10,6 +10,7 @@
 // bitwise reproducible, and atomics would be bound at ~1.3 TB/s on gfx950).
 #include "common.hpp"
 #include "prof.hpp"
+#include "finish.hpp"
 #include "pair.hpp"
 #include "wgrad_fast.hpp"
 
@@ -242,15 +243,6 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradArgs a, int 
 //  * few slices (S <= 8): one thread per float4 / float, a plain pass over the slices;
 //  * many slices: 16 split-lanes x 16 element-lanes; lane j sums s = j, j+16, ... , then a fixed shuffle tree
 //    and a 4-wave LDS combine.  With VEC the element lane covers a float4 (64 elements per block).
-struct ReduceJob {
-  const float* part;
-  float* dst;
-  long n;
-  int S;
-  long stride;
-  int small;   // block shape
-  int vec;     // float4 lanes (n % 4 == 0 and stride % 4 == 0)
-};
 
 template <typename T>
 __device__ __forceinline__ T rzero();
@@ -298,8 +290,13 @@ __device__ __forceinline__ void reduce_split(const ReduceJob& j, int blk, int ac
   }
 }
 
-__global__ __launch_bounds__(256) void reduce_partials_kernel(ReduceJob j1, ReduceJob j2, int nb1, int accumulate) {
+// blocks [0, nb1) job 1, [nb1, nb12) job 2, [nb12, ...) the split-K finish of the paired data gradient (sk.nblk blocks, may be 0)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(ReduceJob j1, ReduceJob j2, int nb1, int accumulate, SplitKJob sk, int nb12) {
   __shared__ f32x4 sm[4][16];
+  if ((int)blockIdx.x >= nb12) {
+    splitk_finish_body(sk, (int)blockIdx.x - nb12);
+    return;
+  }
   const bool second = (int)blockIdx.x >= nb1;
   const ReduceJob j = second ? j2 : j1;
   const int blk = second ? blockIdx.x - nb1 : blockIdx.x;
@@ -325,7 +322,7 @@ static void launch_reduce2(const float* p1, float* d1, long n1, int S1, long st1
   ReduceJob j1{p1, d1, n1, S1, st1, 0, 0}, j2{p2, d2, n2, S2, st2, 0, 0};
   const int nb1 = reduce_job_blocks(j1), nb2 = reduce_job_blocks(j2);
   if (nb1 + nb2 == 0) return;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(nb1 + nb2), dim3(256), 0, st, j1, j2, nb1, accumulate);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(nb1 + nb2), dim3(256), 0, st, j1, j2, nb1, accumulate, SplitKJob{}, nb1 + nb2);
 }
 
 static void launch_reduce(const float* part, float* dst, long n, int S, long stride, int accumulate, hipStream_t st) {
@@ -524,21 +521,33 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
   const float* part = a.part;
   const float* pbias = a.pbias;
   const int ncls = g.ncls, N_ = a.N;
-  auto reduce = [=]() -> int {
-    char rname[96];
-    snprintf(rname, sizeof rname, "reduce_partials_kernel");
-    if (prof_detailed()) snprintf(rname, sizeof rname, "reduce_partials_kernel n=%ld S=%d", n, S);
-    ProfScope ps2(rname, st, 0.0, 4.0 * (double)(S + 1) * n);
-    if (dbias) launch_reduce2(part, dW, n, S, n, pbias, dbias, (long)N_, S * ncls, (long)N_, accumulate, st);
-    else launch_reduce(part, dW, n, S, n, accumulate, st);
-    CTVAE_LAUNCH_CHECK();
-    return 0;
-  };
-  if (PairCtx* pc = pair_ctx()) {   // ctvae_conv_backward: behind the paired main launch
-    pc->later.push_back(reduce);
+  if (PairCtx* pc = pair_ctx()) {   // ctvae_conv_backward: behind the paired main launch, together with the split-K finish
+    pc->j1 = ReduceJob{part, dW, n, S, n, 0, 0};
+    pc->j2 = dbias ? ReduceJob{pbias, dbias, (long)N_, S * ncls, (long)N_, 0, 0} : ReduceJob{nullptr, nullptr, 0, 0, 0, 0, 0};
+    pc->nb1 = reduce_job_blocks(pc->j1);
+    pc->nb2 = reduce_job_blocks(pc->j2);
+    pc->accumulate = accumulate;
+    pc->bytesRed = 4.0 * (double)(S + 1) * n;
+    pc->haveRed = pc->nb1 + pc->nb2 > 0;
     return 0;
   }
-  return reduce();
+  char rname[96];
+  snprintf(rname, sizeof rname, "reduce_partials_kernel");
+  if (prof_detailed()) snprintf(rname, sizeof rname, "reduce_partials_kernel n=%ld S=%d", n, S);
+  ProfScope ps2(rname, st, 0.0, 4.0 * (double)(S + 1) * n);
+  if (dbias) launch_reduce2(part, dW, n, S, n, pbias, dbias, (long)N_, S * ncls, (long)N_, accumulate, st);
+  else launch_reduce(part, dW, n, S, n, accumulate, st);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_finish_recorded(const PairCtx& c, hipStream_t st) {
+  const int nsk = c.haveSK ? c.sk.nblk : 0;
+  ProfScope ps(nsk ? "reduce_partials_kernel (+ split-K finish)" : "reduce_partials_kernel", st, 0.0, c.bytesRed + (nsk ? c.bytesSK : 0.0));
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(c.nb1 + c.nb2 + nsk), dim3(256), 0, st, c.j1, c.j2, c.nb1, c.accumulate,
+                     nsk ? c.sk : SplitKJob{}, c.nb1 + c.nb2);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
 }
 
 int launch_wgrad_fast_recorded(const PairCtx& c, hipStream_t st) {
