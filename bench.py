@@ -59,21 +59,20 @@ def parse():
 
 
 def pmc_traffic(kernel_name):
-    """HBM-side bytes per launch of `kernel_name` from the newest committed PMC summary (profiles/*_pmc_traffic.json,
+    """HBM-side bytes per launch of `kernel_name` from the newest committed PMC summary that lists it (profiles/*_pmc_traffic.json,
     written by tools/pmc_summary.py from two separate `rocprofv3 --pmc` passes of this same command) or None."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-    if not files:
-        return None, None
-    try:
-        with open(files[-1]) as f:
-            d = json.load(f)
-    except (OSError, ValueError):
-        return None, None
     want = kernel_name.replace(" ", "")
-    for k, v in d.get("kernels", {}).items():
-        if k.replace(" ", "") == want:
-            return v["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    for path in reversed(files):          # newest summary that holds this kernel (a round re-measures the kernels it changed)
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        for k, v in d.get("kernels", {}).items():
+            if k.replace(" ", "") == want:
+                return v["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
     return None, None
 
 

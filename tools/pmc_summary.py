@@ -7,13 +7,23 @@ WRITE_SIZE is taken as is."""
 import collections, csv, glob, json, os, sys
 
 
+def norm(name):
+    return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("ctvae::", "")
+
+
 def load(d):
-    f = glob.glob(os.path.join(d, "*counter_collection.csv"))[0]
     agg = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("ctvae::", "")
-        agg[name][0] += 1
-        agg[name][1] += float(r["Counter_Value"])
+    files = glob.glob(os.path.join(d, "*counter_collection.csv"))
+    if files:
+        for r in csv.DictReader(open(files[0])):
+            agg[norm(r["Kernel_Name"])][0] += 1
+            agg[norm(r["Kernel_Name"])][1] += float(r["Counter_Value"])
+        return agg
+    import sqlite3   # rocprofv3 of ROCm 7.2 writes a rocpd database instead of CSV files
+    con = sqlite3.connect(glob.glob(os.path.join(d, "*_results.db"))[0])
+    for name, val in con.execute("select kernel_name, value from counters_collection"):
+        agg[norm(name)][0] += 1
+        agg[norm(name)][1] += float(val)
     return agg
 
 
