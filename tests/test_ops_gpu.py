@@ -222,6 +222,40 @@ def test_mmd_kernel(K, N, D, kind):
     np.testing.assert_allclose(zd.grad.cpu().numpy(), z.grad.numpy(), atol=1e-7, rtol=2e-4)
 
 
+@pytest.mark.parametrize("case", [
+    # transposed, Ci, Co, H, k, s, p, op, B, bias    (shapes whose two backward GEMMs take the 64x64 tile kernels -> ONE launch)
+    (False, 64, 128, 16, 3, 2, 1, 0, 16, True),      # encoder.2-like: data gradient in 4 parity classes
+    (True, 256, 128, 4, 3, 2, 1, 1, 32, True),       # decoder.1-like: split-K data gradient (finish rides with the slab reduction)
+    (False, 2048, 256, 1, 1, 1, 0, 0, 64, True),     # fc heads
+    (False, 256, 256, 8, 1, 1, 0, 0, 8, False),      # 1x1 conv of a residual block
+    (False, 32, 3, 32, 3, 1, 1, 0, 2, True),         # picture-side layer: neither side pairs, same entry point
+])
+def test_paired_backward_matches_separate_launches(K, case):
+    """ctvae_conv_backward (data + weight gradient in one launch, shared finishing launch) against the separate
+    ctvae_conv_wgrad / ctvae_conv_dgrad calls on the same inputs: same kernels' arithmetic, so bit-identical."""
+    transposed, Ci, Co, H, k, s, p, op, B, bias = case
+    g = torch.Generator().manual_seed(Ci * 7 + Co)
+    spec = K.ConvSpec(K.CONVT if transposed else K.CONV, Ci, Co, k, s, p, op, K.ACT_NONE)
+    ho, wo = spec.out_hw(H, H)
+    x = torch.randn(B, H, H, Ci, generator=g).cuda()
+    dy = torch.randn(B, ho, wo, Co, generator=g).cuda()
+    w = torch.randn((Ci, Co, k, k) if transposed else (Co, Ci, k, k), generator=g) * 0.05
+    res = []
+    for paired in (True, False):
+        wp = as_param(pack(w, transposed).cuda(), transposed)
+        bp = torch.nn.Parameter(torch.zeros(Co).cuda()) if bias else None
+        if paired:
+            dx = K.conv_backward_raw(x, dy, wp, bp, spec)
+        else:
+            K.conv_wgrad_raw(x, dy, wp, bp, spec)
+            dx = K.conv_dgrad_raw(dy, wp, spec, (H, H))
+        torch.cuda.synchronize()
+        res.append((dx.clone(), wp.grad.clone(), bp.grad.clone() if bias else None))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    if bias:
+        assert torch.equal(res[0][2], res[1][2])
+
+
 def test_permute_roundtrip(K):
     x = torch.randn(3, 5, 6, 7)
     xd = x.cuda()
