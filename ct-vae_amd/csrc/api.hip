@@ -226,6 +226,18 @@ int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float
   return launch_wgrad(g, x, dy, dw, dbias, ws, ws_bytes, accumulate, (hipStream_t)stream, &xf, &dyx);
 }
 
+int ctvae_conv_backward_bn_rows(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
+                                size_t ws_bytes) {
+  if (kind != CTVAE_CONV && kind != CTVAE_CONVT) return 0;
+  ConvGeom g;
+  if (build_geom(g, kind == CTVAE_CONV ? 2 : 3, B, H, W, Ci, Co, k, stride, pad, out_pad)) return 0;
+  PairCtx ctx;                      // plan as ctvae_conv_backward does
+  pair_ctx() = &ctx;
+  const int rows = tapgemm_bnb_rows(g, ((ws_bytes / 2) & ~(size_t)255) / sizeof(float));
+  pair_ctx() = nullptr;
+  return rows;
+}
+
 int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* w, float* dw, float* dbias, float* dx, int B,
                         int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int accumulate, const float* mask,
                         int mask_act, const float* wino_filters, const float* bn_y, const float* bn_mean,
@@ -242,14 +254,16 @@ int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* 
   float* ws_d = ws + half_floats;
   if (wino_filters != nullptr && !ctvae_conv_wino_filter_floats(kind, B, H, W, Ci, Co, k, stride, pad, out_pad, half_bytes))
     return kErrBadArg;
-  if (bn) {
-    const int rows = tapgemm_bnb_rows(gd, half_floats);
-    if (rows <= 0 || rows != bn_part_rows) return kErrBadArg;
-    if (img_dgrad_supported(gd) && mask != nullptr) return kErrBadArg;
-  }
   const hipStream_t st = (hipStream_t)stream;
   PairCtx ctx;
   pair_ctx() = &ctx;
+  if (bn) {
+    const int rows = tapgemm_bnb_rows(gd, half_floats);
+    if (rows <= 0 || rows != bn_part_rows || (img_dgrad_supported(gd) && mask != nullptr)) {
+      pair_ctx() = nullptr;
+      return kErrBadArg;
+    }
+  }
   const InXform xf{nullptr, nullptr, 0};
   const DyXform dyx{nullptr, nullptr, nullptr, 0};
   int rc = launch_wgrad(gw, x, dy, dw, dbias, ws, half_bytes, accumulate, st, &xf, &dyx);

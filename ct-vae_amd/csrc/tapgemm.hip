@@ -585,8 +585,16 @@ void tapgemm_plan(const ConvGeom& g, size_t ws_floats, TapGemmPlan& p) {
   }
   static const int sk_target = [] { const char* e = getenv("CTVAE_SK_TARGET"); return e ? atoi(e) : 768; }();   // diagnostic
   static const int sk_maxwgs = [] { const char* e = getenv("CTVAE_SK_MAXWGS"); return e ? atoi(e) : 384; }();   // diagnostic
-  if (avec && bvec && (N % 4) == 0 && wgs < sk_maxwgs && nch_min >= 8) {
-    int sk = (int)((sk_target + wgs - 1) / wgs);
+  // a data gradient that shares its launch with the weight gradient (ctvae_conv_backward) does not have to fill the chip
+  // on its own: the ~1000 weight-gradient workgroups do.  It is split only as far as its workgroups would otherwise be the
+  // launch's long pole -- fewer partial sums to write and finish, and an unsplit launch keeps the fused BatchNorm-backward
+  // sums in its epilogue (no bn_bwd_partial pass)
+  static const int pair_target = [] { const char* e = getenv("CTVAE_PAIR_SK_TARGET"); return e ? atoi(e) : 256; }();   // sweep, ms per step: 768 1.804, 512 1.798, 384 1.800, 256 1.796, 128 1.813, no split 1.847
+  static const int pair_maxwgs = [] { const char* e = getenv("CTVAE_PAIR_SK_MAXWGS"); return e ? atoi(e) : 384; }();
+  const bool paired = pair_ctx() != nullptr && g.wT != 0;
+  const int tgt = paired ? pair_target : sk_target, maxw = paired ? pair_maxwgs : sk_maxwgs;
+  if (avec && bvec && (N % 4) == 0 && wgs < maxw && nch_min >= 8) {
+    int sk = (int)((tgt + wgs - 1) / wgs);
     if (sk > nch_min / 4) sk = nch_min / 4;
     if (sk > 16) sk = 16;
     const size_t per = (size_t)g.B * g.sH * g.sW * N;

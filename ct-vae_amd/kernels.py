@@ -252,10 +252,10 @@ def conv_backward_raw(x, dy, w_param, b_param, spec: ConvSpec, link=None, mask=N
     dx = torch.empty((B, H, W, spec.ci), dtype=torch.float32, device=dy.device)
     part, rows = None, 0
     if link is not None and tuple(link.y.shape) == (B, H, W, spec.ci):
-        key = (spec.kind, B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, ws.numel() // 2)
+        key = (spec.kind, B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, -ws.numel())
         rows = _bn_rows_cache.get(key)
         if rows is None:
-            rows = _bn_rows_cache[key] = native.load().ctvae_conv_dgrad_bn_rows(*key[:-1], (ws.numel() * 4) // 2)
+            rows = _bn_rows_cache[key] = native.load().ctvae_conv_backward_bn_rows(*key[:-1], ws.numel() * 4)
         if rows > 0:
             part = torch.empty(rows * spec.ci * 2, dtype=torch.float32, device=dy.device)
         else:

@@ -65,6 +65,7 @@ _RESTYPES = {
     "ctvae_prof_calibrate": None,
     "ctvae_prof_report": _c.c_size_t,
     "ctvae_conv_dgrad_bn_rows": _c.c_int,
+    "ctvae_conv_backward_bn_rows": _c.c_int,
     "ctvae_winograd_enable": _c.c_int,
     "ctvae_conv_wino_filter_floats": _c.c_size_t,
     "ctvae_conv_input_transform_supported": _c.c_int,
@@ -103,6 +104,7 @@ def load():
                        "ctvae_prof_calibrate": [_c.c_void_p, _c.c_int],
                        "ctvae_prof_report": [_c.c_char_p, _c.c_size_t],
                        "ctvae_conv_dgrad_bn_rows": [_c.c_int] * 10 + [_c.c_size_t],
+                       "ctvae_conv_backward_bn_rows": [_c.c_int] * 10 + [_c.c_size_t],
                        "ctvae_winograd_enable": [_c.c_int],
                        "ctvae_conv_wino_filter_floats": [_c.c_int] * 10 + [_c.c_size_t],
                        "ctvae_conv_input_transform_supported": [_c.c_int] * 10,

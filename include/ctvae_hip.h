@@ -100,7 +100,10 @@ int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float
  * sums).  The two GEMMs are independent; when both take their 64x64 tile kernels they are issued as ONE launch
  * (conv_bwd_pair_kernel: one kernel boundary instead of two, the weight-gradient workgroups start while the data
  * gradient's stores drain), otherwise as the separate launches of those entry points.  Each GEMM uses one half of ws:
- * query bn_part_rows with ctvae_conv_dgrad_bn_rows(..., ws_bytes / 2).  bn_part == NULL: no BatchNorm fusion. */
+ * query bn_part_rows with ctvae_conv_backward_bn_rows (0: this layer's data gradient cannot emit the sums).
+ * bn_part == NULL: no BatchNorm fusion. */
+int ctvae_conv_backward_bn_rows(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
+                                size_t ws_bytes);
 int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* w, float* dw, float* dbias, float* dx, int B,
                         int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int accumulate, const float* mask,
                         int mask_act, const float* wino_filters, const float* bn_y, const float* bn_mean,

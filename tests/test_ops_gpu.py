@@ -232,7 +232,9 @@ def test_mmd_kernel(K, N, D, kind):
 ])
 def test_paired_backward_matches_separate_launches(K, case):
     """ctvae_conv_backward (data + weight gradient in one launch, shared finishing launch) against the separate
-    ctvae_conv_wgrad / ctvae_conv_dgrad calls on the same inputs: same kernels' arithmetic, so bit-identical."""
+    ctvae_conv_wgrad / ctvae_conv_dgrad calls on the same inputs: the weight gradient runs the same arithmetic in the same
+    order (bit-identical); the data gradient may be split over fewer K slices when it shares the launch (summation order
+    of the slices differs: a few ulp)."""
     transposed, Ci, Co, H, k, s, p, op, B, bias = case
     g = torch.Generator().manual_seed(Ci * 7 + Co)
     spec = K.ConvSpec(K.CONVT if transposed else K.CONV, Ci, Co, k, s, p, op, K.ACT_NONE)
@@ -251,7 +253,8 @@ def test_paired_backward_matches_separate_launches(K, case):
             dx = K.conv_dgrad_raw(dy, wp, spec, (H, H))
         torch.cuda.synchronize()
         res.append((dx.clone(), wp.grad.clone(), bp.grad.clone() if bias else None))
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[0][1], res[1][1])
+    np.testing.assert_allclose(res[0][0].cpu().numpy(), res[1][0].cpu().numpy(), rtol=2e-5, atol=2e-5 * float(res[1][0].abs().max()))
     if bias:
         assert torch.equal(res[0][2], res[1][2])
 
