@@ -156,7 +156,9 @@ class VAEXperiment:
             n = 0
             for i, batch in enumerate(train_batches()):
                 real_img, _labels, kwargs = self._unpack(batch)
-                if self.params.get('hipgraph', True) and not kwargs and real_img.is_cuda:
+                # graph_safe = False: the model's step depends on host state that changes per call (e.g. BetaVAE type 'B':
+                # the capacity C follows the loss-call counter), so a captured step would freeze it
+                if self.params.get('hipgraph', True) and not kwargs and real_img.is_cuda and getattr(self.model, 'graph_safe', True):
                     key = (tuple(real_img.shape), real_img.dtype)
                     gs = self._graphed.get(key)
                     if gs is None:
