@@ -463,7 +463,10 @@ def test_every_registered_model_trains_through_the_harness(dev, name, cfg):
     m.eval()
     with torch.no_grad():
         assert m.generate(batches[0][0]).shape == (8, 3, 64, 64)
-        assert m.sample(4, dev).shape == (4, 3, 64, 64)
+        try:
+            assert m.sample(4, dev).shape == (4, 3, 64, 64)
+        except Warning:        # the reference's "sampler is not implemented" for the quantised models (vq_vae.py, mcq_vae.py)
+            assert name in ("VQVAE", "MCQVAE")
 
 
 def test_vqvae_vs_golden(dev, golden):
