@@ -627,6 +627,16 @@ class Reparameterize(Function):
         return g_mu, g_lv, None
 
 
+def _scalar_outputs(ctx, out):
+    """The 4-vector a loss kernel wrote, handed out as four 0-dim views.  Callers index the returned tuple, so no autograd
+    select node sits between the loss and this Function: indexing a tensor output (out[0]) made ``loss.backward()`` build
+    zeros[4] and copy the root gradient into it -- two launches per step for nothing.  Only the first carries gradient."""
+    o = out.unbind(0)
+    ctx.mark_non_differentiable(*o[1:])
+    ctx.set_materialize_grads(False)
+    return o
+
+
 class VAELoss(Function):
     """out = [loss, mse, kld, -kld]: mse = F.mse_loss(recons, x); kld as vanilla_vae.py:143; loss = mse + M_N*kld (+ extra).
     recons/x are same-layout contiguous tensors.  Only out[0] carries gradient."""
@@ -657,13 +667,15 @@ class VAELoss(Function):
         ctx.save_for_backward(recons, x, mu_, lv_)
         ctx.meta = (mrs, lrs, B, L, float(M_N), tuple(extra.shape) if extra is not None else None)
         ctx.logcosh_alpha = float(logcosh_alpha)
-        return out
+        return _scalar_outputs(ctx, out)
 
     @staticmethod
-    def backward(ctx, g_out):
+    def backward(ctx, g_loss, *_unused):
         recons, x, mu_, lv_ = ctx.saved_tensors
         mrs, lrs, B, L, M_N, has_extra = ctx.meta
-        g_loss = _c(g_out[0:1])                      # d/d loss; mse and kld outputs are reported detached
+        if g_loss is None:
+            return (None,) * 7
+        g_loss = _c(g_loss.reshape(1))               # d/d loss; mse and kld outputs are reported detached
         g_r = None
         if ctx.needs_input_grad[0]:
             g_r = torch.empty_like(recons)
@@ -757,13 +769,15 @@ class IWLoss(Function):
                     int(S), float(M_N), rows[0].data_ptr(), rows[1].data_ptr(), rows[2].data_ptr(), out.data_ptr())
         ctx.save_for_backward(recons, x, mu, logvar, rows)
         ctx.meta = (n, R, R // B, L, float(M_N))
-        return out
+        return _scalar_outputs(ctx, out)
 
     @staticmethod
-    def backward(ctx, g_out):
+    def backward(ctx, g_loss, *_unused):
         recons, x, mu, logvar, rows = ctx.saved_tensors
         n, R, rep, L, M_N = ctx.meta
-        g_loss = _c(g_out[0:1])
+        if g_loss is None:
+            return (None,) * 6
+        g_loss = _c(g_loss.reshape(1))
         g_r = torch.empty_like(recons) if ctx.needs_input_grad[0] else None
         g_mu = g_lv = None
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
@@ -792,12 +806,12 @@ class MMD(Function):
         native.call("ctvae_mmd_forward", z.data_ptr(), prior.data_ptr(), N, D, 0 if kind == "imq" else 1, float(c), 1e-7,
                     float(w_pp), float(w_zz), float(w_pz), out.data_ptr(), grad.data_ptr(), ws.data_ptr(), ws.numel() * 4)
         ctx.save_for_backward(grad)
-        return out
+        return _scalar_outputs(ctx, out)
 
     @staticmethod
-    def backward(ctx, g_out):
+    def backward(ctx, g_mmd, *_unused):
         (grad,) = ctx.saved_tensors
-        return grad * g_out[0], None, None, None, None, None, None
+        return (grad * g_mmd if g_mmd is not None else None), None, None, None, None, None, None
 
 
 class PairMLP(Function):

@@ -217,7 +217,7 @@ def test_mmd_kernel(K, N, D, kind):
     out = K.MMD.apply(zd, p.cuda(), kind, 2.0 * D * 2.0, *w)
     (out[0] * 1.0).backward()
     torch.cuda.synchronize()
-    for got, want in zip(out[1:].tolist(), (pp.item(), zz.item(), pz.item())):
+    for got, want in zip([o.item() for o in out[1:]], (pp.item(), zz.item(), pz.item())):
         assert abs(got - want) <= 2e-5 * max(1.0, abs(want)), (got, want)
     np.testing.assert_allclose(zd.grad.cpu().numpy(), z.grad.numpy(), atol=1e-7, rtol=2e-4)
 
