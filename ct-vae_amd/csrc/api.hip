@@ -68,6 +68,10 @@ int launch_iw_loss_backward(const float* recons, const float* x, long n, int R, 
                             hipStream_t st);
 int launch_mmd_forward(const float* z, const float* p, int N, int D, int kind, float c, float eps, float w_pp, float w_zz,
                        float w_pz, float* out4, float* grad, float* ws, size_t ws_bytes, hipStream_t st);
+size_t dip_state_floats(int B, int D);
+int launch_dip_forward(const float* mu, long mu_rs, const float* lv, long lv_rs, int B, int D, float l_diag, float l_off,
+                       float* state, hipStream_t st);
+int launch_dip_backward(const float* state, const float* go, float* g_mu, float* g_lv, int B, int D, hipStream_t st);
 int launch_loss_forward(const float* r, const float* x, long n, const float* mu, long mu_rs, const float* lv, long lv_rs,
                         int B, int L, float M_N, const float* extra, float* out3, float* ws, size_t ws_bytes, hipStream_t st,
                         float logcosh_alpha);
@@ -472,6 +476,19 @@ int ctvae_mmd_forward(const float* z, const float* prior, int N, int D, int kind
                       float w_pz, float* out4, float* grad_z, float* ws, size_t ws_bytes, void* stream) {
   if (!z || !prior || !out4 || !grad_z || !ws || N <= 0 || D <= 0 || (kind != 0 && kind != 1) || !(c > 0.f)) return kErrBadArg;
   return launch_mmd_forward(z, prior, N, D, kind, c, eps, w_pp, w_zz, w_pz, out4, grad_z, ws, ws_bytes, (hipStream_t)stream);
+}
+
+size_t ctvae_dip_state_floats(int B, int D) { return dip_state_floats(B, D); }
+
+int ctvae_dip_forward(const float* mu, long mu_rs, const float* logvar, long lv_rs, int B, int D, float lambda_diag,
+                      float lambda_offdiag, float* state, void* stream) {
+  if (!mu || !logvar || !state || B <= 0 || D <= 0) return kErrBadArg;
+  return launch_dip_forward(mu, mu_rs, logvar, lv_rs, B, D, lambda_diag, lambda_offdiag, state, (hipStream_t)stream);
+}
+
+int ctvae_dip_backward(const float* state, const float* g_dip, float* g_mu, float* g_logvar, int B, int D, void* stream) {
+  if (!state || !g_dip || !g_mu || !g_logvar || B <= 0 || D <= 0) return kErrBadArg;
+  return launch_dip_backward(state, g_dip, g_mu, g_logvar, B, D, (hipStream_t)stream);
 }
 
 int ctvae_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* state, long n,

@@ -814,6 +814,34 @@ class MMD(Function):
         return (grad * g_mmd if g_mmd is not None else None), None, None, None, None, None, None
 
 
+class DIPLoss(Function):
+    """DIP-VAE II regulariser of dip_vae.py:147-159 on mu / log_var [B,D] (csrc/dip.hip) -> 0-dim tensor."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, lambda_diag, lambda_offdiag):
+        _req_cuda(mu, logvar)
+        mu_, mrs = _rows(mu)
+        lv_, lrs = _rows(logvar)
+        B, D = mu.shape
+        n = native.load().ctvae_dip_state_floats(B, D)
+        state = torch.empty(n, dtype=torch.float32, device=mu.device)
+        native.call("ctvae_dip_forward", mu_.data_ptr(), mrs, lv_.data_ptr(), lrs, B, D, float(lambda_diag), float(lambda_offdiag),
+                    state.data_ptr())
+        ctx.save_for_backward(state)
+        ctx.dims = (B, D)
+        return state[B * D + D * D + 3 * D].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (state,) = ctx.saved_tensors
+        B, D = ctx.dims
+        g = _c(g.reshape(1))
+        g_mu = torch.empty((B, D), dtype=torch.float32, device=state.device)
+        g_lv = torch.empty((B, D), dtype=torch.float32, device=state.device)
+        native.call("ctvae_dip_backward", state.data_ptr(), g.data_ptr(), g_mu.data_ptr(), g_lv.data_ptr(), B, D)
+        return g_mu, g_lv, None, None
+
+
 class PairMLP(Function):
     """out[b,i,j] = sigmoid(b2 + sum_h w2[h] * leaky_relu(u[b,i,h] + v[b,j,h])): the all-pairs tail of
     ``CausalTransition.graph_discovers[k]`` (ct_mcq_vae.py:86-95,147-151) without the [B,N,N,H] intermediates.

@@ -10,6 +10,7 @@ from .cat_vae import CategoricalVAE
 from .iwae import IWAE, MIWAE
 from .logcosh_vae import LogCoshVAE
 from .wae_mmd import WAE_MMD, InfoVAE
+from .dip_vae import DIPVAE
 
 # Aliases (models/__init__.py:29-32)
 VAE = VanillaVAE
@@ -28,6 +29,7 @@ vae_models = {
     'LogCoshVAE': LogCoshVAE, # VanillaVAE's network, log-cosh reconstruction term (logcosh_vae.py)
     'WAE_MMD': WAE_MMD,       # VanillaVAE's stacks, one deterministic head, mse + MMD (wae_mmd.py)
     'InfoVAE': InfoVAE,       # VanillaVAE's network, beta*mse + (1-alpha)*KL + MMD (info_vae.py)
+    'DIPVAE': DIPVAE,         # VanillaVAE's network, sum-reduced objective + DIP-II covariance regulariser (dip_vae.py)
     'CategoricalVAE': CategoricalVAE,   # VanillaVAE's stacks around a Gumbel-softmax categorical latent (cat_vae.py)
 }
 

@@ -54,6 +54,8 @@ SIGNATURES = {
     "ctvae_iw_loss_forward": [_fp, _fp, _l, _i, _i, _fp, _fp, _i, _i, _f, _fp, _fp, _fp, _fp, _vp],
     "ctvae_iw_loss_backward": [_fp, _fp, _l, _i, _i, _fp, _fp, _i, _f, _fp, _fp, _fp, _fp, _fp, _vp],
     "ctvae_mmd_forward": [_fp, _fp, _i, _i, _i, _f, _f, _f, _f, _f, _fp, _fp, _fp, _sz, _vp],
+    "ctvae_dip_forward": [_fp, _l, _fp, _l, _i, _i, _f, _f, _fp, _vp],
+    "ctvae_dip_backward": [_fp, _fp, _fp, _fp, _i, _i, _vp],
     "ctvae_adam_step": [_fp, _fp, _fp, _fp, _fp, _l, _f, _vp],
 }
 _RESTYPES = {
@@ -68,6 +70,7 @@ _RESTYPES = {
     "ctvae_conv_backward_bn_rows": _c.c_int,
     "ctvae_winograd_enable": _c.c_int,
     "ctvae_conv_wino_filter_floats": _c.c_size_t,
+    "ctvae_dip_state_floats": _c.c_size_t,
     "ctvae_conv_input_transform_supported": _c.c_int,
     "ctvae_conv_wgrad_bn_apply_supported": _c.c_int,
 }
@@ -106,6 +109,7 @@ def load():
                        "ctvae_conv_dgrad_bn_rows": [_c.c_int] * 10 + [_c.c_size_t],
                        "ctvae_conv_backward_bn_rows": [_c.c_int] * 10 + [_c.c_size_t],
                        "ctvae_winograd_enable": [_c.c_int],
+                       "ctvae_dip_state_floats": [_c.c_int, _c.c_int],
                        "ctvae_conv_wino_filter_floats": [_c.c_int] * 10 + [_c.c_size_t],
                        "ctvae_conv_input_transform_supported": [_c.c_int] * 10,
                        "ctvae_conv_wgrad_bn_apply_supported": [_c.c_int] * 10}.get(name, [])

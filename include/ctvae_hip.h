@@ -248,6 +248,16 @@ int ctvae_iw_loss_backward(const float* recons, const float* x, long n, int R, i
 int ctvae_mmd_forward(const float* z, const float* prior, int N, int D, int kind, float c, float eps, float w_pp, float w_zz,
                       float w_pz, float* out4, float* grad_z, float* ws, size_t ws_bytes, void* stream);
 
+/* DIP-VAE II regulariser (dip_vae.py:147-159) on the posterior parameters mu / logvar [B][D] (row strides in floats, D <= 1024):
+ * c = mu - mean over the latent dimension, cov = c^T c, v = mean of the main diagonal of exp(2*logvar) (one scalar, as the
+ * reference computes it), cz = cov + v, dip = lambda_offdiag * sum_{i != j} cz_ij^2 + lambda_diag * sum_i (cz_ii - 1)^2.
+ * state: ctvae_dip_state_floats(B, D) floats kept by the caller between the two calls; dip = state[B*D + D*D + 3*D].
+ * Backward writes dense g_mu / g_logvar [B][D] scaled by g_dip[0]. */
+size_t ctvae_dip_state_floats(int B, int D);
+int ctvae_dip_forward(const float* mu, long mu_row_stride, const float* logvar, long lv_row_stride, int B, int D,
+                      float lambda_diag, float lambda_offdiag, float* state, void* stream);
+int ctvae_dip_backward(const float* state, const float* g_dip, float* g_mu, float* g_logvar, int B, int D, void* stream);
+
 /* torch.optim.Adam step over one flat buffer (experiment.py:158-160).  state (device, 8 floats):
  * {step, lr, beta1, beta2, eps, weight_decay, beta1^step, beta2^step}; the call advances step. */
 int ctvae_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* state, long n,

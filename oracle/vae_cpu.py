@@ -131,6 +131,19 @@ def infovae_loss(recons, x, z, mu, log_var, prior_z, M_N, alpha, beta, reg_weigh
     return {"loss": loss, "Reconstruction_Loss": rl, "MMD": mmd, "KLD": -kld}
 
 
+def dip_loss(recons, x, mu, log_var, M_N, lambda_diag, lambda_offdiag):
+    """DIPVAE.loss_function (dip_vae.py:136-165), quirks included (centring over dim 1, scalar variance term)."""
+    recons_loss = F.mse_loss(recons, x, reduction='sum')
+    kld = torch.sum(-0.5 * torch.sum(1 + log_var - mu ** 2 - log_var.exp(), dim=1), dim=0)
+    centered = mu - mu.mean(dim=1, keepdim=True)
+    cov_mu = centered.t().matmul(centered).squeeze()
+    cov_z = cov_mu + torch.mean(torch.diagonal((2. * log_var).exp(), dim1=0), dim=0)
+    cov_diag = torch.diag(cov_z)
+    cov_off = cov_z - torch.diag(cov_diag)
+    dip = lambda_offdiag * torch.sum(cov_off ** 2) + lambda_diag * torch.sum((cov_diag - 1) ** 2)
+    return {"loss": recons_loss + M_N * kld + dip, "Reconstruction_Loss": recons_loss, "KLD": -kld, "DIP_Loss": dip}
+
+
 def logcosh_loss(recons, x, mu, log_var, M_N, alpha, beta):
     """LogCoshVAE.loss_function (logcosh_vae.py:135-155), written as the reference writes it."""
     t = recons - x

@@ -437,6 +437,7 @@ ZOO = [("VanillaVAE", dict(in_channels=3, latent_dim=128)),
        ("MIWAE", dict(in_channels=3, latent_dim=128, num_samples=5, num_estimates=3)),
        ("WAE_MMD", dict(in_channels=3, latent_dim=128, reg_weight=100, kernel_type="imq")),
        ("InfoVAE", dict(in_channels=3, latent_dim=128, reg_weight=110, kernel_type="imq", alpha=-9.0, beta=10.5)),
+       ("DIPVAE", dict(in_channels=3, latent_dim=128, lambda_diag=0.05, lambda_offdiag=0.1)),
        ("CategoricalVAE", dict(in_channels=3, latent_dim=64, categorical_dim=40, temperature=0.5, alpha=1.0)),
        ("VQVAE", dict(in_channels=3, embedding_dim=64, num_embeddings=512, img_size=64, beta=0.25)),
        ("MCQVAE", dict(in_channels=3, embedding_dim=128, hidden_dims=[64, 128, 256], num_embeddings=64, img_size=64, codebooks=4, beta=0.25))]
@@ -467,6 +468,30 @@ def test_every_registered_model_trains_through_the_harness(dev, name, cfg):
             assert m.sample(4, dev).shape == (4, 3, 64, 64)
         except Warning:        # the reference's "sampler is not implemented" for the quantised models (vq_vae.py, mcq_vae.py)
             assert name in ("VQVAE", "MCQVAE")
+
+
+def test_dip_vae_vs_golden(dev, golden):
+    """DIPVAE against the reference's own dip_vae.py fixture: loss dict (sums + DIP term) and every parameter gradient."""
+    from ctvae_amd.models import vae_models
+    g = golden("dip_b4")
+    seed = int(g["seed"])
+    m = vae_models["DIPVAE"](in_channels=3, latent_dim=128, lambda_diag=0.05, lambda_offdiag=0.1)
+    m.load_state_dict(filler.fill_state(H.vanilla_specs(), seed + 1))
+    m = m.to(dev).train()
+    x, eps = filler.synthetic_batch(seed, 4)
+    out = m(x.to(dev), eps=eps.to(dev))
+    np.testing.assert_allclose(out[2].detach().cpu().numpy(), g["mu"], atol=TOL, rtol=0)
+    losses = m.loss_function(*out, M_N=float(g["M_N"]))
+    losses["loss"].backward()
+    for k, v in losses.items():
+        want = float(g["loss." + k])
+        assert abs(float(v.detach()) - want) <= TOL * max(1.0, abs(want)), (k, float(v.detach()), want)
+    for k in ("fc_mu.bias", "fc_var.bias"):
+        np.testing.assert_allclose(getattr(m, k.split(".")[0]).bias.grad.cpu().numpy(), g["grad." + k], atol=2e-3, rtol=2e-3)
+    for k, p in m.named_parameters():
+        if k.endswith(".0.bias") and not k.startswith("final_layer.3"):
+            continue    # bias of a conv in front of a BatchNorm: analytically zero gradient, rounding noise x the sum-reduced loss scale
+        H.assert_cks_close(H.cks(p.grad), g["gradcks." + k], rtol=2e-3, atol=2e-3, what=k)
 
 
 def test_vqvae_vs_golden(dev, golden):

@@ -259,6 +259,28 @@ def test_paired_backward_matches_separate_launches(K, case):
         assert torch.equal(res[0][2], res[1][2])
 
 
+@pytest.mark.parametrize("B,D", [(4, 128), (256, 128), (7, 20), (300, 40), (3, 300)])
+def test_dip_regulariser(K, B, D):
+    """csrc/dip.hip against the torch expression of dip_vae.py:147-159 (B < D and B > D: the scalar variance term takes the
+    main diagonal of the [B,D] matrix), value and both gradients."""
+    g = torch.Generator().manual_seed(B * 31 + D)
+    mu = torch.randn(B, D, generator=g).requires_grad_(True)
+    lv = (0.3 * torch.randn(B, D, generator=g)).requires_grad_(True)
+    centered = mu - mu.mean(dim=1, keepdim=True)
+    cov_z = centered.t().matmul(centered) + torch.mean(torch.diagonal((2. * lv).exp(), dim1=0), dim=0)
+    cd = torch.diag(cov_z)
+    want = 0.1 * torch.sum((cov_z - torch.diag(cd)) ** 2) + 0.05 * torch.sum((cd - 1) ** 2)
+    (want * 0.5).backward()
+    md, ld = (t.detach().cuda().requires_grad_(True) for t in (mu, lv))
+    got = K.DIPLoss.apply(md, ld, 0.05, 0.1)
+    (got * 0.5).backward()
+    torch.cuda.synchronize()
+    assert abs(got.item() - want.item()) <= 2e-5 * max(1.0, abs(want.item()))
+    sc = float(mu.grad.abs().max())
+    np.testing.assert_allclose(md.grad.cpu().numpy(), mu.grad.numpy(), atol=2e-5 * sc, rtol=2e-4)
+    np.testing.assert_allclose(ld.grad.cpu().numpy(), lv.grad.numpy(), atol=2e-5 * max(1e-6, float(lv.grad.abs().max())), rtol=2e-4)
+
+
 def test_permute_roundtrip(K):
     x = torch.randn(3, 5, 6, 7)
     xd = x.cuda()

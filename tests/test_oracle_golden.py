@@ -220,6 +220,26 @@ def test_mmd_models_forward_loss_grads(golden, tag):
             H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
 
 
+def test_dip_vae_loss_grads(golden):
+    """DIPVAE (VanillaVAE's network, sum-reduced objective + DIP-II regulariser): oracle against the reference's dip_vae.py fixture."""
+    g = golden("dip_b4")
+    seed = int(g["seed"])
+    sd = O.leafify(filler.fill_state(H.vanilla_specs(), seed + 1))
+    x, eps = filler.synthetic_batch(seed, 4)
+    recons, inp, mu, log_var = O.vanilla_forward(sd, x, eps, True, {})
+    np.testing.assert_allclose(mu.detach().numpy(), g["mu"], atol=TOL, rtol=0)
+    l = O.dip_loss(recons, inp, mu, log_var, float(g["M_N"]), 0.05, 0.1)
+    for k, v in l.items():
+        want = float(g["loss." + k])
+        assert abs(v.item() - want) <= TOL * max(1.0, abs(want)), k
+    l["loss"].backward()
+    for k in ("fc_mu.bias", "fc_var.bias"):
+        np.testing.assert_allclose(sd[k].grad.numpy(), g["grad." + k], atol=1e-3, rtol=1e-3)
+    for k, v in sd.items():
+        if v.requires_grad and not (k.endswith(".0.bias") and not k.startswith("final_layer.3")):   # see the GPU twin of this test
+            H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-3, what=k)
+
+
 def test_vqvae_forward_loss_grads(golden):
     """VQVAE = MCQ-VAE's stacks around ONE codebook: oracle (single-codebook path of the MCQ restatement) against the
     reference's own vq_vae.py fixture."""
