@@ -229,6 +229,10 @@ def test_mmd_kernel(K, N, D, kind):
     (False, 2048, 256, 1, 1, 1, 0, 0, 64, True),     # fc heads
     (False, 256, 256, 8, 1, 1, 0, 0, 8, False),      # 1x1 conv of a residual block
     (False, 32, 3, 32, 3, 1, 1, 0, 2, True),         # picture-side layer: neither side pairs, same entry point
+    (False, 96, 160, 5, 3, 1, 1, 0, 3, True),        # ragged tiles on every side: M = 75, N = 96 / 160, K = 864
+    (True, 160, 96, 3, 4, 2, 1, 0, 5, False),        # k4 s2 transposed conv, channels not multiples of 64
+    (False, 64, 64, 6, 3, 2, 1, 0, 1, True),         # B = 1: 3 x 3 output, one partial tile per class (odd sizes are refused by the stride-2 data-gradient geometry)
+    (False, 128, 32, 9, 1, 1, 0, 0, 7, True),        # N = 32 on the weight-gradient side (128 x 32 tiles: only the data gradient records)
 ])
 def test_paired_backward_matches_separate_launches(K, case):
     """ctvae_conv_backward (data + weight gradient in one launch, shared finishing launch) against the separate
