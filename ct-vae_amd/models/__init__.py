@@ -11,6 +11,7 @@ from .iwae import IWAE, MIWAE
 from .logcosh_vae import LogCoshVAE
 from .wae_mmd import WAE_MMD, InfoVAE
 from .dip_vae import DIPVAE
+from .joint_vae import JointVAE
 
 # Aliases (models/__init__.py:29-32)
 VAE = VanillaVAE
@@ -30,6 +31,7 @@ vae_models = {
     'WAE_MMD': WAE_MMD,       # VanillaVAE's stacks, one deterministic head, mse + MMD (wae_mmd.py)
     'InfoVAE': InfoVAE,       # VanillaVAE's network, beta*mse + (1-alpha)*KL + MMD (info_vae.py)
     'DIPVAE': DIPVAE,         # VanillaVAE's network, sum-reduced objective + DIP-II covariance regulariser (dip_vae.py)
+    'JointVAE': JointVAE,     # VanillaVAE's stacks, Gaussian + one categorical latent, capacity objective (joint_vae.py)
     'CategoricalVAE': CategoricalVAE,   # VanillaVAE's stacks around a Gumbel-softmax categorical latent (cat_vae.py)
 }
 

@@ -75,16 +75,23 @@ class PackedLinearGroup:
 
 
 class PackedLinear(nn.Module):
-    def __init__(self, fin, fout):
+    """``in_padded``: rows of the weight block in the flat buffer (>= in_features).  The tile kernels gather whole 32-wide
+    K chunks, so a layer whose in_features is not a multiple of 32 (JointVAE.decoder_input: 128 + 40) reserves the rows up
+    to the next multiple: they hold zeros, the caller pads the activation with zeros, their gradient is zero, Adam leaves
+    them zero; the parameter itself keeps its logical [out, in] shape as a view of the first rows."""
+
+    def __init__(self, fin, fout, pad_in_to=1):
         super().__init__()
         self.in_features, self.out_features = fin, fout
+        self.in_padded = (fin + pad_in_to - 1) // pad_in_to * pad_in_to
         self.weight = nn.Parameter(torch.empty(fin, fout).t())      # logical [out,in], memory [in][out]
         self.bias = nn.Parameter(torch.empty(fout))
         _uniform_(self.weight, 1.0 / math.sqrt(fin))
         _uniform_(self.bias, 1.0 / math.sqrt(fin))
 
     def storage_blocks(self):
-        return PackedLinearGroup([self]).storage_blocks()
+        w, b = PackedLinearGroup([self]).storage_blocks()
+        return [(self.in_padded * self.out_features, w[1]), b]
 
 
 class PackedBN(nn.Module):

@@ -131,6 +131,36 @@ def infovae_loss(recons, x, z, mu, log_var, prior_z, M_N, alpha, beta, reg_weigh
     return {"loss": loss, "Reconstruction_Loss": rl, "MMD": mmd, "KLD": -kld}
 
 
+def joint_forward(sd, x, e, u, temp, training=True, new_buffers=None, eps=1e-7):
+    """JointVAE.forward (joint_vae.py:110-170) with both noises injected -> [recons, input, q, mu, log_var]."""
+    h = x
+    for i in range(5):
+        h = F.conv2d(h, sd[f"encoder.{i}.0.weight"], sd[f"encoder.{i}.0.bias"], stride=2, padding=1)
+        h = _bn_lrelu(sd, f"encoder.{i}.1", h, training, new_buffers)
+    flat = torch.flatten(h, start_dim=1)
+    mu = F.linear(flat, sd["fc_mu.weight"], sd["fc_mu.bias"])
+    log_var = F.linear(flat, sd["fc_var.weight"], sd["fc_var.bias"])
+    q = F.linear(flat, sd["fc_z.weight"], sd["fc_z.bias"])
+    z = e * torch.exp(0.5 * log_var) + mu
+    g = -torch.log(-torch.log(u + eps) + eps)
+    s = F.softmax((q + g) / temp, dim=-1)
+    return [vanilla_decode(sd, torch.cat([z, s], dim=1), training, new_buffers), x, q, mu, log_var]
+
+
+def joint_loss(recons, x, q, mu, log_var, M_N, num_iter, alpha, cont=(0.0, 25.0, 30.0, 25000), disc=(0.0, 25.0, 30.0, 25000), eps=1e-7):
+    """joint_vae.py:172-237; cont / disc = (min capacity, max capacity, gamma, iterations); num_iter = counter value used."""
+    import math
+    Q = q.shape[-1]
+    q_p = F.softmax(q, dim=-1)
+    rl = F.mse_loss(recons, x)
+    disc_curr = min((disc[1] - disc[0]) * num_iter / float(disc[3]) + disc[0], math.log(Q))
+    kld_disc = torch.mean(torch.sum(q_p * torch.log(q_p + eps) - q_p * math.log(1. / Q + eps), dim=1), dim=0)
+    cont_curr = min((cont[1] - cont[0]) * num_iter / float(cont[3]) + cont[0], cont[1])
+    kld_cont = torch.mean(-0.5 * torch.sum(1 + log_var - mu ** 2 - log_var.exp(), dim=1), dim=0)
+    cap = disc[2] * torch.abs(disc_curr - kld_disc) + cont[2] * torch.abs(cont_curr - kld_cont)
+    return {"loss": alpha * rl + M_N * cap, "Reconstruction_Loss": rl, "Capacity_Loss": cap}
+
+
 def dip_loss(recons, x, mu, log_var, M_N, lambda_diag, lambda_offdiag):
     """DIPVAE.loss_function (dip_vae.py:136-165), quirks included (centring over dim 1, scalar variance term)."""
     recons_loss = F.mse_loss(recons, x, reduction='sum')

@@ -127,6 +127,27 @@ MMD_CASES = {"wae_imq": ("WAE_MMD", dict(in_channels=3, latent_dim=128, reg_weig
              "infovae": ("InfoVAE", dict(in_channels=3, latent_dim=128, reg_weight=110, kernel_type='imq', alpha=-9.0, beta=10.5))}
 
 
+JOINT_CFG = dict(in_channels=3, latent_dim=128, categorical_dim=40, latent_min_capacity=0.0, latent_max_capacity=20.0,
+                 latent_gamma=10., latent_num_iter=25000, categorical_min_capacity=0.0, categorical_max_capacity=20.0,
+                 categorical_gamma=10., categorical_num_iter=25000, temperature=0.5, anneal_rate=0.00003, anneal_interval=100,
+                 alpha=10.0)
+
+
+def joint_specs():
+    """state_dict keys/shapes of JointVAE(**JOINT_CFG): VanillaVAE's plus the head fc_z, decoder_input widened by categorical_dim."""
+    out = []
+    for k, sh, dt in vanilla_specs():
+        if k == "decoder_input.weight":
+            out.extend([("fc_z.weight", (40, 2048), dt), ("fc_z.bias", (40,), dt)])
+            sh = (2048, 128 + 40)
+        out.append((k, sh, dt))
+    return out
+
+
+def joint_uniform(seed, B, Q=40):
+    return torch.rand(B, Q, generator=torch.Generator().manual_seed(seed + 2))
+
+
 def cks(t):
     t = t.detach().double().cpu()
     return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()], dtype=np.float64)

@@ -240,6 +240,31 @@ def test_dip_vae_loss_grads(golden):
             H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-3, what=k)
 
 
+def test_joint_vae_forward_loss_grads(golden):
+    """JointVAE (Gaussian + one categorical latent, capacity objective): oracle against the reference's joint_vae.py fixture
+    (two consecutive loss calls: the capacities follow the call counter)."""
+    g = golden("joint_b4")
+    seed = int(g["seed"])
+    sd = O.leafify(filler.fill_state(H.joint_specs(), seed + 1))
+    x, e = filler.synthetic_batch(seed, 4)
+    res = O.joint_forward(sd, x, e, H.joint_uniform(seed, 4), 0.5, True, {})
+    np.testing.assert_allclose(res[2].detach().numpy(), g["q"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(res[3].detach().numpy(), g["mu"], atol=TOL, rtol=0)
+    caps = dict(cont=(0.0, 20.0, 10.0, 25000), disc=(0.0, 20.0, 10.0, 25000))
+    l1 = O.joint_loss(*res, float(g["M_N"]), 1, 10.0, **caps)
+    l2 = O.joint_loss(*res, float(g["M_N"]), 2, 10.0, **caps)
+    for call, l in (("call1", l1), ("call2", l2)):
+        for k, v in l.items():
+            want = float(g[f"{call}.{k}"])
+            assert abs(v.item() - want) <= TOL * max(1.0, abs(want)), (call, k)
+    l1["loss"].backward()
+    for k in ("fc_z.bias", "fc_var.bias"):
+        np.testing.assert_allclose(sd[k].grad.numpy(), g["grad." + k], atol=1e-6, rtol=1e-3)
+    for k, v in sd.items():
+        if v.requires_grad:
+            H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
+
+
 def test_vqvae_forward_loss_grads(golden):
     """VQVAE = MCQ-VAE's stacks around ONE codebook: oracle (single-codebook path of the MCQ restatement) against the
     reference's own vq_vae.py fixture."""
