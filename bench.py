@@ -152,6 +152,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from ctvae_amd import filler, native
+    from ctvae_amd import kernels as kernels_mod
     from ctvae_amd.ddp import GradBucketAllReduce
     from ctvae_amd.optim import FlatAdam
     native.load()
@@ -174,7 +175,7 @@ def main():
         model.zero_grad()
         out = model(static_x, **ct_kw) if ct_kw is not None else model(static_x)
         losses = model.loss_function(*out, M_N=kld_w)
-        losses["loss"].backward()
+        kernels_mod.backward(losses["loss"])       # loss.backward() with a cached root gradient (as the harness does)
         return losses["loss"].detach()
 
     def local_step():

@@ -13,6 +13,7 @@ import time
 
 import torch
 
+from . import kernels as K
 from .ddp import GradBucketAllReduce
 from .optim import ExponentialLR, FlatAdam
 
@@ -38,7 +39,7 @@ class _GraphedTrainStep:
         exp.model.zero_grad()
         results = exp.forward(self.x, labels=None)
         losses = exp.model.loss_function(*results, M_N=exp.params['kld_weight'], optimizer_idx=0, batch_idx=0)
-        losses['loss'].backward()
+        K.backward(losses['loss'])
         if exp.ddp is None:
             exp.optimizer.step()
         return losses
@@ -171,7 +172,7 @@ class VAEXperiment:
                 else:
                     self.model.zero_grad()
                     loss = self.training_step(batch, i)
-                    loss.backward()
+                    K.backward(loss)
                     self.optimizer_step()
                 n += batch[0].size(0)
             if self.scheduler is not None:

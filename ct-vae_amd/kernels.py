@@ -842,6 +842,19 @@ class DIPLoss(Function):
         return g_mu, g_lv, None, None
 
 
+_ones = {}
+
+
+def backward(loss):
+    """``loss.backward()`` with the root gradient taken from a cached ones tensor: autograd otherwise fills a fresh
+    ``ones_like(loss)`` on every call (one launch per step; the harness and bench.py call this)."""
+    key = (loss.device, loss.dtype, tuple(loss.shape))
+    one = _ones.get(key)
+    if one is None:
+        one = _ones[key] = torch.ones_like(loss)
+    loss.backward(gradient=one)
+
+
 class PairMLP(Function):
     """out[b,i,j] = sigmoid(b2 + sum_h w2[h] * leaky_relu(u[b,i,h] + v[b,j,h])): the all-pairs tail of
     ``CausalTransition.graph_discovers[k]`` (ct_mcq_vae.py:86-95,147-151) without the [B,N,N,H] intermediates.
