@@ -620,7 +620,7 @@ int tapgemm_bnb_rows(const ConvGeom& g, size_t ws_floats) {
 
 bool wino_supported(const ConvGeom& g, size_t ws_floats);
 int launch_wino_conv(const ConvGeom& g, const float* X, const float* Wp, const float* bias, float* Y, int act, float* ws,
-                     size_t ws_floats, hipStream_t st, const float* filters_ready, float* bwd_out);
+                     size_t ws_floats, hipStream_t st, const float* filters_ready, float* bwd_out, const float* add);
 
 bool wino_enabled();
 
@@ -628,10 +628,11 @@ int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const floa
                    const float* mask, int mask_act, float* S, int act, float* bn_part, float* ws, size_t ws_floats,
                    hipStream_t st, const BnBwdFuse* bnb, const InXform* xf, const WinoFilters* wf) {
   // 3x3 / stride 1 / same-padding layers with plain epilogues: Winograd F(2x2,3x3), see wino.hip
-  if (add == nullptr && mask == nullptr && bn_part == nullptr && (bnb == nullptr || bnb->part == nullptr) &&
+  // (the skip operand `add` is taken by the Winograd epilogue; a mask is not)
+  if (mask == nullptr && bn_part == nullptr && (bnb == nullptr || bnb->part == nullptr) &&
       (xf == nullptr || xf->scale == nullptr) && ws != nullptr && wino_enabled() && wino_supported(g, ws_floats))
     return launch_wino_conv(g, G, W, bias, S, act, ws, ws_floats, st, wf != nullptr ? wf->ready : nullptr,
-                            wf != nullptr ? wf->bwd_out : nullptr);
+                            wf != nullptr ? wf->bwd_out : nullptr, add);
   // data gradient of the 3x3 image-side conv (3 gathered channels): dedicated kernel, see image.hip
   if (img_dgrad_supported(g) && bias == nullptr && add == nullptr && mask == nullptr && act == ACT_NONE && bn_part == nullptr &&
       (xf == nullptr || xf->scale == nullptr))

@@ -71,6 +71,7 @@ struct WinoArgs {
   const float* X;      // [B][H][W][K]
   const float* Ut;     // [16][K/8][N][8]
   const float* bias;   // [N] or null
+  const float* add;    // [B][H][W][N] or null: added before the activation (residual skip / its gradient)
   float* Y;            // [B][H][W][N]
   int B, H, W, K, N;
   int bh, bw, nb;      // workgroup block: nb images x (bh x bw) tiles, nb*bh*bw == 64
@@ -437,10 +438,15 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
     const float y10 = t1[0] + t1[1] + t1[2], y11 = t1[1] - t1[2] - t1[3];
     if (op >= 0) {
       float* dst = a.Y + (long)op * N + col;
-      dst[0] = act_fwd(y00 + bv, a.act);
-      dst[N] = act_fwd(y01 + bv, a.act);
-      dst[(long)a.W * N] = act_fwd(y10 + bv, a.act);
-      dst[(long)a.W * N + N] = act_fwd(y11 + bv, a.act);
+      float s00 = bv, s01 = bv, s10 = bv, s11 = bv;
+      if (a.add != nullptr) {
+        const float* ad = a.add + (long)op * N + col;
+        s00 += ad[0]; s01 += ad[N]; s10 += ad[(long)a.W * N]; s11 += ad[(long)a.W * N + N];
+      }
+      dst[0] = act_fwd(y00 + s00, a.act);
+      dst[N] = act_fwd(y01 + s01, a.act);
+      dst[(long)a.W * N] = act_fwd(y10 + s10, a.act);
+      dst[(long)a.W * N + N] = act_fwd(y11 + s11, a.act);
     }
   }
 }
@@ -688,10 +694,15 @@ __global__ __launch_bounds__(256) void wino_conv_fs_kernel(WinoArgs a) {
     const int op = sOut[row];
     if (op >= 0) {
       float* dst = a.Y + (long)op * N + col;
-      dst[0] = act_fwd(y[0] + bv, a.act);
-      dst[N] = act_fwd(y[1] + bv, a.act);
-      dst[(long)a.W * N] = act_fwd(y[2] + bv, a.act);
-      dst[(long)a.W * N + N] = act_fwd(y[3] + bv, a.act);
+      float s4[4] = {bv, bv, bv, bv};
+      if (a.add != nullptr) {
+        const float* ad = a.add + (long)op * N + col;
+        s4[0] += ad[0]; s4[1] += ad[N]; s4[2] += ad[(long)a.W * N]; s4[3] += ad[(long)a.W * N + N];
+      }
+      dst[0] = act_fwd(y[0] + s4[0], a.act);
+      dst[N] = act_fwd(y[1] + s4[1], a.act);
+      dst[(long)a.W * N] = act_fwd(y[2] + s4[2], a.act);
+      dst[(long)a.W * N + N] = act_fwd(y[3] + s4[3], a.act);
     }
   }
 }
@@ -1121,7 +1132,7 @@ bool wino_supported(const ConvGeom& g, size_t ws_floats) {
 // filters_ready: this launch's transformed filters (what an earlier forward launch left in its bwd_out) -> no transform.
 // bwd_out (forward launches only): also write the data gradient's filter set there, in the same transform launch.
 int launch_wino_conv(const ConvGeom& g, const float* X, const float* Wp, const float* bias, float* Y, int act, float* ws,
-                     size_t ws_floats, hipStream_t st, const float* filters_ready, float* bwd_out) {
+                     size_t ws_floats, hipStream_t st, const float* filters_ready, float* bwd_out, const float* add) {
   WTaps wt;
   int bh, bw, nb;
   if (!wino_supported(g, ws_floats) || !wino_taps(g, wt) || !wino_block(g, bh, bw, nb)) return kErrBadArg;
@@ -1149,7 +1160,7 @@ int launch_wino_conv(const ConvGeom& g, const float* X, const float* Wp, const f
     CTVAE_LAUNCH_CHECK();
   }
   WinoArgs a{};
-  a.X = X; a.Ut = Ut; a.bias = bias; a.Y = Y;
+  a.X = X; a.Ut = Ut; a.bias = bias; a.add = add; a.Y = Y;
   a.B = g.B; a.H = g.gH; a.W = g.gW; a.K = K; a.N = N;
   a.bh = bh; a.bw = bw; a.nb = nb;
   a.by_n = (g.gH / 2) / bh; a.bx_n = (g.gW / 2) / bw;

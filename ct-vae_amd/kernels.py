@@ -404,6 +404,48 @@ class ConvAct(Function):
         return g_x, None, None, g_add, None
 
 
+class ResBlock(Function):
+    """out = post_act(x + Conv1x1(ReLU(Conv3x3(x)))), both convs bias-free: ResidualLayer (vq_vae.py:57-70) as ONE autograd
+    node.  As two ConvAct nodes the input x has two consumers (the 3x3 conv and the skip), and autograd adds their
+    gradients with a launch of its own per block; here the skip gradient enters the 3x3 conv's data gradient as the
+    ``add`` operand of its epilogue (direct and Winograd kernels alike), and the ReLU derivative is the ``mask`` operand of
+    the 1x1 conv's data gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w3, w1, spec3, spec1):
+        _req_cuda(x, w3, w1)
+        x = _c(x)
+        ctx.wino_u = None
+        if ctx.needs_input_grad[0]:
+            n = wino_filter_floats(spec3, x.shape[0], x.shape[1], x.shape[2], native.workspace(x.device).numel())
+            if n:
+                ctx.wino_u = torch.empty(n, dtype=torch.float32, device=x.device)
+        h = conv_forward_raw(x, w3, None, spec3, wino_out=ctx.wino_u)
+        out = conv_forward_raw(h, w1, None, spec1, x)
+        ctx.specs = (spec3, spec1)
+        ctx.w = (w3, w1)
+        ctx.save_for_backward(x, h, out if spec1.act != ACT_NONE else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        spec3, spec1 = ctx.specs
+        w3, w1 = ctx.w
+        x, h, out = ctx.saved_tensors
+        g_out = _c(g_out)
+        g_pre = act_backward_raw(g_out, out, spec1.act) if spec1.act != ACT_NONE else g_out
+        if _PAIR:
+            g_h = conv_backward_raw(h, g_pre, w1, None, spec1, mask=h, mask_act=spec3.act)
+        else:
+            conv_wgrad_raw(h, g_pre, w1, None, spec1)
+            g_h = conv_dgrad_raw(g_pre, w1, spec1, (h.shape[1], h.shape[2]), mask=h, mask_act=spec3.act)
+        conv_wgrad_raw(x, g_h, w3, None, spec3)
+        g_x = None
+        if ctx.needs_input_grad[0]:
+            g_x = conv_dgrad_raw(g_h, w3, spec3, (x.shape[1], x.shape[2]), add=g_pre, wino_filters=ctx.wino_u)
+        return g_x, None, None, None, None
+
+
 class ConvBNAct(Function):
     """a = act(BatchNorm2d(conv(x, w) + b)) with train-mode batch statistics (vanilla_vae.py:25-35,47-75)."""
 

@@ -68,11 +68,7 @@ class ResidualLayer(nn.Module):
         self.spec1 = K.ConvSpec(K.CONV, c, c, 1, 1, 0, 0, post_act)
 
     def forward(self, x):
-        h = K.ConvAct.apply(x, self.resblock._modules["0"].weight, None, None, self.spec3)
-        link = K.pop_act_link()
-        if link is not None:
-            h._ctvae_act_link = link      # h is local: the 1x1 conv below is its only consumer (kernels.ActLink)
-        return K.ConvAct.apply(h, self.resblock._modules["2"].weight, None, x, self.spec1)
+        return K.ResBlock.apply(x, self.resblock._modules["0"].weight, self.resblock._modules["2"].weight, self.spec3, self.spec1)
 
 
 class LeakyReLU(nn.Module):
