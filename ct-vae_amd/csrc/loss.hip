@@ -92,12 +92,11 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
 
 // g_r = go * term'(r - x) * scale      (MSE: 2 (r - x) / n;  log-cosh: tanh(alpha (r - x)) / n)
 template <int MODE>
-__global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ r, const float* __restrict__ x,
-                                                      const float* __restrict__ go, float* __restrict__ gr, long n4, long n,
-                                                      float scale, float alpha) {
+__device__ __forceinline__ void mse_bwd_body(const float* __restrict__ r, const float* __restrict__ x, const float* __restrict__ go,
+                                             float* __restrict__ gr, long n4, long n, float scale, float alpha, int blk, int nblk) {
   const float sc = go[0] * scale;
-  const long stride = (long)gridDim.x * 256;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+  const long stride = (long)nblk * 256;
+  for (long i = (long)blk * 256 + threadIdx.x; i < n4; i += stride) {
     f32x4 a = reinterpret_cast<const f32x4*>(r)[i];
     f32x4 b = reinterpret_cast<const f32x4*>(x)[i];
     f32x4 o;
@@ -105,20 +104,44 @@ __global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ 
     for (int k = 0; k < 4; ++k) o[k] = sc * recon_term_grad<MODE>(a[k] - b[k], alpha);
     reinterpret_cast<f32x4*>(gr)[i] = o;
   }
-  if (blockIdx.x == 0)
+  if (blk == 0)
     for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) gr[i] = sc * recon_term_grad<MODE>(r[i] - x[i], alpha);
 }
 
+template <int MODE>
+__global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ r, const float* __restrict__ x,
+                                                      const float* __restrict__ go, float* __restrict__ gr, long n4, long n,
+                                                      float scale, float alpha) {
+  mse_bwd_body<MODE>(r, x, go, gr, n4, n, scale, alpha, blockIdx.x, gridDim.x);
+}
+
 // g_mu = go*M_N*mu/B ; g_lv = go*M_N*0.5*(e^lv - 1)/B     (dense [B][L] outputs)
-__global__ __launch_bounds__(256) void kl_bwd_kernel(const float* __restrict__ mu, long mu_rs, const float* __restrict__ lv,
-                                                     long lv_rs, const float* __restrict__ go, float* __restrict__ gmu,
-                                                     float* __restrict__ glv, int B, int L, float M_N) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void kl_bwd_body(const float* __restrict__ mu, long mu_rs, const float* __restrict__ lv, long lv_rs,
+                                            const float* __restrict__ go, float* __restrict__ gmu, float* __restrict__ glv, int B,
+                                            int L, float M_N, int blk) {
+  const int i = blk * 256 + threadIdx.x;
   if (i >= B * L) return;
   const int b = i / L, d = i - b * L;
   const float sc = go[0] * M_N / (float)B;
   gmu[i] = sc * mu[b * mu_rs + d];
   glv[i] = sc * 0.5f * (expf(lv[b * lv_rs + d]) - 1.f);
+}
+
+__global__ __launch_bounds__(256) void kl_bwd_kernel(const float* __restrict__ mu, long mu_rs, const float* __restrict__ lv,
+                                                     long lv_rs, const float* __restrict__ go, float* __restrict__ gmu,
+                                                     float* __restrict__ glv, int B, int L, float M_N) {
+  kl_bwd_body(mu, mu_rs, lv, lv_rs, go, gmu, glv, B, L, M_N, blockIdx.x);
+}
+
+// both gradients of loss = recon + M_N * kld in ONE launch: blocks [0, nb) the reconstruction term, the rest the KL term
+template <int MODE>
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ r, const float* __restrict__ x,
+                                                       const float* __restrict__ go, float* __restrict__ gr, long n4, long n,
+                                                       float scale, float alpha, int nb, const float* __restrict__ mu, long mu_rs,
+                                                       const float* __restrict__ lv, long lv_rs, float* __restrict__ gmu,
+                                                       float* __restrict__ glv, int B, int L, float M_N) {
+  if ((int)blockIdx.x < nb) mse_bwd_body<MODE>(r, x, go, gr, n4, n, scale, alpha, blockIdx.x, nb);
+  else kl_bwd_body(mu, mu_rs, lv, lv_rs, go, gmu, glv, B, L, M_N, (int)blockIdx.x - nb);
 }
 
 size_t loss_workspace_floats() { return 2 * kLossBlocks; }
@@ -164,6 +187,24 @@ int launch_mse_backward(const float* r, const float* x, const float* go, float* 
 int launch_kl_backward(const float* mu, long mu_rs, const float* lv, long lv_rs, const float* go, float* gmu, float* glv,
                        int B, int L, float M_N, hipStream_t st) {
   hipLaunchKernelGGL(kl_bwd_kernel, dim3(ceil_div(B * L, 256)), dim3(256), 0, st, mu, mu_rs, lv, lv_rs, go, gmu, glv, B, L, M_N);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_loss_backward(const float* r, const float* x, const float* go, float* gr, long n, float logcosh_alpha, const float* mu,
+                         long mu_rs, const float* lv, long lv_rs, float* gmu, float* glv, int B, int L, float M_N, hipStream_t st) {
+  const long n4 = n / 4;
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  const int nb = (int)blocks, nkl = ceil_div(B * L, 256);
+  ProfScope ps("loss_bwd_kernel", st, 0.0, 12.0 * (double)n + 16.0 * (double)B * L);
+  if (logcosh_alpha > 0.f)
+    hipLaunchKernelGGL(loss_bwd_kernel<1>, dim3(nb + nkl), dim3(256), 0, st, r, x, go, gr, n4, n, (float)(1.0 / ((double)n * logcosh_alpha)),
+                       logcosh_alpha, nb, mu, mu_rs, lv, lv_rs, gmu, glv, B, L, M_N);
+  else
+    hipLaunchKernelGGL(loss_bwd_kernel<0>, dim3(nb + nkl), dim3(256), 0, st, r, x, go, gr, n4, n, (float)(1.0 / (double)n), 0.f, nb, mu,
+                       mu_rs, lv, lv_rs, gmu, glv, B, L, M_N);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }

@@ -718,20 +718,26 @@ class VAELoss(Function):
         if g_loss is None:
             return (None,) * 7
         g_loss = _c(g_loss.reshape(1))               # d/d loss; mse and kld outputs are reported detached
-        g_r = None
-        if ctx.needs_input_grad[0]:
-            g_r = torch.empty_like(recons)
-            if ctx.logcosh_alpha > 0.0:
-                native.call("ctvae_logcosh_backward", recons.data_ptr(), x.data_ptr(), g_loss.data_ptr(), g_r.data_ptr(),
-                            recons.numel(), ctx.logcosh_alpha)
-            else:
-                native.call("ctvae_mse_backward", recons.data_ptr(), x.data_ptr(), g_loss.data_ptr(), g_r.data_ptr(), recons.numel())
+        want_r = ctx.needs_input_grad[0]
+        want_kl = mu_ is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
+        g_r = torch.empty_like(recons) if want_r else None
         g_mu = g_lv = None
-        if mu_ is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
+        if want_kl:
             g_mu = torch.empty((B, L), dtype=torch.float32, device=recons.device)
             g_lv = torch.empty((B, L), dtype=torch.float32, device=recons.device)
-            native.call("ctvae_kl_backward", mu_.data_ptr(), mrs, lv_.data_ptr(), lrs, g_loss.data_ptr(), g_mu.data_ptr(),
-                        g_lv.data_ptr(), B, L, M_N)
+        if want_r and want_kl:      # the usual case: both gradients in one launch
+            native.call("ctvae_loss_backward", recons.data_ptr(), x.data_ptr(), g_loss.data_ptr(), g_r.data_ptr(), recons.numel(),
+                        ctx.logcosh_alpha, mu_.data_ptr(), mrs, lv_.data_ptr(), lrs, g_mu.data_ptr(), g_lv.data_ptr(), B, L, M_N)
+        else:
+            if want_r:
+                if ctx.logcosh_alpha > 0.0:
+                    native.call("ctvae_logcosh_backward", recons.data_ptr(), x.data_ptr(), g_loss.data_ptr(), g_r.data_ptr(),
+                                recons.numel(), ctx.logcosh_alpha)
+                else:
+                    native.call("ctvae_mse_backward", recons.data_ptr(), x.data_ptr(), g_loss.data_ptr(), g_r.data_ptr(), recons.numel())
+            if want_kl:
+                native.call("ctvae_kl_backward", mu_.data_ptr(), mrs, lv_.data_ptr(), lrs, g_loss.data_ptr(), g_mu.data_ptr(),
+                            g_lv.data_ptr(), B, L, M_N)
         g_extra = g_loss.reshape(has_extra) if (has_extra is not None and ctx.needs_input_grad[4]) else None
         return g_r, None, g_mu, g_lv, g_extra, None, None
 

@@ -180,6 +180,10 @@ int ctvae_loss_forward(const float* recons, const float* x, long n, const float*
                        const float* logvar, long lv_row_stride, int B, int L, float M_N, const float* extra, float* out4,
                        float* ws, size_t ws_bytes, void* stream);
 int ctvae_mse_backward(const float* recons, const float* x, const float* g_loss, float* g_recons, long n, void* stream);
+/* ctvae_mse_backward (or ctvae_logcosh_backward when logcosh_alpha > 0) and ctvae_kl_backward in ONE launch. */
+int ctvae_loss_backward(const float* recons, const float* x, const float* g_loss, float* g_recons, long n, float logcosh_alpha,
+                        const float* mu, long mu_row_stride, const float* logvar, long lv_row_stride, float* g_mu, float* g_logvar,
+                        int B, int L, float M_N, void* stream);
 /* LogCoshVAE's objective (logcosh_vae.py:141-155): out4 = {loss, rl, kld, -kld} with
  * rl = 1/alpha * mean(alpha t + log(1 + exp(-2 alpha t)) - log 2), t = recons - x; loss = rl + M_N * kld (the caller passes
  * M_N = beta * kld_weight).  Backward of the reconstruction term: g_recons = g_loss[0] * tanh(alpha t) / n; the KL term
