@@ -74,3 +74,24 @@ def synthetic_pairs(seed: int, batch: int, action_dim: int = 12, img: int = 64, 
     a = torch.zeros(batch, action_dim)
     a[torch.arange(batch), torch.arange(batch) % action_dim] = 1.0
     return x, y, a
+
+
+CT_NOISE_TAGS = ("mask_dropout", "mask_gumbel", "pos_dropout", "adj_gumbel", "kl_target", "exo_noise", "endo_noise")
+
+
+def ct_noise(seed: int, tag: str, k: int, shape, p: float = 0.0):
+    """The k-th injected draw of kind ``tag`` of CausalTransition (every stochastic op takes its noise from a CPU
+    generator so that the reference modules, the CPU oracle and the HIP path see identical bits).
+
+    *_dropout -> keep mask (1.0 where U >= p), *_gumbel -> standard exponential draws E (the Gumbel noise is -log E, which
+    is how ``F.gumbel_softmax`` forms it), kl_target -> U[0,1) (``torch.rand`` in ct_mcq_vae.py:316), *_noise -> N(0,1)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(int(seed) * 1000003 + CT_NOISE_TAGS.index(tag) * 1009 + int(k))
+    shape = tuple(int(s) for s in shape)
+    if tag.endswith("_dropout"):
+        return (torch.rand(shape, generator=g) >= p).to(torch.float32)
+    if tag.endswith("_gumbel"):
+        return torch.empty(shape, dtype=torch.float32).exponential_(generator=g)
+    if tag.endswith("_noise"):
+        return torch.randn(shape, generator=g)
+    return torch.rand(shape, generator=g)

@@ -160,3 +160,68 @@ def assert_cks_close(got, want, rtol, atol, what=""):
     assert abs(got[0] - want[0]) <= rtol * scale + atol, f"{what}: sum {got[0]} vs {want[0]}"
     assert abs(got[1] - want[1]) <= rtol * scale + atol, f"{what}: abs-sum {got[1]} vs {want[1]}"
     assert abs(got[2] - want[2]) <= 2 * rtol * max(want[2], atol) + atol, f"{what}: sq-sum {got[2]} vs {want[2]}"
+
+
+# ---- CausalTransition (ct_mcq_vae.py:42-333): specs, injected noise and the stand-in for the GNN --------------------
+def ct_layer_specs(action_dim, input_dim=64, hidden=800):
+    """state_dict keys/shapes of CausalTransition(input_dim, action_dim) WITHOUT graph_transitioner (torch_geometric's
+    GATv2Conv, absent here), in the reference's registration order (ct_mcq_vae.py:78-100)."""
+    f32 = torch.float32
+    s = [("a_dense.weight", (input_dim, action_dim), f32), ("a_dense.bias", (input_dim,), f32),
+         ("pos_encoding.pe", (4096, 1, input_dim), f32)]
+    for k in range(action_dim + 1):
+        s.extend([(f"graph_discovers.{k}.0.weight", (hidden, 2 * input_dim), f32), (f"graph_discovers.{k}.0.bias", (hidden,), f32),
+                  (f"graph_discovers.{k}.2.weight", (1, hidden), f32), (f"graph_discovers.{k}.2.bias", (1,), f32)])
+    s.extend([("mask.0.weight", (input_dim, action_dim + input_dim), f32), ("mask.0.bias", (input_dim,), f32)])
+    return s
+
+
+class GNNDouble(torch.nn.Module):
+    """TEST DOUBLE for ``CausalTransition.graph_transitioner`` — NOT GATv2.  torch_geometric is absent, so the two GATv2Conv
+    layers stay "parity unpinned"; everything AROUND them (node / adjacency padding, head gather, mask blend, softmax, the
+    modes and losses built on top) is pinned by installing this same differentiable function of (nodes, dense adjacency) on
+    the reference's module (oracle/gen_ct_golden.py) and on the product.  x [B,N,D], adj [B,N,N] (adj[b,r,c]: edge r -> c)
+    -> [B,N,heads*D]."""
+
+    def __init__(self, D, heads, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(int(seed))
+        self.P = torch.nn.Parameter((torch.rand(D, heads * D, generator=g) - 0.5) * 2.0)
+        self.Q = torch.nn.Parameter((torch.rand(D, heads * D, generator=g) - 0.5) * 1.0)
+
+    def forward(self, x, adj):
+        agg = torch.einsum('brc,brd->bcd', adj, x) * 0.25          # target c collects its sources r
+        return torch.tanh(agg) @ self.P + x @ self.Q
+
+
+class CTNoise:
+    """Noise source for ctvae_amd.models.causal (set_noise_source): the draws of filler.ct_noise, counted per tag."""
+
+    def __init__(self, seed, device):
+        self.seed, self.device, self.counts = seed, device, {}
+
+    def reset(self):
+        self.counts = {}
+
+    def draw(self, tag, shape, p=0.0):
+        k = self.counts.get(tag, 0)
+        self.counts[tag] = k + 1
+        return filler.ct_noise(self.seed, tag, k, shape, p).to(self.device)
+
+
+def ct_actions(B, A, shift=0):
+    """One-hot actions [B,A] with ids (3*b + shift) mod A: at least three distinct actions for B >= 3."""
+    a = torch.zeros(B, A)
+    a[torch.arange(B), (3 * torch.arange(B) + shift) % A] = 1.0
+    return a
+
+
+def ct_codes(seed, B, S=64, D=64):
+    """Random code indices [B,S] and their one-hot rows [B,S,D] (what ct_preprocess hands to the causal layer)."""
+    idx = torch.randint(0, D, (B, S), generator=torch.Generator().manual_seed(int(seed)))
+    return idx, torch.nn.functional.one_hot(idx, D).to(torch.float32)
+
+
+def ct_w(seed, i, shape):
+    """Deterministic cotangent number i of the CT fixtures (oracle/gen_ct_golden.py uses the same rule)."""
+    return torch.randn(tuple(shape), generator=torch.Generator().manual_seed(int(seed) * 31 + 7 + int(i)))
