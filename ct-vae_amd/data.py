@@ -164,6 +164,21 @@ class TransitionBatchSampler:
             yield per_mode[m][k * self.batch_size:(k + 1) * self.batch_size].tolist()
 
 
+def shard_rows(order: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """Rows of one rank for a plain (non-transition) dataset: ``torch.utils.data.DistributedSampler`` semantics — the
+    order is wrap-padded with its own head to a multiple of ``world`` and dealt round-robin, so EVERY rank gets
+    ceil(N / world) rows and therefore the same number of batches.  (Each training step issues a gradient all-reduce
+    and each validation batch a scalar all-reduce: a rank with one batch more than its peers would wait in RCCL for ever.)"""
+    n = int(order.numel())
+    if world <= 1 or n == 0:
+        return order
+    total = -(-n // world) * world
+    if total > n:
+        reps = -(-total // n)
+        order = order.repeat(reps)[:total]
+    return order[rank::world]
+
+
 class HbmImageStore:
     """A decoded uint8 dataset ``[N,H,W,3]`` resident in HBM; ``fetch`` is the reference's per-sample transform pipeline
     (ToTensor -> CenterCrop -> Resize, dataset.py:72-80) for a whole batch in one launch."""

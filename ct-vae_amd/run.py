@@ -113,7 +113,7 @@ class HbmData:
         else:
             g = torch.Generator().manual_seed(self.seed + 7919 * (self.epoch + 1))
             order = rows[torch.randperm(len(rows), generator=g)] if shuffle else rows
-            order = order[self.rank::self.world]
+            order = D.shard_rows(order, self.rank, self.world)      # same number of batches on every rank
             for i in range(0, len(order), batch_size):
                 r = order[i:i + batch_size]
                 yield store.fetch(r), torch.zeros(len(r), device=self.dev)
