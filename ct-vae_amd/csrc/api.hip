@@ -3,6 +3,7 @@
 #include "../../include/ctvae_hip.h"
 
 #include "common.hpp"
+#include "gatlayer.hpp"
 #include "pair.hpp"
 
 namespace ctvae {
@@ -325,6 +326,26 @@ int ctvae_gat_score_backward(const float* xl, const float* xr, const float* attr
   if (!xl || !xr || !attr || !we || !att || !g || !d_xl || !d_xr || !d_att_part || !d_we_part) return kErrBadArg;
   return launch_gat_score_backward(xl, xr, attr, we, att, g, d_xl, d_xr, d_att_part, d_we_part, B, N, H, C, slope,
                                    (hipStream_t)stream);
+}
+
+int ctvae_gat_layer_forward(const float* xl, const float* xr, int ld, const float* adj, const float* we, const float* att,
+                            const float* bias, const int32_t* head_map, float* out, int ldo, float* alpha, int B, int Hs, int C,
+                            float slope, int act, void* stream) {
+  const GatLayerArgs a{xl, xr, ld, adj, we, att, bias, head_map, out, ldo, alpha, B, Hs, C, slope, act};
+  return launch_gat_layer_forward(a, (hipStream_t)stream);
+}
+
+int ctvae_gat_layer_backward(const float* xl, const float* xr, int ld, const float* adj, const float* we, const float* att,
+                             const float* bias, const int32_t* head_map, const float* out, int ldo, const float* alpha,
+                             const float* g_out, float* dS, float* dattr, float* d_xl, float* d_xr, int ldd, float* d_bias_part,
+                             float* d_att_part, float* d_we_part, float* d_adj, int accumulate_dadj, int B, int Hs, int C,
+                             float slope, int act, void* stream) {
+  GatBwdArgs p{};
+  p.f = GatLayerArgs{xl, xr, ld, adj, we, att, bias, head_map, const_cast<float*>(out), ldo, const_cast<float*>(alpha), B, Hs, C,
+                     slope, act};
+  p.g_out = g_out; p.dS = dS; p.dattr = dattr; p.dxl = d_xl; p.dxr = d_xr; p.ldd = ldd;
+  p.dbias_part = d_bias_part; p.datt_part = d_att_part; p.dwe_part = d_we_part;
+  return launch_gat_layer_backward(p, d_adj, accumulate_dadj, (hipStream_t)stream);
 }
 
 int ctvae_pair_mlp_forward(const float* u, const float* v, const float* w2, const float* b2, float* out, int B, int N, int H,

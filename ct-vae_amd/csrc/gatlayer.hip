@@ -1,0 +1,599 @@
+// One GATv2Conv layer of CausalTransition.graph_transitioner (ct_mcq_vae.py:103-114: gnn.GATv2Conv(in, out, edge_dim=1,
+// heads)) on a batch of dense weighted graphs over the 64 latent nodes, fused:
+//
+//   forward   S[r,c]   = sum_k att[k] * lrelu(xl[r,k] + xr[c,k] + a'[r,c] * we[k], 0.2)        (r source, c target)
+//             alpha    = softmax over the sources r of the kept pairs (edges a[r,c] != 0, r != c, plus the self loop)
+//             out[c,:] = act(sum_r alpha[r,c] * xl[r,:] + bias)
+//   a' = a off the diagonal; a'[c,c] = mean of the incoming edge attributes of c (add_self_loops, fill_value 'mean').
+//
+// One workgroup per (sample, head slot): both projections of the head sit transposed in LDS, a thread owns a 4 x 4 block
+// of (source, target) pairs (two 16-byte LDS reads feed 16 pair evaluations per channel), the score tile never leaves
+// the CU: masked column softmax and the alpha-weighted aggregation run on the LDS-resident tile.  As torch ops the same
+// layer was a score kernel + masked_fill + softmax + einsum over [B,H,65,65] tensors (and their autograd mirrors).
+//
+// What is NOT here on purpose: the action node the reference appends (ct_mcq_vae.py:203-209).  Its row of the padded
+// adjacency is zero (no outgoing edge) and its own output row is discarded (:221), so it never reaches a latent node;
+// the 64 latent nodes are the whole graph as far as the layer's result and every gradient are concerned.
+//
+// Head slots: a sample evaluates Hs <= H heads; head_map[b*Hs + hs] names the head whose att / we / bias the slot uses
+// (null: slot == head).  CausalTransition._compute_y reads only head 0 and head 1+action of the LAST layer (:224-226), so
+// that layer runs two slots per sample instead of all 13 / 21 heads.
+//
+//   gat_layer_fwd_kernel   above
+//   gat_layer_bwd_kernel   d alpha = xl . g^T, softmax backward -> dS; the aggregation's share of d xl; d a' per head slot
+//                          (dS * sum_k att we lrelu'(.)); bias-gradient partials
+//   gat_proj_bwd_kernel    thread = (channel, quarter of the sources): d xl, d xr, d att, d we from dS -- every element has
+//                          one producer, partial sums meet in shuffles (no atomics: bit-reproducible)
+//   gat_adj_reduce_kernel  d a = edge * (sum_slots d a' + (sum_slots d a'[c,c]) / deg[c])
+#include "common.hpp"
+#include "gatlayer.hpp"
+#include "prof.hpp"
+
+namespace ctvae {
+
+namespace {
+
+constexpr int GN = 64;   // nodes per graph
+constexpr int LS = 68;   // LDS row stride of the [channel][node] operand tiles (16-byte aligned rows)
+constexpr int SS = 65;   // LDS row stride of the [source][target] tile
+
+__device__ __forceinline__ float relu(float v) { return fmaxf(v, 0.f); }
+
+// The thread's 4 x 4 block of the adjacency (rows 4tr.., columns 4tc..) with the self-loop attribute on the diagonal.
+// keep: bit (4i+j) set for pairs inside the softmax (edge or self loop).  scratch: >= 2*16*64 floats of LDS.
+__device__ __forceinline__ void load_adj_block(const float* __restrict__ adj, int b, int tr, int tc, float (&a)[4][4],
+                                               unsigned& keep, float* scratch, float* sLoop, float* sDeg) {
+  const int tid = threadIdx.x;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f}, cd[4] = {0.f, 0.f, 0.f, 0.f};
+  keep = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(adj + ((long)b * GN + 4 * tr + i) * GN + 4 * tc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool diag = (tr == tc) && (i == j);
+      const bool e = v[j] != 0.f && !diag;          // existing self loops are removed first
+      a[i][j] = e ? v[j] : 0.f;
+      if (e) { keep |= 1u << (4 * i + j); cs[j] += v[j]; cd[j] += 1.f; }
+      if (diag) keep |= 1u << (4 * i + j);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    scratch[tr * GN + 4 * tc + j] = cs[j];
+    scratch[16 * GN + tr * GN + 4 * tc + j] = cd[j];
+  }
+  __syncthreads();
+  if (tid < GN) {
+    float s = 0.f, d = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { s += scratch[t * GN + tid]; d += scratch[16 * GN + t * GN + tid]; }
+    sDeg[tid] = d;
+    sLoop[tid] = s / fmaxf(d, 1.f);
+  }
+  __syncthreads();
+  if (tr == tc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i][i] = sLoop[4 * tc + i];
+  }
+}
+
+// xl / xr of one head slot, transposed into LDS: T[k][n]
+__device__ __forceinline__ void stage_T(const float* __restrict__ src, long row0, int ld, int col0, int C, float* T) {
+  for (int e = threadIdx.x; e < GN * C; e += 256) {
+    const int n = e / C, k = e - n * C;
+    T[k * LS + n] = src[(row0 + n) * ld + col0 + k];
+  }
+}
+
+template <int KQ>   // channels per thread in the aggregation: ceil(C / 4) <= KQ
+__global__ __launch_bounds__(256, 2) void gat_layer_fwd_kernel(GatLayerArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int C = a.C;
+  float* XL = smem;                 // [C][LS]
+  float* XR = XL + C * LS;          // [C][LS]; later O[c][C|1]
+  float* Ss = XR + C * LS;          // [GN][SS]
+  float* sWe = Ss + GN * SS;        // [C]
+  float* sAt = sWe + C;             // [C]  att * (1 - slope)
+  float* sCol = sAt + C;            // [4][GN]
+  float* sLoop = sCol + 4 * GN;     // [GN]
+  float* sDeg = sLoop + GN;         // [GN]
+  float* sAL = sDeg + GN;           // [GN] sum_k att xl[r,k]
+  float* sAR = sAL + GN;            // [GN]
+  float* sAW = sAR + GN;            // [1]
+  const int tid = threadIdx.x, hs = blockIdx.x, b = blockIdx.y;
+  const int head = a.head_map ? a.head_map[b * a.Hs + hs] : hs;
+  const int tr = tid >> 4, tc = tid & 15;
+  stage_T(a.xl, (long)b * GN, a.ld, hs * C, C, XL);
+  stage_T(a.xr, (long)b * GN, a.ld, hs * C, C, XR);
+  for (int k = tid; k < C; k += 256) {
+    sWe[k] = a.we[head * C + k];
+    sAt[k] = a.att[head * C + k] * (1.f - a.slope);
+  }
+  float av[4][4];
+  unsigned keep;
+  load_adj_block(a.adj, b, tr, tc, av, keep, Ss, sLoop, sDeg);      // two barriers inside: the staging above is visible
+  // lrelu(m) = slope*m + (1-slope)*relu(m): the first term is linear in xl, xr, a' and is summed per node, not per pair
+  if (tid < 2 * GN) {
+    const float* T = tid < GN ? XL : XR;
+    const int n = tid & (GN - 1);
+    float s = 0.f;
+    for (int k = 0; k < C; ++k) s += a.att[head * C + k] * T[k * LS + n];
+    (tid < GN ? sAL : sAR)[n] = s;
+  } else if (tid == 2 * GN) {
+    float s = 0.f;
+    for (int k = 0; k < C; ++k) s += a.att[head * C + k] * a.we[head * C + k];
+    sAW[0] = s;
+  }
+  f32x2 acc[4][2], a2[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      acc[i][jp] = f32x2{0.f, 0.f};
+      a2[i][jp] = f32x2{av[i][2 * jp], av[i][2 * jp + 1]};
+    }
+  for (int k = 0; k < C; ++k) {
+    const f32x4 l4 = *reinterpret_cast<const f32x4*>(XL + k * LS + 4 * tr);
+    const f32x4 r4 = *reinterpret_cast<const f32x4*>(XR + k * LS + 4 * tc);
+    const float wk = sWe[k], ak = sAt[k];
+    const f32x2 wk2 = {wk, wk}, ak2 = {ak, ak};
+    const f32x2 r01 = {r4[0], r4[1]}, r23 = {r4[2], r4[3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x2 li = {l4[i], l4[i]};
+      const f32x2 m0 = (li + r01) + a2[i][0] * wk2;
+      const f32x2 m1 = (li + r23) + a2[i][1] * wk2;
+      acc[i][0] += ak2 * f32x2{relu(m0[0]), relu(m0[1])};
+      acc[i][1] += ak2 * f32x2{relu(m1[0]), relu(m1[1])};
+    }
+  }
+  __syncthreads();
+  {
+    const float aw = sAW[0];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float al = sAL[4 * tr + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float s = a.slope * (al + sAR[4 * tc + j] + av[i][j] * aw) + acc[i][j >> 1][j & 1];
+        Ss[(4 * tr + i) * SS + 4 * tc + j] = ((keep >> (4 * i + j)) & 1u) ? s : -INFINITY;
+      }
+    }
+  }
+  __syncthreads();
+  // softmax over the sources r of every target column c: thread = (c, quarter of the rows)
+  {
+    const int c = tid & (GN - 1), q = tid >> 6;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, Ss[(16 * q + i) * SS + c]);
+    sCol[q * GN + c] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sCol[c], sCol[GN + c]), fmaxf(sCol[2 * GN + c], sCol[3 * GN + c]));   // finite: the self loop is kept
+    __syncthreads();
+    float e[16], sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      e[i] = __expf(Ss[(16 * q + i) * SS + c] - mx);
+      sum += e[i];
+    }
+    sCol[q * GN + c] = sum;
+    __syncthreads();
+    const float inv = 1.f / (sCol[c] + sCol[GN + c] + sCol[2 * GN + c] + sCol[3 * GN + c]);
+    float* al = a.alpha + (((long)b * a.Hs + hs) * GN + 16 * q) * GN + c;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float p = e[i] * inv;
+      Ss[(16 * q + i) * SS + c] = p;
+      al[i * GN] = p;
+    }
+  }
+  __syncthreads();
+  // out[c][k] = sum_r alpha[r][c] * xl[r][k]: thread = (c, quarter of the channels)
+  {
+    const int c = tid & (GN - 1), k0 = (tid >> 6) * KQ;
+    float o[KQ];
+#pragma unroll
+    for (int kk = 0; kk < KQ; ++kk) o[kk] = 0.f;
+    for (int r4 = 0; r4 < 16; ++r4) {
+      const float p0 = Ss[(4 * r4) * SS + c], p1 = Ss[(4 * r4 + 1) * SS + c], p2 = Ss[(4 * r4 + 2) * SS + c],
+                  p3 = Ss[(4 * r4 + 3) * SS + c];
+#pragma unroll
+      for (int kk = 0; kk < KQ; ++kk) {
+        if (k0 + kk < C) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(XL + (k0 + kk) * LS + 4 * r4);     // same address in the whole wave
+          o[kk] += p0 * v[0] + p1 * v[1] + p2 * v[2] + p3 * v[3];
+        }
+      }
+    }
+    float* O = XR;                     // XR is dead: every wave passed the barriers behind the score loop
+    const int os = C | 1;
+#pragma unroll
+    for (int kk = 0; kk < KQ; ++kk)
+      if (k0 + kk < C) O[c * os + k0 + kk] = o[kk];
+  }
+  __syncthreads();
+  {
+    const float* O = XR;
+    const int os = C | 1;
+    for (int e = tid; e < GN * C; e += 256) {
+      const int n = e / C, k = e - n * C;
+      float v = O[n * os + k] + a.bias[head * C + k];
+      if (a.act == ACT_LRELU) v = v > 0.f ? v : v * kLeaky;
+      a.out[((long)b * GN + n) * a.ldo + hs * C + k] = v;
+    }
+  }
+}
+
+template <int KQ>
+__global__ __launch_bounds__(256, 2) void gat_layer_bwd_kernel(GatBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const GatLayerArgs& a = p.f;
+  const int C = a.C;
+  float* XL = smem;                 // [C][LS]
+  float* R2 = XL + C * LS;          // [C][LS]: G[k][c], then O[r][C|1], then XR[k][c]
+  float* Ss = R2 + C * LS;          // [GN][SS] alpha
+  float* sWe = Ss + GN * SS;        // [C]
+  float* sAw = sWe + C;             // [C]  att*we*(1-slope)
+  float* sRed = sAw + C;            // [16][GN] scratch (also load_adj_block's 2*16*GN)
+  float* sT = sRed + 2 * 16 * GN;   // [GN]
+  float* sLoop = sT + GN;
+  float* sDeg = sLoop + GN;
+  float* sAW = sDeg + GN;           // [1]
+  const int tid = threadIdx.x, hs = blockIdx.x, b = blockIdx.y;
+  const int head = a.head_map ? a.head_map[b * a.Hs + hs] : hs;
+  const int tr = tid >> 4, tc = tid & 15;
+  stage_T(a.xl, (long)b * GN, a.ld, hs * C, C, XL);
+  for (int e = tid; e < GN * C; e += 256) {           // G[k][c] = g_out[c][k] * act'(out[c][k])
+    const int n = e / C, k = e - n * C;
+    const long o = ((long)b * GN + n) * a.ldo + hs * C + k;
+    float g = p.g_out[o];
+    if (a.act == ACT_LRELU) g *= a.out[o] > 0.f ? 1.f : kLeaky;
+    R2[k * LS + n] = g;
+  }
+  for (int k = tid; k < C; k += 256) {
+    const float w = a.we[head * C + k];
+    sWe[k] = w;
+    sAw[k] = a.att[head * C + k] * w * (1.f - a.slope);
+  }
+  {
+    const float* al = a.alpha + ((long)b * a.Hs + hs) * GN * GN;
+    for (int e = tid; e < GN * GN; e += 256) Ss[(e >> 6) * SS + (e & 63)] = al[e];
+  }
+  float av[4][4];
+  unsigned keep;
+  load_adj_block(a.adj, b, tr, tc, av, keep, sRed, sLoop, sDeg);
+  if (tid < C) {                                        // bias gradient: sum over the targets
+    float s = 0.f;
+    for (int c = 0; c < GN; ++c) s += R2[tid * LS + c];
+    p.dbias_part[((long)b * a.Hs + hs) * C + tid] = s;
+  } else if (tid == 255) {
+    float s = 0.f;
+    for (int k = 0; k < C; ++k) s += a.att[head * C + k] * a.we[head * C + k];
+    sAW[0] = s;
+  }
+  // d alpha[r][c] = sum_k xl[r][k] * G[k][c]
+  f32x2 da[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) da[i][0] = da[i][1] = f32x2{0.f, 0.f};
+  for (int k = 0; k < C; ++k) {
+    const f32x4 l4 = *reinterpret_cast<const f32x4*>(XL + k * LS + 4 * tr);
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(R2 + k * LS + 4 * tc);
+    const f32x2 g01 = {g4[0], g4[1]}, g23 = {g4[2], g4[3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x2 li = {l4[i], l4[i]};
+      da[i][0] += li * g01;
+      da[i][1] += li * g23;
+    }
+  }
+  // softmax backward per target column: dS = alpha * (d alpha - sum_r alpha * d alpha)
+  float al[4][4];
+  {
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        al[i][j] = Ss[(4 * tr + i) * SS + 4 * tc + j];
+        part[j] += al[i][j] * da[i][j >> 1][j & 1];
+      }
+    __syncthreads();                                   // sRed was load_adj_block's scratch
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sRed[tr * GN + 4 * tc + j] = part[j];
+    __syncthreads();
+    if (tid < GN) {
+      float s = 0.f;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) s += sRed[t * GN + tid];
+      sT[tid] = s;
+    }
+    __syncthreads();
+  }
+  float ds[4][4];
+  {
+    float* dS = p.dS + (((long)b * a.Hs + hs) * GN + 4 * tr) * GN + 4 * tc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ds[i][j] = al[i][j] * (da[i][j >> 1][j & 1] - sT[4 * tc + j]);
+        v[j] = ds[i][j];
+      }
+      *reinterpret_cast<f32x4*>(dS + i * GN) = v;
+    }
+  }
+  // the aggregation's share of d xl[r][k] = sum_c alpha[r][c] * G[k][c]: thread = (r, quarter of the channels)
+  float o[KQ];
+  {
+    const int r = tid & (GN - 1), k0 = (tid >> 6) * KQ;
+#pragma unroll
+    for (int kk = 0; kk < KQ; ++kk) o[kk] = 0.f;
+    for (int c4 = 0; c4 < 16; ++c4) {
+      const float p0 = Ss[r * SS + 4 * c4], p1 = Ss[r * SS + 4 * c4 + 1], p2 = Ss[r * SS + 4 * c4 + 2],
+                  p3 = Ss[r * SS + 4 * c4 + 3];
+#pragma unroll
+      for (int kk = 0; kk < KQ; ++kk) {
+        if (k0 + kk < C) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(R2 + (k0 + kk) * LS + 4 * c4);
+          o[kk] += p0 * v[0] + p1 * v[1] + p2 * v[2] + p3 * v[3];
+        }
+      }
+    }
+  }
+  __syncthreads();                                     // G is dead
+  {
+    const int r = tid & (GN - 1), k0 = (tid >> 6) * KQ, os = C | 1;
+#pragma unroll
+    for (int kk = 0; kk < KQ; ++kk)
+      if (k0 + kk < C) R2[r * os + k0 + kk] = o[kk];
+  }
+  __syncthreads();
+  {
+    const int os = C | 1;
+    for (int e = tid; e < GN * C; e += 256) {
+      const int n = e / C, k = e - n * C;
+      p.dxl[((long)b * GN + n) * p.ldd + hs * C + k] = R2[n * os + k];
+    }
+  }
+  __syncthreads();
+  stage_T(a.xr, (long)b * GN, a.ld, hs * C, C, R2);
+  __syncthreads();
+  // d a'[r][c] = dS * sum_k att we lrelu'(m) = dS * (slope * sum_k att we + (1-slope) * sum_k att we [m > 0])
+  f32x2 t[4][2], a2[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      t[i][jp] = f32x2{0.f, 0.f};
+      a2[i][jp] = f32x2{av[i][2 * jp], av[i][2 * jp + 1]};
+    }
+  const f32x2 big = {1e30f, 1e30f};
+  for (int k = 0; k < C; ++k) {
+    const f32x4 l4 = *reinterpret_cast<const f32x4*>(XL + k * LS + 4 * tr);
+    const f32x4 r4 = *reinterpret_cast<const f32x4*>(R2 + k * LS + 4 * tc);
+    const float wk = sWe[k], awk = sAw[k];
+    const f32x2 wk2 = {wk, wk}, aw2 = {awk, awk};
+    const f32x2 r01 = {r4[0], r4[1]}, r23 = {r4[2], r4[3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x2 li = {l4[i], l4[i]};
+      const f32x2 m0 = ((li + r01) + a2[i][0] * wk2) * big;       // [m > 0] = med3(m * 1e30, 0, 1) (m == 0 -> 0, like m > 0)
+      const f32x2 m1 = ((li + r23) + a2[i][1] * wk2) * big;
+      t[i][0] += aw2 * f32x2{__builtin_amdgcn_fmed3f(m0[0], 0.f, 1.f), __builtin_amdgcn_fmed3f(m0[1], 0.f, 1.f)};
+      t[i][1] += aw2 * f32x2{__builtin_amdgcn_fmed3f(m1[0], 0.f, 1.f), __builtin_amdgcn_fmed3f(m1[1], 0.f, 1.f)};
+    }
+  }
+  {
+    const float aw = sAW[0] * a.slope;
+    float* dA = p.dattr + (((long)b * a.Hs + hs) * GN + 4 * tr) * GN + 4 * tc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = ds[i][j] * (aw + t[i][j >> 1][j & 1]);
+      *reinterpret_cast<f32x4*>(dA + i * GN) = v;
+    }
+  }
+}
+
+// d xl (added to what gat_layer_bwd_kernel left), d xr, d att, d we from dS.  grid (Hs, B); blockDim = 4 * CP, CP = C rounded
+// up to 16: thread = (channel k, quarter of the sources).  xl[r,k] and its gradient stay in registers (16 sources per
+// thread), dS and a' of the head are read from LDS as broadcasts, the four partial sums over the sources meet in two
+// shuffles.
+__global__ __launch_bounds__(512) void gat_proj_bwd_kernel(GatBwdArgs p) {
+  __shared__ __attribute__((aligned(16))) float sG[GN][GN + 4];   // [c][r]
+  __shared__ __attribute__((aligned(16))) float sA[GN][GN + 4];
+  __shared__ float sLoop[GN];
+  const GatLayerArgs& a = p.f;
+  const int C = a.C;
+  const int tid = threadIdx.x, hs = blockIdx.x, b = blockIdx.y, k = tid >> 2, qt = tid & 3;
+  const int head = a.head_map ? a.head_map[b * a.Hs + hs] : hs;
+  const bool kok = k < C;
+  const int r0 = 16 * qt;
+  {
+    const float* dS = p.dS + ((long)b * a.Hs + hs) * GN * GN;
+    const float* adj = a.adj + (long)b * GN * GN;
+    for (int e = tid; e < GN * GN; e += blockDim.x) {
+      const int r = e >> 6, c = e & 63;
+      const float v = adj[e];
+      sG[c][r] = dS[e];
+      sA[c][r] = (r == c) ? 0.f : v;
+    }
+  }
+  __syncthreads();
+  if (tid < GN) {                    // self-loop attribute: mean of the incoming edges of target c = tid
+    float s = 0.f, d = 0.f;
+    for (int r = 0; r < GN; ++r) {
+      const float v = sA[tid][r];
+      s += v;
+      d += v != 0.f ? 1.f : 0.f;
+    }
+    sLoop[tid] = s / fmaxf(d, 1.f);
+  }
+  __syncthreads();
+  if (tid < GN) sA[tid][tid] = sLoop[tid];
+  f32x2 xlr[8], dl[8];
+  const long rowl = ((long)b * GN + r0) * a.ld + hs * C + k;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    xlr[i >> 1][i & 1] = kok ? a.xl[rowl + (long)i * a.ld] : 0.f;
+    dl[i >> 1][i & 1] = 0.f;
+  }
+  const float wk = kok ? a.we[head * C + k] : 0.f, ak = kok ? a.att[head * C + k] : 0.f;
+  const f32x2 wk2 = {wk, wk};
+  const float slope = a.slope;
+  f32x2 datt2 = {0.f, 0.f}, dwe2 = {0.f, 0.f};
+  __syncthreads();
+  const long rowr = ((long)b * GN) * a.ld + hs * C + k;
+  float xr_next = kok ? a.xr[rowr] : 0.f;                        // one target ahead: the load is off the dependency chain
+  for (int c = 0; c < GN; ++c) {
+    const float xrc = xr_next;
+    if (c + 1 < GN) xr_next = kok ? a.xr[rowr + (long)(c + 1) * a.ld] : 0.f;
+    const f32x2 xrc2 = {xrc, xrc};
+    f32x2 dr2 = {0.f, 0.f};
+#pragma unroll
+    for (int i2 = 0; i2 < 8; ++i2) {
+      const f32x2 g2 = *reinterpret_cast<const f32x2*>(&sG[c][r0 + 2 * i2]);
+      const f32x2 a2 = *reinterpret_cast<const f32x2*>(&sA[c][r0 + 2 * i2]);
+      const f32x2 m = (xlr[i2] + xrc2) + a2 * wk2;
+      const f32x2 sl = {m[0] > 0.f ? 1.f : slope, m[1] > 0.f ? 1.f : slope};
+      const f32x2 gs = g2 * sl;            // dS * lrelu'(m); the factor att[k] is applied once at the end
+      datt2 += gs * m;                     // dS * lrelu(m)
+      dl[i2] += gs;
+      dr2 += gs;
+      dwe2 += gs * a2;
+    }
+    float dr = dr2[0] + dr2[1];
+    dr += __shfl_xor(dr, 1, 64);
+    dr += __shfl_xor(dr, 2, 64);
+    if (kok && qt == 0) p.dxr[((long)b * GN + c) * p.ldd + hs * C + k] = dr * ak;
+  }
+  float datt = datt2[0] + datt2[1], dwe = dwe2[0] + dwe2[1];
+  datt += __shfl_xor(datt, 1, 64);
+  datt += __shfl_xor(datt, 2, 64);
+  dwe += __shfl_xor(dwe, 1, 64);
+  dwe += __shfl_xor(dwe, 2, 64);
+  if (kok) {
+    const long rowd = ((long)b * GN + r0) * p.ldd + hs * C + k;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) p.dxl[rowd + (long)i * p.ldd] += dl[i >> 1][i & 1] * ak;
+    if (qt == 0) {
+      p.datt_part[((long)b * a.Hs + hs) * C + k] = datt;
+      p.dwe_part[((long)b * a.Hs + hs) * C + k] = dwe * ak;
+    }
+  }
+}
+
+// d adj[b][r][c] = edge[r][c] * (sum_slots d a'[r][c] + (sum_slots d a'[c][c]) / deg[c]); grid B, 256 threads
+__global__ __launch_bounds__(256) void gat_adj_reduce_kernel(const float* __restrict__ dattr, const float* __restrict__ adj,
+                                                            float* __restrict__ dadj, int Hs, int accumulate) {
+  __shared__ float sD[16][GN];
+  __shared__ float sDiag[GN], sDeg[GN];
+  const int tid = threadIdx.x, b = blockIdx.x, tr = tid >> 4, tc = tid & 15;
+  float v[4][4], d[4][4], cd[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long o = ((long)b * GN + 4 * tr + i) * GN + 4 * tc;
+    const f32x4 av = *reinterpret_cast<const f32x4*>(adj + o);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < Hs; ++h) s += *reinterpret_cast<const f32x4*>(dattr + (((long)b * Hs + h) * GN + 4 * tr + i) * GN + 4 * tc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool diag = (tr == tc) && (i == j);
+      const bool e = av[j] != 0.f && !diag;
+      v[i][j] = e ? 1.f : 0.f;
+      d[i][j] = s[j];
+      if (e) cd[j] += 1.f;
+      if (diag) sDiag[4 * tc + j] = s[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sD[tr][4 * tc + j] = cd[j];
+  __syncthreads();
+  if (tid < GN) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s += sD[t][tid];
+    sDeg[tid] = fmaxf(s, 1.f);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long o = ((long)b * GN + 4 * tr + i) * GN + 4 * tc;
+    f32x4 r = accumulate ? *reinterpret_cast<const f32x4*>(dadj + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] += v[i][j] * (d[i][j] + sDiag[4 * tc + j] / sDeg[4 * tc + j]);
+    *reinterpret_cast<f32x4*>(dadj + o) = r;
+  }
+}
+
+size_t fwd_smem(int C) { return ((size_t)2 * C * LS + GN * SS + 2 * C + 4 * GN + 4 * GN + 4) * sizeof(float); }
+size_t bwd_smem(int C) { return ((size_t)2 * C * LS + GN * SS + 2 * C + 2 * 16 * GN + 3 * GN + 4) * sizeof(float); }
+
+bool args_ok(const GatLayerArgs& a) {
+  return a.xl && a.xr && a.adj && a.we && a.att && a.bias && a.out && a.alpha && a.B > 0 && a.Hs > 0 && a.C >= 16 && a.C <= 128 &&
+         a.ld >= a.Hs * a.C && a.ldo >= a.Hs * a.C && a.slope > 0.f && a.slope < 1.f && (a.act == ACT_NONE || a.act == ACT_LRELU);
+}
+
+}  // namespace
+
+int launch_gat_layer_forward(const GatLayerArgs& a, hipStream_t st) {
+  if (!args_ok(a)) return kErrBadArg;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_fwd_kernel<25>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_fwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const double pairs = (double)a.B * a.Hs * GN * GN;
+  ProfScope ps("gat_layer_fwd_kernel", st, 6.0 * pairs * a.C, 4.0 * a.B * a.Hs * (3.0 * GN * a.C + 2.0 * GN * GN));
+  const size_t smem = fwd_smem(a.C);
+  const dim3 grid(a.Hs, a.B);
+  if (a.C <= 64) hipLaunchKernelGGL(gat_layer_fwd_kernel<16>, grid, dim3(256), smem, st, a);
+  else if (a.C <= 100) hipLaunchKernelGGL(gat_layer_fwd_kernel<25>, grid, dim3(256), smem, st, a);
+  else hipLaunchKernelGGL(gat_layer_fwd_kernel<32>, grid, dim3(256), smem, st, a);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_gat_layer_backward(const GatBwdArgs& p, float* dadj, int accumulate_dadj, hipStream_t st) {
+  const GatLayerArgs& a = p.f;
+  if (!args_ok(a) || !p.g_out || !p.dS || !p.dattr || !p.dxl || !p.dxr || !p.dbias_part || !p.datt_part || !p.dwe_part ||
+      p.ldd < a.Hs * a.C)
+    return kErrBadArg;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_bwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_bwd_kernel<25>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const double pairs = (double)a.B * a.Hs * GN * GN;
+  const dim3 grid(a.Hs, a.B);
+  {
+    ProfScope ps("gat_layer_bwd_kernel", st, 10.0 * pairs * a.C, 4.0 * a.B * a.Hs * (4.0 * GN * a.C + 4.0 * GN * GN));
+    const size_t smem = bwd_smem(a.C);
+    if (a.C <= 64) hipLaunchKernelGGL(gat_layer_bwd_kernel<16>, grid, dim3(256), smem, st, p);
+    else if (a.C <= 100) hipLaunchKernelGGL(gat_layer_bwd_kernel<25>, grid, dim3(256), smem, st, p);
+    else hipLaunchKernelGGL(gat_layer_bwd_kernel<32>, grid, dim3(256), smem, st, p);
+    CTVAE_LAUNCH_CHECK();
+  }
+  {
+    ProfScope ps("gat_proj_bwd_kernel", st, 9.0 * pairs * a.C, 4.0 * a.B * a.Hs * (4.0 * GN * a.C + 2.0 * GN * GN));
+    const int threads = 4 * ((a.C + 15) / 16 * 16);
+    hipLaunchKernelGGL(gat_proj_bwd_kernel, grid, dim3(threads), 0, st, p);
+    CTVAE_LAUNCH_CHECK();
+  }
+  if (dadj != nullptr) {
+    ProfScope ps("gat_adj_reduce_kernel", st, 0.0, 4.0 * a.B * (a.Hs + 2.0) * GN * GN);
+    hipLaunchKernelGGL(gat_adj_reduce_kernel, dim3(a.B), dim3(256), 0, st, p.dattr, a.adj, dadj, a.Hs, accumulate_dadj);
+    CTVAE_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+}  // namespace ctvae

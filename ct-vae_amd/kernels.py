@@ -978,6 +978,58 @@ class GATScore(Function):
         return dxl, dxr, dattr, dwep.sum(0), dattp.sum(0), None
 
 
+class GATLayer(Function):
+    """One GATv2Conv layer on B dense graphs over the 64 latent nodes (csrc/gatlayer.hip; ct_mcq_vae.py:103-114): scores,
+    masked softmax over the sources and the alpha-weighted aggregation in one launch.
+
+    xlr [B,64,2*Hs*C]: lin_l(x) of the Hs head slots, then lin_r(x) (one GEMM output); adj [B,64,64] weighted adjacency
+    (adj[b,r,c] != 0: edge r -> c); we / att [H,C], bias [H*C]; head_map int32 [B,Hs] or None (slot == head).
+    Returns act(out) [B,64,Hs*C]."""
+
+    @staticmethod
+    def forward(ctx, xlr, adj, we, att, bias, head_map, Hs, C, slope, act):
+        _req_cuda(xlr, adj, we, att, bias)
+        xlr, adj, we, att, bias = _c(xlr), _c(adj), _c(we), _c(att), _c(bias)
+        B, N, ld = xlr.shape
+        if N != 64 or ld != 2 * Hs * C or tuple(adj.shape) != (B, 64, 64):
+            raise RuntimeError("GATLayer: needs xlr [B,64,2*Hs*C] and adj [B,64,64]")
+        if head_map is not None:
+            head_map = _c(head_map.to(torch.int32))
+            if tuple(head_map.shape) != (B, Hs):
+                raise RuntimeError("GATLayer: head_map must be [B,Hs]")
+        out = torch.empty((B, 64, Hs * C), dtype=torch.float32, device=xlr.device)
+        alpha = torch.empty((B, Hs, 64, 64), dtype=torch.float32, device=xlr.device)
+        native.call("ctvae_gat_layer_forward", xlr.data_ptr(), xlr.data_ptr() + 4 * Hs * C, ld, adj.data_ptr(), we.data_ptr(),
+                    att.data_ptr(), bias.data_ptr(), native.ptr(head_map), out.data_ptr(), Hs * C, alpha.data_ptr(), B, Hs, C,
+                    float(slope), int(act))
+        ctx.save_for_backward(xlr, adj, we, att, bias, head_map, out, alpha)
+        ctx.meta = (Hs, C, float(slope), int(act))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xlr, adj, we, att, bias, head_map, out, alpha = ctx.saved_tensors
+        Hs, C, slope, act = ctx.meta
+        B, _, ld = xlr.shape
+        H = we.shape[0]
+        g = _c(g)
+        dev = xlr.device
+        scratch = torch.empty((2, B, Hs, 64, 64), dtype=torch.float32, device=dev)
+        d_xlr = torch.empty_like(xlr)
+        parts = torch.empty((3, B * Hs, C), dtype=torch.float32, device=dev)
+        dadj = torch.empty_like(adj) if ctx.needs_input_grad[1] else None
+        native.call("ctvae_gat_layer_backward", xlr.data_ptr(), xlr.data_ptr() + 4 * Hs * C, ld, adj.data_ptr(), we.data_ptr(),
+                    att.data_ptr(), bias.data_ptr(), native.ptr(head_map), out.data_ptr(), Hs * C, alpha.data_ptr(), g.data_ptr(),
+                    scratch[0].data_ptr(), scratch[1].data_ptr(), d_xlr.data_ptr(), d_xlr.data_ptr() + 4 * Hs * C, ld,
+                    parts[0].data_ptr(), parts[1].data_ptr(), parts[2].data_ptr(), native.ptr(dadj), 0, B, Hs, C, slope, act)
+        if head_map is None:
+            red = parts.view(3, B, Hs * C).sum(1).view(3, H, C)
+        else:   # per-head sums of the per-(sample, slot) partials as one small GEMM (deterministic, no atomics)
+            sel = torch.nn.functional.one_hot(head_map.view(-1).long(), H).to(torch.float32)      # [B*Hs, H]
+            red = torch.matmul(sel.t().unsqueeze(0), parts)                                        # [3, H, C]
+        return d_xlr, dadj, red[2], red[1], red[0].reshape(-1), None, None, None, None, None
+
+
 class GumbelBernoulliST(Function):
     """Straight-through Bernoulli(p) sample via hard 2-class Gumbel-softmax (ct_mcq_vae.py:177-183); noise [...,2]."""
 

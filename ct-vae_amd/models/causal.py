@@ -81,8 +81,10 @@ class PositionalEncoding(nn.Module):
 
 
 class DenseGATv2(nn.Module):
-    """GATv2Conv(in, out, heads, edge_dim=1, concat=True, add_self_loops=True(fill 'mean'), negative_slope=0.2)
-    on a batch of dense weighted graphs.  adj[b, r, c] != 0 is an edge r -> c carrying attribute adj[b, r, c]."""
+    """GATv2Conv(in, out, heads, edge_dim=1, concat=True, add_self_loops=True(fill 'mean'), negative_slope=0.2) on a batch
+    of dense weighted graphs.  adj[b, r, c] != 0 is an edge r -> c carrying attribute adj[b, r, c].  PARITY UNPINNED
+    (torch_geometric is absent): written from the published GATv2 algorithm, cross-checked against the oracle's edge-list
+    restatement."""
 
     def __init__(self, in_channels, out_channels, heads, negative_slope=0.2):
         super().__init__()
@@ -97,7 +99,29 @@ class DenseGATv2(nn.Module):
         nn.init.zeros_(self.lin_l.bias)
         nn.init.zeros_(self.lin_r.bias)
 
-    def forward(self, x, adj):                    # x [B,N,Cin], adj [B,N,N]
+    def fused_ok(self, x):
+        return x.is_cuda and x.size(1) == 64 and 16 <= self.out_channels <= 128
+
+    def forward_fused(self, x, adj, heads_sel=None, act=K.ACT_NONE):
+        """HIP path (csrc/gatlayer.hip): x [B,64,Cin], adj [B,64,64]; heads_sel int [B,Hs] evaluates only those heads of each
+        sample (slot order) -> [B,64,Hs*C]; act: the activation behind the layer, applied in the kernel's epilogue."""
+        B = x.size(0)
+        H, C = self.heads, self.out_channels
+        if heads_sel is None:
+            Hs = H
+            xlr = F.linear(x, torch.cat([self.lin_l.weight, self.lin_r.weight], 0), torch.cat([self.lin_l.bias, self.lin_r.bias], 0))
+        else:
+            Hs = heads_sel.size(1)
+            idx = heads_sel.long()
+            wl = self.lin_l.weight.view(H, C, -1)[idx].reshape(B, Hs * C, -1)
+            wr = self.lin_r.weight.view(H, C, -1)[idx].reshape(B, Hs * C, -1)
+            bl = self.lin_l.bias.view(H, C)[idx].reshape(B, Hs * C)
+            br = self.lin_r.bias.view(H, C)[idx].reshape(B, Hs * C)
+            xlr = torch.baddbmm(torch.cat([bl, br], 1).unsqueeze(1), x, torch.cat([wl, wr], 1).transpose(1, 2))
+        return K.GATLayer.apply(xlr, adj, self.lin_edge.weight.view(H, C), self.att[0], self.bias, heads_sel, Hs, C,
+                                self.negative_slope, act)
+
+    def forward(self, x, adj):                    # x [B,N,Cin], adj [B,N,N]: every head, any N (torch device ops)
         B, N, _ = x.shape
         H, C = self.heads, self.out_channels
         xl = self.lin_l(x).view(B, N, H, C)       # source side
@@ -109,11 +133,6 @@ class DenseGATv2(nn.Module):
         attr = w + torch.diag_embed(w.sum(1) / deg)   # self loops carry the mean incoming attribute
         keep = edge | eye
         we = self.lin_edge.weight.view(H, C)
-        if x.is_cuda and N * N <= 17 * 256 and C <= 128:
-            # HIP: all heads' attention logits in one launch, no [B,N,N,C] tensors (kernels.GATScore / csrc/gat.hip)
-            s = K.GATScore.apply(xl, xr, attr, we, self.att[0], self.negative_slope)               # [B,H,N(r),N(c)]
-            alpha = torch.softmax(s.masked_fill(~keep.unsqueeze(1), float('-inf')), dim=2)           # over sources r
-            return torch.einsum('bhrc,brhk->bchk', alpha, xl).reshape(B, N, H * C) + self.bias
         outs = []
         for h in range(H):                        # head by head keeps the [B,N,N,C] score tensor small
             m = xl[:, :, None, h, :] + xr[:, None, :, h, :] + attr.unsqueeze(-1) * we[h]
@@ -138,6 +157,19 @@ class _GraphTransitioner(nn.Module):
             c = dim * heads
         self.add_module(f"module_{idx}", DenseGATv2(c, input_dim, heads))
         self.order.append(f"module_{idx}")
+
+    def gat_layers(self):
+        return [self._modules[n] for n in self.order if isinstance(self._modules[n], DenseGATv2)]
+
+    def fused_ok(self, x):
+        return all(l.fused_ok(x) for l in self.gat_layers())
+
+    def forward_fused(self, x, adj, heads_sel):
+        """The 64 latent nodes only, the last layer restricted to the head slots ``heads_sel`` [B,Hs] -> [B,64,Hs*D]."""
+        layers = self.gat_layers()
+        for l in layers[:-1]:
+            x = l.forward_fused(x, adj, None, K.ACT_LRELU)      # nn.LeakyReLU() behind the layer, in its epilogue
+        return layers[-1].forward_fused(x, adj, heads_sel, K.ACT_NONE)
 
     def forward(self, x, adj):
         for name in self.order:
@@ -240,6 +272,12 @@ class CausalTransition(nn.Module):
         return no_inter * (1 - mask) + inter * mask
 
     def _compute_y(self, latent, action, adjacency, mask):
+        """ct_mcq_vae.py:188-228.  With the layer's own GATv2 stack on the device the fused form runs (below); any other
+        ``graph_transitioner`` module (dense calling convention (nodes [B,N,D], adjacency [B,N,N]) -> [B,N,heads*D]) gets the
+        reference's data flow: nodes padded with the action (and noise) node, adjacency padded with their edges."""
+        gt = self.graph_transitioner
+        if isinstance(gt, _GraphTransitioner) and latent.size(1) == 64 and gt.fused_ok(latent):
+            return self._compute_y_fused(latent, action, adjacency, mask)
         B, S, D = latent.shape
         action_node = self.a_dense(action)
         if self.noise == "exo":
@@ -253,12 +291,34 @@ class CausalTransition(nn.Module):
         nodes = torch.cat([latent, supp], 1)
         # extra nodes: edges from every latent node to them (column of ones), none leaving (row of zeros)
         adj = F.pad(F.pad(adjacency, (0, ns, 0, 0), value=1.0), (0, 0, 0, ns), value=0.0)
-        y = self.graph_transitioner(nodes, adj)[:, :S].view(B, S, self.nb_heads, D)
+        y = gt(nodes, adj)[:, :S].view(B, S, self.nb_heads, D)
         base = y[:, :, 0]
         if mask is None:
             return base.softmax(dim=-1)
         head = (action.argmax(dim=-1) + 1).view(B, 1, 1, 1).expand(B, S, 1, D)
         return (base * (1 - mask) + torch.gather(y, 2, head).squeeze(2) * mask).softmax(dim=-1)
+
+    def _compute_y_fused(self, latent, action, adjacency, mask):
+        """Same result on the HIP GATv2 kernels, computing only what reaches it:
+        * the appended action / noise nodes have no outgoing edge (their rows of the padded adjacency are zero) and their own
+          outputs are dropped (ct_mcq_vae.py:203-221), so the graph is the 64 latent nodes (``a_dense`` gets the exact zero
+          gradient it has in the reference);
+        * of the last layer only head 0 and head 1 + argmax(action) are read (:224-226): two head slots per sample instead of
+          13 / 21 heads (one slot when there is no intervention mask)."""
+        B, S, D = latent.shape
+        if self.noise == "exo":
+            latent = latent + _draw("exo_noise", latent.shape, device=latent.device)
+        elif self.noise == "endo":
+            _draw("endo_noise", (B, D), device=latent.device)      # the draw the reference makes for its isolated noise node
+        zero = torch.zeros(B, dtype=torch.int32, device=latent.device)
+        if mask is None:
+            heads = zero.unsqueeze(1)
+        else:
+            heads = torch.stack([zero, action.argmax(dim=-1).to(torch.int32) + 1], dim=1)
+        y = self.graph_transitioner.forward_fused(latent, adjacency, heads).view(B, S, heads.size(1), D)
+        if mask is None:
+            return y[:, :, 0].softmax(dim=-1)
+        return (y[:, :, 0] * (1 - mask) + y[:, :, 1] * mask).softmax(dim=-1)
 
     # ---- modes -----------------------------------------------------------------------------------
     def forward(self, latent: Tensor, **kwargs) -> List[Tensor]:

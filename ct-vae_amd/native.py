@@ -31,6 +31,9 @@ SIGNATURES = {
     "ctvae_crop_resize_u8": [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _vp],
     "ctvae_gat_score": [_i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _f, _vp],
     "ctvae_gat_score_backward": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _f, _vp],
+    "ctvae_gat_layer_forward": [_fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, _f, _i, _vp],
+    "ctvae_gat_layer_backward": [_fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _fp,
+                                 _fp, _i, _i, _i, _i, _f, _i, _vp],
     "ctvae_pair_mlp_forward": [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _f, _i, _vp],
     "ctvae_pair_mlp_backward": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _f, _i, _vp],
     "ctvae_act_forward": [_fp, _fp, _l, _i, _vp],

@@ -162,6 +162,27 @@ int ctvae_gat_score_backward(const float* xl, const float* xr, const float* attr
                              const float* g, float* d_xl, float* d_xr, float* d_att_part, float* d_we_part, int B, int N, int H,
                              int C, float slope, void* stream);
 
+/* One whole GATv2Conv layer of CausalTransition.graph_transitioner (ct_mcq_vae.py:103-114; torch_geometric GATv2Conv(in, C,
+ * edge_dim=1, heads=H), add_self_loops / fill_value 'mean', negative_slope = slope) on B dense graphs over the 64 LATENT
+ * nodes (the appended action node has no outgoing edge and its own output is discarded, ct_mcq_vae.py:203-221, so it never
+ * reaches a latent node).  xl / xr: rows [B*64] of stride ld, head slot hs at columns hs*C..; adj [B,64,64] weighted
+ * adjacency (adj[b,r,c] != 0: edge r -> c); we, att, bias [H][C].  head_map [B*Hs] (or NULL: slot == head): the head whose
+ * parameters slot hs of sample b uses -- _compute_y reads only head 0 and head 1+action of the last layer (:224-226).
+ *   out[b,c,hs,:] = act(sum_r alpha[b,hs,r,c] * xl[b,r,hs,:] + bias[head]),  alpha = softmax over the kept sources of
+ *   S[r,c] = sum_k att[k] * leaky_relu(xl[r,k] + xr[c,k] + a'[r,c]*we[k], slope);  alpha [B,Hs,64,64] is kept for backward.
+ * act: 0 or 1 (nn.LeakyReLU() between the two layers).  16 <= C <= 128.
+ * Backward: g_out like out; writes dS, dattr [B,Hs,64,64] (scratch the caller provides), d_xl / d_xr (rows of stride ldd),
+ * per-sample partials d_bias_part / d_att_part / d_we_part [B][Hs][C] (the caller sums them per head: deterministic, no
+ * atomics) and, when d_adj != NULL, d_adj [B,64,64] (+= when accumulate_dadj). */
+int ctvae_gat_layer_forward(const float* xl, const float* xr, int ld, const float* adj, const float* we, const float* att,
+                            const float* bias, const int32_t* head_map, float* out, int ldo, float* alpha, int B, int Hs, int C,
+                            float slope, int act, void* stream);
+int ctvae_gat_layer_backward(const float* xl, const float* xr, int ld, const float* adj, const float* we, const float* att,
+                             const float* bias, const int32_t* head_map, const float* out, int ldo, const float* alpha,
+                             const float* g_out, float* dS, float* dattr, float* d_xl, float* d_xr, int ldd, float* d_bias_part,
+                             float* d_att_part, float* d_we_part, float* d_adj, int accumulate_dadj, int B, int Hs, int C,
+                             float slope, int act, void* stream);
+
 /* layout change at the NCHW API boundary: to_nhwc=1: in [B,C,P] -> out [B,P,C]; 0: the inverse
  * (torch.flatten on NCHW, vanilla_vae.py:85; .view(-1,512,2,2), vanilla_vae.py:102) */
 int ctvae_permute(const float* in, float* out, int B, int C, int P, int to_nhwc, void* stream);
