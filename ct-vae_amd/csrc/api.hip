@@ -4,6 +4,7 @@
 
 #include "common.hpp"
 #include "gatlayer.hpp"
+#include "glinear.hpp"
 #include "pair.hpp"
 
 namespace ctvae {
@@ -43,11 +44,11 @@ int launch_gat_score(int mode, const float* xl, const float* xr, const float* at
 int launch_gat_score_backward(const float* xl, const float* xr, const float* attr, const float* we, const float* att,
                               const float* g, float* dxl, float* dxr, float* datt_part, float* dwe_part, int B, int N, int H,
                               int C, float slope, hipStream_t st);
-int launch_pair_mlp_forward(const float* u, const float* v, const float* w2, const float* b2, float* out, int B, int N, int H,
-                            float slope, int per_sample, hipStream_t st);
-int launch_pair_mlp_backward(const float* u, const float* v, const float* w2, const float* out, const float* g_out, float* dU,
-                             float* dV, float* dw2_part, float* db2_part, int B, int N, int H, float slope, int per_sample,
-                             hipStream_t st);
+int launch_pair_mlp_forward(const float* u, const float* v, int ld, const float* w2, const float* b2, float* out, int B, int N,
+                            int H, float slope, int per_sample, const int* row_of, hipStream_t st);
+int launch_pair_mlp_backward(const float* u, const float* v, int ld, const float* w2, const float* out, const float* g_out,
+                             float* dU, float* dV, int ldd, float* dw2_part, float* db2_part, int B, int N, int H, float slope,
+                             int per_sample, const int* row_of, hipStream_t st);
 int launch_act_bwd(const float* gout, const float* out, float* gin, long n, int act, hipStream_t st);
 int launch_act_fwd(const float* in, float* out, long n, int act, hipStream_t st);
 int launch_reparam_fwd(const float* mu, long mu_rs, const float* lv, long lv_rs, const float* eps, float* z, int B, int L,
@@ -348,18 +349,59 @@ int ctvae_gat_layer_backward(const float* xl, const float* xr, int ld, const flo
   return launch_gat_layer_backward(p, d_adj, accumulate_dadj, (hipStream_t)stream);
 }
 
-int ctvae_pair_mlp_forward(const float* u, const float* v, const float* w2, const float* b2, float* out, int B, int N, int H,
-                           float slope, int per_sample, void* stream) {
-  if (!u || !v || !w2 || !out) return kErrBadArg;
-  return launch_pair_mlp_forward(u, v, w2, b2, out, B, N, H, slope, per_sample, (hipStream_t)stream);
+static int glin_fill(GLinArgs& a, int nseg, int N, const float* const* W, const int* ldw, const int64_t* w_gstride,
+                     const float* const* bias, const int* b_gstride, const int32_t* const* group) {
+  if (nseg < 1 || nseg > kGLinMaxSeg || !W || !ldw || !w_gstride) return kErrBadArg;
+  a.nseg = nseg;
+  a.N = N;
+  for (int s = 0; s < nseg; ++s) {
+    a.W[s] = W[s];
+    a.ldw[s] = ldw[s];
+    a.wgs[s] = (long)w_gstride[s];
+    a.bias[s] = bias ? bias[s] : nullptr;
+    a.bgs[s] = b_gstride ? b_gstride[s] : 0;
+    a.group[s] = group ? group[s] : nullptr;
+  }
+  return 0;
 }
 
-int ctvae_pair_mlp_backward(const float* u, const float* v, const float* w2, const float* out, const float* g_out, float* d_u,
-                            float* d_v, float* d_w2_part, float* d_b2_part, int B, int N, int H, float slope, int per_sample,
-                            void* stream) {
+int ctvae_glinear_forward(const float* x, int ldx, int K, int nseg, int N, const float* const* W, const int* ldw,
+                          const int64_t* w_gstride, const float* const* bias, const int* b_gstride,
+                          const int32_t* const* group, float* y, int ldy, int B, void* stream) {
+  GLinArgs a{};
+  if (int rc = glin_fill(a, nseg, N, W, ldw, w_gstride, bias, b_gstride, group)) return rc;
+  a.x = x; a.ldx = ldx; a.K = K; a.y = y; a.ldy = ldy; a.B = B;
+  return launch_glinear_forward(a, (hipStream_t)stream);
+}
+
+int ctvae_glinear_dgrad(const float* dy, int ldy, int nseg, int N, const float* const* W, const int* ldw,
+                        const int64_t* w_gstride, const int32_t* const* group, float* dx, int ldx, int K, int B, void* stream) {
+  GLinArgs a{};
+  if (int rc = glin_fill(a, nseg, N, W, ldw, w_gstride, nullptr, nullptr, group)) return rc;
+  a.x = nullptr; a.ldx = ldx; a.K = K; a.y = const_cast<float*>(dy); a.ldy = ldy; a.B = B;
+  return launch_glinear_dgrad(a, dx, (hipStream_t)stream);
+}
+
+size_t ctvae_glinear_wgrad_ws_bytes(int G, int N, int K) { return glinear_wgrad_ws_floats(G, N, K, 1) * sizeof(float); }
+
+int ctvae_glinear_wgrad(const float* x, int ldx, int K, const float* dy, int ldy, int col0, int N, const int32_t* group, int G,
+                        int B, float* dW, int ldo, float* dbias, int accumulate, float* ws, size_t ws_bytes, void* stream) {
+  return launch_glinear_wgrad(x, ldx, K, dy, ldy, col0, N, group, G, B, dW, ldo, dbias, accumulate, ws, ws_bytes / sizeof(float),
+                              (hipStream_t)stream);
+}
+
+int ctvae_pair_mlp_forward(const float* u, const float* v, int ld, const float* w2, const float* b2, float* out, int B, int N,
+                           int H, float slope, int per_sample, const int32_t* row_of, void* stream) {
+  if (!u || !v || !w2 || !out) return kErrBadArg;
+  return launch_pair_mlp_forward(u, v, ld, w2, b2, out, B, N, H, slope, per_sample, row_of, (hipStream_t)stream);
+}
+
+int ctvae_pair_mlp_backward(const float* u, const float* v, int ld, const float* w2, const float* out, const float* g_out,
+                            float* d_u, float* d_v, int ldd, float* d_w2_part, float* d_b2_part, int B, int N, int H, float slope,
+                            int per_sample, const int32_t* row_of, void* stream) {
   if (!u || !v || !w2 || !out || !g_out || !d_u || !d_v || !d_w2_part || !d_b2_part) return kErrBadArg;
-  return launch_pair_mlp_backward(u, v, w2, out, g_out, d_u, d_v, d_w2_part, d_b2_part, B, N, H, slope, per_sample,
-                                  (hipStream_t)stream);
+  return launch_pair_mlp_backward(u, v, ld, w2, out, g_out, d_u, d_v, ldd, d_w2_part, d_b2_part, B, N, H, slope, per_sample,
+                                  row_of, (hipStream_t)stream);
 }
 
 int ctvae_permute(const float* in, float* out, int B, int C, int P, int to_nhwc, void* stream) {

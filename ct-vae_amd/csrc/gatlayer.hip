@@ -79,10 +79,12 @@ __device__ __forceinline__ void load_adj_block(const float* __restrict__ adj, in
 }
 
 // xl / xr of one head slot, transposed into LDS: T[k][n]
+// (a wave walks whole rows: no integer division per element, 256-byte global reads)
 __device__ __forceinline__ void stage_T(const float* __restrict__ src, long row0, int ld, int col0, int C, float* T) {
-  for (int e = threadIdx.x; e < GN * C; e += 256) {
-    const int n = e / C, k = e - n * C;
-    T[k * LS + n] = src[(row0 + n) * ld + col0 + k];
+  const int lane = threadIdx.x & 63;
+  for (int n = threadIdx.x >> 6; n < GN; n += 4) {
+    const float* row = src + (row0 + n) * ld + col0;
+    for (int k = lane; k < C; k += 64) T[k * LS + n] = row[k];
   }
 }
 
@@ -217,11 +219,13 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fwd_kernel(GatLayerArgs a) {
   {
     const float* O = XR;
     const int os = C | 1;
-    for (int e = tid; e < GN * C; e += 256) {
-      const int n = e / C, k = e - n * C;
-      float v = O[n * os + k] + a.bias[head * C + k];
-      if (a.act == ACT_LRELU) v = v > 0.f ? v : v * kLeaky;
-      a.out[((long)b * GN + n) * a.ldo + hs * C + k] = v;
+    for (int n = tid >> 6; n < GN; n += 4) {
+      float* row = a.out + ((long)b * GN + n) * a.ldo + hs * C;
+      for (int k = tid & 63; k < C; k += 64) {
+        float v = O[n * os + k] + a.bias[head * C + k];
+        if (a.act == ACT_LRELU) v = v > 0.f ? v : v * kLeaky;
+        row[k] = v;
+      }
     }
   }
 }
@@ -245,12 +249,13 @@ __global__ __launch_bounds__(256, 2) void gat_layer_bwd_kernel(GatBwdArgs p) {
   const int head = a.head_map ? a.head_map[b * a.Hs + hs] : hs;
   const int tr = tid >> 4, tc = tid & 15;
   stage_T(a.xl, (long)b * GN, a.ld, hs * C, C, XL);
-  for (int e = tid; e < GN * C; e += 256) {           // G[k][c] = g_out[c][k] * act'(out[c][k])
-    const int n = e / C, k = e - n * C;
-    const long o = ((long)b * GN + n) * a.ldo + hs * C + k;
-    float g = p.g_out[o];
-    if (a.act == ACT_LRELU) g *= a.out[o] > 0.f ? 1.f : kLeaky;
-    R2[k * LS + n] = g;
+  for (int n = tid >> 6; n < GN; n += 4) {              // G[k][c] = g_out[c][k] * act'(out[c][k])
+    const long o = ((long)b * GN + n) * a.ldo + hs * C;
+    for (int k = tid & 63; k < C; k += 64) {
+      float g = p.g_out[o + k];
+      if (a.act == ACT_LRELU) g *= a.out[o + k] > 0.f ? 1.f : kLeaky;
+      R2[k * LS + n] = g;
+    }
   }
   for (int k = tid; k < C; k += 256) {
     const float w = a.we[head * C + k];
@@ -353,9 +358,9 @@ __global__ __launch_bounds__(256, 2) void gat_layer_bwd_kernel(GatBwdArgs p) {
   __syncthreads();
   {
     const int os = C | 1;
-    for (int e = tid; e < GN * C; e += 256) {
-      const int n = e / C, k = e - n * C;
-      p.dxl[((long)b * GN + n) * p.ldd + hs * C + k] = R2[n * os + k];
+    for (int n = tid >> 6; n < GN; n += 4) {
+      float* row = p.dxl + ((long)b * GN + n) * p.ldd + hs * C;
+      for (int k = tid & 63; k < C; k += 64) row[k] = R2[n * os + k];
     }
   }
   __syncthreads();

@@ -26,17 +26,18 @@ constexpr int NMAX = 64;  // backward keeps u[i], dU[i] of one h in registers
 
 __global__ __launch_bounds__(256) void pair_mlp_fwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
                                                           const float* __restrict__ w2, const float* __restrict__ b2,
-                                                          float* __restrict__ out, int N, int H, float slope, int w2_bs,
-                                                          int b2_bs) {
+                                                          float* __restrict__ out, int N, int H, int ld, float slope, int w2_bs,
+                                                          int b2_bs, const int* __restrict__ row_of) {
   __shared__ float sV[HC][JT + 1];
   __shared__ __attribute__((aligned(8))) float sU[IT][HC];
   __shared__ __attribute__((aligned(8))) float sW[HC];
   const int tid = threadIdx.x, j_l = tid & (JT - 1), i_l = tid / JT;
   const int b = blockIdx.y, i = blockIdx.x * IT + i_l;
-  const float* ub = u + (long)b * N * H;
-  const float* vb = v + (long)b * N * H;
-  const float bias = b2 != nullptr ? b2[(long)b * b2_bs] : 0.f;
-  w2 += (long)b * w2_bs;               // per-sample scorer (w2_bs = H) or one shared scorer (0)
+  const float* ub = u + (long)b * N * ld;      // rows of stride ld (u / v may be column blocks of one wider GEMM output)
+  const float* vb = v + (long)b * N * ld;
+  const int wr = row_of ? row_of[b] : b;   // which row of the scorer bank this sample uses (row_of: the discoverer of its action)
+  const float bias = b2 != nullptr ? b2[(long)wr * b2_bs] : 0.f;
+  w2 += (long)wr * w2_bs;              // per-sample scorer (w2_bs = H) or one shared scorer (0)
   for (int j0 = 0; j0 < N; j0 += JT) {
     f32x2 acc2 = {0.f, 0.f};
     for (int h0 = 0; h0 < H; h0 += HC) {
@@ -45,12 +46,12 @@ __global__ __launch_bounds__(256) void pair_mlp_fwd_kernel(const float* __restri
       for (int e = tid; e < JT * HC; e += 256) {
         const int jj = e / HC, hh = e - jj * HC;
         const int j = j0 + jj, h = h0 + hh;
-        sV[hh][jj] = (j < N && h < H) ? vb[(long)j * H + h] : 0.f;
+        sV[hh][jj] = (j < N && h < H) ? vb[(long)j * ld + h] : 0.f;
       }
       if (tid < IT * HC) {
         const int ii = tid / HC, hh = tid - ii * HC;
         const int gi = blockIdx.x * IT + ii, h = h0 + hh;
-        sU[ii][hh] = (gi < N && h < H) ? ub[(long)gi * H + h] : 0.f;
+        sU[ii][hh] = (gi < N && h < H) ? ub[(long)gi * ld + h] : 0.f;
       }
       if (tid < HC) sW[tid] = (h0 + tid < H) ? w2[h0 + tid] : 0.f;   // zero weight masks the h tail
       __syncthreads();
@@ -75,12 +76,13 @@ __global__ __launch_bounds__(256) void pair_mlp_bwd_kernel(const float* __restri
                                                           const float* __restrict__ w2, const float* __restrict__ out,
                                                           const float* __restrict__ g_out, float* __restrict__ dU,
                                                           float* __restrict__ dV, float* __restrict__ dw2_part,
-                                                          float* __restrict__ db2_part, int N, int H, float slope, int w2_bs) {
+                                                          float* __restrict__ db2_part, int N, int H, int ld, int ldd, float slope,
+                                                          int w2_bs, const int* __restrict__ row_of) {
   __shared__ __attribute__((aligned(16))) float sG[NMAX][NMAX];   // [j][i] = g * s * (1 - s)
   __shared__ float sRed[4];
   const int tid = threadIdx.x, b = blockIdx.y, h = blockIdx.x * 256 + tid;
   const bool hok = h < H;
-  const long bo = (long)b * N * H;
+  const long bo = (long)b * N * ld, bd = (long)b * N * ldd;
   float gsum = 0.f;
   for (int e = tid; e < NMAX * NMAX; e += 256) {
     const int i = e / NMAX, j = e - i * NMAX;   // coalesced along j
@@ -99,15 +101,15 @@ __global__ __launch_bounds__(256) void pair_mlp_bwd_kernel(const float* __restri
   f32x2 ur[NMAX / 2], du[NMAX / 2];
 #pragma unroll
   for (int i = 0; i < NMAX; ++i) {
-    ur[i >> 1][i & 1] = (hok && i < N) ? u[bo + (long)i * H + h] : 0.f;
+    ur[i >> 1][i & 1] = (hok && i < N) ? u[bo + (long)i * ld + h] : 0.f;
     du[i >> 1][i & 1] = 0.f;
   }
-  const float wh = hok ? w2[(long)b * w2_bs + h] : 0.f;
+  const float wh = hok ? w2[(long)(row_of ? row_of[b] : b) * w2_bs + h] : 0.f;
   f32x2 dw2 = {0.f, 0.f};
   float v_next = hok ? v[bo + h] : 0.f;
   for (int j = 0; j < N; ++j) {
     const float vj = v_next;
-    if (j + 1 < N) v_next = hok ? v[bo + (long)(j + 1) * H + h] : 0.f;
+    if (j + 1 < N) v_next = hok ? v[bo + (long)(j + 1) * ld + h] : 0.f;
     const f32x2 vj2 = {vj, vj};
     f32x2 dvj2 = {0.f, 0.f};
 #pragma unroll
@@ -124,36 +126,36 @@ __global__ __launch_bounds__(256) void pair_mlp_bwd_kernel(const float* __restri
         dw2 += gd * t;                // g * lrelu(t) = g * sl * t
       }
     }
-    if (hok) dV[bo + (long)j * H + h] = wh * (dvj2[0] + dvj2[1]);
+    if (hok) dV[bd + (long)j * ldd + h] = wh * (dvj2[0] + dvj2[1]);
   }
   const float dw = dw2[0] + dw2[1];
   if (hok) {
 #pragma unroll
     for (int i = 0; i < NMAX; ++i)
-      if (i < N) dU[bo + (long)i * H + h] = wh * du[i >> 1][i & 1];
+      if (i < N) dU[bd + (long)i * ldd + h] = wh * du[i >> 1][i & 1];
     dw2_part[(long)b * H + h] = dw;
   }
 }
 
 }  // namespace
 
-int launch_pair_mlp_forward(const float* u, const float* v, const float* w2, const float* b2, float* out, int B, int N, int H,
-                            float slope, int per_sample, hipStream_t st) {
-  if (B <= 0 || N <= 0 || H <= 0) return kErrBadArg;
+int launch_pair_mlp_forward(const float* u, const float* v, int ld, const float* w2, const float* b2, float* out, int B, int N,
+                            int H, float slope, int per_sample, const int* row_of, hipStream_t st) {
+  if (B <= 0 || N <= 0 || H <= 0 || ld < H) return kErrBadArg;
   ProfScope ps("pair_mlp_fwd_kernel", st, 3.0 * B * (double)N * N * H, 4.0 * B * (2.0 * N * H + (double)N * N));
-  hipLaunchKernelGGL(pair_mlp_fwd_kernel, dim3((N + IT - 1) / IT, B), dim3(256), 0, st, u, v, w2, b2, out, N, H, slope,
-                     per_sample ? H : 0, per_sample ? 1 : 0);
+  hipLaunchKernelGGL(pair_mlp_fwd_kernel, dim3((N + IT - 1) / IT, B), dim3(256), 0, st, u, v, w2, b2, out, N, H, ld, slope,
+                     per_sample ? H : 0, per_sample ? 1 : 0, per_sample ? row_of : nullptr);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }
 
-int launch_pair_mlp_backward(const float* u, const float* v, const float* w2, const float* out, const float* g_out, float* dU,
-                             float* dV, float* dw2_part, float* db2_part, int B, int N, int H, float slope, int per_sample,
-                             hipStream_t st) {
-  if (B <= 0 || N <= 0 || H <= 0 || N > NMAX) return kErrBadArg;
+int launch_pair_mlp_backward(const float* u, const float* v, int ld, const float* w2, const float* out, const float* g_out,
+                             float* dU, float* dV, int ldd, float* dw2_part, float* db2_part, int B, int N, int H, float slope,
+                             int per_sample, const int* row_of, hipStream_t st) {
+  if (B <= 0 || N <= 0 || H <= 0 || N > NMAX || ld < H || ldd < H) return kErrBadArg;
   ProfScope ps("pair_mlp_bwd_kernel", st, 7.0 * B * (double)N * N * H, 4.0 * B * (4.0 * N * H + 2.0 * N * N));
   hipLaunchKernelGGL(pair_mlp_bwd_kernel, dim3((H + 255) / 256, B), dim3(256), 0, st, u, v, w2, out, g_out, dU, dV, dw2_part,
-                     db2_part, N, H, slope, per_sample ? H : 0);
+                     db2_part, N, H, ld, ldd, slope, per_sample ? H : 0, per_sample ? row_of : nullptr);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }

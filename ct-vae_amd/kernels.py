@@ -921,8 +921,8 @@ class PairMLP(Function):
         w2 = _c(w2) if per_sample else _c(w2.reshape(-1))
         b2 = _c(b2.reshape(-1))
         out = torch.empty((B, N, N), dtype=torch.float32, device=u.device)
-        native.call("ctvae_pair_mlp_forward", u.data_ptr(), v.data_ptr(), w2.data_ptr(), b2.data_ptr(), out.data_ptr(),
-                    B, N, H, PairMLP.SLOPE, 1 if per_sample else 0)
+        native.call("ctvae_pair_mlp_forward", u.data_ptr(), v.data_ptr(), H, w2.data_ptr(), b2.data_ptr(), out.data_ptr(),
+                    B, N, H, PairMLP.SLOPE, 1 if per_sample else 0, None)
         ctx.save_for_backward(u, v, w2, out)
         ctx.per_sample = per_sample
         return out
@@ -935,9 +935,9 @@ class PairMLP(Function):
         du, dv = torch.empty_like(u), torch.empty_like(v)
         dw2p = torch.empty((B, H), dtype=torch.float32, device=u.device)
         db2p = torch.empty(B, dtype=torch.float32, device=u.device)
-        native.call("ctvae_pair_mlp_backward", u.data_ptr(), v.data_ptr(), w2.data_ptr(), out.data_ptr(), g.data_ptr(),
-                    du.data_ptr(), dv.data_ptr(), dw2p.data_ptr(), db2p.data_ptr(), B, N, H, PairMLP.SLOPE,
-                    1 if ctx.per_sample else 0)
+        native.call("ctvae_pair_mlp_backward", u.data_ptr(), v.data_ptr(), H, w2.data_ptr(), out.data_ptr(), g.data_ptr(),
+                    du.data_ptr(), dv.data_ptr(), H, dw2p.data_ptr(), db2p.data_ptr(), B, N, H, PairMLP.SLOPE,
+                    1 if ctx.per_sample else 0, None)
         if ctx.per_sample:
             return du, dv, dw2p, db2p
         return du, dv, dw2p.sum(0), db2p.sum().reshape(1)
@@ -976,6 +976,157 @@ class GATScore(Function):
                         t.data_ptr(), B, N, H, C, ctx.slope)
             dattr = (g * t).sum(1)
         return dxl, dxr, dattr, dwep.sum(0), dattp.sum(0), None
+
+
+def banked(params) -> bool:
+    """True when the same-shaped contiguous tensors lie back to back in memory (FlatParamMixin places a module bank so)."""
+    p0 = params[0]
+    n = p0.numel() * p0.element_size()
+    return all(p.is_contiguous() and p.shape == p0.shape and p.data_ptr() == p0.data_ptr() + k * n for k, p in enumerate(params))
+
+
+class BankView(Function):
+    """The G same-shaped parameters of a module bank (back to back in memory, see ``banked``) as ONE [G, *shape] tensor
+    without a copy; backward hands every parameter its slice of the bank's gradient (views, no copies either)."""
+
+    @staticmethod
+    def forward(ctx, *params):
+        p0 = params[0]
+        if not banked(params):
+            raise RuntimeError("BankView: the parameters are not laid out as one bank")
+        n = p0.numel()
+        return p0.detach().as_strided((len(params),) + tuple(p0.shape), (n,) + tuple(p0.stride()))
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g[k] for k in range(g.shape[0]))
+
+
+def glinear_ok(K, N, *lds):
+    return K % 4 == 0 and N % 4 == 0 and all(l % 4 == 0 for l in lds)
+
+
+class GroupLinear(Function):
+    """y[b, m, s*N + n] = sum_k x[b, m, k] * W_s[group_s[b]][n][koff_s + k] + bias_s[group_s[b]][n] on blocks of 64 rows per
+    sample (csrc/glinear.hip).  x [B,64,K]; spec: per segment (koff, group) with group an int32 [B] tensor or None (everybody
+    uses matrix 0); wb: per segment the bank W [G,N,ldw >= koff+K] and its bias [G,N] or None.  Several segments may name the
+    same bank (autograd adds their gradients)."""
+
+    @staticmethod
+    def forward(ctx, x, K, N, spec, *wb):
+        import ctypes as C
+        _req_cuda(x, *[t for t in wb if t is not None])
+        x = _c(x)
+        B, M, ldx = x.shape
+        nseg = len(spec)
+        if M != 64 or ldx != K or len(wb) != 2 * nseg or not 1 <= nseg <= 4:
+            raise RuntimeError("GroupLinear: needs x [B,64,K] and (bank, bias) per segment, 1..4 segments")
+        Ws, bs, gs = [], [], []
+        for s, (koff, grp) in enumerate(spec):
+            W, b = wb[2 * s], wb[2 * s + 1]
+            if W.dim() != 3 or W.shape[1] != N or W.stride(2) != 1 or koff + K > W.shape[2] or (b is not None and not b.is_contiguous()):
+                raise RuntimeError("GroupLinear: bank must be [G,N,ldw] with unit inner stride")
+            if grp is not None and (grp.dtype != torch.int32 or grp.numel() != B or not grp.is_contiguous()):
+                raise RuntimeError("GroupLinear: group ids must be a contiguous int32 [B] tensor")
+            Ws.append(W)
+            bs.append(b)
+            gs.append(grp)
+        y = torch.empty((B, 64, nseg * N), dtype=torch.float32, device=x.device)
+        ctx.host = (
+            (C.c_void_p * nseg)(*[W.data_ptr() + 4 * spec[s][0] for s, W in enumerate(Ws)]),
+            (C.c_int * nseg)(*[W.stride(1) for W in Ws]),
+            (C.c_int64 * nseg)(*[W.stride(0) for W in Ws]),
+            (C.c_void_p * nseg)(*[native.ptr(b) for b in bs]),
+            (C.c_int * nseg)(*[(b.shape[-1] if b is not None else 0) for b in bs]),
+            (C.c_void_p * nseg)(*[native.ptr(g) for g in gs]),
+        )
+        h = ctx.host
+        native.call("ctvae_glinear_forward", x.data_ptr(), ldx, K, nseg, N, h[0], h[1], h[2], h[3], h[4], h[5], y.data_ptr(),
+                    nseg * N, B)
+        ctx.save_for_backward(x, *[t for t in Ws], *[g for g in gs if g is not None])
+        ctx.meta = (K, N, nseg, tuple(k for k, _ in spec), tuple(g is not None for g in gs), tuple(b is not None for b in bs))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        K, N, nseg, koffs, has_g, has_b = ctx.meta
+        saved = ctx.saved_tensors
+        x, Ws = saved[0], saved[1:1 + nseg]
+        grp_it = iter(saved[1 + nseg:])
+        gs = [next(grp_it) if hg else None for hg in has_g]
+        g = _c(g)
+        B = x.shape[0]
+        h = ctx.host
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            native.call("ctvae_glinear_dgrad", g.data_ptr(), nseg * N, nseg, N, h[0], h[1], h[2], h[5], dx.data_ptr(), K, K, B)
+        ws = native.workspace(x.device)
+        grads = []
+        for s in range(nseg):
+            W = Ws[s]
+            G = W.shape[0]
+            dW = db = None
+            if ctx.needs_input_grad[4 + 2 * s]:
+                full = koffs[s] == 0 and W.shape[2] == K and W.is_contiguous()
+                dW = torch.empty_like(W, memory_format=torch.contiguous_format) if full else torch.zeros_like(W, memory_format=torch.contiguous_format)
+                if has_b[s]:
+                    db = torch.empty((G, N), dtype=torch.float32, device=x.device)
+                native.call("ctvae_glinear_wgrad", x.data_ptr(), K, K, g.data_ptr(), nseg * N, s * N, N, native.ptr(gs[s]), G, B,
+                            dW.data_ptr() + 4 * koffs[s], dW.stride(1), native.ptr(db), 0, ws.data_ptr(), ws.numel() * 4)
+            grads += [dW, db]
+        return (dx, None, None, None) + tuple(grads)
+
+
+class PairScores(Function):
+    """Edge scores of every ordered node pair for the all-sample discoverer 0 and (grp given) the discoverer of each sample's
+    action, from the projections uv [B,64,nd*2*H] = [u0 | v0 | u_a | v_a] (GroupLinear), reading the scorer bank w2 [G,H] / b2 [G]
+    in place: out [nd,B,64,64], out[d][b,i,j] = sigmoid(b2 + sum_h w2[h] * lrelu(u[b,i,h] + v[b,j,h])) (csrc/pairmlp.hip;
+    ct_mcq_vae.py:86-95,147-151)."""
+
+    @staticmethod
+    def forward(ctx, uv, w2, b2, grp, H):
+        _req_cuda(uv, w2, b2)
+        uv, w2, b2 = _c(uv), _c(w2), _c(b2)
+        B, N, ld = uv.shape
+        nd = 2 if grp is not None else 1
+        if N != 64 or ld != nd * 2 * H or w2.shape[-1] != H:
+            raise RuntimeError("PairScores: uv must be [B,64,nd*2*H]")
+        out = torch.empty((nd, B, 64, 64), dtype=torch.float32, device=uv.device)
+        p = uv.data_ptr()
+        native.call("ctvae_pair_mlp_forward", p, p + 4 * H, ld, w2.data_ptr(), b2.data_ptr(), out[0].data_ptr(), B, 64, H,
+                    PairMLP.SLOPE, 0, None)
+        if nd == 2:
+            native.call("ctvae_pair_mlp_forward", p + 8 * H, p + 12 * H, ld, w2.data_ptr(), b2.data_ptr(), out[1].data_ptr(), B, 64,
+                        H, PairMLP.SLOPE, 1, grp.data_ptr())
+        ctx.save_for_backward(uv, w2, b2, grp, out)
+        ctx.H = H
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        uv, w2, b2, grp, out = ctx.saved_tensors
+        H = ctx.H
+        B, _, ld = uv.shape
+        nd = out.shape[0]
+        G = w2.shape[0]
+        g = _c(g)
+        d_uv = torch.empty_like(uv)
+        dw2p = torch.empty((nd, B, H), dtype=torch.float32, device=uv.device)
+        db2p = torch.empty((nd, B), dtype=torch.float32, device=uv.device)
+        p, d = uv.data_ptr(), d_uv.data_ptr()
+        native.call("ctvae_pair_mlp_backward", p, p + 4 * H, ld, w2.data_ptr(), out[0].data_ptr(), g[0].data_ptr(), d, d + 4 * H, ld,
+                    dw2p[0].data_ptr(), db2p[0].data_ptr(), B, 64, H, PairMLP.SLOPE, 0, None)
+        sel = torch.zeros((G, B), dtype=torch.float32, device=uv.device)
+        sel[0] = 1.0
+        parts = torch.cat([dw2p[0], db2p[0].unsqueeze(1)], 1)                      # [B, H+1]
+        dbank = sel @ parts                                                        # rows of the bank: discoverer 0 <- every sample
+        if nd == 2:
+            native.call("ctvae_pair_mlp_backward", p + 8 * H, p + 12 * H, ld, w2.data_ptr(), out[1].data_ptr(), g[1].data_ptr(),
+                        d + 8 * H, d + 12 * H, ld, dw2p[1].data_ptr(), db2p[1].data_ptr(), B, 64, H, PairMLP.SLOPE, 1, grp.data_ptr())
+            sel_a = torch.nn.functional.one_hot(grp.long(), G).to(torch.float32).t()         # [G,B]
+            dbank = dbank + sel_a @ torch.cat([dw2p[1], db2p[1].unsqueeze(1)], 1)
+        return d_uv, dbank[:, :H].contiguous(), dbank[:, H].contiguous(), None, None
 
 
 class GATLayer(Function):

@@ -100,24 +100,29 @@ class DenseGATv2(nn.Module):
         nn.init.zeros_(self.lin_r.bias)
 
     def fused_ok(self, x):
-        return x.is_cuda and x.size(1) == 64 and 16 <= self.out_channels <= 128
+        H, C = self.heads, self.out_channels
+        return (x.is_cuda and x.size(1) == 64 and 16 <= C <= 128 and C % 4 == 0 and self.lin_l.in_features % 4 == 0
+                and self.lin_l.weight.is_contiguous() and self.lin_r.weight.is_contiguous() and H <= 64)
 
     def forward_fused(self, x, adj, heads_sel=None, act=K.ACT_NONE):
         """HIP path (csrc/gatlayer.hip): x [B,64,Cin], adj [B,64,64]; heads_sel int [B,Hs] evaluates only those heads of each
         sample (slot order) -> [B,64,Hs*C]; act: the activation behind the layer, applied in the kernel's epilogue."""
         B = x.size(0)
         H, C = self.heads, self.out_channels
-        if heads_sel is None:
+        Kin = x.size(-1)
+        wl, wr = self.lin_l.weight, self.lin_r.weight
+        if heads_sel is None:           # every head: lin_l | lin_r as two segments of one grouped GEMM (group 0 for everybody)
             Hs = H
-            xlr = F.linear(x, torch.cat([self.lin_l.weight, self.lin_r.weight], 0), torch.cat([self.lin_l.bias, self.lin_r.bias], 0))
-        else:
+            xlr = K.GroupLinear.apply(x, Kin, H * C, ((0, None), (0, None)), wl.view(1, H * C, Kin), self.lin_l.bias.view(1, H * C),
+                                      wr.view(1, H * C, Kin), self.lin_r.bias.view(1, H * C))
+        else:                           # head slots: each slot reads the C rows of its head inside lin_l / lin_r
             Hs = heads_sel.size(1)
-            idx = heads_sel.long()
-            wl = self.lin_l.weight.view(H, C, -1)[idx].reshape(B, Hs * C, -1)
-            wr = self.lin_r.weight.view(H, C, -1)[idx].reshape(B, Hs * C, -1)
-            bl = self.lin_l.bias.view(H, C)[idx].reshape(B, Hs * C)
-            br = self.lin_r.bias.view(H, C)[idx].reshape(B, Hs * C)
-            xlr = torch.baddbmm(torch.cat([bl, br], 1).unsqueeze(1), x, torch.cat([wl, wr], 1).transpose(1, 2))
+            cols = [heads_sel[:, i].contiguous() for i in range(Hs)]
+            wb = []
+            for w, b in ((wl, self.lin_l.bias), (wr, self.lin_r.bias)):
+                for _ in range(Hs):
+                    wb += [w.view(H, C, Kin), b.view(H, C)]
+            xlr = K.GroupLinear.apply(x, Kin, C, tuple((0, g) for g in cols + cols), *wb)
         return K.GATLayer.apply(xlr, adj, self.lin_edge.weight.view(H, C), self.att[0], self.bias, heads_sel, Hs, C,
                                 self.negative_slope, act)
 
@@ -178,6 +183,40 @@ class _GraphTransitioner(nn.Module):
         return x
 
 
+class _DiscoverBank(nn.ModuleList):
+    """``graph_discovers``: 1 + action_dim edge scorers Sequential(Linear(2D, H), LeakyReLU, Linear(H, 1), Sigmoid)
+    (ct_mcq_vae.py:86-95) under the reference's parameter names, stored as four BANKS -- all first-layer weights back to
+    back, then the first-layer biases, the scorer rows, the scorer biases -- so that the kernels index the discoverer of a
+    sample's action inside the bank instead of gathering per-sample copies of the weights.  FlatParamMixin lays the banks
+    out (storage_blocks); a stand-alone module that is not under a flat root falls back to torch.stack."""
+
+    autograd_grads = True        # placed by storage_blocks(), but the gradients arrive through autograd (kernels.BankView)
+
+    def __init__(self, n, in_dim, hidden):
+        super().__init__([nn.Sequential(nn.Linear(in_dim, hidden), nn.LeakyReLU(), nn.Linear(hidden, 1), nn.Sigmoid())
+                          for _ in range(n)])
+        self.in_dim, self.hidden = in_dim, hidden
+
+    def _lists(self):
+        return ([d[0].weight for d in self], [d[0].bias for d in self], [d[2].weight for d in self], [d[2].bias for d in self])
+
+    def storage_blocks(self):
+        blocks = []
+        for plist in self._lists():
+            n = plist[0].numel()
+            views = [(p, k * n, tuple(p.shape), tuple(p.detach().contiguous().stride())) for k, p in enumerate(plist)]
+            blocks.append((-(-len(plist) * n // 4) * 4, views))       # every bank starts 16-byte aligned
+        return blocks
+
+    def tensors(self):
+        """(W1 [G,H,2D], b1 [G,H], w2 [G,H], b2 [G])"""
+        G, Hd = len(self), self.hidden
+        out = []
+        for plist in self._lists():
+            out.append(K.BankView.apply(*plist) if (plist[0].is_cuda and K.banked(plist)) else torch.stack(plist))
+        return out[0], out[1], out[2].reshape(G, Hd), out[3].reshape(G)
+
+
 class _ProdLastDim(torch.autograd.Function):
     """x.prod(-1) with a backward that never leaves the device: d/dx_i = g * prod_{j != i} x_j from an exclusive prefix
     and suffix product.  torch's own prod backward counts the zeros of x with .item() (a host sync, which also makes the
@@ -216,9 +255,7 @@ class CausalTransition(nn.Module):
         if latent_dims is None:
             latent_dims = [800, 100]
         self.latent_dims = latent_dims
-        self.graph_discovers = nn.ModuleList([
-            nn.Sequential(nn.Linear(2 * input_dim, latent_dims[0]), nn.LeakyReLU(), nn.Linear(latent_dims[0], 1), nn.Sigmoid())
-            for _ in range(action_dim + 1)])
+        self.graph_discovers = _DiscoverBank(action_dim + 1, 2 * input_dim, latent_dims[0])
         self.mask = nn.Sequential(nn.Linear(action_dim + input_dim, input_dim), nn.Sigmoid())
         self.nb_heads = 1 + action_dim
         self.graph_transitioner = _GraphTransitioner(input_dim, latent_dims[1:], self.nb_heads)
@@ -248,23 +285,23 @@ class CausalTransition(nn.Module):
         return sample_bernoulli_st(adjacency, "adj_gumbel")
 
     def _compute_adj(self, latent, action, mask):
+        """ct_mcq_vae.py:140-154.  W1 [x_i ; x_j] = W1a x_i + W1b x_j: the projections u = x W1a^T, v = x W1b^T + b1 of
+        discoverer 0 and of every sample's own discoverer are ONE grouped GEMM (kernels.GroupLinear), the all-pairs scorer
+        reads them and the scorer bank in place (kernels.PairScores).  mask None: no intervention (base mode)."""
+        D, Hd = latent.size(-1), self.latent_dims[0]
+        if latent.is_cuda and latent.size(1) == 64 and K.glinear_ok(D, Hd, 2 * D):
+            W1, b1, w2, b2 = self.graph_discovers.tensors()
+            if mask is None:
+                uv = K.GroupLinear.apply(latent, D, Hd, ((0, None), (D, None)), W1, None, W1, b1)
+                return K.PairScores.apply(uv, w2, b2, None, Hd)[0]
+            grp = (torch.argmax(action, dim=-1) + 1).to(torch.int32)
+            uv = K.GroupLinear.apply(latent, D, Hd, ((0, None), (D, None), (0, grp), (D, grp)), W1, None, W1, b1, W1, None, W1, b1)
+            s = K.PairScores.apply(uv, w2, b2, grp, Hd)
+            return s[0] * (1 - mask) + s[1] * mask
         no_inter = self._pair_coeffs(self.graph_discovers[0], latent)
         if mask is None:
             return no_inter
         ids = torch.argmax(action, dim=-1)
-        if latent.is_cuda and latent.size(1) <= 64:
-            # one launch for the whole batch: every sample is scored by the discoverer of its own action (weights
-            # gathered per sample), instead of one masked call per distinct action (no host sync on the action ids)
-            D = latent.size(-1)
-            discs = self.graph_discovers[1:]
-            w1 = torch.stack([d[0].weight for d in discs])[ids]            # [B,hidden,2D]
-            b1 = torch.stack([d[0].bias for d in discs])[ids]              # [B,hidden]
-            w2 = torch.stack([d[2].weight.view(-1) for d in discs])[ids]   # [B,hidden]
-            b2 = torch.stack([d[2].bias.view(()) for d in discs])[ids]     # [B]
-            u = torch.bmm(latent, w1[:, :, :D].transpose(1, 2))
-            v = torch.bmm(latent, w1[:, :, D:].transpose(1, 2)) + b1.unsqueeze(1)
-            inter = K.PairMLP.apply(u, v, w2, b2)
-            return no_inter * (1 - mask) + inter * mask
         inter = torch.zeros_like(no_inter)
         for i in set(ids.tolist()):
             sel = torch.where(ids == i)[0]

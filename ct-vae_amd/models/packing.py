@@ -128,8 +128,13 @@ class FlatParamMixin:
     """Mixin for nn.Module roots: one flat parameter buffer + one flat gradient buffer."""
 
     def _collect_blocks(self):
-        blocks, seen_groups = [], set()
-        claimed = set()
+        """[(numel, [(param, offset, size, stride), ...]), ...] in flat-buffer order; numel < 0 is an alignment marker (the
+        next block starts at a multiple of -numel floats).  Order: the HIP-layout blocks of the conv / BN / VQ modules, then the
+        banks of autograd-managed modules (``autograd_grads``: placed by the module, gradients from autograd), then every
+        other parameter in registration order -- so a sub-module made of torch-level parameters and banks (ct_layer) stays
+        one contiguous range (flat_range)."""
+        blocks, late, seen_groups = [], [], set()
+        claimed, autograd_ids = set(), set()
         for m in self.modules():
             grp = getattr(m, "_linear_group", None)
             if grp is not None:
@@ -138,11 +143,18 @@ class FlatParamMixin:
                     blocks.extend(grp.storage_blocks())
                 continue
             if hasattr(m, "storage_blocks") and m is not self:
-                blocks.extend(m.storage_blocks())
+                mb = m.storage_blocks()
+                if getattr(m, "autograd_grads", False):
+                    late.extend(mb)
+                    autograd_ids.update(id(p) for _, views in mb for p, *_ in views)
+                else:
+                    blocks.extend(mb)
+        blocks.append((-4, []))               # 16-byte aligned from here on: the grouped-Linear kernels read weights as float4
+        blocks.extend(late)
         for _, views in blocks:
             for p, *_ in views:
                 claimed.add(id(p))
-        self._torch_param_ids = set()
+        self._torch_param_ids = set(autograd_ids)
         for name, p in self.named_parameters():
             if id(p) not in claimed:   # any other parameter (e.g. torch-level sub-modules): contiguous block
                 pc = p.detach().contiguous()
@@ -153,7 +165,9 @@ class FlatParamMixin:
     def flatten_parameters(self):
         """(Re)build the flat parameter / gradient buffers on the parameters' current device, keeping values."""
         blocks = self._collect_blocks()
-        total = sum(n for n, _ in blocks)
+        total = 0
+        for n, _ in blocks:
+            total = -(-total // -n) * -n if n < 0 else total + n
         dev = next(self.parameters()).device
         flat = torch.zeros(total, dtype=torch.float32, device=dev)
         gflat = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -161,6 +175,9 @@ class FlatParamMixin:
         self._grad_views = []
         with torch.no_grad():
             for n, views in blocks:
+                if n < 0:
+                    off = -(-off // -n) * -n
+                    continue
                 for p, o, size, stride in views:
                     v = flat.as_strided(size, stride, off + o)
                     v.copy_(p.detach().to(dev))
@@ -202,8 +219,9 @@ class FlatParamMixin:
         if not spans:
             raise KeyError(prefix)
         lo, hi = spans[0][0], spans[-1][0] + spans[-1][1]
-        if sum(n for _, n in spans) != hi - lo:
-            raise RuntimeError(f"parameters of '{prefix}' are not contiguous in the flat buffer")
+        for n, p in self.named_parameters():       # (padding inside the range is fine: zero values, zero gradients)
+            if not n.startswith(prefix + ".") and lo <= (p.data_ptr() - base) // 4 < hi:
+                raise RuntimeError(f"parameters of '{prefix}' are not one contiguous range of the flat buffer ('{n}' lies inside)")
         return slice(lo, hi)
 
     @property

@@ -34,8 +34,11 @@ SIGNATURES = {
     "ctvae_gat_layer_forward": [_fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, _f, _i, _vp],
     "ctvae_gat_layer_backward": [_fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _fp,
                                  _fp, _i, _i, _i, _i, _f, _i, _vp],
-    "ctvae_pair_mlp_forward": [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _f, _i, _vp],
-    "ctvae_pair_mlp_backward": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _f, _i, _vp],
+    "ctvae_glinear_forward": [_fp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _fp, _i, _i, _vp],
+    "ctvae_glinear_dgrad": [_fp, _i, _i, _i, _vp, _vp, _vp, _vp, _fp, _i, _i, _i, _vp],
+    "ctvae_glinear_wgrad": [_fp, _i, _i, _fp, _i, _i, _i, _fp, _i, _i, _fp, _i, _fp, _i, _fp, _sz, _vp],
+    "ctvae_pair_mlp_forward": [_fp, _fp, _i, _fp, _fp, _fp, _i, _i, _i, _f, _i, _fp, _vp],
+    "ctvae_pair_mlp_backward": [_fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _f, _i, _fp, _vp],
     "ctvae_act_forward": [_fp, _fp, _l, _i, _vp],
     "ctvae_act_backward": [_fp, _fp, _fp, _l, _i, _vp],
     "ctvae_reparam_forward": [_fp, _l, _fp, _l, _fp, _fp, _i, _i, _vp],
@@ -75,6 +78,7 @@ _RESTYPES = {
     "ctvae_winograd_enable": _c.c_int,
     "ctvae_conv_wino_filter_floats": _c.c_size_t,
     "ctvae_dip_state_floats": _c.c_size_t,
+    "ctvae_glinear_wgrad_ws_bytes": _c.c_size_t,
     "ctvae_conv_input_transform_supported": _c.c_int,
     "ctvae_conv_wgrad_bn_apply_supported": _c.c_int,
 }
@@ -114,6 +118,7 @@ def load():
                        "ctvae_conv_backward_bn_rows": [_c.c_int] * 10 + [_c.c_size_t],
                        "ctvae_winograd_enable": [_c.c_int],
                        "ctvae_dip_state_floats": [_c.c_int, _c.c_int],
+                       "ctvae_glinear_wgrad_ws_bytes": [_c.c_int, _c.c_int, _c.c_int],
                        "ctvae_conv_wino_filter_floats": [_c.c_int] * 10 + [_c.c_size_t],
                        "ctvae_conv_input_transform_supported": [_c.c_int] * 10,
                        "ctvae_conv_wgrad_bn_apply_supported": [_c.c_int] * 10}.get(name, [])

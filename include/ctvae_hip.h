@@ -142,12 +142,15 @@ int ctvae_bn_backward(const float* g_a, const float* beta, const float* y, int R
  * No [B,N,N,H] tensor is ever materialised.  Backward (N <= 64): d_u, d_v [B,N,H]; d_w2_part [B][H] and d_b2_part [B]
  * are per-sample partials the caller sums over B (deterministic, no atomics).
  * per_sample = 1: w2 is [B][H] and b2 [B] -- every sample has its own scorer (the per-action discoverers of one batch in
- * ONE launch, ct_mcq_vae.py:149-151); the partials then ARE the gradients of those rows. */
-int ctvae_pair_mlp_forward(const float* u, const float* v, const float* w2, const float* b2, float* out, int B, int N, int H,
-                           float slope, int per_sample, void* stream);
-int ctvae_pair_mlp_backward(const float* u, const float* v, const float* w2, const float* out, const float* g_out, float* d_u,
-                            float* d_v, float* d_w2_part, float* d_b2_part, int B, int N, int H, float slope, int per_sample,
-                            void* stream);
+ * ONE launch, ct_mcq_vae.py:149-151); the partials then ARE the gradients of those rows.
+ * row_of [B] (per_sample only, may be NULL = the sample's own row): the row of the w2 / b2 bank sample b uses -- the bank of
+ * all discoverers is then read in place, indexed by the sample's action.
+ * u / v rows have stride ld (>= H), d_u / d_v rows stride ldd: they may be column blocks of one wider GEMM output / gradient. */
+int ctvae_pair_mlp_forward(const float* u, const float* v, int ld, const float* w2, const float* b2, float* out, int B, int N,
+                           int H, float slope, int per_sample, const int32_t* row_of, void* stream);
+int ctvae_pair_mlp_backward(const float* u, const float* v, int ld, const float* w2, const float* out, const float* g_out,
+                            float* d_u, float* d_v, int ldd, float* d_w2_part, float* d_b2_part, int B, int N, int H, float slope,
+                            int per_sample, const int32_t* row_of, void* stream);
 
 /* GATv2 attention scores of CausalTransition.graph_transitioner (ct_mcq_vae.py:103-114; torch_geometric GATv2Conv with
  * edge_dim=1 on dense graphs): xl, xr [B,N,H,C] = lin_l(x), lin_r(x); attr [B,N,N] edge attribute of r -> c (self loops
@@ -182,6 +185,28 @@ int ctvae_gat_layer_backward(const float* xl, const float* xr, int ld, const flo
                              const float* g_out, float* dS, float* dattr, float* d_xl, float* d_xr, int ldd, float* d_bias_part,
                              float* d_att_part, float* d_we_part, float* d_adj, int accumulate_dadj, int B, int Hs, int C,
                              float slope, int act, void* stream);
+
+/* Grouped Linear on blocks of 64 rows per sample (the 64 latent nodes of CausalTransition): per output segment s < nseg
+ * (<= 4) every sample picks one matrix of a stacked weight bank by its group id,
+ *   y[b, m, s*N + n] = sum_k x[b, m, k] * W[s][group[s][b]][n][k] + bias[s][group[s][b]][n],
+ * element (g, n, k) of bank s at W[s] + g*w_gstride[s] + n*ldw[s] + k, bias (may be NULL) at bias[s] + g*b_gstride[s] + n;
+ * group[s] == NULL: everybody uses matrix 0 (a plain nn.Linear).  Replaces the per-group nn.Linear calls + batch splitting
+ * of ct_mcq_vae.py:129-154 (graph_discovers[0] and graph_discovers[1+argmax(action)]) and the lin_l / lin_r rows of the two
+ * heads of the last GATv2Conv that _compute_y reads (:224-226), without gathering weights per sample.  W / ldw / w_gstride /
+ * bias / b_gstride / group are HOST arrays of nseg entries holding device pointers / ints.  K, N, ld*, strides: multiples of 4.
+ * dgrad: dx[b,m,k] = sum_s sum_n dy[b,m,s*N+n] * W[s][g][n][k].
+ * wgrad (one segment, columns col0..col0+N-1 of dy): dW[(g*N + n)*ldo + k] (+)= sum_{b: group[b]==g} sum_m dy[b,m,col0+n] *
+ * x[b,m,k] (ldo >= K: the destination may be a column block of a wider bank), dbias[g*N + n] (+)= column sums (may be NULL);
+ * batch slices meet in a fixed-order slab
+ * reduction inside ws (>= ctvae_glinear_wgrad_ws_bytes): deterministic, no atomics. */
+int ctvae_glinear_forward(const float* x, int ldx, int K, int nseg, int N, const float* const* W, const int* ldw,
+                          const int64_t* w_gstride, const float* const* bias, const int* b_gstride,
+                          const int32_t* const* group, float* y, int ldy, int B, void* stream);
+int ctvae_glinear_dgrad(const float* dy, int ldy, int nseg, int N, const float* const* W, const int* ldw,
+                        const int64_t* w_gstride, const int32_t* const* group, float* dx, int ldx, int K, int B, void* stream);
+size_t ctvae_glinear_wgrad_ws_bytes(int G, int N, int K);
+int ctvae_glinear_wgrad(const float* x, int ldx, int K, const float* dy, int ldy, int col0, int N, const int32_t* group, int G,
+                        int B, float* dW, int ldo, float* dbias, int accumulate, float* ws, size_t ws_bytes, void* stream);
 
 /* layout change at the NCHW API boundary: to_nhwc=1: in [B,C,P] -> out [B,P,C]; 0: the inverse
  * (torch.flatten on NCHW, vanilla_vae.py:85; .view(-1,512,2,2), vanilla_vae.py:102) */
