@@ -44,6 +44,16 @@ int launch_gat_score(int mode, const float* xl, const float* xr, const float* at
 int launch_gat_score_backward(const float* xl, const float* xr, const float* attr, const float* we, const float* att,
                               const float* g, float* dxl, float* dxr, float* datt_part, float* dwe_part, int B, int N, int H,
                               int C, float slope, hipStream_t st);
+int launch_ct_reg_forward(const float* adj, const float* graph, const float* uni, float* part, float ckl, float cgs, float cpt,
+                          int B, int N, hipStream_t st);
+int launch_ct_reg_backward(const float* adj, const float* graph, const float* uni, const float* part, const float* g_loss,
+                           float ckl, float cgs, float cpt, float* d_adj, float* d_graph, int B, int N, hipStream_t st);
+int launch_ct_blend_softmax_forward(const float* y, const float* mask, float* probs, long R, int Hs, int D, hipStream_t st);
+int launch_ct_blend_softmax_backward(const float* g, const float* probs, const float* y, const float* mask, float* dy, float* dmask,
+                                     long R, int Hs, int D, hipStream_t st);
+int launch_ct_latent_ce_forward(const float* probs, const long long* target, float* row_loss, long R, int D, hipStream_t st);
+int launch_ct_latent_ce_backward(const float* probs, const long long* target, const float* g_loss, float* d_probs, long R, int D,
+                                 hipStream_t st);
 int launch_pair_mlp_forward(const float* u, const float* v, int ld, const float* w2, const float* b2, float* out, int B, int N,
                             int H, float slope, int per_sample, const int* row_of, hipStream_t st);
 int launch_pair_mlp_backward(const float* u, const float* v, int ld, const float* w2, const float* out, const float* g_out,
@@ -347,6 +357,34 @@ int ctvae_gat_layer_backward(const float* xl, const float* xr, int ld, const flo
   p.g_out = g_out; p.dS = dS; p.dattr = dattr; p.dxl = d_xl; p.dxr = d_xr; p.ldd = ldd;
   p.dbias_part = d_bias_part; p.datt_part = d_att_part; p.dwe_part = d_we_part;
   return launch_gat_layer_backward(p, d_adj, accumulate_dadj, (hipStream_t)stream);
+}
+
+int ctvae_ct_reg_forward(const float* adj, const float* graph, const float* uniform, float* part4, float ckl, float cgs, float cpt,
+                         int B, int N, void* stream) {
+  return launch_ct_reg_forward(adj, graph, uniform, part4, ckl, cgs, cpt, B, N, (hipStream_t)stream);
+}
+
+int ctvae_ct_reg_backward(const float* adj, const float* graph, const float* uniform, const float* part4, const float* g_loss,
+                          float ckl, float cgs, float cpt, float* d_adj, float* d_graph, int B, int N, void* stream) {
+  return launch_ct_reg_backward(adj, graph, uniform, part4, g_loss, ckl, cgs, cpt, d_adj, d_graph, B, N, (hipStream_t)stream);
+}
+
+int ctvae_ct_blend_softmax_forward(const float* y, const float* mask, float* probs, long R, int Hs, int D, void* stream) {
+  return launch_ct_blend_softmax_forward(y, mask, probs, R, Hs, D, (hipStream_t)stream);
+}
+
+int ctvae_ct_blend_softmax_backward(const float* g, const float* probs, const float* y, const float* mask, float* dy, float* dmask,
+                                    long R, int Hs, int D, void* stream) {
+  return launch_ct_blend_softmax_backward(g, probs, y, mask, dy, dmask, R, Hs, D, (hipStream_t)stream);
+}
+
+int ctvae_ct_latent_ce_forward(const float* probs, const int64_t* target, float* row_loss, long R, int D, void* stream) {
+  return launch_ct_latent_ce_forward(probs, (const long long*)target, row_loss, R, D, (hipStream_t)stream);
+}
+
+int ctvae_ct_latent_ce_backward(const float* probs, const int64_t* target, const float* g_loss, float* d_probs, long R, int D,
+                                void* stream) {
+  return launch_ct_latent_ce_backward(probs, (const long long*)target, g_loss, d_probs, R, D, (hipStream_t)stream);
 }
 
 static int glin_fill(GLinArgs& a, int nseg, int N, const float* const* W, const int* ldw, const int64_t* w_gstride,

@@ -1,0 +1,279 @@
+// Row / sample-wise pieces of CausalTransition (ct_mcq_vae.py) that were chains of 5-15 tiny torch launches each, forward and
+// again in autograd's backward.  All are HBM / launch bound (a few MB per launch); the point is one launch instead of ten.
+//
+//   ct_reg_fwd/bwd_kernel        forward_action's regulariser (ct_mcq_vae.py:275, 314-323), one workgroup per sample:
+//                                  beta * KL(softmax(u) || softmax(adj))  (adjacency_KL_loss: kl_div(log_softmax(adj), target,
+//                                  'batchmean') with target = softmax(rand))
+//                                + delta * mean_b ||graph_b||_F            (graph_size_loss)
+//                                + epsilon * mean_b || prod_j (1 - adj_b[i,j]) ||_2   (positive_trial_loss)
+//                                the product's gradient through exclusive prefix / suffix products in the wave (exact with
+//                                zeros, no division)
+//   ct_blend_softmax_fwd/bwd     _compute_y's tail (:226-228): softmax_d( y0 * (1 - mask) + y1 * mask ), one wave per node
+//   ct_latent_ce_fwd/bwd         latent_CrossEntropy_loss (:306-311): cross_entropy(log(clamp(p, 1e-4)), target), one wave per node
+#include "common.hpp"
+#include "prof.hpp"
+
+namespace ctvae {
+
+namespace {
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float wave_prod(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v *= __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide (256 threads) reductions of two values at once; results valid in every thread
+__device__ __forceinline__ void block_max2(float& a, float& b, float* sm /* >= 8 */) {
+  a = wave_max(a);
+  b = wave_max(b);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { sm[w] = a; sm[4 + w] = b; }
+  __syncthreads();
+  a = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+  b = fmaxf(fmaxf(sm[4], sm[5]), fmaxf(sm[6], sm[7]));
+}
+
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* sm /* >= 8 */) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { sm[w] = a; sm[4 + w] = b; }
+  __syncthreads();
+  a = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+  b = (sm[4] + sm[5]) + (sm[6] + sm[7]);
+}
+
+constexpr int RN = 64;            // nodes
+constexpr int RE = RN * RN / 256; // elements per thread (16): element e = tid + 256*i -> row (tid >> 6) + 4*i, column tid & 63
+
+struct RegStats {                 // what the backward needs again (recomputed, not stored)
+  float ma, lsa, mu, lsu;         // max / log-sum-exp of adj and of the uniform draws
+};
+
+__device__ __forceinline__ RegStats reg_softmax_stats(const float (&a)[RE], const float (&u)[RE], float* sm) {
+  float ma = -INFINITY, mu = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < RE; ++i) { ma = fmaxf(ma, a[i]); mu = fmaxf(mu, u[i]); }
+  block_max2(ma, mu, sm);
+  float sa = 0.f, su = 0.f;
+#pragma unroll
+  for (int i = 0; i < RE; ++i) { sa += __expf(a[i] - ma); su += __expf(u[i] - mu); }
+  block_sum2(sa, su, sm);
+  return RegStats{ma, __logf(sa), mu, __logf(su)};
+}
+
+// part [B][4] = {kl_b, ||graph_b||_F, ||prod||_2, ckl*kl_b + cgs*||graph_b||_F + cpt*||prod||_2}
+__global__ __launch_bounds__(256) void ct_reg_fwd_kernel(const float* __restrict__ adj, const float* __restrict__ graph,
+                                                        const float* __restrict__ uni, float* __restrict__ part, float ckl,
+                                                        float cgs, float cpt) {
+  __shared__ float sm[8];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const long o = (long)b * RN * RN;
+  float a[RE], u[RE], g2 = 0.f, pp = 0.f;
+#pragma unroll
+  for (int i = 0; i < RE; ++i) {
+    a[i] = adj[o + tid + 256 * i];
+    u[i] = uni[o + tid + 256 * i];
+    const float g = graph[o + tid + 256 * i];
+    g2 += g * g;
+    const float p = wave_prod(1.f - a[i]);     // the wave holds one whole row of the adjacency
+    pp += p * p;                                // (identical in every lane; counted once below)
+  }
+  const RegStats st = reg_softmax_stats(a, u, sm);
+  float kl = 0.f;
+#pragma unroll
+  for (int i = 0; i < RE; ++i) {
+    const float lt = u[i] - st.mu - st.lsu;    // log target
+    kl += __expf(lt) * (lt - (a[i] - st.ma - st.lsa));
+  }
+  if ((tid & 63) != 0) pp = 0.f;
+  block_sum2(kl, g2, sm);
+  float zero = 0.f;
+  block_sum2(pp, zero, sm);
+  if (tid == 0) {
+    part[4 * b] = kl;
+    part[4 * b + 1] = sqrtf(g2);
+    part[4 * b + 2] = sqrtf(pp);
+    part[4 * b + 3] = ckl * kl + cgs * sqrtf(g2) + cpt * sqrtf(pp);
+  }
+}
+
+// d adj = ckl * (softmax(adj) - target) - cpt / pt_b * P_i * prod_{j' != j}(1 - adj[i,j']);  d graph = cgs * graph / gs_b
+__global__ __launch_bounds__(256) void ct_reg_bwd_kernel(const float* __restrict__ adj, const float* __restrict__ graph,
+                                                        const float* __restrict__ uni, const float* __restrict__ part,
+                                                        const float* __restrict__ g_loss, float ckl, float cgs, float cpt,
+                                                        float* __restrict__ d_adj, float* __restrict__ d_graph) {
+  __shared__ float sm[8];
+  const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
+  const long o = (long)b * RN * RN;
+  const float gl = g_loss[0];
+  float a[RE], u[RE];
+#pragma unroll
+  for (int i = 0; i < RE; ++i) {
+    a[i] = adj[o + tid + 256 * i];
+    u[i] = uni[o + tid + 256 * i];
+  }
+  const RegStats st = reg_softmax_stats(a, u, sm);
+  const float gs = part[4 * b + 1], pt = part[4 * b + 2];
+  const float kgs = gs > 0.f ? gl * cgs / gs : 0.f, kpt = pt > 0.f ? gl * cpt / pt : 0.f, kkl = gl * ckl;
+#pragma unroll
+  for (int i = 0; i < RE; ++i) {
+    const float q = 1.f - a[i];
+    // exclusive prefix and suffix products along the row (the wave), log-step scans
+    float pre = q, suf = q;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const float up = __shfl_up(pre, d, 64), dn = __shfl_down(suf, d, 64);
+      if (lane >= d) pre *= up;
+      if (lane + d < 64) suf *= dn;
+    }
+    const float row = __shfl(pre, 63, 64);                         // P_i
+    float ex = __shfl_up(pre, 1, 64), sx = __shfl_down(suf, 1, 64);
+    if (lane == 0) ex = 1.f;
+    if (lane == 63) sx = 1.f;
+    const float others = ex * sx;                                  // prod over j' != j
+    const float dkl = __expf(a[i] - st.ma - st.lsa) - __expf(u[i] - st.mu - st.lsu);
+    d_adj[o + tid + 256 * i] = kkl * dkl - kpt * row * others;
+    d_graph[o + tid + 256 * i] = kgs * graph[o + tid + 256 * i];
+  }
+}
+
+// one wave per row r < R; y [R][Hs][D], mask [R] (Hs == 2), D <= 64
+__global__ __launch_bounds__(256) void ct_blend_softmax_fwd_kernel(const float* __restrict__ y, const float* __restrict__ mask,
+                                                                  float* __restrict__ probs, long R, int Hs, int D) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const bool ok = lane < D;
+  float v = ok ? y[(r * Hs) * D + lane] : -INFINITY;
+  if (Hs == 2) {
+    const float m = mask[r];
+    const float v1 = ok ? y[(r * Hs + 1) * D + lane] : 0.f;
+    v = ok ? v * (1.f - m) + v1 * m : -INFINITY;
+  }
+  const float mx = wave_max(v);
+  const float e = ok ? __expf(v - mx) : 0.f;
+  const float s = wave_sum(e);
+  if (ok) probs[r * D + lane] = e / s;
+}
+
+__global__ __launch_bounds__(256) void ct_blend_softmax_bwd_kernel(const float* __restrict__ g, const float* __restrict__ probs,
+                                                                  const float* __restrict__ y, const float* __restrict__ mask,
+                                                                  float* __restrict__ dy, float* __restrict__ dmask, long R, int Hs,
+                                                                  int D) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const bool ok = lane < D;
+  const float p = ok ? probs[r * D + lane] : 0.f, gv = ok ? g[r * D + lane] : 0.f;
+  const float dot = wave_sum(p * gv);
+  const float dv = p * (gv - dot);
+  if (Hs == 2) {
+    const float m = mask[r];
+    float dm = 0.f;
+    if (ok) {
+      dy[(r * 2) * D + lane] = dv * (1.f - m);
+      dy[(r * 2 + 1) * D + lane] = dv * m;
+      dm = dv * (y[(r * 2 + 1) * D + lane] - y[(r * 2) * D + lane]);
+    }
+    dm = wave_sum(dm);
+    if (lane == 0 && dmask != nullptr) dmask[r] = dm;
+  } else if (ok) {
+    dy[r * D + lane] = dv;
+  }
+}
+
+// row_loss[r] = logsumexp_d(lp) - lp[target[r]], lp = log(max(p, 1e-4))
+__global__ __launch_bounds__(256) void ct_latent_ce_fwd_kernel(const float* __restrict__ probs, const long long* __restrict__ target,
+                                                              float* __restrict__ row_loss, long R, int D) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const bool ok = lane < D;
+  const float lp = ok ? __logf(fmaxf(probs[r * D + lane], 1e-4f)) : -INFINITY;
+  const float mx = wave_max(lp);
+  const float s = wave_sum(ok ? __expf(lp - mx) : 0.f);
+  const float lt = __shfl(lp, (int)target[r], 64);
+  if (lane == 0) row_loss[r] = mx + __logf(s) - lt;
+}
+
+__global__ __launch_bounds__(256) void ct_latent_ce_bwd_kernel(const float* __restrict__ probs, const long long* __restrict__ target,
+                                                              const float* __restrict__ g_loss, float* __restrict__ d_probs, long R,
+                                                              int D) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const bool ok = lane < D;
+  const float p = ok ? probs[r * D + lane] : 1.f;
+  const float lp = ok ? __logf(fmaxf(p, 1e-4f)) : -INFINITY;
+  const float mx = wave_max(lp);
+  const float e = ok ? __expf(lp - mx) : 0.f;
+  const float s = wave_sum(e);
+  const float dlp = (e / s - (lane == (int)target[r] ? 1.f : 0.f)) * (g_loss[0] / (float)R);
+  if (ok) d_probs[r * D + lane] = p > 1e-4f ? dlp / p : 0.f;      // clamp(min=1e-4) passes no gradient below the bound
+}
+
+}  // namespace
+
+int launch_ct_reg_forward(const float* adj, const float* graph, const float* uni, float* part, float ckl, float cgs, float cpt,
+                          int B, int N, hipStream_t st) {
+  if (!adj || !graph || !uni || !part || B <= 0 || N != RN) return kErrBadArg;
+  ProfScope ps("ct_reg_fwd_kernel", st, 0.0, 4.0 * B * 3.0 * N * N);
+  hipLaunchKernelGGL(ct_reg_fwd_kernel, dim3(B), dim3(256), 0, st, adj, graph, uni, part, ckl, cgs, cpt);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_ct_reg_backward(const float* adj, const float* graph, const float* uni, const float* part, const float* g_loss,
+                           float ckl, float cgs, float cpt, float* d_adj, float* d_graph, int B, int N, hipStream_t st) {
+  if (!adj || !graph || !uni || !part || !g_loss || !d_adj || !d_graph || B <= 0 || N != RN) return kErrBadArg;
+  ProfScope ps("ct_reg_bwd_kernel", st, 0.0, 4.0 * B * 5.0 * N * N);
+  hipLaunchKernelGGL(ct_reg_bwd_kernel, dim3(B), dim3(256), 0, st, adj, graph, uni, part, g_loss, ckl, cgs, cpt, d_adj, d_graph);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_ct_blend_softmax_forward(const float* y, const float* mask, float* probs, long R, int Hs, int D, hipStream_t st) {
+  if (!y || !probs || R <= 0 || D <= 0 || D > 64 || (Hs != 1 && Hs != 2) || (Hs == 2 && !mask)) return kErrBadArg;
+  ProfScope ps("ct_blend_softmax_fwd_kernel", st, 0.0, 4.0 * R * (Hs + 1.0) * D);
+  hipLaunchKernelGGL(ct_blend_softmax_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, y, mask, probs, R, Hs, D);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_ct_blend_softmax_backward(const float* g, const float* probs, const float* y, const float* mask, float* dy, float* dmask,
+                                     long R, int Hs, int D, hipStream_t st) {
+  if (!g || !probs || !y || !dy || R <= 0 || D <= 0 || D > 64 || (Hs != 1 && Hs != 2) || (Hs == 2 && !mask)) return kErrBadArg;
+  ProfScope ps("ct_blend_softmax_bwd_kernel", st, 0.0, 4.0 * R * (2.0 * Hs + 2.0) * D);
+  hipLaunchKernelGGL(ct_blend_softmax_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, g, probs, y, mask, dy, dmask, R, Hs, D);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_ct_latent_ce_forward(const float* probs, const long long* target, float* row_loss, long R, int D, hipStream_t st) {
+  if (!probs || !target || !row_loss || R <= 0 || D <= 0 || D > 64) return kErrBadArg;
+  ProfScope ps("ct_latent_ce_fwd_kernel", st, 0.0, 4.0 * R * D);
+  hipLaunchKernelGGL(ct_latent_ce_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, probs, target, row_loss, R, D);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_ct_latent_ce_backward(const float* probs, const long long* target, const float* g_loss, float* d_probs, long R, int D,
+                                 hipStream_t st) {
+  if (!probs || !target || !g_loss || !d_probs || R <= 0 || D <= 0 || D > 64) return kErrBadArg;
+  ProfScope ps("ct_latent_ce_bwd_kernel", st, 0.0, 8.0 * R * D);
+  hipLaunchKernelGGL(ct_latent_ce_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, probs, target, g_loss, d_probs, R, D);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace ctvae

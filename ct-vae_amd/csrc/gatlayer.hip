@@ -78,13 +78,26 @@ __device__ __forceinline__ void load_adj_block(const float* __restrict__ adj, in
   }
 }
 
-// xl / xr of one head slot, transposed into LDS: T[k][n]
-// (a wave walks whole rows: no integer division per element, 256-byte global reads)
+// xl / xr of one head slot, transposed into LDS: T[k][n].  16-byte global loads, all of a thread's loads issued before the
+// first LDS store (<= 8 per thread for C <= 128), so their latencies overlap; C % 4 == 0.
 __device__ __forceinline__ void stage_T(const float* __restrict__ src, long row0, int ld, int col0, int C, float* T) {
-  const int lane = threadIdx.x & 63;
-  for (int n = threadIdx.x >> 6; n < GN; n += 4) {
-    const float* row = src + (row0 + n) * ld + col0;
-    for (int k = lane; k < C; k += 64) T[k * LS + n] = row[k];
+  const int c4 = C >> 2, n4 = GN * c4;
+  f32x4 v[8];
+  int nn[8], kk[8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int e = threadIdx.x + 256 * it;
+    const int n = e / c4;
+    nn[it] = n;
+    kk[it] = (e - n * c4) * 4;
+    if (e < n4) v[it] = *reinterpret_cast<const f32x4*>(src + (row0 + n) * ld + col0 + kk[it]);
+  }
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    if (threadIdx.x + 256 * it < n4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) T[(kk[it] + j) * LS + nn[it]] = v[it][j];
+    }
   }
 }
 
@@ -249,12 +262,31 @@ __global__ __launch_bounds__(256, 2) void gat_layer_bwd_kernel(GatBwdArgs p) {
   const int head = a.head_map ? a.head_map[b * a.Hs + hs] : hs;
   const int tr = tid >> 4, tc = tid & 15;
   stage_T(a.xl, (long)b * GN, a.ld, hs * C, C, XL);
-  for (int n = tid >> 6; n < GN; n += 4) {              // G[k][c] = g_out[c][k] * act'(out[c][k])
-    const long o = ((long)b * GN + n) * a.ldo + hs * C;
-    for (int k = tid & 63; k < C; k += 64) {
-      float g = p.g_out[o + k];
-      if (a.act == ACT_LRELU) g *= a.out[o + k] > 0.f ? 1.f : kLeaky;
-      R2[k * LS + n] = g;
+  {                                                     // G[k][c] = g_out[c][k] * act'(out[c][k])
+    const int c4 = C >> 2, n4 = GN * c4;
+    f32x4 gv[8], ov[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int e = tid + 256 * it;
+      const int n = e / c4;
+      const long o = ((long)b * GN + n) * a.ldo + hs * C + (e - n * c4) * 4;
+      if (e < n4) {
+        gv[it] = *reinterpret_cast<const f32x4*>(p.g_out + o);
+        if (a.act == ACT_LRELU) ov[it] = *reinterpret_cast<const f32x4*>(a.out + o);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int e = tid + 256 * it;
+      if (e < n4) {
+        const int n = e / c4, k = (e - n * c4) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float g = gv[it][j];
+          if (a.act == ACT_LRELU) g *= ov[it][j] > 0.f ? 1.f : kLeaky;
+          R2[(k + j) * LS + n] = g;
+        }
+      }
     }
   }
   for (int k = tid; k < C; k += 256) {
@@ -540,7 +572,7 @@ size_t bwd_smem(int C) { return ((size_t)2 * C * LS + GN * SS + 2 * C + 2 * 16 *
 
 bool args_ok(const GatLayerArgs& a) {
   return a.xl && a.xr && a.adj && a.we && a.att && a.bias && a.out && a.alpha && a.B > 0 && a.Hs > 0 && a.C >= 16 && a.C <= 128 &&
-         a.ld >= a.Hs * a.C && a.ldo >= a.Hs * a.C && a.slope > 0.f && a.slope < 1.f && (a.act == ACT_NONE || a.act == ACT_LRELU);
+         a.C % 4 == 0 && a.ld % 4 == 0 && a.ldo % 4 == 0 && a.ld >= a.Hs * a.C && a.ldo >= a.Hs * a.C && a.slope > 0.f && a.slope < 1.f && (a.act == ACT_NONE || a.act == ACT_LRELU);
 }
 
 }  // namespace
@@ -568,7 +600,7 @@ int launch_gat_layer_forward(const GatLayerArgs& a, hipStream_t st) {
 int launch_gat_layer_backward(const GatBwdArgs& p, float* dadj, int accumulate_dadj, hipStream_t st) {
   const GatLayerArgs& a = p.f;
   if (!args_ok(a) || !p.g_out || !p.dS || !p.dattr || !p.dxl || !p.dxr || !p.dbias_part || !p.datt_part || !p.dwe_part ||
-      p.ldd < a.Hs * a.C)
+      p.ldd < a.Hs * a.C || p.ldd % 4)
     return kErrBadArg;
   static bool attr_set = false;
   if (!attr_set) {

@@ -46,16 +46,21 @@ __global__ __launch_bounds__(256) void glinear_fwd_kernel(GLinArgs a) {
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  // the next chunk's global loads are in flight while the MFMAs of the current one run (register double buffer)
+  f32x4 a0 = ld4(xrow + lk, lk < a.K), a1 = ld4(xrow + lk + 4, lk + 4 < a.K);
+  f32x4 b0 = ld4(wrow + lk, wok && lk < a.K), b1 = ld4(wrow + lk + 4, wok && lk + 4 < a.K);
   for (int k0 = 0; k0 < a.K; k0 += 32) {
-    const int k = k0 + lk;
-    const f32x4 a0 = ld4(xrow + k, k < a.K), a1 = ld4(xrow + k + 4, k + 4 < a.K);
-    const f32x4 b0 = ld4(wrow + k, wok && k < a.K), b1 = ld4(wrow + k + 4, wok && k + 4 < a.K);
     __syncthreads();
     *reinterpret_cast<f32x4*>(&As[lrow * LP + lk]) = a0;
     *reinterpret_cast<f32x4*>(&As[lrow * LP + lk + 4]) = a1;
     *reinterpret_cast<f32x4*>(&Bs[lrow * LP + lk]) = b0;
     *reinterpret_cast<f32x4*>(&Bs[lrow * LP + lk + 4]) = b1;
     __syncthreads();
+    const int k = k0 + 32 + lk;
+    if (k0 + 32 < a.K) {
+      a0 = ld4(xrow + k, k < a.K); a1 = ld4(xrow + k + 4, k + 4 < a.K);
+      b0 = ld4(wrow + k, wok && k < a.K); b1 = ld4(wrow + k + 4, wok && k + 4 < a.K);
+    }
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) {
       const f32x4 af = *reinterpret_cast<const f32x4*>(&As[(wm * 32 + li) * LP + kg * 8 + 4 * lh]);
@@ -86,30 +91,35 @@ __global__ __launch_bounds__(256) void glinear_dgrad_kernel(GLinArgs a, float* _
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  for (int seg = 0; seg < a.nseg; ++seg) {
+  const int cps = (a.N + 31) >> 5, nch = cps * a.nseg;       // chunks per segment, chunks in all
+  f32x4 a0, a1, b0, b1;
+  auto fetch = [&](int ch) {
+    const int seg = ch / cps, n0 = (ch - seg * cps) * 32;
     const int g = a.group[seg] ? a.group[seg][b] : 0;
-    const float* Wg = a.W[seg] + (long)g * a.wgs[seg];
-    const int ldw = a.ldw[seg];
     const float* yrow = a.y + ((long)b * 64 + lrow) * a.ldy + seg * a.N;
-    for (int n0 = 0; n0 < a.N; n0 += 32) {
-      const int n = n0 + lk;
-      const f32x4 a0 = ld4(yrow + n, n < a.N), a1 = ld4(yrow + n + 4, n + 4 < a.N);
-      const bool nok = n0 + brow < a.N;
-      const float* wr = Wg + (long)(n0 + brow) * ldw + kt0 + bk;
-      const f32x4 b0 = ld4(wr, nok && kt0 + bk < a.K), b1 = ld4(wr + 4, nok && kt0 + bk + 4 < a.K);
-      __syncthreads();
-      *reinterpret_cast<f32x4*>(&As[lrow * LP + lk]) = a0;
-      *reinterpret_cast<f32x4*>(&As[lrow * LP + lk + 4]) = a1;
-      *reinterpret_cast<f32x4*>(&Bs[brow * LQ + bk]) = b0;
-      *reinterpret_cast<f32x4*>(&Bs[brow * LQ + bk + 4]) = b1;
-      __syncthreads();
+    const int n = n0 + lk;
+    a0 = ld4(yrow + n, n < a.N);
+    a1 = ld4(yrow + n + 4, n + 4 < a.N);
+    const bool nok = n0 + brow < a.N;
+    const float* wr = a.W[seg] + (long)g * a.wgs[seg] + (long)(n0 + brow) * a.ldw[seg] + kt0 + bk;
+    b0 = ld4(wr, nok && kt0 + bk < a.K);
+    b1 = ld4(wr + 4, nok && kt0 + bk + 4 < a.K);
+  };
+  fetch(0);
+  for (int ch = 0; ch < nch; ++ch) {
+    __syncthreads();
+    *reinterpret_cast<f32x4*>(&As[lrow * LP + lk]) = a0;
+    *reinterpret_cast<f32x4*>(&As[lrow * LP + lk + 4]) = a1;
+    *reinterpret_cast<f32x4*>(&Bs[brow * LQ + bk]) = b0;
+    *reinterpret_cast<f32x4*>(&Bs[brow * LQ + bk + 4]) = b1;
+    __syncthreads();
+    if (ch + 1 < nch) fetch(ch + 1);
 #pragma unroll
-      for (int kg = 0; kg < 4; ++kg) {
-        const f32x4 af = *reinterpret_cast<const f32x4*>(&As[(wm * 32 + li) * LP + kg * 8 + 4 * lh]);
+    for (int kg = 0; kg < 4; ++kg) {
+      const f32x4 af = *reinterpret_cast<const f32x4*>(&As[(wm * 32 + li) * LP + kg * 8 + 4 * lh]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], Bs[(kg * 8 + 4 * lh + j) * LQ + wn * 32 + li], acc, 0, 0, 0);
-      }
+      for (int j = 0; j < 4; ++j)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], Bs[(kg * 8 + 4 * lh + j) * LQ + wn * 32 + li], acc, 0, 0, 0);
     }
   }
   const int col = kt0 + wn * 32 + li;
@@ -144,31 +154,45 @@ __global__ __launch_bounds__(256) void glinear_wgrad_kernel(GLinWgArgs a) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   float bsum = 0.f;                                     // column sum of dy for column n0 + tid (tid < 64), k-tile 0 only
-  for (int b = b_lo; b < b_hi; ++b) {
-    if ((a.group ? a.group[b] : 0) != g) continue;      // uniform across the workgroup (no group ids: everybody is in group 0)
-#pragma unroll 1
-    for (int m0 = 0; m0 < 64; m0 += 32) {
-      const float* dr = a.dy + ((long)b * 64 + m0 + row) * a.ldy + a.col0 + n0 + cq;
-      const float* xr = a.x + ((long)b * 64 + m0 + row) * a.ldx + k0 + cq;
-      const f32x4 d0 = ld4(dr, n0 + cq < a.N), d1 = ld4(dr + 4, n0 + cq + 4 < a.N);
-      const f32x4 x0 = ld4(xr, k0 + cq < a.K), x1 = ld4(xr + 4, k0 + cq + 4 < a.K);
-      __syncthreads();
-      *reinterpret_cast<f32x4*>(&Ds[row * LQ + cq]) = d0;
-      *reinterpret_cast<f32x4*>(&Ds[row * LQ + cq + 4]) = d1;
-      *reinterpret_cast<f32x4*>(&Xs[row * LQ + cq]) = x0;
-      *reinterpret_cast<f32x4*>(&Xs[row * LQ + cq + 4]) = x1;
-      __syncthreads();
+  __shared__ int sList[64];                             // the samples of this slice that belong to group g (<= 64 per slice)
+  __shared__ int sCount;
+  if (tid == 0) {
+    int c = 0;
+    for (int b = b_lo; b < b_hi; ++b)
+      if ((a.group ? a.group[b] : 0) == g) sList[c++] = b;
+    sCount = c;
+  }
+  __syncthreads();
+  const int nch = 2 * sCount;                           // two 32-row chunks per sample
+  f32x4 d0, d1, x0, x1;
+  auto fetch = [&](int ch) {
+    const int b = sList[ch >> 1], m0 = (ch & 1) * 32;
+    const float* dr = a.dy + ((long)b * 64 + m0 + row) * a.ldy + a.col0 + n0 + cq;
+    const float* xr = a.x + ((long)b * 64 + m0 + row) * a.ldx + k0 + cq;
+    d0 = ld4(dr, n0 + cq < a.N);
+    d1 = ld4(dr + 4, n0 + cq + 4 < a.N);
+    x0 = ld4(xr, k0 + cq < a.K);
+    x1 = ld4(xr + 4, k0 + cq + 4 < a.K);
+  };
+  if (nch > 0) fetch(0);
+  for (int ch = 0; ch < nch; ++ch) {
+    __syncthreads();
+    *reinterpret_cast<f32x4*>(&Ds[row * LQ + cq]) = d0;
+    *reinterpret_cast<f32x4*>(&Ds[row * LQ + cq + 4]) = d1;
+    *reinterpret_cast<f32x4*>(&Xs[row * LQ + cq]) = x0;
+    *reinterpret_cast<f32x4*>(&Xs[row * LQ + cq + 4]) = x1;
+    __syncthreads();
+    if (ch + 1 < nch) fetch(ch + 1);
 #pragma unroll
-      for (int kg = 0; kg < 4; ++kg)
+    for (int kg = 0; kg < 4; ++kg)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int m = kg * 8 + 4 * lh + j;
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ds[m * LQ + wm * 32 + li], Xs[m * LQ + wn * 32 + li], acc, 0, 0, 0);
-        }
-      if (kt == 0 && tid < 64) {
-#pragma unroll
-        for (int m = 0; m < 32; ++m) bsum += Ds[m * LQ + tid];
+      for (int j = 0; j < 4; ++j) {
+        const int m = kg * 8 + 4 * lh + j;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ds[m * LQ + wm * 32 + li], Xs[m * LQ + wn * 32 + li], acc, 0, 0, 0);
       }
+    if (kt == 0 && tid < 64) {
+#pragma unroll
+      for (int m = 0; m < 32; ++m) bsum += Ds[m * LQ + tid];
     }
   }
   float* slab = a.slab + ((long)s * a.G + g) * a.N * a.K;
@@ -242,10 +266,13 @@ int launch_glinear_wgrad(const float* x, int ldx, int K, const float* dy, int ld
   if (!x || !dy || !dW || !ws || B <= 0 || K <= 0 || K % 4 || N <= 0 || N % 4 || G <= 0 || ldx % 4 || ldy % 4 || col0 % 4 ||
       ldo < K || ldo % 4)
     return kErrBadArg;
-  int S = 4;
-  while (S > 1 && glinear_wgrad_ws_floats(G, N, K, S) > ws_floats) S >>= 1;
+  // slices of the batch: no group ids -> one group holds every sample and its 64x64 tiles are few (13-42): many slices fill
+  // the chip; group ids -> a group holds B/G samples on average and there are G times the tiles: few slices (a slab is
+  // written per (slice, group) whether or not the slice holds a sample of the group)
+  int S = group == nullptr ? B / 8 : B / (4 * G);
+  S = S < 1 ? 1 : (S > 16 ? 16 : S);
+  while ((B + S - 1) / S > 64) ++S;      // a slice's list of samples has 64 entries
   if (glinear_wgrad_ws_floats(G, N, K, S) > ws_floats) return kErrWorkspace;
-  if (S > B) S = 1;
   GLinWgArgs a{x, ldx, K, dy, ldy, col0, N, group, G, B, S, ws};
   {
     ProfScope ps("glinear_wgrad_kernel", st, 2.0 * B * 64.0 * K * N, 4.0 * (B * 64.0 * (K + N) + (double)S * G * N * K));

@@ -1068,11 +1068,12 @@ class GroupLinear(Function):
             G = W.shape[0]
             dW = db = None
             if ctx.needs_input_grad[4 + 2 * s]:
-                full = koffs[s] == 0 and W.shape[2] == K and W.is_contiguous()
+                Gk = G if gs[s] is not None else 1        # no group ids: only matrix 0 is used, the other rows of the bank get zeros
+                full = koffs[s] == 0 and W.shape[2] == K and Gk == G
                 dW = torch.empty_like(W, memory_format=torch.contiguous_format) if full else torch.zeros_like(W, memory_format=torch.contiguous_format)
                 if has_b[s]:
-                    db = torch.empty((G, N), dtype=torch.float32, device=x.device)
-                native.call("ctvae_glinear_wgrad", x.data_ptr(), K, K, g.data_ptr(), nseg * N, s * N, N, native.ptr(gs[s]), G, B,
+                    db = torch.empty((G, N), dtype=torch.float32, device=x.device) if Gk == G else torch.zeros((G, N), dtype=torch.float32, device=x.device)
+                native.call("ctvae_glinear_wgrad", x.data_ptr(), K, K, g.data_ptr(), nseg * N, s * N, N, native.ptr(gs[s]), Gk, B,
                             dW.data_ptr() + 4 * koffs[s], dW.stride(1), native.ptr(db), 0, ws.data_ptr(), ws.numel() * 4)
             grads += [dW, db]
         return (dx, None, None, None) + tuple(grads)
@@ -1179,6 +1180,86 @@ class GATLayer(Function):
             sel = torch.nn.functional.one_hot(head_map.view(-1).long(), H).to(torch.float32)      # [B*Hs, H]
             red = torch.matmul(sel.t().unsqueeze(0), parts)                                        # [3, H, C]
         return d_xlr, dadj, red[2], red[1], red[0].reshape(-1), None, None, None, None, None
+
+
+class CTActionReg(Function):
+    """beta * adjacency_KL_loss(adj) + delta * graph_size_loss(graph) + epsilon * positive_trial_loss(adj) of
+    CausalTransition.forward_action (ct_mcq_vae.py:275,314-323) in one launch each way (csrc/ctmisc.hip).  adj, graph [B,64,64];
+    uni [B,4096]: the uniform draws behind the KL target softmax(rand)."""
+
+    @staticmethod
+    def forward(ctx, adj, graph, uni, beta, delta, epsilon):
+        _req_cuda(adj, graph, uni)
+        adj, graph, uni = _c(adj), _c(graph), _c(uni)
+        B, N, _ = adj.shape
+        part = torch.empty((B, 4), dtype=torch.float32, device=adj.device)
+        ctx.coef = (float(beta) / B, float(delta) / B, float(epsilon) / B)
+        native.call("ctvae_ct_reg_forward", adj.data_ptr(), graph.data_ptr(), uni.data_ptr(), part.data_ptr(), ctx.coef[0],
+                    ctx.coef[1], ctx.coef[2], B, N)
+        ctx.save_for_backward(adj, graph, uni, part)
+        return part[:, 3].sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        adj, graph, uni, part = ctx.saved_tensors
+        B, N, _ = adj.shape
+        g = _c(g.reshape(1))
+        d_adj, d_graph = torch.empty_like(adj), torch.empty_like(graph)
+        native.call("ctvae_ct_reg_backward", adj.data_ptr(), graph.data_ptr(), uni.data_ptr(), part.data_ptr(), g.data_ptr(),
+                    ctx.coef[0], ctx.coef[1], ctx.coef[2], d_adj.data_ptr(), d_graph.data_ptr(), B, N)
+        return d_adj, d_graph, None, None, None, None
+
+
+class BlendSoftmax(Function):
+    """softmax_d(y[..., 0, :] * (1 - mask) + y[..., 1, :] * mask) (two head slots) or softmax_d(y[..., 0, :]) (one): the tail of
+    CausalTransition._compute_y (ct_mcq_vae.py:226-228).  y [B,S,Hs,D], mask [B,S,1] or None -> [B,S,D]."""
+
+    @staticmethod
+    def forward(ctx, y, mask):
+        _req_cuda(y)
+        y = _c(y)
+        B, S, Hs, D = y.shape
+        m = _c(mask.reshape(B * S)) if mask is not None else None
+        probs = torch.empty((B, S, D), dtype=torch.float32, device=y.device)
+        native.call("ctvae_ct_blend_softmax_forward", y.data_ptr(), native.ptr(m), probs.data_ptr(), B * S, Hs, D)
+        ctx.save_for_backward(y, m, probs)
+        ctx.mask_shape = tuple(mask.shape) if mask is not None else None
+        return probs
+
+    @staticmethod
+    def backward(ctx, g):
+        y, m, probs = ctx.saved_tensors
+        B, S, Hs, D = y.shape
+        g = _c(g)
+        dy = torch.empty_like(y)
+        dm = torch.empty(B * S, dtype=torch.float32, device=y.device) if (m is not None and ctx.needs_input_grad[1]) else None
+        native.call("ctvae_ct_blend_softmax_backward", g.data_ptr(), probs.data_ptr(), y.data_ptr(), native.ptr(m), dy.data_ptr(),
+                    native.ptr(dm), B * S, Hs, D)
+        return dy, (dm.view(ctx.mask_shape) if dm is not None else None)
+
+
+class LatentCE(Function):
+    """F.cross_entropy(log(clamp(p, 1e-4)), target) over node rows (latent_CrossEntropy_loss, ct_mcq_vae.py:306-311).
+    probs [R,D] rows contiguous, target int64 [R]."""
+
+    @staticmethod
+    def forward(ctx, probs, target):
+        _req_cuda(probs, target)
+        probs, target = _c(probs), _c(target)
+        R, D = probs.shape
+        rows = torch.empty(R, dtype=torch.float32, device=probs.device)
+        native.call("ctvae_ct_latent_ce_forward", probs.data_ptr(), target.data_ptr(), rows.data_ptr(), R, D)
+        ctx.save_for_backward(probs, target)
+        return rows.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        probs, target = ctx.saved_tensors
+        R, D = probs.shape
+        g = _c(g.reshape(1))
+        d = torch.empty_like(probs)
+        native.call("ctvae_ct_latent_ce_backward", probs.data_ptr(), target.data_ptr(), g.data_ptr(), d.data_ptr(), R, D)
+        return d, None
 
 
 class GumbelBernoulliST(Function):

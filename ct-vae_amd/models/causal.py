@@ -353,6 +353,8 @@ class CausalTransition(nn.Module):
         else:
             heads = torch.stack([zero, action.argmax(dim=-1).to(torch.int32) + 1], dim=1)
         y = self.graph_transitioner.forward_fused(latent, adjacency, heads).view(B, S, heads.size(1), D)
+        if D <= 64:
+            return K.BlendSoftmax.apply(y, mask)          # head blend + softmax in one launch (csrc/ctmisc.hip)
         if mask is None:
             return y[:, :, 0].softmax(dim=-1)
         return (y[:, :, 0] * (1 - mask) + y[:, :, 1] * mask).softmax(dim=-1)
@@ -371,7 +373,7 @@ class CausalTransition(nn.Module):
         ct_reg = self.alpha * (F.cross_entropy(y_id.reshape(-1, shape[1]).clamp(min=1e-4).log(),
                                                lat.reshape(-1, shape[1]).argmax(dim=-1))
                                + F.mse_loss(graph, ident))
-        return [latent_y.permute(0, 2, 1).reshape(shape), ct_reg, {"ct_adjacency": adj.mean(0)}]
+        return [latent_y.permute(0, 2, 1).unflatten(2, tuple(shape[2:])), ct_reg, {"ct_adjacency": adj.mean(0)}]
 
     def forward_action(self, latent: Tensor, action: Tensor, **kwargs) -> List[Tensor]:
         shape = latent.shape
@@ -381,9 +383,13 @@ class CausalTransition(nn.Module):
         adj = self._compute_adj(pos, action, mask)
         graph = self._sample_bernoulli(adj)
         latent_y = self._compute_y(pos, action, adj * graph, mask)
-        ct_reg = self.beta * self.adjacency_KL_loss(adj) + self.delta * self.graph_size_loss(graph) \
-            + self.epsilon * self.positive_trial_loss(adj)
-        return [latent_y.permute(0, 2, 1).reshape(shape), ct_reg,
+        if adj.is_cuda and adj.size(-1) == 64:            # the three regularisers in one launch each way (csrc/ctmisc.hip)
+            uni = _draw("kl_target", (adj.size(0), adj.size(1) * adj.size(2)), device=adj.device)
+            ct_reg = K.CTActionReg.apply(adj, graph, uni, self.beta, self.delta, self.epsilon)
+        else:
+            ct_reg = self.beta * self.adjacency_KL_loss(adj) + self.delta * self.graph_size_loss(graph) \
+                + self.epsilon * self.positive_trial_loss(adj)
+        return [latent_y.permute(0, 2, 1).unflatten(2, tuple(shape[2:])), ct_reg,
                 {"ct_mask": mask.view(shape[:1] + shape[2:]).mean(0), "ct_adjacency": adj.mean(0)}]
 
     def forward_transition(self, latent: Tensor, latent_y: Tensor, **kwargs) -> List[Tensor]:
@@ -399,9 +405,11 @@ class CausalTransition(nn.Module):
 
     # ---- losses / metrics (ct_mcq_vae.py:297-333) --------------------------------------------------
     def latent_loss(self, latent, latent_y):
-        lat = latent.permute(0, 2, 3, 1).reshape(-1, latent.size(1)).clamp(min=1e-4).log()
+        lat = latent.permute(0, 2, 3, 1).reshape(-1, latent.size(1))        # a view when latent is [B,S,D] memory (forward*)
         tgt = latent_y.detach().permute(0, 2, 3, 1).reshape(-1, latent_y.size(1)).argmax(dim=-1)
-        return F.cross_entropy(lat, tgt)
+        if lat.is_cuda and lat.size(1) <= 64:
+            return K.LatentCE.apply(lat, tgt)             # clamp + log + cross-entropy in one launch (csrc/ctmisc.hip)
+        return F.cross_entropy(lat.clamp(min=1e-4).log(), tgt)
 
     def adjacency_KL_loss(self, adj):
         logc = adj.reshape(adj.size(0), -1).log_softmax(dim=-1)

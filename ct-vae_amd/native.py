@@ -34,6 +34,12 @@ SIGNATURES = {
     "ctvae_gat_layer_forward": [_fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, _f, _i, _vp],
     "ctvae_gat_layer_backward": [_fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _fp,
                                  _fp, _i, _i, _i, _i, _f, _i, _vp],
+    "ctvae_ct_reg_forward": [_fp, _fp, _fp, _fp, _f, _f, _f, _i, _i, _vp],
+    "ctvae_ct_reg_backward": [_fp, _fp, _fp, _fp, _fp, _f, _f, _f, _fp, _fp, _i, _i, _vp],
+    "ctvae_ct_blend_softmax_forward": [_fp, _fp, _fp, _l, _i, _i, _vp],
+    "ctvae_ct_blend_softmax_backward": [_fp, _fp, _fp, _fp, _fp, _fp, _l, _i, _i, _vp],
+    "ctvae_ct_latent_ce_forward": [_fp, _fp, _fp, _l, _i, _vp],
+    "ctvae_ct_latent_ce_backward": [_fp, _fp, _fp, _fp, _l, _i, _vp],
     "ctvae_glinear_forward": [_fp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _fp, _i, _i, _vp],
     "ctvae_glinear_dgrad": [_fp, _i, _i, _i, _vp, _vp, _vp, _vp, _fp, _i, _i, _i, _vp],
     "ctvae_glinear_wgrad": [_fp, _i, _i, _fp, _i, _i, _i, _fp, _i, _i, _fp, _i, _fp, _i, _fp, _sz, _vp],

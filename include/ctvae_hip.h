@@ -208,6 +208,27 @@ size_t ctvae_glinear_wgrad_ws_bytes(int G, int N, int K);
 int ctvae_glinear_wgrad(const float* x, int ldx, int K, const float* dy, int ldy, int col0, int N, const int32_t* group, int G,
                         int B, float* dW, int ldo, float* dbias, int accumulate, float* ws, size_t ws_bytes, void* stream);
 
+/* forward_action's regulariser (ct_mcq_vae.py:275): beta * adjacency_KL_loss(adj) + delta * graph_size_loss(graph) + epsilon *
+ * positive_trial_loss(adj) (:314-323) on adj, graph [B,64,64] with the uniform draws of the KL target [B,4096] given
+ * (torch.rand in :316).  forward writes part4 [B][4] = {KL_b, ||graph_b||_F, ||prod_j(1 - adj_b[i,j])||_2,
+ * ckl*KL_b + cgs*||.||_F + cpt*||.||_2}; the regulariser is the sum of the last column over the batch.  backward (g_loss: device scalar) writes
+ * d_adj, d_graph for ckl = beta/B, cgs = delta/B, cpt = epsilon/B; the row products' gradient uses exclusive prefix / suffix
+ * products (exact when a factor is 0). */
+int ctvae_ct_reg_forward(const float* adj, const float* graph, const float* uniform, float* part4, float ckl, float cgs, float cpt,
+                         int B, int N, void* stream);
+int ctvae_ct_reg_backward(const float* adj, const float* graph, const float* uniform, const float* part4, const float* g_loss,
+                          float ckl, float cgs, float cpt, float* d_adj, float* d_graph, int B, int N, void* stream);
+/* Tail of _compute_y (ct_mcq_vae.py:226-228) per node row r < R: probs[r,:] = softmax_d(y[r,0,:] * (1 - mask[r]) + y[r,1,:] *
+ * mask[r]) (Hs == 2) or softmax_d(y[r,0,:]) (Hs == 1, mask unused); D <= 64.  Backward: dy like y, dmask [R] (may be NULL). */
+int ctvae_ct_blend_softmax_forward(const float* y, const float* mask, float* probs, long R, int Hs, int D, void* stream);
+int ctvae_ct_blend_softmax_backward(const float* g, const float* probs, const float* y, const float* mask, float* dy, float* dmask,
+                                    long R, int Hs, int D, void* stream);
+/* latent_CrossEntropy_loss (ct_mcq_vae.py:306-311) per node row: row_loss[r] = logsumexp_d(lp) - lp[target[r]] with
+ * lp = log(max(probs, 1e-4)); the loss is the mean of row_loss.  Backward: d_probs for d loss = g_loss[0] (device scalar). */
+int ctvae_ct_latent_ce_forward(const float* probs, const int64_t* target, float* row_loss, long R, int D, void* stream);
+int ctvae_ct_latent_ce_backward(const float* probs, const int64_t* target, const float* g_loss, float* d_probs, long R, int D,
+                                void* stream);
+
 /* layout change at the NCHW API boundary: to_nhwc=1: in [B,C,P] -> out [B,P,C]; 0: the inverse
  * (torch.flatten on NCHW, vanilla_vae.py:85; .view(-1,512,2,2), vanilla_vae.py:102) */
 int ctvae_permute(const float* in, float* out, int B, int C, int P, int to_nhwc, void* stream);
