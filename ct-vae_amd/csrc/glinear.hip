@@ -156,11 +156,12 @@ __global__ __launch_bounds__(256) void glinear_wgrad_kernel(GLinWgArgs a) {
   float bsum = 0.f;                                     // column sum of dy for column n0 + tid (tid < 64), k-tile 0 only
   __shared__ int sList[64];                             // the samples of this slice that belong to group g (<= 64 per slice)
   __shared__ int sCount;
-  if (tid == 0) {
-    int c = 0;
-    for (int b = b_lo; b < b_hi; ++b)
-      if ((a.group ? a.group[b] : 0) == g) sList[c++] = b;
-    sCount = c;
+  if (tid < 64) {                                       // one wave compacts the slice (<= 64 samples): ballot + prefix popcount
+    const int b = b_lo + tid;
+    const bool mine = b < b_hi && (a.group ? a.group[b] : 0) == g;
+    const unsigned long long m = __ballot(mine);
+    if (mine) sList[__popcll(m & ((1ull << tid) - 1ull))] = b;
+    if (tid == 0) sCount = __popcll(m);
   }
   __syncthreads();
   const int nch = 2 * sCount;                           // two 32-row chunks per sample
@@ -243,7 +244,10 @@ bool args_ok(const GLinArgs& a, bool need_x) {
 
 int launch_glinear_forward(const GLinArgs& a, hipStream_t st) {
   if (!args_ok(a, true)) return kErrBadArg;
-  ProfScope ps("glinear_fwd_kernel", st, 2.0 * a.B * 64.0 * a.K * a.N * a.nseg,
+  char name[96];
+  snprintf(name, sizeof name, "glinear_fwd_kernel");
+  if (prof_detailed()) snprintf(name, sizeof name, "glinear_fwd_kernel K=%d N=%d nseg=%d", a.K, a.N, a.nseg);
+  ProfScope ps(name, st, 2.0 * a.B * 64.0 * a.K * a.N * a.nseg,
                4.0 * a.B * 64.0 * (a.K + (double)a.nseg * a.N));
   hipLaunchKernelGGL(glinear_fwd_kernel, dim3(((a.N + 63) / 64) * a.nseg, a.B), dim3(256), 0, st, a);
   CTVAE_LAUNCH_CHECK();
@@ -275,7 +279,10 @@ int launch_glinear_wgrad(const float* x, int ldx, int K, const float* dy, int ld
   if (glinear_wgrad_ws_floats(G, N, K, S) > ws_floats) return kErrWorkspace;
   GLinWgArgs a{x, ldx, K, dy, ldy, col0, N, group, G, B, S, ws};
   {
-    ProfScope ps("glinear_wgrad_kernel", st, 2.0 * B * 64.0 * K * N, 4.0 * (B * 64.0 * (K + N) + (double)S * G * N * K));
+    char name[96];
+    snprintf(name, sizeof name, "glinear_wgrad_kernel");
+    if (prof_detailed()) snprintf(name, sizeof name, "glinear_wgrad_kernel K=%d N=%d G=%d S=%d grp=%d", K, N, G, S, group != nullptr);
+    ProfScope ps(name, st, 2.0 * B * 64.0 * K * N, 4.0 * (B * 64.0 * (K + N) + (double)S * G * N * K));
     hipLaunchKernelGGL(glinear_wgrad_kernel, dim3(((N + 63) / 64) * ((K + 63) / 64), G, S), dim3(256), 0, st, a);
     CTVAE_LAUNCH_CHECK();
   }

@@ -71,6 +71,103 @@ __global__ __launch_bounds__(256) void pair_mlp_fwd_kernel(const float* __restri
   }
 }
 
+// Forward, N == 64 (the 64 latent nodes): grid (4, B) -- a workgroup scores 16 rows i x 64 columns j of one sample, a
+// thread owns (i, 4 consecutive j).  lrelu(t) = slope*t + (1-slope)*relu(t): the linear part sums per node (a dot product
+// of the node's row with w2, formed while the row is staged), the pair loop is add / max / fma only -- 2 instructions per
+// (pair, h) with packed f32x2 arithmetic.  u / v chunks of 32 h are staged transposed in LDS ([h][node]) through registers,
+// the next chunk's 16-byte global loads are in flight while the current one is evaluated.
+constexpr int PH = 32;     // h per chunk
+constexpr int PLS = 68;    // LDS row stride ([h][node]); 16-byte aligned rows
+
+__global__ __launch_bounds__(256) void pair_mlp_fwd64_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                            const float* __restrict__ w2, const float* __restrict__ b2,
+                                                            float* __restrict__ out, int H, int ld, float slope, int w2_bs,
+                                                            int b2_bs, const int* __restrict__ row_of) {
+  __shared__ __attribute__((aligned(16))) float sV[2][PH * PLS];
+  __shared__ __attribute__((aligned(16))) float sU[2][PH * 16];
+  __shared__ __attribute__((aligned(16))) float sW[2][PH];
+  __shared__ float sAL[16], sAR[64];
+  const int tid = threadIdx.x, b = blockIdx.y, i0 = blockIdx.x * 16;
+  const int ti = tid >> 4, tj = (tid & 15) * 4;
+  const int wr = row_of ? row_of[b] : b;
+  const float bias = b2 != nullptr ? b2[(long)wr * b2_bs] : 0.f;
+  w2 += (long)wr * w2_bs;
+  const float* ub = u + ((long)b * 64 + i0) * ld;
+  const float* vb = v + (long)b * 64 * ld;
+  // staging roles: v: thread -> (node tid >> 2, 8 h at (tid & 3) * 8); u: threads < 128 -> (row tid >> 3, 4 h at (tid & 7) * 4)
+  const int vn = tid >> 2, vh = (tid & 3) * 8, un = tid >> 3, uh = (tid & 7) * 4;
+  f32x4 rv0, rv1, ru;
+  float wv[8], wu[4];
+  auto fetch = [&](int h0) {
+    const bool ok0 = h0 + vh < H, ok1 = h0 + vh + 4 < H;      // H % 4 == 0
+    rv0 = ok0 ? *reinterpret_cast<const f32x4*>(vb + (long)vn * ld + h0 + vh) : f32x4{0.f, 0.f, 0.f, 0.f};
+    rv1 = ok1 ? *reinterpret_cast<const f32x4*>(vb + (long)vn * ld + h0 + vh + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[j] = (h0 + vh + j < H) ? w2[h0 + vh + j] : 0.f;
+    if (tid < 128) {
+      const bool oku = h0 + uh < H;
+      ru = oku ? *reinterpret_cast<const f32x4*>(ub + (long)un * ld + h0 + uh) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wu[j] = (h0 + uh + j < H) ? w2[h0 + uh + j] : 0.f;
+    }
+  };
+  float dotv = 0.f, dotu = 0.f;        // sum_h w2[h] * v[node][h] (this thread's h) / same for u
+  f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+  const int nch = (H + PH - 1) / PH;
+  fetch(0);
+  for (int c = 0; c < nch; ++c) {
+    const int buf = c & 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sV[buf][(vh + j) * PLS + vn] = rv0[j];
+      sV[buf][(vh + 4 + j) * PLS + vn] = rv1[j];
+      dotv += wv[j] * rv0[j] + wv[4 + j] * rv1[j];
+    }
+    if (tid < 128) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sU[buf][(uh + j) * 16 + un] = ru[j];
+        dotu += wu[j] * ru[j];
+      }
+    }
+    if (vn == 0) {                      // node 0's four staging threads hold w2[h0 + 0..31] between them
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sW[buf][vh + j] = wv[j] * (1.f - slope);
+    }
+    __syncthreads();                    // one barrier per chunk: the buffers alternate
+    if (c + 1 < nch) fetch((c + 1) * PH);
+    const float* V = sV[buf];
+    const float* U = sU[buf];
+#pragma unroll 8
+    for (int h = 0; h < PH; ++h) {
+      const f32x4 v4 = *reinterpret_cast<const f32x4*>(V + h * PLS + tj);
+      const float ui = U[h * 16 + ti], wh = sW[buf][h];
+      const f32x2 u2 = {ui, ui}, w2v = {wh, wh};
+      const f32x2 t0 = u2 + f32x2{v4[0], v4[1]}, t1 = u2 + f32x2{v4[2], v4[3]};
+      acc0 += w2v * f32x2{fmaxf(t0[0], 0.f), fmaxf(t0[1], 0.f)};
+      acc1 += w2v * f32x2{fmaxf(t1[0], 0.f), fmaxf(t1[1], 0.f)};
+    }
+  }
+  // the linear part: per-node dot products, summed over the threads that staged the node's row
+  dotv += __shfl_xor(dotv, 1, 64);
+  dotv += __shfl_xor(dotv, 2, 64);
+  dotu += __shfl_xor(dotu, 1, 64);
+  dotu += __shfl_xor(dotu, 2, 64);
+  dotu += __shfl_xor(dotu, 4, 64);
+  __syncthreads();
+  if ((tid & 3) == 0) sAR[vn] = dotv;
+  if (tid < 128 && (tid & 7) == 0) sAL[un] = dotu;
+  __syncthreads();
+  const float al = sAL[ti];
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = (j < 2 ? acc0[j & 1] : acc1[j & 1]) + slope * (al + sAR[tj + j]) + bias;
+    o[j] = 1.f / (1.f + __expf(-a));
+  }
+  *reinterpret_cast<f32x4*>(out + ((long)b * 64 + i0 + ti) * 64 + tj) = o;
+}
+
 // grid (ceil(H/256), B).  dw2_part [B][H], dgs_part [B][gridDim.x] (sum of g*s*(1-s), identical for every h block)
 __global__ __launch_bounds__(256) void pair_mlp_bwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
                                                           const float* __restrict__ w2, const float* __restrict__ out,
@@ -143,6 +240,12 @@ int launch_pair_mlp_forward(const float* u, const float* v, int ld, const float*
                             int H, float slope, int per_sample, const int* row_of, hipStream_t st) {
   if (B <= 0 || N <= 0 || H <= 0 || ld < H) return kErrBadArg;
   ProfScope ps("pair_mlp_fwd_kernel", st, 3.0 * B * (double)N * N * H, 4.0 * B * (2.0 * N * H + (double)N * N));
+  if (N == 64 && H % 4 == 0 && ld % 4 == 0) {
+    hipLaunchKernelGGL(pair_mlp_fwd64_kernel, dim3(4, B), dim3(256), 0, st, u, v, w2, b2, out, H, ld, slope, per_sample ? H : 0,
+                       per_sample ? 1 : 0, per_sample ? row_of : nullptr);
+    CTVAE_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(pair_mlp_fwd_kernel, dim3((N + IT - 1) / IT, B), dim3(256), 0, st, u, v, w2, b2, out, N, H, ld, slope,
                      per_sample ? H : 0, per_sample ? 1 : 0, per_sample ? row_of : nullptr);
   CTVAE_LAUNCH_CHECK();

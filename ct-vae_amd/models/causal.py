@@ -104,20 +104,24 @@ class DenseGATv2(nn.Module):
         return (x.is_cuda and x.size(1) == 64 and 16 <= C <= 128 and C % 4 == 0 and self.lin_l.in_features % 4 == 0
                 and self.lin_l.weight.is_contiguous() and self.lin_r.weight.is_contiguous() and H <= 64)
 
-    def forward_fused(self, x, adj, heads_sel=None, act=K.ACT_NONE):
-        """HIP path (csrc/gatlayer.hip): x [B,64,Cin], adj [B,64,64]; heads_sel int [B,Hs] evaluates only those heads of each
-        sample (slot order) -> [B,64,Hs*C]; act: the activation behind the layer, applied in the kernel's epilogue."""
+    def forward_fused(self, x, adj, slots=None, act=K.ACT_NONE):
+        """HIP path (csrc/gatlayer.hip): x [B,64,Cin], adj [B,64,64]; slots: None = every head, or a list with one entry per
+        head slot -- None (head 0 for every sample) or an int32 [B] tensor naming each sample's head -> [B,64,Hs*C];
+        act: the activation behind the layer, applied in the kernel's epilogue."""
         B = x.size(0)
         H, C = self.heads, self.out_channels
         Kin = x.size(-1)
         wl, wr = self.lin_l.weight, self.lin_r.weight
-        if heads_sel is None:           # every head: lin_l | lin_r as two segments of one grouped GEMM (group 0 for everybody)
+        heads_sel = None
+        if slots is None:               # every head: lin_l | lin_r as two segments of one grouped GEMM (group 0 for everybody)
             Hs = H
             xlr = K.GroupLinear.apply(x, Kin, H * C, ((0, None), (0, None)), wl.view(1, H * C, Kin), self.lin_l.bias.view(1, H * C),
                                       wr.view(1, H * C, Kin), self.lin_r.bias.view(1, H * C))
         else:                           # head slots: each slot reads the C rows of its head inside lin_l / lin_r
-            Hs = heads_sel.size(1)
-            cols = [heads_sel[:, i].contiguous() for i in range(Hs)]
+            Hs = len(slots)
+            cols = list(slots)
+            zero = torch.zeros(B, dtype=torch.int32, device=x.device) if any(c is None for c in cols) else None
+            heads_sel = torch.stack([zero if c is None else c for c in cols], dim=1)
             wb = []
             for w, b in ((wl, self.lin_l.bias), (wr, self.lin_r.bias)):
                 for _ in range(Hs):
@@ -169,12 +173,13 @@ class _GraphTransitioner(nn.Module):
     def fused_ok(self, x):
         return all(l.fused_ok(x) for l in self.gat_layers())
 
-    def forward_fused(self, x, adj, heads_sel):
-        """The 64 latent nodes only, the last layer restricted to the head slots ``heads_sel`` [B,Hs] -> [B,64,Hs*D]."""
+    def forward_fused(self, x, adj, slots):
+        """The 64 latent nodes only, the last layer restricted to the head slots ``slots`` (DenseGATv2.forward_fused)
+        -> [B,64,len(slots)*D]."""
         layers = self.gat_layers()
         for l in layers[:-1]:
             x = l.forward_fused(x, adj, None, K.ACT_LRELU)      # nn.LeakyReLU() behind the layer, in its epilogue
-        return layers[-1].forward_fused(x, adj, heads_sel, K.ACT_NONE)
+        return layers[-1].forward_fused(x, adj, slots, K.ACT_NONE)
 
     def forward(self, x, adj):
         for name in self.order:
@@ -347,12 +352,8 @@ class CausalTransition(nn.Module):
             latent = latent + _draw("exo_noise", latent.shape, device=latent.device)
         elif self.noise == "endo":
             _draw("endo_noise", (B, D), device=latent.device)      # the draw the reference makes for its isolated noise node
-        zero = torch.zeros(B, dtype=torch.int32, device=latent.device)
-        if mask is None:
-            heads = zero.unsqueeze(1)
-        else:
-            heads = torch.stack([zero, action.argmax(dim=-1).to(torch.int32) + 1], dim=1)
-        y = self.graph_transitioner.forward_fused(latent, adjacency, heads).view(B, S, heads.size(1), D)
+        slots = [None] if mask is None else [None, action.argmax(dim=-1).to(torch.int32) + 1]      # head 0 (, head 1 + action)
+        y = self.graph_transitioner.forward_fused(latent, adjacency, slots).view(B, S, len(slots), D)
         if D <= 64:
             return K.BlendSoftmax.apply(y, mask)          # head blend + softmax in one launch (csrc/ctmisc.hip)
         if mask is None:
