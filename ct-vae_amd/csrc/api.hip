@@ -54,6 +54,15 @@ int launch_ct_blend_softmax_backward(const float* g, const float* probs, const f
 int launch_ct_latent_ce_forward(const float* probs, const long long* target, float* row_loss, long R, int D, hipStream_t st);
 int launch_ct_latent_ce_backward(const float* probs, const long long* target, const float* g_loss, float* d_probs, long R, int D,
                                  hipStream_t st);
+int launch_ct_mask_forward(const float* x, const float* action, const float* pe, const float* keep, float scale, const float* W,
+                           const float* bias, const float* expo, int B, int S, int D, int A, float* inter, float* p, float* sample,
+                           float* soft, hipStream_t st);
+int launch_ct_mask_backward(const float* x, const float* action, const float* pe, const float* keep, float scale,
+                            const float* inter, const float* p, const float* soft, const float* g, int B, int S, int D, int A,
+                            float* dWp, float* dbp, hipStream_t st);
+int launch_ct_sample_forward(const float* p, const float* expo, float* out, float* soft, float* weighted, long n, hipStream_t st);
+int launch_ct_sample_backward(const float* gs, const float* gw, const float* p, const float* soft, const float* sample, float* gp,
+                              long n, hipStream_t st);
 int launch_pair_mlp_forward(const float* u, const float* v, int ld, const float* w2, const float* b2, float* out, int B, int N,
                             int H, float slope, int per_sample, const int* row_of, hipStream_t st);
 int launch_pair_mlp_backward(const float* u, const float* v, int ld, const float* w2, const float* out, const float* g_out,
@@ -385,6 +394,27 @@ int ctvae_ct_latent_ce_forward(const float* probs, const int64_t* target, float*
 int ctvae_ct_latent_ce_backward(const float* probs, const int64_t* target, const float* g_loss, float* d_probs, long R, int D,
                                 void* stream) {
   return launch_ct_latent_ce_backward(probs, (const long long*)target, g_loss, d_probs, R, D, (hipStream_t)stream);
+}
+
+int ctvae_ct_mask_forward(const float* x, const float* action, const float* pe, const float* keep, float scale, const float* W,
+                          const float* bias, const float* expo, int B, int S, int D, int A, float* inter, float* p, float* sample,
+                          float* soft, void* stream) {
+  return launch_ct_mask_forward(x, action, pe, keep, scale, W, bias, expo, B, S, D, A, inter, p, sample, soft, (hipStream_t)stream);
+}
+
+int ctvae_ct_mask_backward(const float* x, const float* action, const float* pe, const float* keep, float scale, const float* inter,
+                           const float* p, const float* soft, const float* g, int B, int S, int D, int A, float* dWp, float* dbp,
+                           void* stream) {
+  return launch_ct_mask_backward(x, action, pe, keep, scale, inter, p, soft, g, B, S, D, A, dWp, dbp, (hipStream_t)stream);
+}
+
+int ctvae_ct_sample_forward(const float* p, const float* expo, float* sample, float* soft, float* weighted, long n, void* stream) {
+  return launch_ct_sample_forward(p, expo, sample, soft, weighted, n, (hipStream_t)stream);
+}
+
+int ctvae_ct_sample_backward(const float* g_sample, const float* g_weighted, const float* p, const float* soft, const float* sample,
+                             float* g_p, long n, void* stream) {
+  return launch_ct_sample_backward(g_sample, g_weighted, p, soft, sample, g_p, n, (hipStream_t)stream);
 }
 
 static int glin_fill(GLinArgs& a, int nseg, int N, const float* const* W, const int* ldw, const int64_t* w_gstride,

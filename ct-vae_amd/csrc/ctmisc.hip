@@ -222,6 +222,160 @@ __global__ __launch_bounds__(256) void ct_latent_ce_bwd_kernel(const float* __re
   if (ok) d_probs[r * D + lane] = p > 1e-4f ? dlp / p : 0.f;      // clamp(min=1e-4) passes no gradient below the bound
 }
 
+// ---- CausalTransition._compute_mask (ct_mcq_vae.py:117-127) ------------------------------------------------------------
+//   pos = dropout(pe)                (PositionalEncoding of zeros, :119; keep = the dropout keep mask or null in eval mode)
+//   inter = sigmoid(W [action ; pos] + b),  p = sum_d x[b,s,d] * inter[b,s,d],  sample = straight-through Bernoulli(p)
+// One workgroup per sample; W^T ([A+D][D]) staged in LDS; thread = (node s, a quarter of the D outputs).  D == S == 64.
+constexpr int MD = 64;
+
+__global__ __launch_bounds__(256) void ct_mask_fwd_kernel(const float* __restrict__ x, const float* __restrict__ action,
+                                                         const float* __restrict__ pe, const float* __restrict__ keep, float scale,
+                                                         const float* __restrict__ W, const float* __restrict__ bias,
+                                                         const float* __restrict__ expo, int A, float* __restrict__ inter,
+                                                         float* __restrict__ p_out, float* __restrict__ sample,
+                                                         float* __restrict__ soft) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sW = smem;                       // [A+D][D]  (W^T)
+  float* sPos = sW + (A + MD) * MD;       // [S][D+1]
+  float* sAct = sPos + MD * (MD + 1);     // [D]  bias + W[:, :A] action
+  const int tid = threadIdx.x, b = blockIdx.x, In = A + MD;
+  for (int e = tid; e < MD * In; e += 256) {
+    const int d = e / In, i = e - d * In;              // W is [D][A+D] row-major
+    sW[i * MD + d] = W[e];
+  }
+  for (int e = tid; e < MD * MD; e += 256) {
+    const int s = e >> 6, d = e & 63;
+    const float k = keep ? keep[(long)b * MD * MD + e] * scale : 1.f;
+    sPos[s * (MD + 1) + d] = pe[e] * k;
+  }
+  __syncthreads();
+  if (tid < MD) {
+    float z = bias[tid];
+    for (int a = 0; a < A; ++a) z += sW[a * MD + tid] * action[(long)b * A + a];
+    sAct[tid] = z;
+  }
+  __syncthreads();
+  const int s = tid >> 2, d0 = (tid & 3) * 16;
+  float z[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) z[j] = sAct[d0 + j];
+  for (int e = 0; e < MD; ++e) {
+    const float pv = sPos[s * (MD + 1) + e];
+    const float* w = sW + (A + e) * MD + d0;
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4) {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(w + 4 * j4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) z[4 * j4 + j] += w4[j] * pv;
+    }
+  }
+  const long row = ((long)b * MD + s) * MD + d0;
+  float p = 0.f;
+#pragma unroll
+  for (int j4 = 0; j4 < 4; ++j4) {
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row + 4 * j4);
+    f32x4 sv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sv[j] = 1.f / (1.f + __expf(-z[4 * j4 + j]));
+      p += xv[j] * sv[j];
+    }
+    *reinterpret_cast<f32x4*>(inter + row + 4 * j4) = sv;
+  }
+  p += __shfl_xor(p, 1, 64);
+  p += __shfl_xor(p, 2, 64);
+  if ((tid & 3) == 0) {
+    const long r = (long)b * MD + s;
+    const float a0 = __logf(fmaxf(1.f - p, 1e-4f)) - __logf(expo[2 * r]);        // Gumbel noise = -log(exponential draw)
+    const float a1 = __logf(fmaxf(p, 1e-4f)) - __logf(expo[2 * r + 1]);
+    const float y1 = 1.f / (1.f + __expf(a0 - a1));
+    const float hard = a1 > a0 ? 1.f : 0.f;
+    p_out[r] = p;
+    sample[r] = (hard - y1) + y1;
+    soft[r] = y1;
+  }
+}
+
+// dWp [B][A+D][D] (W^T layout), dbp [B][D]: per-sample partials, summed by the caller
+__global__ __launch_bounds__(256) void ct_mask_bwd_kernel(const float* __restrict__ x, const float* __restrict__ action,
+                                                         const float* __restrict__ pe, const float* __restrict__ keep, float scale,
+                                                         const float* __restrict__ inter, const float* __restrict__ p_in,
+                                                         const float* __restrict__ soft, const float* __restrict__ g, int A,
+                                                         float* __restrict__ dWp, float* __restrict__ dbp) {
+  __shared__ float sDz[MD * (MD + 1)];    // [s][d]
+  __shared__ float sPos[MD * (MD + 1)];   // [s][e]
+  __shared__ float sCol[MD];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  for (int e = tid; e < MD * MD; e += 256) {
+    const int s = e >> 6, d = e & 63;
+    const long r = (long)b * MD + s;
+    const float pi = p_in[r], y1 = soft[r];
+    const float dd = (pi > 1e-4f ? 1.f / pi : 0.f) + ((1.f - pi) > 1e-4f ? 1.f / (1.f - pi) : 0.f);
+    const float dp = g[r] * y1 * (1.f - y1) * dd;                   // straight-through estimator (gumbel_st_bwd_kernel)
+    const float sg = inter[(long)b * MD * MD + e];
+    sDz[s * (MD + 1) + d] = dp * x[(long)b * MD * MD + e] * sg * (1.f - sg);
+    const float k = keep ? keep[(long)b * MD * MD + e] * scale : 1.f;
+    sPos[s * (MD + 1) + d] = pe[e] * k;
+  }
+  __syncthreads();
+  if (tid < MD) {
+    float c = 0.f;
+    for (int s = 0; s < MD; ++s) c += sDz[s * (MD + 1) + tid];
+    sCol[tid] = c;
+    dbp[(long)b * MD + tid] = c;
+  }
+  __syncthreads();
+  float* out = dWp + (long)b * (A + MD) * MD;
+  for (int e = tid; e < A * MD; e += 256) {                         // action rows: act[a] * sum_s dz[s][d]
+    const int a = e >> 6, d = e & 63;
+    out[e] = action[(long)b * A + a] * sCol[d];
+  }
+  const int ei = tid >> 2, d0 = (tid & 3) * 16;                     // position rows: sum_s pos[s][e] * dz[s][d]
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int s = 0; s < MD; ++s) {
+    const float pv = sPos[s * (MD + 1) + ei];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] += pv * sDz[s * (MD + 1) + d0 + j];
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) out[(A + ei) * MD + d0 + j] = acc[j];
+}
+
+// Straight-through Bernoulli(p) with the exponential draws given (Gumbel = -log E), optionally also w = p * sample
+// (weighted_graph = adjacency_coeffs * causal_graph, ct_mcq_vae.py:241-244,268-271)
+__global__ __launch_bounds__(256) void ct_sample_fwd_kernel(const float* __restrict__ p, const float* __restrict__ expo,
+                                                           float* __restrict__ out, float* __restrict__ soft,
+                                                           float* __restrict__ weighted, long n) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float pi = p[i];
+    const f32x2 e = *reinterpret_cast<const f32x2*>(expo + 2 * i);
+    const float a0 = __logf(fmaxf(1.f - pi, 1e-4f)) - __logf(e[0]);
+    const float a1 = __logf(fmaxf(pi, 1e-4f)) - __logf(e[1]);
+    const float y1 = 1.f / (1.f + __expf(a0 - a1));
+    const float hard = a1 > a0 ? 1.f : 0.f;
+    const float sm = (hard - y1) + y1;
+    out[i] = sm;
+    soft[i] = y1;
+    if (weighted) weighted[i] = pi * sm;
+  }
+}
+
+// gp = (g_sample + g_w * p) * d sample / d p + g_w * sample
+__global__ __launch_bounds__(256) void ct_sample_bwd_kernel(const float* __restrict__ gs, const float* __restrict__ gw,
+                                                           const float* __restrict__ p, const float* __restrict__ soft,
+                                                           const float* __restrict__ sample, float* __restrict__ gp, long n) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float pi = p[i], y1 = soft[i];
+    const float d = (pi > 1e-4f ? 1.f / pi : 0.f) + ((1.f - pi) > 1e-4f ? 1.f / (1.f - pi) : 0.f);
+    const float g_s = (gs ? gs[i] : 0.f) + (gw ? gw[i] * pi : 0.f);
+    gp[i] = g_s * y1 * (1.f - y1) * d + (gw ? gw[i] * sample[i] : 0.f);
+  }
+}
+
 }  // namespace
 
 int launch_ct_reg_forward(const float* adj, const float* graph, const float* uni, float* part, float ckl, float cgs, float cpt,
@@ -272,6 +426,56 @@ int launch_ct_latent_ce_backward(const float* probs, const long long* target, co
   if (!probs || !target || !g_loss || !d_probs || R <= 0 || D <= 0 || D > 64) return kErrBadArg;
   ProfScope ps("ct_latent_ce_bwd_kernel", st, 0.0, 8.0 * R * D);
   hipLaunchKernelGGL(ct_latent_ce_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, probs, target, g_loss, d_probs, R, D);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_ct_mask_forward(const float* x, const float* action, const float* pe, const float* keep, float scale, const float* W,
+                           const float* bias, const float* expo, int B, int S, int D, int A, float* inter, float* p, float* sample,
+                           float* soft, hipStream_t st) {
+  if (!x || !action || !pe || !W || !bias || !expo || !inter || !p || !sample || !soft || B <= 0 || S != MD || D != MD || A <= 0 ||
+      A > 256)
+    return kErrBadArg;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ct_mask_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const size_t smem = ((size_t)(A + MD) * MD + MD * (MD + 1) + MD) * sizeof(float);
+  ProfScope ps("ct_mask_fwd_kernel", st, 2.0 * B * S * D * (A + D), 4.0 * B * S * D * 3.0);
+  hipLaunchKernelGGL(ct_mask_fwd_kernel, dim3(B), dim3(256), smem, st, x, action, pe, keep, scale, W, bias, expo, A, inter, p, sample,
+                     soft);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_ct_mask_backward(const float* x, const float* action, const float* pe, const float* keep, float scale,
+                            const float* inter, const float* p, const float* soft, const float* g, int B, int S, int D, int A,
+                            float* dWp, float* dbp, hipStream_t st) {
+  if (!x || !action || !pe || !inter || !p || !soft || !g || !dWp || !dbp || B <= 0 || S != MD || D != MD || A <= 0) return kErrBadArg;
+  ProfScope ps("ct_mask_bwd_kernel", st, 2.0 * B * S * D * D, 4.0 * B * (S * D * 3.0 + (A + D) * D));
+  hipLaunchKernelGGL(ct_mask_bwd_kernel, dim3(B), dim3(256), 0, st, x, action, pe, keep, scale, inter, p, soft, g, A, dWp, dbp);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_ct_sample_forward(const float* p, const float* expo, float* out, float* soft, float* weighted, long n, hipStream_t st) {
+  if (!p || !expo || !out || !soft || n <= 0) return kErrBadArg;
+  ProfScope ps("ct_sample_fwd_kernel", st, 0.0, 4.0 * n * (weighted ? 6.0 : 5.0));
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(ct_sample_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, expo, out, soft, weighted, n);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_ct_sample_backward(const float* gs, const float* gw, const float* p, const float* soft, const float* sample, float* gp,
+                              long n, hipStream_t st) {
+  if ((!gs && !gw) || !p || !soft || !sample || !gp || n <= 0) return kErrBadArg;
+  ProfScope ps("ct_sample_bwd_kernel", st, 0.0, 4.0 * n * 6.0);
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(ct_sample_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, gs, gw, p, soft, sample, gp, n);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }

@@ -1262,6 +1262,70 @@ class LatentCE(Function):
         return d, None
 
 
+class CTMask(Function):
+    """CausalTransition._compute_mask (ct_mcq_vae.py:117-127) in one launch each way (csrc/ctmisc.hip): x [B,64,64] (one-hot
+    latent, no gradient), action [B,A], pe [64,64], keep [B,64,64] or None (dropout keep mask of the positional encoding),
+    W [64,A+64] / bias [64] (mask.0), expo [B,64,2] exponential draws -> straight-through sample [B,64]."""
+
+    @staticmethod
+    def forward(ctx, x, action, pe, keep, scale, W, bias, expo):
+        _req_cuda(x, action, pe, W, bias, expo)
+        x, action, pe, W, bias, expo = _c(x), _c(action), _c(pe), _c(W), _c(bias), _c(expo)
+        keep = _c(keep) if keep is not None else None
+        B, S, D = x.shape
+        A = action.shape[1]
+        dev = x.device
+        inter = torch.empty((B, S, D), dtype=torch.float32, device=dev)
+        psoft = torch.empty((3, B, S), dtype=torch.float32, device=dev)      # p, sample, soft
+        native.call("ctvae_ct_mask_forward", x.data_ptr(), action.data_ptr(), pe.data_ptr(), native.ptr(keep), float(scale),
+                    W.data_ptr(), bias.data_ptr(), expo.data_ptr(), B, S, D, A, inter.data_ptr(), psoft[0].data_ptr(),
+                    psoft[1].data_ptr(), psoft[2].data_ptr())
+        ctx.save_for_backward(x, action, pe, keep, inter, psoft)
+        ctx.scale = float(scale)
+        return psoft[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, action, pe, keep, inter, psoft = ctx.saved_tensors
+        B, S, D = x.shape
+        A = action.shape[1]
+        g = _c(g)
+        dWp = torch.empty((B, A + D, D), dtype=torch.float32, device=x.device)
+        dbp = torch.empty((B, D), dtype=torch.float32, device=x.device)
+        native.call("ctvae_ct_mask_backward", x.data_ptr(), action.data_ptr(), pe.data_ptr(), native.ptr(keep), ctx.scale,
+                    inter.data_ptr(), psoft[0].data_ptr(), psoft[2].data_ptr(), g.data_ptr(), B, S, D, A, dWp.data_ptr(), dbp.data_ptr())
+        return None, None, None, None, None, dWp.sum(0).t(), dbp.sum(0), None
+
+
+class CTSample(Function):
+    """Straight-through Bernoulli(p) from exponential draws expo [...,2] (what F.gumbel_softmax draws: Gumbel = -log E;
+    ct_mcq_vae.py:180-183) -> sample, and with ``weighted`` also p * sample (weighted_graph, :244,271) from the same launch."""
+
+    @staticmethod
+    def forward(ctx, p, expo, weighted):
+        _req_cuda(p, expo)
+        p, expo = _c(p), _c(expo)
+        out = torch.empty_like(p)
+        soft = torch.empty_like(p)
+        w = torch.empty_like(p) if weighted else None
+        native.call("ctvae_ct_sample_forward", p.data_ptr(), expo.data_ptr(), out.data_ptr(), soft.data_ptr(), native.ptr(w), p.numel())
+        ctx.save_for_backward(p, soft, out)
+        ctx.set_materialize_grads(False)
+        return (out, w) if weighted else out
+
+    @staticmethod
+    def backward(ctx, g_s, g_w=None):
+        p, soft, out = ctx.saved_tensors
+        if g_s is None and g_w is None:
+            return None, None, None
+        g_s = _c(g_s) if g_s is not None else None
+        g_w = _c(g_w) if g_w is not None else None
+        gp = torch.empty_like(p)
+        native.call("ctvae_ct_sample_backward", native.ptr(g_s), native.ptr(g_w), p.data_ptr(), soft.data_ptr(), out.data_ptr(),
+                    gp.data_ptr(), p.numel())
+        return gp, None, None
+
+
 class GumbelBernoulliST(Function):
     """Straight-through Bernoulli(p) sample via hard 2-class Gumbel-softmax (ct_mcq_vae.py:177-183); noise [...,2]."""
 

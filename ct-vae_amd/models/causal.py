@@ -241,10 +241,11 @@ class _ProdLastDim(torch.autograd.Function):
         return g.unsqueeze(-1) * prefix * suffix
 
 
-def sample_bernoulli_st(p, tag):
+def sample_bernoulli_st(p, tag, weighted=False):
     """Straight-through Bernoulli sample via 2-class Gumbel-softmax(tau=1, hard=True) of log(clamp([1-p, p], 1e-4))
-    (ct_mcq_vae.py:124-126,180-183): HIP kernel; the two exponential draws per element come from the noise source."""
-    return K.GumbelBernoulliST.apply(p, -_draw(tag, tuple(p.shape) + (2,), device=p.device).log())
+    (ct_mcq_vae.py:124-126,180-183): HIP kernel; the two exponential draws per element come from the noise source.
+    weighted: also p * sample from the same launch."""
+    return K.CTSample.apply(p, _draw(tag, tuple(p.shape) + (2,), device=p.device), weighted)
 
 
 class CausalTransition(nn.Module):
@@ -279,7 +280,14 @@ class CausalTransition(nn.Module):
         return torch.sigmoid(F.linear(h, lin2.weight, lin2.bias)).squeeze(-1)
 
     def _compute_mask(self, one_hot_latent, action):
-        B, S, _ = one_hot_latent.shape
+        B, S, D = one_hot_latent.shape
+        if one_hot_latent.is_cuda and S == 64 and D == 64 and not one_hot_latent.requires_grad:
+            pe = self.pos_encoding                                   # one launch each way (kernels.CTMask, csrc/ctmisc.hip)
+            drop = pe.training and pe.p > 0.0
+            keep = _draw("mask_dropout", (B, S, D), pe.p, one_hot_latent.device) if drop else None
+            expo = _draw("mask_gumbel", (B, S, 2), device=one_hot_latent.device)
+            return K.CTMask.apply(one_hot_latent, action.to(torch.float32), pe.pe[:S, 0], keep, 1.0 / (1.0 - pe.p) if drop else 1.0,
+                                  self.mask[0].weight, self.mask[0].bias, expo).unsqueeze(-1)
         act = action.unsqueeze(1).expand(B, S, action.size(-1)).to(torch.float32)
         pos = self.pos_encoding(torch.zeros_like(one_hot_latent), "mask_dropout")
         inter = self.mask(torch.cat([act, pos], dim=-1))
@@ -367,8 +375,8 @@ class CausalTransition(nn.Module):
         pos = self.pos_encoding(lat)
         action = torch.zeros(lat.size(0), self.action_dim, device=lat.device)
         adj = self._compute_adj(pos, action, None)             # mask == 0 in base mode
-        graph = self._sample_bernoulli(adj)
-        latent_y = self._compute_y(pos, action, adj * graph, None)
+        graph, weighted = sample_bernoulli_st(adj, "adj_gumbel", True)
+        latent_y = self._compute_y(pos, action, weighted, None)
         ident = torch.eye(graph.size(-1), device=lat.device, dtype=graph.dtype).expand_as(graph)
         y_id = self._compute_y(pos, action, ident, None)
         ct_reg = self.alpha * (F.cross_entropy(y_id.reshape(-1, shape[1]).clamp(min=1e-4).log(),
@@ -382,8 +390,8 @@ class CausalTransition(nn.Module):
         mask = self._compute_mask(lat, action)
         pos = self.pos_encoding(lat)
         adj = self._compute_adj(pos, action, mask)
-        graph = self._sample_bernoulli(adj)
-        latent_y = self._compute_y(pos, action, adj * graph, mask)
+        graph, weighted = sample_bernoulli_st(adj, "adj_gumbel", True)
+        latent_y = self._compute_y(pos, action, weighted, mask)
         if adj.is_cuda and adj.size(-1) == 64:            # the three regularisers in one launch each way (csrc/ctmisc.hip)
             uni = _draw("kl_target", (adj.size(0), adj.size(1) * adj.size(2)), device=adj.device)
             ct_reg = K.CTActionReg.apply(adj, graph, uni, self.beta, self.delta, self.epsilon)

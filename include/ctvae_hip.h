@@ -229,6 +229,24 @@ int ctvae_ct_latent_ce_forward(const float* probs, const int64_t* target, float*
 int ctvae_ct_latent_ce_backward(const float* probs, const int64_t* target, const float* g_loss, float* d_probs, long R, int D,
                                 void* stream);
 
+/* CausalTransition._compute_mask (ct_mcq_vae.py:117-127) for S == D == 64: pos = pe [S,D] * keep [B,S,D] * scale (the dropout of
+ * PositionalEncoding applied to zeros; keep == NULL: eval mode), inter = sigmoid(W [action_b ; pos] + bias) with W [D][A+D]
+ * (mask.0.weight), p[b,s] = sum_d x[b,s,d] * inter[b,s,d], sample = straight-through Bernoulli(p) from the exponential draws
+ * expo [B,S,2] (Gumbel = -log E).  Outputs inter [B,S,D], p, sample, soft [B,S].  Backward for g = d loss / d sample: per-sample
+ * partials dWp [B][A+D][D] (transposed like W^T) and dbp [B][D], which the caller sums over B (deterministic). */
+int ctvae_ct_mask_forward(const float* x, const float* action, const float* pe, const float* keep, float scale, const float* W,
+                          const float* bias, const float* expo, int B, int S, int D, int A, float* inter, float* p, float* sample,
+                          float* soft, void* stream);
+int ctvae_ct_mask_backward(const float* x, const float* action, const float* pe, const float* keep, float scale, const float* inter,
+                           const float* p, const float* soft, const float* g, int B, int S, int D, int A, float* dWp, float* dbp,
+                           void* stream);
+/* Straight-through Bernoulli(p) like ctvae_gumbel_st_forward but from exponential draws expo [n][2] (what F.gumbel_softmax
+ * draws: Gumbel = -log E) and, when weighted != NULL, also weighted = p * sample (weighted_graph, ct_mcq_vae.py:244,271).
+ * Backward: gp = (g_sample + g_weighted * p) * d sample/d p + g_weighted * sample (either gradient may be NULL). */
+int ctvae_ct_sample_forward(const float* p, const float* expo, float* sample, float* soft, float* weighted, long n, void* stream);
+int ctvae_ct_sample_backward(const float* g_sample, const float* g_weighted, const float* p, const float* soft, const float* sample,
+                             float* g_p, long n, void* stream);
+
 /* layout change at the NCHW API boundary: to_nhwc=1: in [B,C,P] -> out [B,P,C]; 0: the inverse
  * (torch.flatten on NCHW, vanilla_vae.py:85; .view(-1,512,2,2), vanilla_vae.py:102) */
 int ctvae_permute(const float* in, float* out, int B, int C, int P, int to_nhwc, void* stream);
