@@ -570,13 +570,13 @@ class ConvBNActConvAct(Function):
             g_a = conv_dgrad_raw(g_pre, w2, spec2, (H, W))
         part, rows = link.take(g_a)
         ws = native.workspace(x.device)
-        g_y = torch.empty_like(y1)
         gg, accg = grad_target(gamma)
         gbt, accb = grad_target(beta)
         if accg != accb:
             (gg if accg == 0 else gbt).zero_()
             accg = 1
         lazy = wgrad_bn_apply_supported(spec1, x.shape[0], x.shape[1], x.shape[2])
+        g_y = torch.empty_like(y1)
         bcoef = torch.empty(5 * C, dtype=torch.float32, device=x.device) if lazy else None
         native.call("ctvae_bn_backward", g_a.data_ptr(), beta.data_ptr(), y1.data_ptr(), B * H * W, C, gamma.data_ptr(),
                     save_mean.data_ptr(), save_invstd.data_ptr(), ctx.bn_act, None if lazy else g_y.data_ptr(), gg.data_ptr(),

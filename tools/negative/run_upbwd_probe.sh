@@ -1,0 +1,8 @@
+# Builds the diagnostic library (upbwd.hip with -DCTVAE_PHASE_TIMING) on the GPU box and prints up_bwd_kernel's phase timeline.
+set -e
+cd $GRAFT_REPO_ROOT
+O=ct-vae_amd/csrc/_obj
+hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DCTVAE_PHASE_TIMING -c ct-vae_amd/csrc/upbwd.hip -o /tmp/upbwd_t.o
+objs=$(ls $O/*.o | grep -v "/upbwd.o")
+hipcc -shared -fPIC --offload-arch=gfx950 -o /tmp/libctvae_timing.so $objs /tmp/upbwd_t.o
+CTVAE_TIMING_LIB=/tmp/libctvae_timing.so python tools/upbwd_phase_probe.py
