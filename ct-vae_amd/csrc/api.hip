@@ -44,6 +44,10 @@ int launch_gat_score(int mode, const float* xl, const float* xr, const float* at
 int launch_gat_score_backward(const float* xl, const float* xr, const float* attr, const float* we, const float* att,
                               const float* g, float* dxl, float* dxr, float* datt_part, float* dwe_part, int B, int N, int H,
                               int C, float slope, hipStream_t st);
+int launch_gauss_latent_fwd(const float* heads, const float* eps_in, const unsigned long long* rng, float* eps_out, float* z, int B,
+                            int L, hipStream_t st);
+int launch_gauss_latent_bwd(const float* g_mu, const float* g_lv, const float* g_z, const float* heads, const float* eps,
+                            float* g_heads, unsigned long long* rng_bump, int B, int L, hipStream_t st);
 int launch_ct_reg_forward(const float* adj, const float* graph, const float* uni, float* part, float ckl, float cgs, float cpt,
                           int B, int N, hipStream_t st);
 int launch_ct_reg_backward(const float* adj, const float* graph, const float* uni, const float* part, const float* g_loss,
@@ -366,6 +370,16 @@ int ctvae_gat_layer_backward(const float* xl, const float* xr, int ld, const flo
   p.g_out = g_out; p.dS = dS; p.dattr = dattr; p.dxl = d_xl; p.dxr = d_xr; p.ldd = ldd;
   p.dbias_part = d_bias_part; p.datt_part = d_att_part; p.dwe_part = d_we_part;
   return launch_gat_layer_backward(p, d_adj, accumulate_dadj, (hipStream_t)stream);
+}
+
+int ctvae_gauss_latent_forward(const float* heads, const float* eps_in, const uint64_t* rng, float* eps_out, float* z, int B, int L,
+                               void* stream) {
+  return launch_gauss_latent_fwd(heads, eps_in, (const unsigned long long*)rng, eps_out, z, B, L, (hipStream_t)stream);
+}
+
+int ctvae_gauss_latent_backward(const float* g_mu, const float* g_logvar, const float* g_z, const float* heads, const float* eps,
+                                float* g_heads, uint64_t* rng_bump, int B, int L, void* stream) {
+  return launch_gauss_latent_bwd(g_mu, g_logvar, g_z, heads, eps, g_heads, (unsigned long long*)rng_bump, B, L, (hipStream_t)stream);
 }
 
 int ctvae_ct_reg_forward(const float* adj, const float* graph, const float* uniform, float* part4, float ckl, float cgs, float cpt,

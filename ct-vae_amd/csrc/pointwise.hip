@@ -63,6 +63,76 @@ __global__ __launch_bounds__(256) void reparam_bwd_kernel(const float* __restric
   glv[i] = g * eps[i] * 0.5f * expf(0.5f * lv[b * lv_rs + d]);
 }
 
+// ---- Gaussian latent as one node (vanilla_vae.py:85-92,107-122): heads [B][2L] = fc_mu | fc_var output ----------------------
+// forward : z = eps * exp(0.5*logvar) + mu with mu = heads[:, :L], logvar = heads[:, L:]; eps given, or drawn here:
+//           Philox4x32-10 keyed by rng[0] with counter (rng[1], element quad), Box-Muller -> N(0,1); eps is kept for backward.
+// backward: g_heads[:, :L] = g_mu + g_z,  g_heads[:, L:] = g_logvar + g_z * eps * 0.5 * exp(0.5*logvar) in one launch (autograd
+//           otherwise adds the two contributions with a launch each and concatenates with a third); when the noise was drawn
+//           here, thread 0 advances rng[1] -- the forward kernel of the next step runs strictly later.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&o)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void gauss_latent_fwd_kernel(const float* __restrict__ heads, const float* __restrict__ eps_in,
+                                                              const unsigned long long* __restrict__ rng, float* __restrict__ eps_out,
+                                                              float* __restrict__ z, int B, int L) {
+  const int q = blockIdx.x * 256 + threadIdx.x;          // one thread = four consecutive elements (L % 4 == 0)
+  const int i = 4 * q;
+  if (i >= B * L) return;
+  const int b = i / L, d = i - b * L;
+  f32x4 e;
+  if (eps_in != nullptr) {
+    e = *reinterpret_cast<const f32x4*>(eps_in + i);
+  } else {
+    const unsigned long long key = rng[0], ctr = rng[1];
+    unsigned o[4];
+    philox4x32_10((unsigned)q, (unsigned)ctr, (unsigned)(ctr >> 32), 0x5eedu, (unsigned)key, (unsigned)(key >> 32), o);
+    // Box-Muller on two pairs; u in (0, 1]
+    const float u0 = ((o[0] >> 8) + 1) * (1.f / 16777216.f), u1 = (o[1] >> 8) * (1.f / 16777216.f);
+    const float u2 = ((o[2] >> 8) + 1) * (1.f / 16777216.f), u3 = (o[3] >> 8) * (1.f / 16777216.f);
+    const float r0 = sqrtf(-2.f * __logf(u0)), r1 = sqrtf(-2.f * __logf(u2));
+    float s0, c0, s1, c1;
+    __sincosf(6.28318530718f * u1, &s0, &c0);
+    __sincosf(6.28318530718f * u3, &s1, &c1);
+    e = f32x4{r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+  }
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(heads + (long)b * 2 * L + d);
+  const f32x4 lv = *reinterpret_cast<const f32x4*>(heads + (long)b * 2 * L + L + d);
+  f32x4 zz;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) zz[k] = e[k] * expf(0.5f * lv[k]) + mu[k];
+  *reinterpret_cast<f32x4*>(z + i) = zz;
+  *reinterpret_cast<f32x4*>(eps_out + i) = e;
+}
+
+__global__ __launch_bounds__(256) void gauss_latent_bwd_kernel(const float* __restrict__ g_mu, const float* __restrict__ g_lv,
+                                                              const float* __restrict__ g_z, const float* __restrict__ heads,
+                                                              const float* __restrict__ eps, float* __restrict__ g_heads,
+                                                              unsigned long long* __restrict__ rng_bump, int B, int L) {
+  const int i = 4 * (blockIdx.x * 256 + threadIdx.x);
+  if (i == 0 && rng_bump != nullptr) rng_bump[1] += 1ull;
+  if (i >= B * L) return;
+  const int b = i / L, d = i - b * L;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 gz = g_z ? *reinterpret_cast<const f32x4*>(g_z + i) : zero;
+  const f32x4 gm = g_mu ? *reinterpret_cast<const f32x4*>(g_mu + i) : zero;
+  const f32x4 gl = g_lv ? *reinterpret_cast<const f32x4*>(g_lv + i) : zero;
+  const f32x4 lv = *reinterpret_cast<const f32x4*>(heads + (long)b * 2 * L + L + d);
+  const f32x4 e = *reinterpret_cast<const f32x4*>(eps + i);
+  f32x4 o1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o1[k] = gl[k] + gz[k] * e[k] * 0.5f * expf(0.5f * lv[k]);
+  *reinterpret_cast<f32x4*>(g_heads + (long)b * 2 * L + d) = gm + gz;
+  *reinterpret_cast<f32x4*>(g_heads + (long)b * 2 * L + L + d) = o1;
+}
+
 // ---- Adam ---------------------------------------------------------------------------------------------
 // state[0]=step (as float), [1]=lr, [2]=beta1, [3]=beta2, [4]=eps, [5]=weight_decay, [6]=beta1^t, [7]=beta2^t
 __global__ void adam_advance_kernel(float* state) {
@@ -177,6 +247,25 @@ int launch_adam(float* p, const float* g, float* m, float* v, float* state, long
   hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, st, state);
   CTVAE_LAUNCH_CHECK();
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, st, p, g, m, v, state, n, grad_scale);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_gauss_latent_fwd(const float* heads, const float* eps_in, const unsigned long long* rng, float* eps_out, float* z, int B,
+                            int L, hipStream_t st) {
+  if (!heads || !eps_out || !z || (!eps_in && !rng) || B <= 0 || L <= 0 || L % 4) return kErrBadArg;
+  ProfScope ps("gauss_latent_fwd_kernel", st, 0.0, 4.0 * 5.0 * B * L);
+  hipLaunchKernelGGL(gauss_latent_fwd_kernel, dim3((B * L / 4 + 255) / 256), dim3(256), 0, st, heads, eps_in, rng, eps_out, z, B, L);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_gauss_latent_bwd(const float* g_mu, const float* g_lv, const float* g_z, const float* heads, const float* eps,
+                            float* g_heads, unsigned long long* rng_bump, int B, int L, hipStream_t st) {
+  if (!heads || !eps || !g_heads || B <= 0 || L <= 0 || L % 4) return kErrBadArg;
+  ProfScope ps("gauss_latent_bwd_kernel", st, 0.0, 4.0 * 7.0 * B * L);
+  hipLaunchKernelGGL(gauss_latent_bwd_kernel, dim3((B * L / 4 + 255) / 256), dim3(256), 0, st, g_mu, g_lv, g_z, heads, eps, g_heads,
+                     rng_bump, B, L);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }

@@ -669,6 +669,44 @@ class Reparameterize(Function):
         return g_mu, g_lv, None
 
 
+class GaussianLatent(Function):
+    """(mu, log_var, z) from the fused fc_mu | fc_var output heads [B,2L] as ONE autograd node (vanilla_vae.py:85-92,107-122):
+    mu / log_var are views of heads, z = eps*exp(0.5*log_var) + mu.  eps None: N(0,1) drawn in the kernel from ``rng`` (a device
+    uint64 pair: Philox key and stream position, advanced by the backward launch).  Backward forms g_heads in one launch;
+    as separate SplitHeads / Reparameterize nodes autograd adds the KL and the reparameterisation contributions to mu and
+    log_var with a launch each and concatenates with a third."""
+
+    @staticmethod
+    def forward(ctx, heads, eps, rng):
+        _req_cuda(heads)
+        heads = _c(heads)
+        B, L2 = heads.shape
+        L = L2 // 2
+        eps_in = _c(eps) if eps is not None else None
+        if eps_in is None and rng is None:
+            raise RuntimeError("GaussianLatent: either eps or the rng state is needed")
+        eps_out = torch.empty((B, L), dtype=torch.float32, device=heads.device)
+        z = torch.empty((B, L), dtype=torch.float32, device=heads.device)
+        native.call("ctvae_gauss_latent_forward", heads.data_ptr(), native.ptr(eps_in), native.ptr(rng) if eps_in is None else None,
+                    eps_out.data_ptr(), z.data_ptr(), B, L)
+        ctx.save_for_backward(heads, eps_out)
+        ctx.rng = rng if eps_in is None else None
+        ctx.set_materialize_grads(False)
+        return heads[:, :L], heads[:, L:], z
+
+    @staticmethod
+    def backward(ctx, g_mu, g_lv, g_z):
+        heads, eps = ctx.saved_tensors
+        B, L2 = heads.shape
+        g_mu = _c(g_mu) if g_mu is not None else None
+        g_lv = _c(g_lv) if g_lv is not None else None
+        g_z = _c(g_z) if g_z is not None else None
+        g_heads = torch.empty_like(heads)
+        native.call("ctvae_gauss_latent_backward", native.ptr(g_mu), native.ptr(g_lv), native.ptr(g_z), heads.data_ptr(), eps.data_ptr(),
+                    g_heads.data_ptr(), native.ptr(ctx.rng), B, L2 // 2)
+        return g_heads, None, None
+
+
 def _scalar_outputs(ctx, out):
     """The 4-vector a loss kernel wrote, handed out as four 0-dim views.  Callers index the returned tuple, so no autograd
     select node sits between the loss and this Function: indexing a tensor output (out[0]) made ``loss.backward()`` build

@@ -94,14 +94,17 @@ class VanillaVAE(BaseVAE):
         return K.to_nhwc(input)
 
     # -- reference API ----------------------------------------------------------------------------
-    def encode(self, input: Tensor) -> List[Tensor]:
-        """[B,C,64,64] -> [mu [B,L], log_var [B,L]] (vanilla_vae.py:77-92)."""
+    def _encode_heads(self, input: Tensor) -> Tensor:
+        """[B,C,64,64] -> [B, 2L]: fc_mu | fc_var of the flattened encoder output as one GEMM."""
         self.attach_grads()
         h = self.encoder(self._input_nhwc(input))                       # [B,2,2,512] NHWC
         B = h.shape[0]
         flat = K._ToNCHW.apply(h).view(B, 1, 1, -1)                      # torch.flatten(start_dim=1) on NCHW
-        heads = K.ConvAct.apply(flat, self.fc_mu.weight, self.fc_mu.bias, None, self._head_spec).view(B, -1)
-        mu, log_var = K.SplitHeads.apply(heads, self.latent_dim)
+        return K.ConvAct.apply(flat, self.fc_mu.weight, self.fc_mu.bias, None, self._head_spec).view(B, -1)
+
+    def encode(self, input: Tensor) -> List[Tensor]:
+        """[B,C,64,64] -> [mu [B,L], log_var [B,L]] (vanilla_vae.py:77-92)."""
+        mu, log_var = K.SplitHeads.apply(self._encode_heads(input), self.latent_dim)
         return [mu, log_var]
 
     def decode(self, z: Tensor) -> Tensor:
@@ -119,9 +122,26 @@ class VanillaVAE(BaseVAE):
             eps = torch.randn(mu.shape, dtype=mu.dtype, device=mu.device)
         return K.Reparameterize.apply(mu, logvar, eps.to(mu.device))
 
+    def _latent_rng(self, device):
+        """Device-side Philox state (key, stream position) of the in-kernel noise: seeded once from torch's generator."""
+        st = getattr(self, "_rng_state", None)
+        if st is None or st.device != device:
+            key = int(torch.randint(0, 2 ** 62, (1,)).item())
+            st = self._rng_state = torch.tensor([key, 0], dtype=torch.int64, device=device)
+        return st
+
     def forward(self, input: Tensor, eps: Tensor = None, **kwargs) -> List[Tensor]:
-        mu, log_var = self.encode(input)
-        z = self.reparameterize(mu, log_var, eps)
+        """encode -> reparameterize -> decode (vanilla_vae.py:119-122).  The latent section runs as one node
+        (kernels.GaussianLatent): with eps None and gradients on, the N(0,1) noise is drawn inside its kernel."""
+        heads = self._encode_heads(input)
+        if self.latent_dim % 4 == 0 and type(self).reparameterize is VanillaVAE.reparameterize:
+            if eps is None and not (torch.is_grad_enabled() and heads.requires_grad):
+                eps = torch.randn((heads.shape[0], self.latent_dim), dtype=heads.dtype, device=heads.device)   # no backward: no state bump
+            rng = self._latent_rng(heads.device) if eps is None else None
+            mu, log_var, z = K.GaussianLatent.apply(heads, eps.to(heads.device) if eps is not None else None, rng)
+        else:
+            mu, log_var = K.SplitHeads.apply(heads, self.latent_dim)
+            z = self.reparameterize(mu, log_var, eps)
         return [self.decode(z), input, mu, log_var]
 
     def loss_function(self, *args, **kwargs) -> dict:

@@ -51,6 +51,8 @@ SIGNATURES = {
     "ctvae_pair_mlp_backward": [_fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _f, _i, _fp, _vp],
     "ctvae_act_forward": [_fp, _fp, _l, _i, _vp],
     "ctvae_act_backward": [_fp, _fp, _fp, _l, _i, _vp],
+    "ctvae_gauss_latent_forward": [_fp, _fp, _fp, _fp, _fp, _i, _i, _vp],
+    "ctvae_gauss_latent_backward": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _vp],
     "ctvae_reparam_forward": [_fp, _l, _fp, _l, _fp, _fp, _i, _i, _vp],
     "ctvae_reparam_backward": [_fp, _fp, _l, _fp, _fp, _fp, _i, _i, _vp],
     "ctvae_loss_forward": [_fp, _fp, _l, _fp, _l, _fp, _l, _i, _i, _f, _fp, _fp, _fp, _sz, _vp],

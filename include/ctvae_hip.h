@@ -253,6 +253,15 @@ int ctvae_permute(const float* in, float* out, int B, int C, int P, int to_nhwc,
 int ctvae_act_forward(const float* in, float* out, long n, int act, void* stream);           /* mcq_vae.py:185,216 */
 int ctvae_act_backward(const float* g_out, const float* out, float* g_in, long n, int act, void* stream);
 
+/* The Gaussian latent as one node (vanilla_vae.py:85-92,107-122): heads [B][2L] holds mu | logvar (the fused fc_mu / fc_var
+ * GEMM output, L % 4 == 0).  forward: z = eps*exp(0.5*logvar) + mu; eps_in given (injected noise), or NULL: N(0,1) drawn in
+ * the kernel (Philox4x32-10 keyed by rng[0], stream position rng[1]; rng: two uint64 on the device) -- eps_out [B,L] keeps it
+ * for backward.  backward: g_heads [B][2L] = (g_mu + g_z | g_logvar + g_z*eps*0.5*exp(0.5*logvar)) in one launch (any of the
+ * three incoming gradients may be NULL = 0); rng_bump != NULL advances rng[1] by one (pass it when eps was drawn in forward). */
+int ctvae_gauss_latent_forward(const float* heads, const float* eps_in, const uint64_t* rng, float* eps_out, float* z, int B, int L,
+                               void* stream);
+int ctvae_gauss_latent_backward(const float* g_mu, const float* g_logvar, const float* g_z, const float* heads, const float* eps,
+                                float* g_heads, uint64_t* rng_bump, int B, int L, void* stream);
 /* z = eps*exp(0.5*logvar)+mu (vanilla_vae.py:115-117); mu/logvar rows may be strided (slices of one head GEMM) */
 int ctvae_reparam_forward(const float* mu, long mu_row_stride, const float* logvar, long lv_row_stride, const float* eps,
                           float* z, int B, int L, void* stream);

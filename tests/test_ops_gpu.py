@@ -461,3 +461,40 @@ def test_winograd_conv3x3(K, case, with_bias):
         db = (bp.grad.cpu() - b.grad).numpy()
         off = np.abs(db) > 1e-3 * max(1.0, float(b.grad.abs().max()))
         assert off.sum() <= 3, "bias gradient (a ReLU flip moves one channel's sum by O(1); more than a few is a bug)"
+
+
+def test_gaussian_latent_node(K):
+    """kernels.GaussianLatent (mu | log_var views + reparameterisation as one node) against the torch expression of
+    vanilla_vae.py:107-117 with injected noise, and the statistics / stream advance of the in-kernel Philox noise."""
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(9)
+    B, L = 64, 128
+    heads = torch.randn(B, 2 * L, generator=g) * 0.5
+    eps = torch.randn(B, L, generator=g)
+    wz, wm, wl = (torch.randn(B, L, generator=g) for _ in range(3))
+    hr = heads.clone().requires_grad_(True)
+    mu_r, lv_r = hr[:, :L], hr[:, L:]
+    z_r = eps * torch.exp(0.5 * lv_r) + mu_r
+    ((z_r * wz).sum() + (mu_r * wm).sum() + (lv_r * wl).sum()).backward()
+    hd = heads.to(dev).requires_grad_(True)
+    mu, lv, z = K.GaussianLatent.apply(hd, eps.to(dev), None)
+    ((z * wz.to(dev)).sum() + (mu * wm.to(dev)).sum() + (lv * wl.to(dev)).sum()).backward()
+    np.testing.assert_allclose(z.detach().cpu().numpy(), z_r.detach().numpy(), atol=1e-6, rtol=1e-6)
+    np.testing.assert_allclose(hd.grad.cpu().numpy(), hr.grad.numpy(), atol=1e-6, rtol=1e-5)
+    # in-kernel noise: N(0,1) moments over 2^20 draws, reproducible for one stream position, fresh after a backward
+    B2 = 8192
+    h2 = torch.zeros(B2, 2 * L, device=dev, requires_grad=True)           # mu = 0, log_var = 0 -> z == eps
+    rng = torch.tensor([1234567, 0], dtype=torch.int64, device=dev)
+    _, _, z1 = K.GaussianLatent.apply(h2, None, rng)
+    _, _, z1b = K.GaussianLatent.apply(h2, None, rng)
+    assert torch.equal(z1, z1b), "same key and stream position must give the same noise"
+    z1.sum().backward()
+    assert int(rng[1]) == 1
+    _, _, z2 = K.GaussianLatent.apply(h2, None, rng)
+    assert not torch.equal(z1, z2)
+    v = z1.detach().double().flatten()
+    n = v.numel()
+    assert abs(float(v.mean())) < 5.0 / n ** 0.5 and abs(float(v.var()) - 1.0) < 0.01
+    assert abs(float((v ** 3).mean())) < 0.02 and abs(float((v ** 4).mean()) - 3.0) < 0.05
+    assert abs(float((z1.detach().flatten()[:-1] * z1.detach().flatten()[1:]).mean())) < 0.01      # neighbours uncorrelated
+    assert abs(float((z1.detach() * z2.detach()).mean())) < 0.01                                      # steps uncorrelated
