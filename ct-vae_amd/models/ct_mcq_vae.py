@@ -41,14 +41,14 @@ class CTMCQVAE(BaseVAE):
     # -- conv path ------------------------------------------------------------------------------------
     def _nhwc(self, t):
         x = K.to_nhwc(t)
-        self._x_cache[(t.data_ptr(), t._version, tuple(t.shape))] = x
+        self._x_cache[id(t)] = (t, t._version, x)     # keyed by the tensor object (held): an address can be reused by a later batch
         if len(self._x_cache) > 4:
             self._x_cache.pop(next(iter(self._x_cache)))
         return x
 
     def _cached_nhwc(self, t):
-        x = self._x_cache.get((t.data_ptr(), t._version, tuple(t.shape)))
-        return x if x is not None else K.to_nhwc(t)
+        c = self._x_cache.get(id(t))
+        return c[2] if (c is not None and c[0] is t and c[1] == t._version) else K.to_nhwc(t)
 
     def encode(self, input: Tensor) -> List[Tensor]:
         self.attach_grads()

@@ -122,13 +122,13 @@ class MCQVAE(BaseVAE):
 
     def _input_nhwc(self, input):
         x = K.to_nhwc(input)
-        self._x_cache = (input.data_ptr(), input._version, tuple(input.shape), x)
+        self._x_cache = (input, input._version, x)        # the tensor itself: an address can be reused by a later batch
         return x
 
     def _cached_nhwc(self, input):
         c = self._x_cache
-        if c is not None and c[0] == input.data_ptr() and c[1] == input._version and c[2] == tuple(input.shape):
-            return c[3]
+        if c is not None and c[0] is input and c[1] == input._version:
+            return c[2]
         return K.to_nhwc(input)
 
     def encode(self, input: Tensor) -> List[Tensor]:
@@ -145,7 +145,8 @@ class MCQVAE(BaseVAE):
         return [self.decode(quantized_inputs), input, vq_loss]
 
     def loss_function(self, *args, **kwargs) -> dict:
-        """mse + vq_loss; values are NOT detached (mcq_vae.py:267-284)."""
+        """mse + vq_loss (mcq_vae.py:267-284).  The reference returns Reconstruction_Loss / VQ_Loss un-detached; here
+        'loss' carries the gradient (mse + vq in one kernel) and 'Reconstruction_Loss' is a reported value of that kernel."""
         recons, input, vq_loss = args[0], args[1], args[2]
         out = K.VAELoss.apply(K.to_nhwc(recons), self._cached_nhwc(input), None, None, vq_loss, 0.0)
         return {'loss': out[0], 'Reconstruction_Loss': out[1], 'VQ_Loss': vq_loss}

@@ -84,13 +84,13 @@ class VanillaVAE(BaseVAE):
     # -- helpers ----------------------------------------------------------------------------------
     def _input_nhwc(self, input):
         x = K.to_nhwc(input)
-        self._x_cache = (input.data_ptr(), input._version, tuple(input.shape), x)
+        self._x_cache = (input, input._version, x)        # the tensor itself: an address can be reused by a later batch
         return x
 
     def _cached_nhwc(self, input):
         c = self._x_cache
-        if c is not None and c[0] == input.data_ptr() and c[1] == input._version and c[2] == tuple(input.shape):
-            return c[3]
+        if c is not None and c[0] is input and c[1] == input._version:
+            return c[2]
         return K.to_nhwc(input)
 
     # -- reference API ----------------------------------------------------------------------------

@@ -4,6 +4,16 @@ Same update rule as ``torch.optim.Adam(lr, weight_decay)`` with default betas/ep
 reference's harness builds (experiment.py:158-160); the schedule is ``ExponentialLR(gamma)`` stepped once
 per epoch (experiment.py:173-175).  One kernel launch per step for the whole model, hyper-parameters and the
 step counter live in a small device tensor so the launch is hipGraph-capturable.
+
+Deviations from ``torch.optim.Adam`` (documented, not pinned by a fixture):
+* ONE step counter for the whole buffer, and every element is updated every step.  torch keeps a step per parameter and
+  skips parameters whose ``.grad`` is None.  The two differ only for parameters that receive NO gradient in some steps --
+  in this repository CT-MCQ-VAE's per-action ``graph_discovers`` whose action is absent from a batch, ``ct_layer.mask`` in
+  base-mode steps, the decoder in causal-mode steps: here they see a zero gradient (first moment decays, the parameter keeps
+  drifting by its momentum, bias correction follows the global count), in torch they are frozen for that step.  VanillaVAE /
+  MCQ-VAE (every parameter gets a gradient every step) are unaffected: tests/test_ct_gpu.py pins their 3-step trajectory.
+* beta1^t / beta2^t are accumulated in fp32 on the device (state[6..7]); torch computes them in double on the host.  After
+  10^4 steps the relative difference of the bias corrections is < 1e-4 (beta2^t has decayed to 4.5e-5 by then).
 """
 import torch
 
