@@ -811,7 +811,10 @@ int launch_img_enc_wgrad(const ConvGeom& g, const float* X, const float* dY, flo
   return 0;
 }
 
-constexpr int kImgFwdWgs = 768, kImgWgradWgs = 512, kImgDgradWgs = 1024;
+// persistent grids (diagnostic overrides: CTVAE_IMG_FWD_WGS / CTVAE_IMG_WGRAD_WGS / CTVAE_IMG_DGRAD_WGS)
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static const int kImgFwdWgs = env_int("CTVAE_IMG_FWD_WGS", 768), kImgWgradWgs = env_int("CTVAE_IMG_WGRAD_WGS", 512),
+                 kImgDgradWgs = env_int("CTVAE_IMG_DGRAD_WGS", 1024);
 
 int img_wgrad_parts(const ConvGeom& g) {
   const int nt = g.B * (g.sH / TH) * (g.sW / TW);

@@ -428,7 +428,7 @@ bool upconv_supported(const ConvGeom& g) {
 }
 bool upconv_wgrad_supported(const ConvGeom& g) { return upconv_supported(g); }
 
-constexpr int kUpWgs = 512;
+static const int kUpWgs = [] { const char* e = getenv("CTVAE_UP_WGS"); return e ? atoi(e) : 512; }();   // diagnostic override
 int upconv_rows(const ConvGeom& g) {
   const int nt = g.B * (g.gH / TH) * (g.gW / TW);
   return nt < kUpWgs ? nt : kUpWgs;

@@ -454,7 +454,7 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
   const size_t ws_floats = ws_bytes / sizeof(float);
   // 128x128 tiles hold two workgroups per CU (64 accumulator + 134 other registers): one resident round, and half the
   // partial slabs for the reduce pass
-  static const int tgt_small = [] { const char* e = getenv("CTVAE_WGRAD_WGS"); return e ? atoi(e) : 1024; }();
+  static const int tgt_small = [] { const char* e = getenv("CTVAE_WGRAD_WGS"); return e ? atoi(e) : 768; }();   // diagnostic override
   const int S = choose_splits(g, KT, NT, ws_floats, big ? 512 : tgt_small);
   if (wgrad_workspace_floats(g, S) > ws_floats) return kErrWorkspace;
   a.S = S;
