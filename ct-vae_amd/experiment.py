@@ -18,18 +18,37 @@ from .ddp import GradBucketAllReduce
 from .optim import ExponentialLR, FlatAdam
 
 
+def _graph_key(real_img, kwargs):
+    """Key of a capturable step: the batch's shape plus, per option, a tensor's shape / dtype or the (one-per-batch) mode name.
+    None when an option is neither (such a step stays eager)."""
+    items = []
+    for k in sorted(kwargs):
+        v = kwargs[k]
+        if torch.is_tensor(v):
+            items.append((k, tuple(v.shape), v.dtype))
+        elif k == "mode" and isinstance(v, (str, list)):
+            items.append((k, v[0] if isinstance(v, list) else v))
+        else:
+            return None
+    return (tuple(real_img.shape), real_img.dtype, tuple(items))
+
+
 class _GraphedTrainStep:
-    """zero_grad + forward + loss + backward (+ Adam when there is no gradient exchange) of one batch shape, captured
-    once into a hipGraph and replayed: ~130 launches per VanillaVAE step are host-bound when issued eagerly (3.5 vs 1.9 ms).
-    The first WARM batches of a shape run eagerly as ordinary training steps; capture itself executes nothing, so the
-    training trajectory is exactly the eager one.  Only for batches without per-step keyword options (the CT-MCQ-VAE
-    modes carry data-dependent host control flow and stay eager)."""
+    """zero_grad + forward + loss + backward (+ Adam when there is no gradient exchange) of one batch signature, captured
+    once into a hipGraph and replayed: ~130 launches per VanillaVAE step -- ~400 per CT-MCQ-VAE step -- are host-bound when
+    issued eagerly (VanillaVAE bs=256: 3.5 vs 1.8 ms; CT-MCQ-VAE at the YAML's 16 pairs per GPU: 7.5 vs 3.4 ms).
+    The first WARM batches of a signature run eagerly as ordinary training steps; capture itself executes nothing, so the
+    training trajectory is exactly the eager one.  A signature = input shape + the shapes of the tensor options (input_y,
+    action) + the mode (datasets/transition.py hands out one mode per batch): the CT-MCQ-VAE modes each get their own graph
+    (none of them reads a device value on the host any more)."""
 
     WARM = 3
 
-    def __init__(self, exp, real_img):
+    def __init__(self, exp, real_img, kwargs):
         self.exp = exp
         self.x = torch.empty_like(real_img)
+        self.static = {k: torch.empty_like(v) for k, v in kwargs.items() if torch.is_tensor(v)}
+        self.const = {k: v for k, v in kwargs.items() if not torch.is_tensor(v)}
         self.seen = 0
         self.graph = None
         self.losses = None
@@ -37,15 +56,20 @@ class _GraphedTrainStep:
     def _body(self):
         exp = self.exp
         exp.model.zero_grad()
-        results = exp.forward(self.x, labels=None)
+        results = exp.forward(self.x, labels=None, **self.static, **self.const)
         losses = exp.model.loss_function(*results, M_N=exp.params['kld_weight'], optimizer_idx=0, batch_idx=0)
         K.backward(losses['loss'])
         if exp.ddp is None:
             exp.optimizer.step()
-        return losses
+        # detached: a live loss keeps the step's autograd graph -- and with it the AccumulateGrad nodes of the parameters
+        # torch accumulates itself (the CT layer's banks), bound to the stream they were made on -- alive into the next
+        # signature's capture, where running them on that other stream ends the capture with a fault
+        return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in losses.items()}
 
-    def run(self, real_img):
+    def run(self, real_img, kwargs=None):
         self.x.copy_(real_img, non_blocking=True)
+        for k, t in self.static.items():
+            t.copy_(kwargs[k], non_blocking=True)
         if self.graph is None and self.seen >= self.WARM:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -159,13 +183,14 @@ class VAEXperiment:
                 real_img, _labels, kwargs = self._unpack(batch)
                 # graph_safe = False: the model's step depends on host state that changes per call (e.g. BetaVAE type 'B':
                 # the capacity C follows the loss-call counter), so a captured step would freeze it
-                if self.params.get('hipgraph', True) and not kwargs and real_img.is_cuda and getattr(self.model, 'graph_safe', True):
-                    key = (tuple(real_img.shape), real_img.dtype)
+                key = _graph_key(real_img, kwargs) if (self.params.get('hipgraph', True) and real_img.is_cuda
+                                                       and getattr(self.model, 'graph_safe', True)) else None
+                if key is not None:
                     gs = self._graphed.get(key)
                     if gs is None:
-                        gs = self._graphed[key] = _GraphedTrainStep(self, real_img)
+                        gs = self._graphed[key] = _GraphedTrainStep(self, real_img, kwargs)
                     self.curr_device = real_img.device
-                    losses = gs.run(real_img)
+                    losses = gs.run(real_img, kwargs)
                     self.global_step -= 1                  # log_all keys on the step that just ran
                     self.log_all(losses, batch_size=real_img.size(0), validation=False)
                     self.global_step += 1

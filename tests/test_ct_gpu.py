@@ -270,3 +270,52 @@ def test_pair_mlp_per_sample_scorers_and_compute_adj(dev):
         if k in want:
             np.testing.assert_allclose(p.grad.cpu().numpy(), want[k].numpy(), atol=1e-5 * max(1.0, float(want[k].abs().max())),
                                        rtol=1e-3, err_msg=k)
+
+
+class _FixedNoise:
+    """Noise source with one cached device tensor per (tag, shape): deterministic and free of host-to-device copies once every
+    tag has been drawn (so a captured step replays the same noise an eager step sees)."""
+
+    def __init__(self, dev):
+        self.dev, self.cache = dev, {}
+
+    def draw(self, tag, shape, p=0.0):
+        key = (tag, tuple(shape), p)
+        if key not in self.cache:
+            self.cache[key] = filler.ct_noise(77, tag, len(self.cache) % 5, shape, p).to(self.dev)
+        return self.cache[key]
+
+
+def test_harness_captures_ct_modes_as_hipgraphs(dev):
+    """VAEXperiment.fit on transition batches: every CT-MCQ-VAE mode (one per batch, datasets/transition.py:128-190) is captured
+    into its own hipGraph after three eager steps, and the parameter trajectory is bit-identical to the all-eager harness."""
+    from ctvae_amd.experiment import VAEXperiment
+    from ctvae_amd.models import causal
+    B, A = 4, 12
+    batches = []
+    for i in range(18):
+        x, y, a = filler.synthetic_pairs(100 + i, B, A)
+        mode = ["base", "action", "causal"][i % 3]
+        opts = {"mode": [mode] * B}
+        if mode != "base":
+            opts.update(input_y=y.to(dev), action=a.to(dev))
+        batches.append((x.to(dev), torch.zeros(B, device=dev), opts))
+    params = {"LR": 5e-4, "weight_decay": 0.0, "scheduler_gamma": 0.99, "kld_weight": 0.00025, "update_parameters": "ct_layer"}
+    finals = {}
+    prev = causal.set_noise_source(_FixedNoise(dev))
+    try:
+        for graphed in (False, True):
+            m = build_ct(dev, 5)
+            exp = VAEXperiment(m, dict(params, hipgraph=graphed))
+            hist = exp.fit(lambda: iter(batches), None, max_epochs=1)
+            torch.cuda.synchronize()
+            assert hist[0]["train_images"] == 18 * B and exp.global_step == 18
+            if graphed:
+                assert len(exp._graphed) == 3 and all(g.graph is not None and g.seen == 6 for g in exp._graphed.values())
+            else:
+                assert not exp._graphed
+            finals[graphed] = m.flat_params.clone()
+    finally:
+        causal.set_noise_source(prev)
+    assert torch.isfinite(finals[True]).all()
+    assert torch.equal(finals[True], finals[False]), float((finals[True] - finals[False]).abs().max())
