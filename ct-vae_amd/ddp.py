@@ -21,6 +21,7 @@ class GradBucketAllReduce:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())
         self.bucket_elems = max(1, bucket_bytes // 4)
+        self.range = None
         if self.active and broadcast_from is not None:
             self.broadcast_parameters(broadcast_from)
 
@@ -31,8 +32,15 @@ class GradBucketAllReduce:
             if b.is_floating_point():
                 dist.broadcast(b, src, group=self.pg)
 
+    def restrict(self, flat_slice):
+        """Exchange only flat_grads[flat_slice]: the harness calls this when it optimises one sub-module
+        (``update_parameters``, experiment.py:156-160) -- the other gradients are never applied, so they need not travel."""
+        self.range = flat_slice
+
     def buckets(self):
         g = self.model.flat_grads
+        if self.range is not None:
+            g = g[self.range]
         n = g.numel()
         out, off = [], 0
         while off < n:

@@ -101,6 +101,8 @@ class VAEXperiment:
         self.log_file = log_file
         self.global_step = 0
         self.optimizer, self.scheduler = self.configure_optimizers()
+        if ddp is not None and "update_parameters" in params:
+            ddp.restrict(self.optimizer.slice)
         self._graphed = {}          # (shape, dtype) -> _GraphedTrainStep
 
     def forward(self, input, **kwargs):

@@ -120,6 +120,20 @@ def _harness_worker(rank, world, port, q):
         dist.all_gather(gathered, m.flat_params)
         assert torch.equal(gathered[0], gathered[1]), "ranks diverged"
         assert exp.global_step == 3 and not torch.equal(m.flat_params, p0)
+        # update_parameters (the YAML's second training stage): only that range of the flat buffer travels and is stepped
+        ddp2 = GradBucketAllReduce(m, bucket_bytes=1 << 12, broadcast_from=None)
+        exp2 = VAEXperiment(m, {"LR": 1e-3, "kld_weight": 1.0, "update_parameters": "decoder"}, ddp=ddp2)
+        sl = m.flat_range("decoder")
+        lo, hi = sl.start, sl.stop
+        assert 0 < lo < hi <= n and ddp2.range == sl and sum(b.numel() for b in ddp2.buckets()) == hi - lo
+        before = m.flat_params.clone()
+        mine_g = torch.full((n,), float(rank + 1))
+        m.flat_grads.copy_(mine_g)
+        exp2.optimizer_step()
+        assert torch.equal(m.flat_grads[lo:hi], torch.full((hi - lo,), 3.0)), "range not summed over the ranks"
+        assert torch.equal(m.flat_grads[:lo], mine_g[:lo]) and torch.equal(m.flat_grads[hi:], mine_g[hi:]), "outside moved"
+        assert torch.equal(m.flat_params[:lo], before[:lo]) and torch.equal(m.flat_params[hi:], before[hi:])
+        assert not torch.equal(m.flat_params[lo:hi], before[lo:hi])
         # plain datasets: every rank must see the same number of batches (129 rows, 2 ranks, bs 64 -> 65 rows each, 2 batches)
         for n_rows, bs in ((129, 64), (130, 64), (7, 4), (64, 64)):
             order = torch.arange(n_rows)
