@@ -36,7 +36,7 @@ size_t bn_workspace_floats(int C, int nparts);
 int launch_bn_backward(const float* ga, const float* beta, const float* y, int R, int C, const float* gamma,
                        const float* save_mean, const float* save_invstd, int act, float* gy, float* dgamma, float* dbeta,
                        int accumulate, float* ws, size_t ws_bytes, const float* part_in, int part_rows, hipStream_t st,
-                       float* coef_out = nullptr);
+                       float* coef_out = nullptr, const float* coef_in = nullptr);
 bool upconv_wgrad_supported(const ConvGeom& g);
 int launch_permute(const float* in, float* out, int B, int C, int P, int to_nhwc, hipStream_t st);
 int launch_gat_score(int mode, const float* xl, const float* xr, const float* attr, const float* we, const float* att, float* out,
@@ -273,9 +273,10 @@ int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* 
                         int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int accumulate, const float* mask,
                         int mask_act, const float* wino_filters, const float* bn_y, const float* bn_mean,
                         const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int bn_act, float* bn_part,
-                        int bn_part_rows, float* ws, size_t ws_bytes, void* stream) {
+                        int bn_part_rows, float* bn_coef_out, float* ws, size_t ws_bytes, void* stream) {
   if (!x || !dy || !w || !dw || !dx || !ws || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
   const bool bn = bn_part != nullptr;
+  if (bn_coef_out != nullptr && !bn) return kErrBadArg;
   if (bn && (!bn_y || !bn_mean || !bn_invstd || !bn_gamma || !bn_beta)) return kErrBadArg;
   ConvGeom gw, gd;
   if (build_geom(gw, kind == CTVAE_CONV ? 0 : 1, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
@@ -306,6 +307,10 @@ int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* 
   }
   pair_ctx() = nullptr;
   if (rc) return rc;
+  if (bn_coef_out != nullptr) {   // the finalize of the BatchNorm below rides in the finishing launch
+    ctx.haveBF = true;
+    ctx.bf = BnFinJob{bn_part, bn_part_rows, Ci, (float)((long)B * H * W), bn_gamma, bn_mean, bn_invstd, bn_beta, bn_coef_out};
+  }
   return pair_flush(ctx, st);
 }
 
@@ -329,13 +334,14 @@ int ctvae_bn_forward(const float* y, int R, int C, const float* gamma, const flo
 
 int ctvae_bn_backward(const float* g_a, const float* beta, const float* y, int R, int C, const float* gamma,
                       const float* save_mean, const float* save_invstd, int act, float* g_y, float* dgamma,
-                      float* dbeta, int accumulate, const float* part_in, int part_rows, float* coef_out, float* ws,
-                      size_t ws_bytes, void* stream) {
+                      float* dbeta, int accumulate, const float* part_in, int part_rows, float* coef_out,
+                      const float* coef_in, float* ws, size_t ws_bytes, void* stream) {
   if (!g_a || !beta || !y || !gamma || !save_mean || !save_invstd || !dgamma || !dbeta || !ws) return kErrBadArg;
   if (!g_y && !coef_out) return kErrBadArg;   // either apply here or hand the coefficients to the consumer
   if ((part_in != nullptr) != (part_rows > 0)) return kErrBadArg;
+  if (coef_in != nullptr && (!g_y || part_in != nullptr || coef_out != nullptr)) return kErrBadArg;
   return launch_bn_backward(g_a, beta, y, R, C, gamma, save_mean, save_invstd, act, g_y, dgamma, dbeta, accumulate, ws,
-                            ws_bytes, part_in, part_rows, (hipStream_t)stream, coef_out);
+                            ws_bytes, part_in, part_rows, (hipStream_t)stream, coef_out, coef_in);
 }
 
 int ctvae_gat_score(int mode, const float* xl, const float* xr, const float* attr, const float* we, const float* att, float* out,

@@ -9,6 +9,7 @@
 //           g_y = gamma*invstd * (g_bn - dbeta/R - xhat*dgamma/R)   (as k1*g_bn + k2*y + k3 per channel)
 // All of these are HBM-bound streaming kernels (roofline: bytes / 8 TB/s): 16-B loads, several in flight per lane.
 #include "common.hpp"
+#include "finish.hpp"
 #include "prof.hpp"
 
 namespace ctvae {
@@ -304,10 +305,24 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   }
 }
 
+__global__ __launch_bounds__(256) void bn_bwd_finalize_job_kernel(BnFinJob j) {
+  __shared__ double sm[8];
+  bn_bwd_finalize_body(j, blockIdx.x, sm);
+}
+
+// dgamma != nullptr: coef carries rows 5, 6 = this pass's d gamma / d beta (finalize rider of ctvae_conv_backward); block 0
+// commits them to the parameter gradients
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ ga, const float* __restrict__ y,
                                                            const float* __restrict__ coef, float* __restrict__ gy, long n4,
-                                                           int C, int act) {
+                                                           int C, int act, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           int accumulate) {
   const long stride = (long)gridDim.x * 256;
+  if (dgamma != nullptr && blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      dgamma[c] = (accumulate ? dgamma[c] : 0.f) + coef[5 * C + c];
+      dbeta[c] = (accumulate ? dbeta[c] : 0.f) + coef[6 * C + c];
+    }
+  }
   if (1024 % C == 0) {   // channel quad fixed per thread (see bn_apply_act_kernel)
     const int c = (int)((threadIdx.x * 4) % C);
     const f32x4 k1 = *reinterpret_cast<const f32x4*>(coef + c);
@@ -427,8 +442,19 @@ int launch_bn_forward(const float* y, int R, int C, const float* gamma, const fl
 int launch_bn_backward(const float* ga, const float* beta, const float* y, int R, int C, const float* gamma,
                        const float* save_mean, const float* save_invstd, int act, float* gy, float* dgamma,
                        float* dbeta, int accumulate, float* ws, size_t ws_bytes, const float* part_in, int part_rows,
-                       hipStream_t st, float* coef_out) {
+                       hipStream_t st, float* coef_out, const float* coef_in) {
   if (!bn_shape_ok(R, C)) return kErrBadArg;
+  if (coef_in != nullptr) {   // finalized already (ctvae_conv_backward bn_coef_out): apply + commit d gamma / d beta
+    if (gy == nullptr) return kErrBadArg;
+    ProfScope ps("bn_bwd_apply_kernel", st, 0.0, 12.0 * (double)R * C);
+    const long n4 = (long)R * C / 4;
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ga, y, coef_in, gy, n4, C, act, dgamma,
+                       dbeta, accumulate);
+    CTVAE_LAUNCH_CHECK();
+    return 0;
+  }
   if (ws_bytes / sizeof(float) < bn_workspace_floats(C, 0)) return kErrWorkspace;
   const float* part = ws;
   float* coef = coef_out != nullptr ? coef_out : ws + (size_t)kBnMaxBlocks * C * 3;   // [5][C]
@@ -454,7 +480,15 @@ int launch_bn_backward(const float* ga, const float* beta, const float* y, int R
   const long n4 = (long)R * C / 4;
   long blocks = (n4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ga, y, coef, gy, n4, C, act);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ga, y, coef, gy, n4, C, act, (float*)nullptr,
+                     (float*)nullptr, 0);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_bn_bwd_finalize_job(const BnFinJob& j, hipStream_t st) {
+  ProfScope ps("bn_bwd_finalize_kernel", st, 0.0, 8.0 * (double)j.nblocks * j.C);
+  hipLaunchKernelGGL(bn_bwd_finalize_job_kernel, dim3(j.C), dim3(256), 0, st, j);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }

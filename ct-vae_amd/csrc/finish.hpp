@@ -54,4 +54,47 @@ __device__ __forceinline__ void splitk_finish_body(const SplitKJob& k, int blk) 
   }
 }
 
+// BatchNorm-backward finalize as a rider of the finishing launch (ctvae_conv_backward with bn_coef_out): the data gradient's
+// tile epilogues left part[nblocks][C][2] = (sum g', sum g'*xhat); block c turns channel c's column into
+//   coef[0..4][C] = k1, k2, k3 of g_y = k1*g' + k2*y + k3 and the forward scale / shift,
+//   coef[5][C], coef[6][C] = d gamma, d beta of this pass (committed to the parameter gradients by the apply launch of
+//   ctvae_bn_backward(coef_in), which is also where it is decided that these sums belong to the gradient that arrived).
+struct BnFinJob {
+  const float* part;
+  int nblocks, C;
+  float R;
+  const float *gamma, *mean, *invstd, *beta;
+  float* coef;   // [7][C]
+};
+
+__device__ __forceinline__ void bn_bwd_finalize_body(const BnFinJob& j, int c, double* sm /* [8] */) {
+  const int tid = threadIdx.x, C = j.C;
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
+  for (int b = tid; b < j.nblocks; b += 256) {
+    s1 += (double)j.part[((long)b * C + c) * 2 + 0];
+    s2 += (double)j.part[((long)b * C + c) * 2 + 1];
+  }
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  if ((tid & 63) == 0) { sm[(tid >> 6) * 2] = s1; sm[(tid >> 6) * 2 + 1] = s2; }
+  __syncthreads();
+  if (tid == 0) {
+    s1 = (sm[0] + sm[2]) + (sm[4] + sm[6]);
+    s2 = (sm[1] + sm[3]) + (sm[5] + sm[7]);
+    const float db = (float)s1, dg = (float)s2;
+    const float invstd = j.invstd[c], mean = j.mean[c];
+    const float k1 = j.gamma[c] * invstd;
+    const float k2 = -k1 * dg / j.R * invstd;
+    const float k3 = -k1 * db / j.R - k2 * mean;
+    j.coef[c] = k1;
+    j.coef[C + c] = k2;
+    j.coef[2 * C + c] = k3;
+    j.coef[3 * C + c] = k1;
+    j.coef[4 * C + c] = j.beta[c] - mean * k1;
+    j.coef[5 * C + c] = dg;
+    j.coef[6 * C + c] = db;
+  }
+}
+
 }  // namespace ctvae

@@ -29,6 +29,10 @@ struct PairCtx {
   ReduceJob j1, j2;
   int nb1 = 0, nb2 = 0, accumulate = 0;
   double bytesSK = 0, bytesRed = 0;
+  // BatchNorm-backward finalize of the layer below (its sums come out of the data gradient's epilogues): rides in the
+  // finishing launch when there is one, else pair_flush() issues it on its own
+  bool haveBF = false;
+  BnFinJob bf;
   std::vector<std::function<int()>> later;
 };
 
@@ -37,5 +41,6 @@ int pair_flush(PairCtx& c, hipStream_t st);              // tapgemm_fast.hip
 int launch_wgrad_fast_recorded(const PairCtx& c, hipStream_t st);   // wgrad.hip: the recorded weight-gradient kernel on its own
 int launch_finish_recorded(const PairCtx& c, hipStream_t st);       // wgrad.hip: recorded reduction (+ split-K finish) in one launch
 int launch_splitk_recorded(const PairCtx& c, hipStream_t st);       // tapgemm.hip: recorded split-K finish on its own
+int launch_bn_bwd_finalize_job(const BnFinJob& j, hipStream_t st);  // bn.hip: the finalize job as a launch of its own
 
 }  // namespace ctvae

@@ -174,12 +174,18 @@ int pair_flush(PairCtx& c, hipStream_t st) {
     const int rc = launch_wgrad_fast_recorded(c, st);
     if (rc) return rc;
   }
-  if (c.haveRed) {            // slab reduction, with the data gradient's split-K finish as extra blocks of the same launch
-    const int rc = launch_finish_recorded(c, st);
+  if (c.haveRed) {            // slab reduction, with the data gradient's split-K finish (and the BatchNorm-backward finalize of
+    const int rc = launch_finish_recorded(c, st);   // the layer below) as extra blocks of the same launch
     if (rc) return rc;
-  } else if (c.haveSK) {
-    const int rc = launch_splitk_recorded(c, st);
-    if (rc) return rc;
+  } else {
+    if (c.haveSK) {
+      const int rc = launch_splitk_recorded(c, st);
+      if (rc) return rc;
+    }
+    if (c.haveBF) {
+      const int rc = launch_bn_bwd_finalize_job(c.bf, st);
+      if (rc) return rc;
+    }
   }
   for (auto& f : c.later) {
     const int rc = f();

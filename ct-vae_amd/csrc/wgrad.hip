@@ -290,9 +290,15 @@ __device__ __forceinline__ void reduce_split(const ReduceJob& j, int blk, int ac
   }
 }
 
-// blocks [0, nb1) job 1, [nb1, nb12) job 2, [nb12, ...) the split-K finish of the paired data gradient (sk.nblk blocks, may be 0)
-__global__ __launch_bounds__(256) void reduce_partials_kernel(ReduceJob j1, ReduceJob j2, int nb1, int accumulate, SplitKJob sk, int nb12) {
+// blocks [0, nb1) job 1, [nb1, nb12) job 2, [nb12, nb123) the split-K finish of the paired data gradient (sk.nblk blocks, may be
+// 0), [nb123, ...) the BatchNorm-backward finalize of the layer below (bf.C blocks, may be 0)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(ReduceJob j1, ReduceJob j2, int nb1, int accumulate, SplitKJob sk, int nb12,
+                                                              BnFinJob bf, int nb123) {
   __shared__ f32x4 sm[4][16];
+  if ((int)blockIdx.x >= nb123) {
+    bn_bwd_finalize_body(bf, (int)blockIdx.x - nb123, reinterpret_cast<double*>(&sm[0][0]));
+    return;
+  }
   if ((int)blockIdx.x >= nb12) {
     splitk_finish_body(sk, (int)blockIdx.x - nb12);
     return;
@@ -322,7 +328,8 @@ static void launch_reduce2(const float* p1, float* d1, long n1, int S1, long st1
   ReduceJob j1{p1, d1, n1, S1, st1, 0, 0}, j2{p2, d2, n2, S2, st2, 0, 0};
   const int nb1 = reduce_job_blocks(j1), nb2 = reduce_job_blocks(j2);
   if (nb1 + nb2 == 0) return;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(nb1 + nb2), dim3(256), 0, st, j1, j2, nb1, accumulate, SplitKJob{}, nb1 + nb2);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(nb1 + nb2), dim3(256), 0, st, j1, j2, nb1, accumulate, SplitKJob{}, nb1 + nb2,
+                     BnFinJob{}, nb1 + nb2);
 }
 
 static void launch_reduce(const float* part, float* dst, long n, int S, long stride, int accumulate, hipStream_t st) {
@@ -542,10 +549,11 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
 }
 
 int launch_finish_recorded(const PairCtx& c, hipStream_t st) {
-  const int nsk = c.haveSK ? c.sk.nblk : 0;
-  ProfScope ps(nsk ? "reduce_partials_kernel (+ split-K finish)" : "reduce_partials_kernel", st, 0.0, c.bytesRed + (nsk ? c.bytesSK : 0.0));
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(c.nb1 + c.nb2 + nsk), dim3(256), 0, st, c.j1, c.j2, c.nb1, c.accumulate,
-                     nsk ? c.sk : SplitKJob{}, c.nb1 + c.nb2);
+  const int nsk = c.haveSK ? c.sk.nblk : 0, nbf = c.haveBF ? c.bf.C : 0;
+  ProfScope ps(nsk ? "reduce_partials_kernel (+ split-K finish)" : (nbf ? "reduce_partials_kernel (+ BN-backward finalize)" : "reduce_partials_kernel"),
+               st, 0.0, c.bytesRed + (nsk ? c.bytesSK : 0.0) + (nbf ? 8.0 * c.bf.nblocks * c.bf.C : 0.0));
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(c.nb1 + c.nb2 + nsk + nbf), dim3(256), 0, st, c.j1, c.j2, c.nb1, c.accumulate,
+                     nsk ? c.sk : SplitKJob{}, c.nb1 + c.nb2, nbf ? c.bf : BnFinJob{}, c.nb1 + c.nb2 + nsk);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }

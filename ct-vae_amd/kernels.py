@@ -114,25 +114,28 @@ class BNLink:
     separate pass over (g_a, y).  The sums are only used when the gradient tensor that arrives is exactly the one the
     dgrad wrote (same storage pointer, same version counter): if autograd summed several contributions, or anything
     modified it in place, the BatchNorm falls back to its own pass."""
-    __slots__ = ("y", "mean", "invstd", "gamma", "beta", "act", "part", "rows", "g_ptr", "g_ver", "g_shape")
+    __slots__ = ("y", "mean", "invstd", "gamma", "beta", "act", "part", "rows", "coef", "g_ptr", "g_ver", "g_shape")
 
     def __init__(self, y, mean, invstd, gamma, beta, act):
         self.y, self.mean, self.invstd, self.gamma, self.beta, self.act = y, mean, invstd, gamma, beta, act
         self.part = None
         self.rows = 0
+        self.coef = None
         self.g_ptr = self.g_ver = self.g_shape = None
 
-    def publish(self, g, part, rows):
-        self.part, self.rows = part, rows
+    def publish(self, g, part, rows, coef=None):
+        """coef [7][C]: the consumer's finishing launch already ran this BatchNorm's backward finalize on the sums
+        (ctvae_conv_backward bn_coef_out)."""
+        self.part, self.rows, self.coef = part, rows, coef
         self.g_ptr, self.g_ver, self.g_shape = g.data_ptr(), g._version, tuple(g.shape)
 
     def take(self, g):
-        """(part, rows) when ``g`` is the tensor the sums were computed for, else (None, 0).  One use only."""
-        part, rows = self.part, self.rows
-        self.part, self.rows = None, 0
+        """(part, rows, coef) when ``g`` is the tensor the sums were computed for, else (None, 0, None).  One use only."""
+        part, rows, coef = self.part, self.rows, self.coef
+        self.part, self.rows, self.coef = None, 0, None
         if part is None or g.data_ptr() != self.g_ptr or g._version != self.g_ver or tuple(g.shape) != self.g_shape:
-            return None, 0
-        return part, rows
+            return None, 0, None
+        return part, rows, coef
 
 
 class ActLink:
@@ -235,6 +238,7 @@ def conv_wgrad_raw(x, dy, w_param, b_param, spec: ConvSpec, in_coef=None, in_act
 
 
 _PAIR = os.environ.get("CTVAE_NO_PAIR", "0") != "1"     # diagnostic: separate wgrad / dgrad launches
+_BN_RIDER = os.environ.get("CTVAE_NO_BN_RIDER", "0") != "1"   # diagnostic: BatchNorm-backward finalize as its own launch
 
 
 def conv_backward_raw(x, dy, w_param, b_param, spec: ConvSpec, link=None, mask=None, mask_act=ACT_NONE, wino_filters=None):
@@ -261,14 +265,15 @@ def conv_backward_raw(x, dy, w_param, b_param, spec: ConvSpec, link=None, mask=N
         else:
             rows = 0
     bn = link if part is not None else None
+    coef = torch.empty(7 * spec.ci, dtype=torch.float32, device=dy.device) if (bn is not None and _BN_RIDER) else None
     native.call("ctvae_conv_backward", spec.kind, x.data_ptr(), dy.data_ptr(), w_param.data_ptr(), gw.data_ptr(), native.ptr(gb),
                 dx.data_ptr(), B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, acc,
                 native.ptr(mask), mask_act, native.ptr(wino_filters),
                 native.ptr(bn.y if bn else None), native.ptr(bn.mean if bn else None), native.ptr(bn.invstd if bn else None),
                 native.ptr(bn.gamma if bn else None), native.ptr(bn.beta if bn else None), bn.act if bn else 0,
-                native.ptr(part), rows, ws.data_ptr(), ws.numel() * 4)
+                native.ptr(part), rows, native.ptr(coef), ws.data_ptr(), ws.numel() * 4)
     if bn is not None:
-        bn.publish(dx, part, rows)
+        bn.publish(dx, part, rows, coef)
     return dx
 
 
@@ -489,10 +494,12 @@ class ConvBNAct(Function):
         if accg != accb:
             (gg if accg == 0 else gbt).zero_()
             accg = 1
-        part, rows = ctx.link_out.take(g_a) if ctx.link_out is not None else (None, 0)
+        part, rows, coef = ctx.link_out.take(g_a) if ctx.link_out is not None else (None, 0, None)
+        if coef is not None:
+            part, rows = None, 0         # finalized by the consumer's finishing launch: apply + commit only
         native.call("ctvae_bn_backward", g_a.data_ptr(), beta.data_ptr(), y.data_ptr(), B * H * W, C, gamma.data_ptr(),
                     save_mean.data_ptr(), save_invstd.data_ptr(), ctx.bn_act, g_y.data_ptr(), gg.data_ptr(), gbt.data_ptr(),
-                    accg, native.ptr(part), rows, None, ws.data_ptr(), ws.numel() * 4)
+                    accg, native.ptr(part), rows, None, native.ptr(coef), ws.data_ptr(), ws.numel() * 4)
         g_x = wgrad_then_dgrad(x, g_y, w, b, spec, ctx.needs_input_grad[0], ctx.link_in)
         return (g_x,) + (None,) * 10
 
@@ -568,7 +575,7 @@ class ConvBNActConvAct(Function):
         g_a = conv_dgrad_bn_raw(g_pre, w2, spec2, (H, W), link)
         if g_a is None:
             g_a = conv_dgrad_raw(g_pre, w2, spec2, (H, W))
-        part, rows = link.take(g_a)
+        part, rows, _ = link.take(g_a)
         ws = native.workspace(x.device)
         gg, accg = grad_target(gamma)
         gbt, accb = grad_target(beta)
@@ -580,7 +587,7 @@ class ConvBNActConvAct(Function):
         bcoef = torch.empty(5 * C, dtype=torch.float32, device=x.device) if lazy else None
         native.call("ctvae_bn_backward", g_a.data_ptr(), beta.data_ptr(), y1.data_ptr(), B * H * W, C, gamma.data_ptr(),
                     save_mean.data_ptr(), save_invstd.data_ptr(), ctx.bn_act, None if lazy else g_y.data_ptr(), gg.data_ptr(),
-                    gbt.data_ptr(), accg, native.ptr(part), rows, native.ptr(bcoef), ws.data_ptr(), ws.numel() * 4)
+                    gbt.data_ptr(), accg, native.ptr(part), rows, native.ptr(bcoef), None, ws.data_ptr(), ws.numel() * 4)
         if lazy:
             # the weight-gradient kernel turns g_a into g_y on load and leaves g_y behind for the data gradient
             conv_wgrad_raw(x, g_a, w1, b1, spec1, dy_bn=(y1, bcoef, ctx.bn_act, g_y))

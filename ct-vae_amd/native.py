@@ -23,9 +23,9 @@ SIGNATURES = {
     "ctvae_conv_dgrad": [_i, _fp, _fp, _fp, _fp, _i, _fp] + [_i] * 9 + [_fp, _fp, _sz, _vp],
     "ctvae_conv_wgrad": [_i, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _sz, _vp],
     "ctvae_conv_backward": [_i, _fp, _fp, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _i,
-                            _fp, _sz, _vp],
+                            _fp, _fp, _sz, _vp],
     "ctvae_bn_forward": [_fp, _i, _i, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _fp, _fp, _fp, _fp, _fp, _sz, _vp],
-    "ctvae_bn_backward": [_fp, _fp, _fp, _i, _i, _fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _fp, _i, _fp, _fp, _sz, _vp],
+    "ctvae_bn_backward": [_fp, _fp, _fp, _i, _i, _fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _fp, _i, _fp, _fp, _fp, _sz, _vp],
     "ctvae_conv_dgrad_bn": [_i, _fp, _fp, _fp, _fp, _i, _fp] + [_i] * 9 + [_fp, _fp, _fp, _fp, _fp, _i, _fp, _i, _fp, _sz, _vp],
     "ctvae_permute": [_fp, _fp, _i, _i, _i, _i, _vp],
     "ctvae_crop_resize_u8": [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _vp],

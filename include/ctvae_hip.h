@@ -101,14 +101,18 @@ int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float
  * (conv_bwd_pair_kernel: one kernel boundary instead of two, the weight-gradient workgroups start while the data
  * gradient's stores drain), otherwise as the separate launches of those entry points.  Each GEMM uses one half of ws:
  * query bn_part_rows with ctvae_conv_backward_bn_rows (0: this layer's data gradient cannot emit the sums).
- * bn_part == NULL: no BatchNorm fusion. */
+ * bn_part == NULL: no BatchNorm fusion.
+ * bn_coef_out [7][Ci] (may be NULL; needs bn_part): that BatchNorm's backward FINALIZE rides as extra blocks of this call's
+ * finishing launch (the slab reduction) -- rows 0-4 = k1,k2,k3,scale,shift as ctvae_bn_backward's coef_out, rows 5,6 = this
+ * pass's d gamma, d beta.  ctvae_bn_backward(coef_in = bn_coef_out) then only applies and commits them: one launch less per
+ * Conv->BN->act->Conv link of the backward pass (vanilla_vae.py:25-35,47-62). */
 int ctvae_conv_backward_bn_rows(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
                                 size_t ws_bytes);
 int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* w, float* dw, float* dbias, float* dx, int B,
                         int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int accumulate, const float* mask,
                         int mask_act, const float* wino_filters, const float* bn_y, const float* bn_mean,
                         const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int bn_act, float* bn_part,
-                        int bn_part_rows, float* ws, size_t ws_bytes, void* stream);
+                        int bn_part_rows, float* bn_coef_out, float* ws, size_t ws_bytes, void* stream);
 
 /* dy_bn_y / dy_bn_coef / gy_out (all or none): `dy` is then g_a, the gradient w.r.t. the output of the BatchNorm +
  * activation that follows this layer; the kernel forms g_y = k1*g_a*act'(y*scale+shift) + k2*y + k3 while loading
@@ -130,11 +134,14 @@ int ctvae_bn_forward(const float* y, int R, int C, const float* gamma, const flo
  * gamma*invstd*(y-mean)+beta, so the activated tensor is not read; dgamma/dbeta (+)= ...
  * part_in/part_rows: the per-tile sums a ctvae_conv_dgrad_bn launch emitted for this g_a (NULL/0: computed here).
  * coef_out [5][C] (may be NULL): k1,k2,k3,scale,shift of g_y = k1*g_a*act'(y*scale+shift) + k2*y + k3; with
- * g_y == NULL the apply pass is left to ctvae_conv_wgrad (dy_bn_*). */
+ * g_y == NULL the apply pass is left to ctvae_conv_wgrad (dy_bn_*).
+ * coef_in [7][C] (NULL normally; excludes part_in / coef_out, needs g_y): the finalize already ran as a rider of
+ * ctvae_conv_backward(bn_coef_out) for exactly this g_a; only the apply pass runs and d gamma / d beta (rows 5,6) are
+ * committed to dgamma / dbeta under `accumulate`. */
 int ctvae_bn_backward(const float* g_a, const float* beta, const float* y, int R, int C, const float* gamma,
                       const float* save_mean, const float* save_invstd, int act, float* g_y, float* dgamma,
-                      float* dbeta, int accumulate, const float* part_in, int part_rows, float* coef_out, float* ws,
-                      size_t ws_bytes, void* stream);
+                      float* dbeta, int accumulate, const float* part_in, int part_rows, float* coef_out,
+                      const float* coef_in, float* ws, size_t ws_bytes, void* stream);
 
 /* Pairwise edge scorer of CausalTransition.graph_discovers[k] (ct_mcq_vae.py:86-95,147-151), after the separable first
  * Linear: u = x W1[:, :D]^T, v = x W1[:, D:]^T + b1 ([B,N,H] each, computed by the caller):
