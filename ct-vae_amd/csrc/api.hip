@@ -273,10 +273,16 @@ int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* 
                         int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int accumulate, const float* mask,
                         int mask_act, const float* wino_filters, const float* bn_y, const float* bn_mean,
                         const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int bn_act, float* bn_part,
-                        int bn_part_rows, float* bn_coef_out, float* ws, size_t ws_bytes, void* stream) {
+                        int bn_part_rows, float* bn_coef_out, float* bn_dgamma, float* bn_dbeta, int bn_accumulate,
+                        const float* in_scale, const float* in_shift, int in_act,
+                        const float* dy_bn_y, const float* dy_bn_coef, int dy_bn_act, float* gy_out, float* ws, size_t ws_bytes,
+                        void* stream) {
   if (!x || !dy || !w || !dw || !dx || !ws || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
   const bool bn = bn_part != nullptr;
   if (bn_coef_out != nullptr && !bn) return kErrBadArg;
+  if ((bn_dgamma != nullptr) != (bn_dbeta != nullptr) || (bn_dgamma != nullptr && bn_coef_out == nullptr)) return kErrBadArg;
+  if ((in_scale != nullptr) != (in_shift != nullptr)) return kErrBadArg;
+  if ((dy_bn_y != nullptr) != (dy_bn_coef != nullptr) || (dy_bn_y != nullptr) != (gy_out != nullptr)) return kErrBadArg;
   if (bn && (!bn_y || !bn_mean || !bn_invstd || !bn_gamma || !bn_beta)) return kErrBadArg;
   ConvGeom gw, gd;
   if (build_geom(gw, kind == CTVAE_CONV ? 0 : 1, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
@@ -296,20 +302,22 @@ int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* 
       return kErrBadArg;
     }
   }
-  const InXform xf{nullptr, nullptr, 0};
-  const DyXform dyx{nullptr, nullptr, nullptr, 0};
+  const InXform xf{in_scale, in_shift, in_act};
+  const DyXform dyx{dy_bn_y, dy_bn_coef, gy_out, dy_bn_act};
   int rc = launch_wgrad(gw, x, dy, dw, dbias, ws, half_bytes, accumulate, st, &xf, &dyx);
   if (!rc) {
     const WinoFilters wf{wino_filters, nullptr};
     const BnBwdFuse f{bn_y, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_act, bn_part};
-    rc = launch_tapgemm(gd, dy, w, nullptr, nullptr, mask, mask_act, dx, ACT_NONE, nullptr, ws_d, half_floats, st, bn ? &f : nullptr,
-                        nullptr, &wf);
+    // dy_bn_*: dy was g_a of the BatchNorm behind this layer; the weight-gradient kernel left g_y in gy_out for the data gradient
+    rc = launch_tapgemm(gd, gy_out != nullptr ? gy_out : dy, w, nullptr, nullptr, mask, mask_act, dx, ACT_NONE, nullptr, ws_d,
+                        half_floats, st, bn ? &f : nullptr, nullptr, &wf);
   }
   pair_ctx() = nullptr;
   if (rc) return rc;
   if (bn_coef_out != nullptr) {   // the finalize of the BatchNorm below rides in the finishing launch
     ctx.haveBF = true;
-    ctx.bf = BnFinJob{bn_part, bn_part_rows, Ci, (float)((long)B * H * W), bn_gamma, bn_mean, bn_invstd, bn_beta, bn_coef_out};
+    ctx.bf = BnFinJob{bn_part, bn_part_rows, Ci, (float)((long)B * H * W), bn_gamma, bn_mean, bn_invstd, bn_beta, bn_coef_out,
+                      bn_dgamma, bn_dbeta, bn_accumulate};
   }
   return pair_flush(ctx, st);
 }

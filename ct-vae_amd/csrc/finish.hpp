@@ -65,6 +65,8 @@ struct BnFinJob {
   float R;
   const float *gamma, *mean, *invstd, *beta;
   float* coef;   // [7][C]
+  float *dgamma, *dbeta;   // non-null: commit here as well (no apply launch follows), under `accumulate`
+  int accumulate;
 };
 
 __device__ __forceinline__ void bn_bwd_finalize_body(const BnFinJob& j, int c, double* sm /* [8] */) {
@@ -94,6 +96,10 @@ __device__ __forceinline__ void bn_bwd_finalize_body(const BnFinJob& j, int c, d
     j.coef[4 * C + c] = j.beta[c] - mean * k1;
     j.coef[5 * C + c] = dg;
     j.coef[6 * C + c] = db;
+    if (j.dgamma != nullptr) {
+      j.dgamma[c] = (j.accumulate ? j.dgamma[c] : 0.f) + dg;
+      j.dbeta[c] = (j.accumulate ? j.dbeta[c] : 0.f) + db;
+    }
   }
 }
 

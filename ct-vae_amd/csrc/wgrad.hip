@@ -336,6 +336,27 @@ static void launch_reduce(const float* part, float* dst, long n, int S, long str
   launch_reduce2(part, dst, n, S, stride, nullptr, nullptr, 0, 0, 0, accumulate, st);
 }
 
+// Slab reduction behind a weight-gradient kernel: issued now, or -- inside ctvae_conv_backward -- recorded so that it shares
+// the call's ONE finishing launch with the data gradient's split-K sum and the BatchNorm-backward finalize (pair.hpp)
+static int finish_reduce(const float* p1, float* d1, long n1, int S1, long st1, const float* p2, float* d2, long n2, int S2, long st2,
+                         int accumulate, hipStream_t st) {
+  if (PairCtx* pc = pair_ctx(); pc != nullptr && !pc->haveRed) {
+    pc->j1 = ReduceJob{p1, d1, n1, S1, st1, 0, 0};
+    pc->j2 = (p2 != nullptr && d2 != nullptr) ? ReduceJob{p2, d2, n2, S2, st2, 0, 0} : ReduceJob{nullptr, nullptr, 0, 0, 0, 0, 0};
+    pc->nb1 = reduce_job_blocks(pc->j1);
+    pc->nb2 = reduce_job_blocks(pc->j2);
+    pc->accumulate = accumulate;
+    pc->bytesRed = 4.0 * (double)(S1 + 1) * n1;
+    pc->haveRed = pc->nb1 + pc->nb2 > 0;
+    return 0;
+  }
+  ProfScope ps("reduce_partials_kernel", st, 0.0, 4.0 * (double)(S1 + 1) * n1);
+  if (p2 != nullptr && d2 != nullptr) launch_reduce2(p1, d1, n1, S1, st1, p2, d2, n2, S2, st2, accumulate, st);
+  else launch_reduce(p1, d1, n1, S1, st1, accumulate, st);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
 size_t wgrad_workspace_floats(const ConvGeom& g, int S) {
   int taps_total = 0;
   for (int c = 0; c < g.ncls; ++c) taps_total += g.ntaps[c];
@@ -387,11 +408,7 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
     int rc = launch_wino_wgrad(g, X, dY, ws, ws_bytes / sizeof(float), &np, dbias != nullptr, &pb, st);
     if (rc) return rc;
     const long n = 9L * g.gC * g.sC;
-    ProfScope ps("reduce_partials_kernel", st, 0.0, 4.0 * (double)(np + 1) * n);
-    if (dbias) launch_reduce2(ws, dW, n, np, n, pb, dbias, (long)g.sC, np, (long)g.sC, accumulate, st);
-    else launch_reduce(ws, dW, n, np, n, accumulate, st);
-    CTVAE_LAUNCH_CHECK();
-    return 0;
+    return finish_reduce(ws, dW, n, np, n, pb, dbias, (long)g.sC, np, (long)g.sC, accumulate, st);
   }
   const bool up = upconv_wgrad_supported(g) && (xf == nullptr || xf->scale == nullptr) &&
                   ws_bytes / sizeof(float) >= (size_t)512 * (9 * 32 * 32 + 32);
@@ -402,11 +419,7 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
     int rc = launch_upconv_wgrad(g, X, dY, ws, &part, &pb, &np, dbias != nullptr, st, dyx);
     if (rc) return rc;
     const long n = 9L * 32 * 32;
-    ProfScope ps("reduce_partials_kernel", st, 0.0, 4.0 * (double)(np + 1) * n);
-    if (dbias) launch_reduce2(part, dW, n, np, n, pb, dbias, 32L, np, 32L, accumulate, st);
-    else launch_reduce(part, dW, n, np, n, accumulate, st);
-    CTVAE_LAUNCH_CHECK();
-    return 0;
+    return finish_reduce(part, dW, n, np, n, pb, dbias, 32L, np, 32L, accumulate, st);
   }
   if (img_enc_supported(g) && (xf == nullptr || xf->scale == nullptr) && ws_bytes / sizeof(float) >= (size_t)512 * (27 * 32 + 32)) {
     float *part = nullptr, *pb = nullptr;
@@ -414,11 +427,7 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
     int rc = launch_img_enc_wgrad(g, X, dY, ws, &part, &pb, &np, dbias != nullptr, st);
     if (rc) return rc;
     const long n = 27L * 32;
-    ProfScope ps("reduce_partials_kernel", st, 0.0, 4.0 * (double)(np + 1) * n);
-    if (dbias) launch_reduce2(part, dW, n, np, n, pb, dbias, 32L, np, 32L, accumulate, st);
-    else launch_reduce(part, dW, n, np, n, accumulate, st);
-    CTVAE_LAUNCH_CHECK();
-    return 0;
+    return finish_reduce(part, dW, n, np, n, pb, dbias, 32L, np, 32L, accumulate, st);
   }
   const bool thin = thin_wgrad_supported(g) && thin_wgrad_workspace_floats(g) <= ws_bytes / sizeof(float);
   if (xf != nullptr && xf->scale != nullptr && !thin) return kErrBadArg;   // only the thin kernels transform on load
@@ -430,11 +439,7 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
     int taps = 0;
     for (int c = 0; c < g.ncls; ++c) taps += g.ntaps[c];
     const long n = (long)taps * g.gC * g.sC;
-    ProfScope ps("reduce_partials_kernel", st, 0.0, 4.0 * (double)(nw + 1) * n);
-    if (dbias) launch_reduce2(part, dW, n, nw, n, pb, dbias, (long)g.sC, nb, (long)g.sC, accumulate, st);
-    else launch_reduce(part, dW, n, nw, n, accumulate, st);
-    CTVAE_LAUNCH_CHECK();
-    return 0;
+    return finish_reduce(part, dW, n, nw, n, pb, dbias, (long)g.sC, nb, (long)g.sC, accumulate, st);
   }
   WgradArgs a{};
   a.g = g;

@@ -46,7 +46,7 @@ class _GraphedTrainStep:
 
     def __init__(self, exp, real_img, kwargs):
         self.exp = exp
-        self.x = torch.empty_like(real_img)
+        self.x = K.staging_like(real_img)            # channels_last: the hand-over below is the layout conversion too
         self.static = {k: torch.empty_like(v) for k, v in kwargs.items() if torch.is_tensor(v)}
         self.const = {k: v for k, v in kwargs.items() if not torch.is_tensor(v)}
         self.seen = 0
@@ -67,7 +67,7 @@ class _GraphedTrainStep:
         return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in losses.items()}
 
     def run(self, real_img, kwargs=None):
-        self.x.copy_(real_img, non_blocking=True)
+        K.stage_batch(self.x, real_img)
         for k, t in self.static.items():
             t.copy_(kwargs[k], non_blocking=True)
         if self.graph is None and self.seen >= self.WARM:

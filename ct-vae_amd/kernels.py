@@ -241,9 +241,13 @@ _PAIR = os.environ.get("CTVAE_NO_PAIR", "0") != "1"     # diagnostic: separate w
 _BN_RIDER = os.environ.get("CTVAE_NO_BN_RIDER", "0") != "1"   # diagnostic: BatchNorm-backward finalize as its own launch
 
 
-def conv_backward_raw(x, dy, w_param, b_param, spec: ConvSpec, link=None, mask=None, mask_act=ACT_NONE, wino_filters=None):
+def conv_backward_raw(x, dy, w_param, b_param, spec: ConvSpec, link=None, mask=None, mask_act=ACT_NONE, wino_filters=None,
+                      in_coef=None, in_act=ACT_NONE, dy_bn=None, bn_commit=None):
     """ctvae_conv_backward: weight (+bias) gradient into ``.grad`` and the data gradient of one layer in one call (the
-    two GEMMs share a launch when both run their 64x64 tile kernels).  ``link``: BNLink of the layer that produced x."""
+    two GEMMs share a launch when both run their 64x64 tile kernels).  ``link``: BNLink of the layer that produced x --
+    its BatchNorm-backward sums come out of the data gradient's epilogues and its finalize rides in this call's finishing
+    launch.  in_coef / in_act / dy_bn: the weight gradient's options of conv_wgrad_raw.  bn_commit = (dgamma, dbeta,
+    accumulate): the rider also commits that BatchNorm's parameter gradients (only where no apply launch follows)."""
     B, H, W, _ = x.shape
     ws = native.workspace(x.device)
     gw, acc = grad_target(w_param)
@@ -266,12 +270,18 @@ def conv_backward_raw(x, dy, w_param, b_param, spec: ConvSpec, link=None, mask=N
             rows = 0
     bn = link if part is not None else None
     coef = torch.empty(7 * spec.ci, dtype=torch.float32, device=dy.device) if (bn is not None and _BN_RIDER) else None
+    sc = in_coef.data_ptr() if in_coef is not None else None
+    sh = in_coef.data_ptr() + 4 * spec.ci if in_coef is not None else None
+    by, bc, bact, bgy = (dy_bn[0].data_ptr(), dy_bn[1].data_ptr(), dy_bn[2], dy_bn[3].data_ptr()) if dy_bn is not None else (None, None, 0, None)
     native.call("ctvae_conv_backward", spec.kind, x.data_ptr(), dy.data_ptr(), w_param.data_ptr(), gw.data_ptr(), native.ptr(gb),
                 dx.data_ptr(), B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, acc,
                 native.ptr(mask), mask_act, native.ptr(wino_filters),
                 native.ptr(bn.y if bn else None), native.ptr(bn.mean if bn else None), native.ptr(bn.invstd if bn else None),
                 native.ptr(bn.gamma if bn else None), native.ptr(bn.beta if bn else None), bn.act if bn else 0,
-                native.ptr(part), rows, native.ptr(coef), ws.data_ptr(), ws.numel() * 4)
+                native.ptr(part), rows, native.ptr(coef),
+                native.ptr(bn_commit[0]) if (bn_commit and coef is not None) else None,
+                native.ptr(bn_commit[1]) if (bn_commit and coef is not None) else None, bn_commit[2] if bn_commit else 0,
+                sc, sh, in_act, by, bc, bact, bgy, ws.data_ptr(), ws.numel() * 4)
     if bn is not None:
         bn.publish(dx, part, rows, coef)
     return dx
@@ -357,6 +367,27 @@ def to_nhwc(x_nchw):
 
 def to_nchw_view(x_nhwc):
     return x_nhwc.permute(0, 3, 1, 2)
+
+
+def staging_like(batch):
+    """Static input buffer for hipGraph replay of steps on batches like ``batch``: an image batch ([B,C,H,W] fp32 on the
+    device) gets channels_last memory -- the layout the encoder reads -- so that the per-step hand-over ``stage_batch`` IS the
+    NCHW -> NHWC conversion instead of a copy followed by one."""
+    if batch.is_cuda and batch.dim() == 4 and batch.dtype == torch.float32:
+        return torch.empty_like(batch, memory_format=torch.channels_last)
+    return torch.empty_like(batch)
+
+
+def stage_batch(dst, src):
+    """dst <- src for a buffer from ``staging_like``: one ctvae_permute launch for an NCHW-contiguous source and a
+    channels_last buffer (what a DataLoader hands over / what the step reads), a plain copy otherwise."""
+    if (src.is_cuda and src.dim() == 4 and src.dtype == torch.float32 and src.shape == dst.shape and src.is_contiguous()
+            and dst.permute(0, 2, 3, 1).is_contiguous() and not dst.is_contiguous()):
+        B, C, H, W = src.shape
+        native.call("ctvae_permute", src.data_ptr(), dst.data_ptr(), B, C, H * W, 1)
+    else:
+        dst.copy_(src, non_blocking=True)
+    return dst
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -569,13 +600,8 @@ class ConvBNActConvAct(Function):
         x, y1, r, coef, save_mean, save_invstd = ctx.saved_tensors
         g_r = _c(g_r)
         g_pre = act_backward_raw(g_r, r, spec2.act) if spec2.act != ACT_NONE else g_r
-        conv_wgrad_raw(y1, g_pre, w2, b2, spec2, in_coef=coef, in_act=ctx.bn_act)
         B, H, W, C = y1.shape
         link = BNLink(y1, save_mean, save_invstd, gamma, beta, ctx.bn_act)
-        g_a = conv_dgrad_bn_raw(g_pre, w2, spec2, (H, W), link)
-        if g_a is None:
-            g_a = conv_dgrad_raw(g_pre, w2, spec2, (H, W))
-        part, rows, _ = link.take(g_a)
         ws = native.workspace(x.device)
         gg, accg = grad_target(gamma)
         gbt, accb = grad_target(beta)
@@ -584,18 +610,43 @@ class ConvBNActConvAct(Function):
             accg = 1
         lazy = wgrad_bn_apply_supported(spec1, x.shape[0], x.shape[1], x.shape[2])
         g_y = torch.empty_like(y1)
-        bcoef = torch.empty(5 * C, dtype=torch.float32, device=x.device) if lazy else None
-        native.call("ctvae_bn_backward", g_a.data_ptr(), beta.data_ptr(), y1.data_ptr(), B * H * W, C, gamma.data_ptr(),
-                    save_mean.data_ptr(), save_invstd.data_ptr(), ctx.bn_act, None if lazy else g_y.data_ptr(), gg.data_ptr(),
-                    gbt.data_ptr(), accg, native.ptr(part), rows, native.ptr(bcoef), None, ws.data_ptr(), ws.numel() * 4)
+        one_call = ran = _PAIR and _BN_RIDER
+        if one_call:
+            # conv2's weight gradient, its data gradient (which emits the BatchNorm's backward sums) and the BatchNorm's
+            # finalize in one call: the finalize rides in the slab-reduction launch (the link is local to this node, so the
+            # rider commits d gamma / d beta itself when no apply launch follows)
+            g_a = conv_backward_raw(y1, g_pre, w2, b2, spec2, link=link, in_coef=coef, in_act=ctx.bn_act,
+                                    bn_commit=(gg, gbt, accg) if lazy else None)
+            part, rows, c7 = link.take(g_a)
+            one_call = c7 is not None
+        if not one_call:
+            if not ran:
+                conv_wgrad_raw(y1, g_pre, w2, b2, spec2, in_coef=coef, in_act=ctx.bn_act)
+                g_a = conv_dgrad_bn_raw(g_pre, w2, spec2, (H, W), link)
+                if g_a is None:
+                    g_a = conv_dgrad_raw(g_pre, w2, spec2, (H, W))
+                part, rows, _ = link.take(g_a)
+            bcoef = torch.empty(5 * C, dtype=torch.float32, device=x.device) if lazy else None
+            native.call("ctvae_bn_backward", g_a.data_ptr(), beta.data_ptr(), y1.data_ptr(), B * H * W, C, gamma.data_ptr(),
+                        save_mean.data_ptr(), save_invstd.data_ptr(), ctx.bn_act, None if lazy else g_y.data_ptr(), gg.data_ptr(),
+                        gbt.data_ptr(), accg, native.ptr(part), rows, native.ptr(bcoef), None, ws.data_ptr(), ws.numel() * 4)
+        elif lazy:
+            bcoef = c7                                           # rows 0-4 are the coefficients the weight-gradient kernel reads
+        else:
+            native.call("ctvae_bn_backward", g_a.data_ptr(), beta.data_ptr(), y1.data_ptr(), B * H * W, C, gamma.data_ptr(),
+                        save_mean.data_ptr(), save_invstd.data_ptr(), ctx.bn_act, g_y.data_ptr(), gg.data_ptr(), gbt.data_ptr(),
+                        accg, None, 0, None, c7.data_ptr(), ws.data_ptr(), ws.numel() * 4)
         if lazy:
             # the weight-gradient kernel turns g_a into g_y on load and leaves g_y behind for the data gradient
-            conv_wgrad_raw(x, g_a, w1, b1, spec1, dy_bn=(y1, bcoef, ctx.bn_act, g_y))
-            g_x = None
-            if ctx.needs_input_grad[0]:
-                g_x = None if ctx.link_in is None else conv_dgrad_bn_raw(g_y, w1, spec1, (x.shape[1], x.shape[2]), ctx.link_in)
-                if g_x is None:
-                    g_x = conv_dgrad_raw(g_y, w1, spec1, (x.shape[1], x.shape[2]))
+            if ctx.needs_input_grad[0] and _PAIR:
+                g_x = conv_backward_raw(x, g_a, w1, b1, spec1, link=ctx.link_in, dy_bn=(y1, bcoef, ctx.bn_act, g_y))
+            else:
+                conv_wgrad_raw(x, g_a, w1, b1, spec1, dy_bn=(y1, bcoef, ctx.bn_act, g_y))
+                g_x = None
+                if ctx.needs_input_grad[0]:
+                    g_x = None if ctx.link_in is None else conv_dgrad_bn_raw(g_y, w1, spec1, (x.shape[1], x.shape[2]), ctx.link_in)
+                    if g_x is None:
+                        g_x = conv_dgrad_raw(g_y, w1, spec1, (x.shape[1], x.shape[2]))
         else:
             g_x = wgrad_then_dgrad(x, g_y, w1, b1, spec1, ctx.needs_input_grad[0], ctx.link_in)
         return (g_x,) + (None,) * 13

@@ -105,14 +105,21 @@ int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float
  * bn_coef_out [7][Ci] (may be NULL; needs bn_part): that BatchNorm's backward FINALIZE rides as extra blocks of this call's
  * finishing launch (the slab reduction) -- rows 0-4 = k1,k2,k3,scale,shift as ctvae_bn_backward's coef_out, rows 5,6 = this
  * pass's d gamma, d beta.  ctvae_bn_backward(coef_in = bn_coef_out) then only applies and commits them: one launch less per
- * Conv->BN->act->Conv link of the backward pass (vanilla_vae.py:25-35,47-62). */
+ * Conv->BN->act->Conv link of the backward pass (vanilla_vae.py:25-35,47-62).  bn_dgamma / bn_dbeta (both or none):
+ * the rider commits the parameter gradients itself (+= under bn_accumulate) -- for a caller that applies the coefficients
+ * on load (ctvae_conv_wgrad dy_bn_*) and therefore never calls ctvae_bn_backward.
+ * in_scale / in_shift / in_act and dy_bn_y / dy_bn_coef / dy_bn_act / gy_out: the weight gradient's options as in
+ * ctvae_conv_wgrad (the layers of the final block, vanilla_vae.py:64-75); with gy_out the data gradient reads g_y from it. */
 int ctvae_conv_backward_bn_rows(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
                                 size_t ws_bytes);
 int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* w, float* dw, float* dbias, float* dx, int B,
                         int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int accumulate, const float* mask,
                         int mask_act, const float* wino_filters, const float* bn_y, const float* bn_mean,
                         const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int bn_act, float* bn_part,
-                        int bn_part_rows, float* bn_coef_out, float* ws, size_t ws_bytes, void* stream);
+                        int bn_part_rows, float* bn_coef_out, float* bn_dgamma, float* bn_dbeta, int bn_accumulate,
+                        const float* in_scale, const float* in_shift, int in_act,
+                        const float* dy_bn_y, const float* dy_bn_coef, int dy_bn_act, float* gy_out, float* ws, size_t ws_bytes,
+                        void* stream);
 
 /* dy_bn_y / dy_bn_coef / gy_out (all or none): `dy` is then g_a, the gradient w.r.t. the output of the BatchNorm +
  * activation that follows this layer; the kernel forms g_y = k1*g_a*act'(y*scale+shift) + k2*y + k3 while loading

@@ -28,6 +28,35 @@ def test_exports_match_header(lib):
     assert b"bad argument" in handle.ctvae_error_string(-22)
 
 
+def test_ctypes_signatures_match_header_prototypes(lib):
+    """Every prototype of include/ctvae_hip.h against the ctypes argtypes of native.py: same number of parameters, and
+    pointer / int / float / size_t / long in the same positions (a shifted argument would otherwise only show up as a
+    wrong result on the GPU)."""
+    import ctypes
+    hdr = open(os.path.join(ROOT, "include", "ctvae_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = dict((m.group(1), m.group(2)) for m in re.finditer(r"\b(ctvae_[a-z_0-9]+)\s*\(([^;{]*?)\)\s*;", hdr, re.S))
+    def kind(param):
+        param = " ".join(param.split())
+        if "*" in param:
+            return "ptr"
+        t = param.rsplit(" ", 1)[0] if " " in param else param
+        return {"int": "int", "float": "float", "size_t": "size", "long": "long", "double": "double"}[t.replace("const ", "")]
+    ck = {ctypes.c_void_p: "ptr", ctypes.c_int: "int", ctypes.c_float: "float", ctypes.c_size_t: "size", ctypes.c_long: "long",
+          ctypes.c_char_p: "ptr"}
+    checked = 0
+    for name, argtypes in lib.SIGNATURES.items():
+        params = [p for p in protos[name].split(",") if p.strip() and p.strip() != "void"]
+        assert len(params) == len(argtypes), f"{name}: header has {len(params)} parameters, native.py {len(argtypes)}"
+        for i, (p_, a) in enumerate(zip(params, argtypes)):
+            hk, nk = kind(p_), ck[a]
+            if {hk, nk} == {"size", "long"}:          # c_size_t and c_long are the same ctypes class on LP64
+                continue
+            assert hk == nk, f"{name} parameter {i} ({' '.join(p_.split())}): header {hk}, native.py {nk}"
+        checked += 1
+    assert checked == len(lib.SIGNATURES) >= 50
+
+
 def test_product_path_has_no_cpu_fallback():
     import torch
     from ctvae_amd import kernels as K
