@@ -100,9 +100,11 @@ int launch_dip_backward(const float* state, const float* go, float* g_mu, float*
 int launch_loss_forward(const float* r, const float* x, long n, const float* mu, long mu_rs, const float* lv, long lv_rs,
                         int B, int L, float M_N, const float* extra, float* out3, float* ws, size_t ws_bytes, hipStream_t st,
                         float logcosh_alpha);
-int launch_mse_backward(const float* r, const float* x, const float* go, float* gr, long n, hipStream_t st, float logcosh_alpha);
+int launch_mse_backward(const float* r, const float* x, const float* go, float* gr, long n, hipStream_t st, float logcosh_alpha,
+                        int ract = 0);
 int launch_loss_backward(const float* r, const float* x, const float* go, float* gr, long n, float logcosh_alpha, const float* mu,
-                         long mu_rs, const float* lv, long lv_rs, float* gmu, float* glv, int B, int L, float M_N, hipStream_t st);
+                         long mu_rs, const float* lv, long lv_rs, float* gmu, float* glv, int B, int L, float M_N, hipStream_t st,
+                         int ract = 0);
 int launch_kl_backward(const float* mu, long mu_rs, const float* lv, long lv_rs, const float* go, float* gmu, float* glv,
                        int B, int L, float M_N, hipStream_t st);
 int launch_vq_inds(const float* lat, const float* cb, long long* inds, int B, int HW, int D, int K, int C, hipStream_t st);
@@ -536,17 +538,18 @@ int ctvae_loss_forward(const float* recons, const float* x, long n, const float*
                              (hipStream_t)stream, 0.f);
 }
 
-int ctvae_mse_backward(const float* recons, const float* x, const float* g_loss, float* g_recons, long n, void* stream) {
+int ctvae_mse_backward(const float* recons, const float* x, const float* g_loss, float* g_recons, long n, int recons_act,
+                       void* stream) {
   if (!recons || !x || !g_loss || !g_recons || n <= 0) return kErrBadArg;
-  return launch_mse_backward(recons, x, g_loss, g_recons, n, (hipStream_t)stream, 0.f);
+  return launch_mse_backward(recons, x, g_loss, g_recons, n, (hipStream_t)stream, 0.f, recons_act);
 }
 
 int ctvae_loss_backward(const float* recons, const float* x, const float* g_loss, float* g_recons, long n, float logcosh_alpha,
                         const float* mu, long mu_rs, const float* logvar, long lv_rs, float* g_mu, float* g_logvar, int B, int L,
-                        float M_N, void* stream) {
+                        float M_N, int recons_act, void* stream) {
   if (!recons || !x || !g_loss || !g_recons || n <= 0 || !mu || !logvar || !g_mu || !g_logvar || B <= 0 || L <= 0) return kErrBadArg;
   return launch_loss_backward(recons, x, g_loss, g_recons, n, logcosh_alpha, mu, mu_rs, logvar, lv_rs, g_mu, g_logvar, B, L, M_N,
-                              (hipStream_t)stream);
+                              (hipStream_t)stream, recons_act);
 }
 
 int ctvae_logcosh_loss_forward(const float* recons, const float* x, long n, float alpha, const float* mu, long mu_rs,
@@ -559,9 +562,9 @@ int ctvae_logcosh_loss_forward(const float* recons, const float* x, long n, floa
 }
 
 int ctvae_logcosh_backward(const float* recons, const float* x, const float* g_loss, float* g_recons, long n, float alpha,
-                           void* stream) {
+                           int recons_act, void* stream) {
   if (!recons || !x || !g_loss || !g_recons || n <= 0 || !(alpha > 0.f)) return kErrBadArg;
-  return launch_mse_backward(recons, x, g_loss, g_recons, n, (hipStream_t)stream, alpha);
+  return launch_mse_backward(recons, x, g_loss, g_recons, n, (hipStream_t)stream, alpha, recons_act);
 }
 
 int ctvae_kl_backward(const float* mu, long mu_rs, const float* logvar, long lv_rs, const float* g_loss, float* g_mu,

@@ -91,9 +91,12 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
 }
 
 // g_r = go * term'(r - x) * scale      (MSE: 2 (r - x) / n;  log-cosh: tanh(alpha (r - x)) / n)
+// ract != ACT_NONE: r is the output of that activation (the Tanh closing final_layer, vanilla_vae.py:74) and the result is
+// the gradient w.r.t. its INPUT, g_r * act'(r) -- the producer's activation-backward pass folded into this one.
 template <int MODE>
 __device__ __forceinline__ void mse_bwd_body(const float* __restrict__ r, const float* __restrict__ x, const float* __restrict__ go,
-                                             float* __restrict__ gr, long n4, long n, float scale, float alpha, int blk, int nblk) {
+                                             float* __restrict__ gr, long n4, long n, float scale, float alpha, int blk, int nblk,
+                                             int ract) {
   const float sc = go[0] * scale;
   const long stride = (long)nblk * 256;
   for (long i = (long)blk * 256 + threadIdx.x; i < n4; i += stride) {
@@ -101,18 +104,19 @@ __device__ __forceinline__ void mse_bwd_body(const float* __restrict__ r, const 
     f32x4 b = reinterpret_cast<const f32x4*>(x)[i];
     f32x4 o;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = sc * recon_term_grad<MODE>(a[k] - b[k], alpha);
+    for (int k = 0; k < 4; ++k) o[k] = sc * recon_term_grad<MODE>(a[k] - b[k], alpha) * act_bwd_from_out(a[k], ract);
     reinterpret_cast<f32x4*>(gr)[i] = o;
   }
   if (blk == 0)
-    for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) gr[i] = sc * recon_term_grad<MODE>(r[i] - x[i], alpha);
+    for (long i = n4 * 4 + threadIdx.x; i < n; i += 256)
+      gr[i] = sc * recon_term_grad<MODE>(r[i] - x[i], alpha) * act_bwd_from_out(r[i], ract);
 }
 
 template <int MODE>
 __global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ r, const float* __restrict__ x,
                                                       const float* __restrict__ go, float* __restrict__ gr, long n4, long n,
-                                                      float scale, float alpha) {
-  mse_bwd_body<MODE>(r, x, go, gr, n4, n, scale, alpha, blockIdx.x, gridDim.x);
+                                                      float scale, float alpha, int ract) {
+  mse_bwd_body<MODE>(r, x, go, gr, n4, n, scale, alpha, blockIdx.x, gridDim.x, ract);
 }
 
 // g_mu = go*M_N*mu/B ; g_lv = go*M_N*0.5*(e^lv - 1)/B     (dense [B][L] outputs)
@@ -139,8 +143,8 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ go, float* __restrict__ gr, long n4, long n,
                                                        float scale, float alpha, int nb, const float* __restrict__ mu, long mu_rs,
                                                        const float* __restrict__ lv, long lv_rs, float* __restrict__ gmu,
-                                                       float* __restrict__ glv, int B, int L, float M_N) {
-  if ((int)blockIdx.x < nb) mse_bwd_body<MODE>(r, x, go, gr, n4, n, scale, alpha, blockIdx.x, nb);
+                                                       float* __restrict__ glv, int B, int L, float M_N, int ract) {
+  if ((int)blockIdx.x < nb) mse_bwd_body<MODE>(r, x, go, gr, n4, n, scale, alpha, blockIdx.x, nb, ract);
   else kl_bwd_body(mu, mu_rs, lv, lv_rs, go, gmu, glv, B, L, M_N, (int)blockIdx.x - nb);
 }
 
@@ -169,7 +173,8 @@ int launch_loss_forward(const float* r, const float* x, long n, const float* mu,
   return 0;
 }
 
-int launch_mse_backward(const float* r, const float* x, const float* go, float* gr, long n, hipStream_t st, float logcosh_alpha) {
+int launch_mse_backward(const float* r, const float* x, const float* go, float* gr, long n, hipStream_t st, float logcosh_alpha,
+                        int ract) {
   const long n4 = n / 4;
   long blocks = (n4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
@@ -177,9 +182,10 @@ int launch_mse_backward(const float* r, const float* x, const float* go, float* 
   ProfScope ps("mse_bwd_kernel", st, 0.0, 12.0 * (double)n);
   if (logcosh_alpha > 0.f)   // d/dt of (alpha t + log(1 + e^{-2 alpha t}) - log 2) / alpha = tanh(alpha t)
     hipLaunchKernelGGL(mse_bwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, r, x, go, gr, n4, n,
-                       (float)(1.0 / ((double)n * logcosh_alpha)), logcosh_alpha);
+                       (float)(1.0 / ((double)n * logcosh_alpha)), logcosh_alpha, ract);
   else
-    hipLaunchKernelGGL(mse_bwd_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, r, x, go, gr, n4, n, (float)(1.0 / (double)n), 0.f);
+    hipLaunchKernelGGL(mse_bwd_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, r, x, go, gr, n4, n, (float)(1.0 / (double)n), 0.f,
+                       ract);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }
@@ -192,7 +198,8 @@ int launch_kl_backward(const float* mu, long mu_rs, const float* lv, long lv_rs,
 }
 
 int launch_loss_backward(const float* r, const float* x, const float* go, float* gr, long n, float logcosh_alpha, const float* mu,
-                         long mu_rs, const float* lv, long lv_rs, float* gmu, float* glv, int B, int L, float M_N, hipStream_t st) {
+                         long mu_rs, const float* lv, long lv_rs, float* gmu, float* glv, int B, int L, float M_N, hipStream_t st,
+                         int ract) {
   const long n4 = n / 4;
   long blocks = (n4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
@@ -201,10 +208,10 @@ int launch_loss_backward(const float* r, const float* x, const float* go, float*
   ProfScope ps("loss_bwd_kernel", st, 0.0, 12.0 * (double)n + 16.0 * (double)B * L);
   if (logcosh_alpha > 0.f)
     hipLaunchKernelGGL(loss_bwd_kernel<1>, dim3(nb + nkl), dim3(256), 0, st, r, x, go, gr, n4, n, (float)(1.0 / ((double)n * logcosh_alpha)),
-                       logcosh_alpha, nb, mu, mu_rs, lv, lv_rs, gmu, glv, B, L, M_N);
+                       logcosh_alpha, nb, mu, mu_rs, lv, lv_rs, gmu, glv, B, L, M_N, ract);
   else
     hipLaunchKernelGGL(loss_bwd_kernel<0>, dim3(nb + nkl), dim3(256), 0, st, r, x, go, gr, n4, n, (float)(1.0 / (double)n), 0.f, nb, mu,
-                       mu_rs, lv, lv_rs, gmu, glv, B, L, M_N);
+                       mu_rs, lv, lv_rs, gmu, glv, B, L, M_N, ract);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }

@@ -13,6 +13,7 @@ Conventions
 """
 import math
 import os
+import weakref
 from dataclasses import dataclass
 
 import torch
@@ -144,12 +145,13 @@ class ActLink:
     act'(h) in its epilogue (the ``mask`` operand of ctvae_conv_dgrad), so the tensor that arrives at the producer's
     backward is already the gradient w.r.t. its pre-activation and the separate activation-backward pass is skipped.
     The producer checks that it received exactly that tensor; anything else cannot be repaired and raises."""
-    __slots__ = ("act", "g_ptr", "g_ver", "g_shape", "done")
+    __slots__ = ("act", "g_ptr", "g_ver", "g_shape", "done", "out_ref", "out_ver")
 
     def __init__(self, act):
         self.act = act
         self.done = False
         self.g_ptr = self.g_ver = self.g_shape = None
+        self.out_ref = self.out_ver = None
 
     def publish_done(self, g):
         self.done = True
@@ -164,6 +166,35 @@ class ActLink:
             raise RuntimeError("ActLink: the activation backward was folded into the consumer's data gradient (sole "
                                "consumer promised), but a different gradient tensor arrived")
         return True
+
+
+# Output-activation links OFFERED by a producer instead of promised by model code: the producer registers the tensor it hands
+# out (final_layer's Tanh output r), and the one consumer that knows how to fold act'(r) into its own backward pass -- the
+# reconstruction loss, which reads r anyway -- claims the link in its forward.  If nobody claims it, or the loss is not
+# asked for that gradient, the producer runs its activation backward as usual; if the loss folded it but a different
+# gradient tensor arrives (r had a second consumer), ActLink.take raises.
+_out_act_links = {}
+
+
+def offer_out_act_link(out, act):
+    link = ActLink(act)
+    link.out_ref, link.out_ver = weakref.ref(out), out._version
+    if len(_out_act_links) > 8:
+        for k in [k for k, l in _out_act_links.items() if l.out_ref() is None]:
+            del _out_act_links[k]
+    _out_act_links[out.data_ptr()] = link
+    return link
+
+
+def claim_out_act_link(t):
+    """The link offered for exactly this tensor (same storage, shape and version, producer's tensor still alive), else None."""
+    link = _out_act_links.pop(t.data_ptr(), None)
+    if link is None:
+        return None
+    o = link.out_ref()
+    if o is None or o.data_ptr() != t.data_ptr() or tuple(o.shape) != tuple(t.shape) or o._version != link.out_ver:
+        return None
+    return link
 
 
 _last_act_link = None  # set by ConvAct.forward (fused activation), picked up by the caller of .apply right after
@@ -239,6 +270,7 @@ def conv_wgrad_raw(x, dy, w_param, b_param, spec: ConvSpec, in_coef=None, in_act
 
 _PAIR = os.environ.get("CTVAE_NO_PAIR", "0") != "1"     # diagnostic: separate wgrad / dgrad launches
 _BN_RIDER = os.environ.get("CTVAE_NO_BN_RIDER", "0") != "1"   # diagnostic: BatchNorm-backward finalize as its own launch
+_OUT_ACT_LINK = os.environ.get("CTVAE_NO_OUT_ACT_LINK", "0") != "1"   # diagnostic: final Tanh backward as its own launch
 
 
 def conv_backward_raw(x, dy, w_param, b_param, spec: ConvSpec, link=None, mask=None, mask_act=ACT_NONE, wino_filters=None,
@@ -586,6 +618,7 @@ class ConvBNActConvAct(Function):
                     coef.data_ptr(), native.ptr(num_batches_tracked) if training else None, B, H, W, spec1.ci, spec1.co,
                     spec1.k, spec1.stride, spec1.pad, spec1.out_pad, ws.data_ptr(), ws.numel() * 4)
         r = conv_forward_raw(y1, w2, b2, spec2, in_coef=coef, in_act=bn_act)
+        ctx.act_out = offer_out_act_link(r, spec2.act) if (training and spec2.act != ACT_NONE and _OUT_ACT_LINK) else None
         ctx.specs, ctx.bn_act, ctx.training = (spec1, spec2), bn_act, training
         ctx.params = (w1, b1, gamma, beta, w2, b2)
         ctx.save_for_backward(x, y1, r, coef, save_mean, save_invstd)
@@ -599,7 +632,10 @@ class ConvBNActConvAct(Function):
         w1, b1, gamma, beta, w2, b2 = ctx.params
         x, y1, r, coef, save_mean, save_invstd = ctx.saved_tensors
         g_r = _c(g_r)
-        g_pre = act_backward_raw(g_r, r, spec2.act) if spec2.act != ACT_NONE else g_r
+        if ctx.act_out is not None and ctx.act_out.take(g_r):
+            g_pre = g_r                                          # the loss's backward pass already applied act'(r)
+        else:
+            g_pre = act_backward_raw(g_r, r, spec2.act) if spec2.act != ACT_NONE else g_r
         B, H, W, C = y1.shape
         link = BNLink(y1, save_mean, save_invstd, gamma, beta, ctx.bn_act)
         ws = native.workspace(x.device)
@@ -805,6 +841,7 @@ class VAELoss(Function):
         ctx.save_for_backward(recons, x, mu_, lv_)
         ctx.meta = (mrs, lrs, B, L, float(M_N), tuple(extra.shape) if extra is not None else None)
         ctx.logcosh_alpha = float(logcosh_alpha)
+        ctx.act_link = claim_out_act_link(recons) if ctx.needs_input_grad[0] else None
         return _scalar_outputs(ctx, out)
 
     @staticmethod
@@ -817,23 +854,28 @@ class VAELoss(Function):
         want_r = ctx.needs_input_grad[0]
         want_kl = mu_ is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
         g_r = torch.empty_like(recons) if want_r else None
+        link = ctx.act_link if want_r else None
+        ract = link.act if link is not None else ACT_NONE        # recons = act(pre): hand back the gradient w.r.t. pre
         g_mu = g_lv = None
         if want_kl:
             g_mu = torch.empty((B, L), dtype=torch.float32, device=recons.device)
             g_lv = torch.empty((B, L), dtype=torch.float32, device=recons.device)
         if want_r and want_kl:      # the usual case: both gradients in one launch
             native.call("ctvae_loss_backward", recons.data_ptr(), x.data_ptr(), g_loss.data_ptr(), g_r.data_ptr(), recons.numel(),
-                        ctx.logcosh_alpha, mu_.data_ptr(), mrs, lv_.data_ptr(), lrs, g_mu.data_ptr(), g_lv.data_ptr(), B, L, M_N)
+                        ctx.logcosh_alpha, mu_.data_ptr(), mrs, lv_.data_ptr(), lrs, g_mu.data_ptr(), g_lv.data_ptr(), B, L, M_N, ract)
         else:
             if want_r:
                 if ctx.logcosh_alpha > 0.0:
                     native.call("ctvae_logcosh_backward", recons.data_ptr(), x.data_ptr(), g_loss.data_ptr(), g_r.data_ptr(),
-                                recons.numel(), ctx.logcosh_alpha)
+                                recons.numel(), ctx.logcosh_alpha, ract)
                 else:
-                    native.call("ctvae_mse_backward", recons.data_ptr(), x.data_ptr(), g_loss.data_ptr(), g_r.data_ptr(), recons.numel())
+                    native.call("ctvae_mse_backward", recons.data_ptr(), x.data_ptr(), g_loss.data_ptr(), g_r.data_ptr(), recons.numel(),
+                                ract)
             if want_kl:
                 native.call("ctvae_kl_backward", mu_.data_ptr(), mrs, lv_.data_ptr(), lrs, g_loss.data_ptr(), g_mu.data_ptr(),
                             g_lv.data_ptr(), B, L, M_N)
+        if link is not None:
+            link.publish_done(g_r)
         g_extra = g_loss.reshape(has_extra) if (has_extra is not None and ctx.needs_input_grad[4]) else None
         return g_r, None, g_mu, g_lv, g_extra, None, None
 

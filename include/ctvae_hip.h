@@ -287,11 +287,15 @@ int ctvae_reparam_backward(const float* g_z, const float* logvar, long lv_row_st
 int ctvae_loss_forward(const float* recons, const float* x, long n, const float* mu, long mu_row_stride,
                        const float* logvar, long lv_row_stride, int B, int L, float M_N, const float* extra, float* out4,
                        float* ws, size_t ws_bytes, void* stream);
-int ctvae_mse_backward(const float* recons, const float* x, const float* g_loss, float* g_recons, long n, void* stream);
+/* recons_act (CTVAE_ACT_*; 0 = none) in the three reconstruction backward calls: recons is the OUTPUT of that activation
+ * (the Tanh closing final_layer, vanilla_vae.py:74 / the decoder, mcq_vae.py:236) and g_recons is the gradient w.r.t. the
+ * activation's input, g * act'(recons): the producer's activation-backward pass folded into this one. */
+int ctvae_mse_backward(const float* recons, const float* x, const float* g_loss, float* g_recons, long n, int recons_act,
+                       void* stream);
 /* ctvae_mse_backward (or ctvae_logcosh_backward when logcosh_alpha > 0) and ctvae_kl_backward in ONE launch. */
 int ctvae_loss_backward(const float* recons, const float* x, const float* g_loss, float* g_recons, long n, float logcosh_alpha,
                         const float* mu, long mu_row_stride, const float* logvar, long lv_row_stride, float* g_mu, float* g_logvar,
-                        int B, int L, float M_N, void* stream);
+                        int B, int L, float M_N, int recons_act, void* stream);
 /* LogCoshVAE's objective (logcosh_vae.py:141-155): out4 = {loss, rl, kld, -kld} with
  * rl = 1/alpha * mean(alpha t + log(1 + exp(-2 alpha t)) - log 2), t = recons - x; loss = rl + M_N * kld (the caller passes
  * M_N = beta * kld_weight).  Backward of the reconstruction term: g_recons = g_loss[0] * tanh(alpha t) / n; the KL term
@@ -300,7 +304,7 @@ int ctvae_logcosh_loss_forward(const float* recons, const float* x, long n, floa
                                const float* logvar, long lv_row_stride, int B, int L, float M_N, float* out4, float* ws,
                                size_t ws_bytes, void* stream);
 int ctvae_logcosh_backward(const float* recons, const float* x, const float* g_loss, float* g_recons, long n, float alpha,
-                           void* stream);
+                           int recons_act, void* stream);
 int ctvae_kl_backward(const float* mu, long mu_row_stride, const float* logvar, long lv_row_stride, const float* g_loss,
                       float* g_mu, float* g_logvar, int B, int L, float M_N, void* stream);
 
