@@ -423,13 +423,58 @@ def stage_batch(dst, src):
 
 
 # ---------------------------------------------------------------------------------------------------
+# Companion rows: a second batch that rides through the same launches without taking part in autograd
+# ---------------------------------------------------------------------------------------------------
+# CT-MCQ-VAE encodes two images per sample (ct_mcq_vae.py:536-539, 565-566): x, whose encoder pass is trained, and y, of which
+# only the code indices are used (no backward).  The encoder has no BatchNorm, so its layers treat rows independently: the
+# layer Functions below take y as ``aux`` and, when aux directly follows x in memory, run ONE launch over both (twice the
+# rows per launch instead of twice the launches: Winograd / tile kernels at 128 images leave half the chip idle).  Only x is
+# an autograd input; the aux output is marked non-differentiable and the saved tensors are the x rows.
+def adjacent_rows(x, aux):
+    """The [Bx+Ba, ...] tensor that x and aux form when aux starts where x ends in the same allocation, else None."""
+    if (aux is None or not x.is_contiguous() or not aux.is_contiguous() or x.shape[1:] != aux.shape[1:] or x.dtype != aux.dtype
+            or x.untyped_storage().data_ptr() != aux.untyped_storage().data_ptr()
+            or x.data_ptr() + x.numel() * x.element_size() != aux.data_ptr()):
+        return None
+    return torch.as_strided(x.detach(), (x.shape[0] + aux.shape[0],) + tuple(x.shape[1:]), x.stride(), x.storage_offset())
+
+
+def to_nhwc_pair(x_nchw, y_nchw):
+    """NHWC tensors of two same-shaped logical [B,C,H,W] batches in ONE buffer (x rows first), one launch each."""
+    _req_cuda(x_nchw, y_nchw)
+    if x_nchw.shape != y_nchw.shape or x_nchw.dtype != torch.float32 or y_nchw.dtype != torch.float32 or x_nchw.requires_grad:
+        return to_nhwc(x_nchw), to_nhwc(y_nchw)
+    B, C, H, W = x_nchw.shape
+    buf = torch.empty((2 * B, H, W, C), dtype=torch.float32, device=x_nchw.device)
+    for half, src in ((buf[:B], x_nchw), (buf[B:], y_nchw)):
+        if src.is_contiguous():
+            native.call("ctvae_permute", src.data_ptr(), half.data_ptr(), B, C, H * W, 1)
+        else:
+            half.copy_(src.permute(0, 2, 3, 1))
+    return buf[:B], buf[B:]
+
+
+def _with_aux(x, aux, fn):
+    """fn(rows) for x and aux: one call on the combined rows when they are adjacent, else one call each."""
+    both = adjacent_rows(x, aux)
+    if both is not None:
+        out = fn(both)
+        outs = out if isinstance(out, tuple) else (out,)
+        B = x.shape[0]
+        return tuple(o[:B] for o in outs), tuple(o[B:] for o in outs)
+    ox, oa = fn(x), fn(aux)
+    return (ox if isinstance(ox, tuple) else (ox,)), (oa if isinstance(oa, tuple) else (oa,))
+
+
+# ---------------------------------------------------------------------------------------------------
 # conv / linear (+ bias + residual + activation)
 # ---------------------------------------------------------------------------------------------------
 class ConvAct(Function):
     """y = act(conv(x, w) + b + add).  Conv2d/ConvTranspose2d/Linear forward, dgrad and wgrad on HIP."""
 
     @staticmethod
-    def forward(ctx, x, w, b, add, spec):
+    def forward(ctx, x, w, b, add, spec, aux=None):
+        """aux: companion rows (see above); returns (y, y_aux) then."""
         global _last_act_link
         _req_cuda(x, w)
         ctx.link_in = link_of(x)
@@ -438,19 +483,37 @@ class ConvAct(Function):
         x = _c(x)
         add_c = _c(add) if add is not None else None
         ctx.wino_u = None
+        ctx.spec = spec
+        ctx.w, ctx.b = w, b
+        ctx.has_add = add is not None
+        if aux is not None:
+            if add is not None:
+                raise RuntimeError("ConvAct: companion rows and a residual operand together are not supported")
+            rows = adjacent_rows(x, _c(aux))
+            Bt = rows.shape[0] if rows is not None else x.shape[0]
+            if ctx.needs_input_grad[0]:
+                n = wino_filter_floats(spec, Bt, x.shape[1], x.shape[2], native.workspace(x.device).numel())
+                if n:
+                    ctx.wino_u = torch.empty(n, dtype=torch.float32, device=x.device)
+            first = [True]
+
+            def run(t):
+                wo, first[0] = (ctx.wino_u if first[0] else None), False
+                return conv_forward_raw(t, w, b, spec, None, wino_out=wo)
+            (y,), (y_aux,) = _with_aux(x, _c(aux), run)
+            ctx.save_for_backward(x, y if spec.act != ACT_NONE else None)
+            ctx.mark_non_differentiable(y_aux)
+            return y, y_aux
         if add is None and ctx.needs_input_grad[0]:
             n = wino_filter_floats(spec, x.shape[0], x.shape[1], x.shape[2], native.workspace(x.device).numel())
             if n:
                 ctx.wino_u = torch.empty(n, dtype=torch.float32, device=x.device)
         y = conv_forward_raw(x, w, b, spec, add_c, wino_out=ctx.wino_u)
-        ctx.spec = spec
-        ctx.w, ctx.b = w, b
-        ctx.has_add = add is not None
         ctx.save_for_backward(x, y if spec.act != ACT_NONE else None)
         return y
 
     @staticmethod
-    def backward(ctx, g_y):
+    def backward(ctx, g_y, *_g_aux):
         spec = ctx.spec
         x, y = ctx.saved_tensors
         g_y = _c(g_y)
@@ -469,7 +532,7 @@ class ConvAct(Function):
         else:
             g_x = wgrad_then_dgrad(x, g_pre, ctx.w, ctx.b, spec, ctx.needs_input_grad[0], ctx.link_in, ctx.wino_u)
         g_add = g_pre if (ctx.has_add and ctx.needs_input_grad[3]) else None
-        return g_x, None, None, g_add, None
+        return g_x, None, None, g_add, None, None
 
 
 class ResBlock(Function):
@@ -480,23 +543,37 @@ class ResBlock(Function):
     the 1x1 conv's data gradient."""
 
     @staticmethod
-    def forward(ctx, x, w3, w1, spec3, spec1):
+    def forward(ctx, x, w3, w1, spec3, spec1, aux=None):
+        """aux: companion rows (see adjacent_rows); returns (out, out_aux) then."""
         _req_cuda(x, w3, w1)
         x = _c(x)
         ctx.wino_u = None
-        if ctx.needs_input_grad[0]:
-            n = wino_filter_floats(spec3, x.shape[0], x.shape[1], x.shape[2], native.workspace(x.device).numel())
-            if n:
-                ctx.wino_u = torch.empty(n, dtype=torch.float32, device=x.device)
-        h = conv_forward_raw(x, w3, None, spec3, wino_out=ctx.wino_u)
-        out = conv_forward_raw(h, w1, None, spec1, x)
         ctx.specs = (spec3, spec1)
         ctx.w = (w3, w1)
+        rows = adjacent_rows(x, _c(aux)) if aux is not None else None
+        Bt = rows.shape[0] if rows is not None else x.shape[0]
+        if ctx.needs_input_grad[0]:
+            n = wino_filter_floats(spec3, Bt, x.shape[1], x.shape[2], native.workspace(x.device).numel())
+            if n:
+                ctx.wino_u = torch.empty(n, dtype=torch.float32, device=x.device)
+        if aux is not None:
+            first = [True]
+
+            def run(t):
+                wo, first[0] = (ctx.wino_u if first[0] else None), False
+                h_ = conv_forward_raw(t, w3, None, spec3, wino_out=wo)
+                return h_, conv_forward_raw(h_, w1, None, spec1, t)
+            (h, out), (_h_aux, out_aux) = _with_aux(x, _c(aux), run)
+            ctx.save_for_backward(x, h, out if spec1.act != ACT_NONE else None)
+            ctx.mark_non_differentiable(out_aux)
+            return out, out_aux
+        h = conv_forward_raw(x, w3, None, spec3, wino_out=ctx.wino_u)
+        out = conv_forward_raw(h, w1, None, spec1, x)
         ctx.save_for_backward(x, h, out if spec1.act != ACT_NONE else None)
         return out
 
     @staticmethod
-    def backward(ctx, g_out):
+    def backward(ctx, g_out, *_g_aux):
         spec3, spec1 = ctx.specs
         w3, w1 = ctx.w
         x, h, out = ctx.saved_tensors
@@ -511,7 +588,7 @@ class ResBlock(Function):
         g_x = None
         if ctx.needs_input_grad[0]:
             g_x = conv_dgrad_raw(g_h, w3, spec3, (x.shape[1], x.shape[2]), add=g_pre, wino_filters=ctx.wino_u)
-        return g_x, None, None, None, None
+        return g_x, None, None, None, None, None
 
 
 class ConvBNAct(Function):
@@ -692,19 +769,28 @@ class ActFn(Function):
     """Standalone activation (nn.LeakyReLU sites mcq_vae.py:185,216)."""
 
     @staticmethod
-    def forward(ctx, x, act):
+    def forward(ctx, x, act, aux=None):
         _req_cuda(x)
         x = _c(x)
-        out = torch.empty_like(x)
-        native.call("ctvae_act_forward", x.data_ptr(), out.data_ptr(), x.numel(), act)
         ctx.act = act
+
+        def run(t):
+            o = torch.empty_like(t)
+            native.call("ctvae_act_forward", t.data_ptr(), o.data_ptr(), t.numel(), act)
+            return o
+        if aux is not None:
+            (out,), (out_aux,) = _with_aux(x, _c(aux), run)
+            ctx.save_for_backward(out)
+            ctx.mark_non_differentiable(out_aux)
+            return out, out_aux
+        out = run(x)
         ctx.save_for_backward(out)
         return out
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, *_g_aux):
         (out,) = ctx.saved_tensors
-        return act_backward_raw(_c(g), out, ctx.act), None
+        return act_backward_raw(_c(g), out, ctx.act), None, None
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -42,8 +42,11 @@ class ConvAct(nn.Module):
         self.add_module("0", PackedConv(ci, co, k, transposed=transposed, bias=True))
         self.spec = K.ConvSpec(K.CONVT if transposed else K.CONV, ci, co, k, stride, pad, out_pad, act)
 
-    def forward(self, x):
+    def forward(self, x, aux=None):
+        """aux: companion rows without autograd (kernels.adjacent_rows); returns (y, y_aux) then."""
         conv = self._modules["0"]
+        if aux is not None:
+            return K.ConvAct.apply(x, conv.weight, conv.bias, None, self.spec, aux)
         return K.ConvAct.apply(x, conv.weight, conv.bias, None, self.spec)
 
 
@@ -67,8 +70,11 @@ class ResidualLayer(nn.Module):
         self.spec3 = K.ConvSpec(K.CONV, c, c, 3, 1, 1, 0, K.ACT_RELU)
         self.spec1 = K.ConvSpec(K.CONV, c, c, 1, 1, 0, 0, post_act)
 
-    def forward(self, x):
-        return K.ResBlock.apply(x, self.resblock._modules["0"].weight, self.resblock._modules["2"].weight, self.spec3, self.spec1)
+    def forward(self, x, aux=None):
+        w3, w1 = self.resblock._modules["0"].weight, self.resblock._modules["2"].weight
+        if aux is not None:
+            return K.ResBlock.apply(x, w3, w1, self.spec3, self.spec1, aux)
+        return K.ResBlock.apply(x, w3, w1, self.spec3, self.spec1)
 
 
 class LeakyReLU(nn.Module):
@@ -79,5 +85,22 @@ class LeakyReLU(nn.Module):
         super().__init__()
         self.fused = fused
 
-    def forward(self, x):
+    def forward(self, x, aux=None):
+        if aux is not None:
+            return (x, aux) if self.fused else K.ActFn.apply(x, K.ACT_LRELU, aux)
         return x if self.fused else K.ActFn.apply(x, K.ACT_LRELU)
+
+
+def run_with_companion(seq, x, aux):
+    """seq(x) with autograd and seq(aux) without, layer by layer through the same launches where the layer can
+    (ConvAct / ResidualLayer / LeakyReLU above take ``aux``); any other module runs twice."""
+    for m in seq:
+        if isinstance(m, nn.Sequential):
+            x, aux = run_with_companion(m, x, aux)
+        elif isinstance(m, (ConvAct, ResidualLayer, LeakyReLU)):
+            x, aux = m(x, aux)
+        else:
+            x = m(x)
+            with torch.no_grad():
+                aux = m(aux)
+    return x, aux

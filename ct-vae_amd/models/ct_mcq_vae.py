@@ -5,6 +5,7 @@ a textual copy of mcq_vae.py:161-239); the causal-transition layer between index
 lookup is ``causal.CausalTransition`` (torch-level + HIP Gumbel kernel; parity unpinned, see its header).
 Modes, return lists, loss-dict keys and ``state_dict`` keys follow the reference.
 """
+import os
 from typing import List, Union
 
 import torch
@@ -12,9 +13,12 @@ from torch.nn import functional as F
 
 from .. import kernels as K
 from .base import BaseVAE
+from .blocks import run_with_companion
 from .causal import CausalTransition
 from .mcq_vae import MultipleCodebookVectorQuantizer, build_mcq_decoder, build_mcq_encoder
 from .types_ import Tensor
+
+_PAIR_ENCODE = os.environ.get("CTVAE_NO_PAIR_ENCODE", "0") != "1"    # diagnostic: x and y through separate encoder passes
 
 
 class CTMCQVAE(BaseVAE):
@@ -54,6 +58,24 @@ class CTMCQVAE(BaseVAE):
         self.attach_grads()
         return [K.to_nchw_view(self.encoder(self._nhwc(input)))]
 
+    def encode_pair(self, input: Tensor, input_y: Tensor):
+        """(latents of input with autograd, latents of input_y without, code indices of both or None): the two encoder passes
+        of a transition sample (ct_mcq_vae.py:536-539, 565-566) through the same launches -- the encoder has no BatchNorm, so
+        rows are independent and y rides along as companion rows (kernels.adjacent_rows).  Only x's pass is trained: of y the
+        modes use the code indices alone."""
+        self.attach_grads()
+        x, y = K.to_nhwc_pair(input, input_y)
+        self._x_cache[id(input)] = (input, input._version, x)
+        self._x_cache[id(input_y)] = (input_y, input_y._version, y)
+        while len(self._x_cache) > 4:
+            self._x_cache.pop(next(iter(self._x_cache)))
+        lx, ly = run_with_companion(self.encoder, x, y)
+        both = K.adjacent_rows(lx, ly)
+        inds = None
+        if both is not None:                   # one index search over both halves
+            inds = self.vq_layer.compute_inds(K.to_nchw_view(both))
+        return K.to_nchw_view(lx), K.to_nchw_view(ly), inds
+
     def decode(self, z: Tensor) -> Tensor:
         self.attach_grads()
         return K.to_nchw_view(self.decoder(K.to_nhwc(z)))
@@ -86,14 +108,26 @@ class CTMCQVAE(BaseVAE):
                 {**{"causal_acc": torch.full((), 0.0, device=dev), "causal_nodir_acc": torch.full((), 0.0, device=dev),
                     "mode": "base", "mode_id": torch.full((), 0.0, device=dev)}, **ct_metrics[0]}]
 
-    def forward_action(self, input: Tensor, action: Tensor, input_y: Tensor = None, **kwargs) -> List[Tensor]:
+    def _encode_xy(self, input, input_y):
+        """latents of x (autograd), code indices of x and of y."""
+        if _PAIR_ENCODE and input_y is not None and input_y.shape == input.shape:
+            latents, lat_y, inds = self.encode_pair(input, input_y)
+            B = input.shape[0]
+            if inds is not None:
+                return latents, inds[:B], inds[B:]
+            with torch.no_grad():
+                return latents, self.vq_layer.compute_inds(latents), self.vq_layer.compute_inds(lat_y)
         latents = self.encode(input)[0]
         encoding_inds = self.vq_layer.compute_inds(latents)
+        with torch.no_grad():                 # indices cut the graph: the encoder pass on y has no backward
+            inds_y = self.vq_layer.compute_inds(self.encode(input_y)[0])
+        return latents, encoding_inds, inds_y
+
+    def forward_action(self, input: Tensor, action: Tensor, input_y: Tensor = None, **kwargs) -> List[Tensor]:
+        latents, encoding_inds, inds_y = self._encode_xy(input, input_y)
         shape = latents.shape
         one_hot = self.ct_preprocess(encoding_inds, shape)
         ct_encodings, ct_reg, *ct_metrics = self.ct_layer.forward_action(one_hot, action)
-        with torch.no_grad():                 # indices cut the graph: the encoder pass on y has no backward
-            inds_y = self.vq_layer.compute_inds(self.encode(input_y)[0])
         ct_loss = ct_reg + self.ct_layer.latent_loss(ct_encodings, self.ct_preprocess(inds_y, shape))
         ct_inds = self.ct_postprocess(ct_encodings, shape)
         q, _ = self.vq_layer.compute_latents(latents, encoding_inds if self.skip_transition else ct_inds)
@@ -103,10 +137,7 @@ class CTMCQVAE(BaseVAE):
                     "mode": "action", "mode_id": torch.full((), 1.0, device=dev)}, **ct_metrics[0]}]
 
     def forward_causal(self, input: Tensor, input_y: Tensor, action: Tensor = None, **kwargs) -> List[Tensor]:
-        lat_x = self.encode(input)[0]
-        lat_y = self.encode(input_y)[0]
-        enc_x = self.vq_layer.compute_inds(lat_x)
-        enc_y = self.vq_layer.compute_inds(lat_y)
+        lat_x, enc_x, enc_y = self._encode_xy(input, input_y)      # the indices cut the graph: no encoder backward in this mode
         shape = lat_x.shape
         recons_action, ct_reg, *ct_metrics = self.ct_layer.forward_transition(self.ct_preprocess(enc_x, shape),
                                                                                self.ct_preprocess(enc_y, shape))

@@ -21,7 +21,7 @@ for name, s, e, *g in rows[lo:hi]:
     gap = s - prev_end
     busy += e - s
     idle += max(gap, 0)
-    short = name.split("(")[0].replace("void ", "").replace("ctvae::", "").replace("(anonymous namespace)::", "")
+    short = name.replace("(anonymous namespace)::", "").replace("void ", "").replace("ctvae::", "").split("(")[0]
     print(f"{(s - t0) / 1e3:9.1f} us  {(e - s) / 1e3:7.1f} us  gap {gap / 1e3:6.1f}  {'x'.join(str(v) for v in g):>12}  {short[:90]}")
     prev_end = max(prev_end, e)
 print(f"# {hi - lo} dispatches, busy {busy / 1e3:.1f} us, idle {idle / 1e3:.1f} us, span {(rows[hi - 1][2] - rows[lo - 1][2]) / 1e3:.1f} us")
