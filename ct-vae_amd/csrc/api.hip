@@ -64,6 +64,11 @@ int launch_ct_mask_forward(const float* x, const float* action, const float* pe,
 int launch_ct_mask_backward(const float* x, const float* action, const float* pe, const float* keep, float scale,
                             const float* inter, const float* p, const float* soft, const float* g, int B, int S, int D, int A,
                             float* dWp, float* dbp, hipStream_t st);
+int launch_ct_blend_forward(const float* s0, const float* s1, const float* mask, float* out, long rows, hipStream_t st);
+int launch_ct_blend_backward(const float* g, const float* s0, const float* s1, const float* mask, float* g0, float* g1, float* gm,
+                             long rows, hipStream_t st);
+int launch_group_rowsum(const float* parts, long mat_stride, int nmat, int rows, int C, int ld, const int* grp, int G, float* out,
+                        int accumulate, hipStream_t st);
 int launch_ct_sample_forward(const float* p, const float* expo, float* out, float* soft, float* weighted, long n, hipStream_t st);
 int launch_ct_sample_backward(const float* gs, const float* gw, const float* p, const float* soft, const float* sample, float* gp,
                               long n, hipStream_t st);
@@ -445,6 +450,20 @@ int ctvae_ct_sample_forward(const float* p, const float* expo, float* sample, fl
 int ctvae_ct_sample_backward(const float* g_sample, const float* g_weighted, const float* p, const float* soft, const float* sample,
                              float* g_p, long n, void* stream) {
   return launch_ct_sample_backward(g_sample, g_weighted, p, soft, sample, g_p, n, (hipStream_t)stream);
+}
+
+int ctvae_ct_blend_forward(const float* s0, const float* s1, const float* mask, float* out, long rows, void* stream) {
+  return launch_ct_blend_forward(s0, s1, mask, out, rows, (hipStream_t)stream);
+}
+
+int ctvae_ct_blend_backward(const float* g, const float* s0, const float* s1, const float* mask, float* g0, float* g1, float* g_mask,
+                            long rows, void* stream) {
+  return launch_ct_blend_backward(g, s0, s1, mask, g0, g1, g_mask, rows, (hipStream_t)stream);
+}
+
+int ctvae_group_rowsum(const float* parts, long mat_stride, int nmat, int rows, int C, int ld, const int32_t* group, int G, float* out,
+                       int accumulate, void* stream) {
+  return launch_group_rowsum(parts, mat_stride, nmat, rows, C, ld, group, G, out, accumulate, (hipStream_t)stream);
 }
 
 static int glin_fill(GLinArgs& a, int nseg, int N, const float* const* W, const int* ldw, const int64_t* w_gstride,

@@ -376,7 +376,89 @@ __global__ __launch_bounds__(256) void ct_sample_bwd_kernel(const float* __restr
   }
 }
 
+// adjacency = s0 * (1 - m) + s1 * m with the intervention mask m per (sample, source node) row of 64 targets
+// (CausalTransition._compute_adj, ct_mcq_vae.py:153): one launch instead of rsub, mul, mul, add -- and one instead of their
+// five autograd mirrors on the way back (a wave owns a row, so d m is a shuffle reduction)
+__global__ __launch_bounds__(256) void ct_blend_fwd_kernel(const float* __restrict__ s0, const float* __restrict__ s1,
+                                                          const float* __restrict__ mask, float* __restrict__ out, long n) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float m = mask[i >> 6];
+    out[i] = s0[i] * (1.f - m) + s1[i] * m;
+  }
+}
+
+__global__ __launch_bounds__(256) void ct_blend_bwd_kernel(const float* __restrict__ g, const float* __restrict__ s0,
+                                                          const float* __restrict__ s1, const float* __restrict__ mask,
+                                                          float* __restrict__ g0, float* __restrict__ g1, float* __restrict__ gm,
+                                                          long n) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {      // n % 64 == 0: a wave walks whole rows
+    const float m = mask[i >> 6], gi = g[i];
+    g0[i] = gi * (1.f - m);
+    g1[i] = gi * m;
+    float d = gi * (s1[i] - s0[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+    if ((threadIdx.x & 63) == 0) gm[i >> 6] = d;
+  }
+}
+
+// out[z][g][c] (+)= sum over the rows r (in order) with grp[r] == g of parts[z][r][c]: per-sample partial gradients gathered
+// into the rows of a parameter bank (scorer rows of the discoverers, per-head vectors of the last GATv2 layer) without
+// atomics -- one thread owns an output element and walks the rows.  grp == NULL: every row belongs to group 0.
+__global__ __launch_bounds__(256) void group_rowsum_kernel(const float* __restrict__ parts, long mat_stride, int rows, int C, int ld,
+                                                          const int* __restrict__ grp, int G, float* __restrict__ out,
+                                                          int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y, z = blockIdx.z;
+  if (c >= C) return;
+  const float* p = parts + (long)z * mat_stride + c;
+  float acc = 0.f;
+  if (grp == nullptr) {
+    if (g == 0)
+      for (int r = 0; r < rows; ++r) acc += p[(long)r * ld];
+  } else {
+    for (int r = 0; r < rows; ++r)
+      if (grp[r] == g) acc += p[(long)r * ld];
+  }
+  float* o = out + ((long)z * G + g) * C + c;
+  *o = accumulate ? *o + acc : acc;
+}
+
 }  // namespace
+
+int launch_ct_blend_forward(const float* s0, const float* s1, const float* mask, float* out, long rows, hipStream_t st) {
+  if (!s0 || !s1 || !mask || !out || rows <= 0) return kErrBadArg;
+  const long n = rows * 64;
+  ProfScope ps("ct_blend_fwd_kernel", st, 0.0, 4.0 * n * 3.0);
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(ct_blend_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, s0, s1, mask, out, n);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_ct_blend_backward(const float* g, const float* s0, const float* s1, const float* mask, float* g0, float* g1, float* gm,
+                             long rows, hipStream_t st) {
+  if (!g || !s0 || !s1 || !mask || !g0 || !g1 || !gm || rows <= 0) return kErrBadArg;
+  const long n = rows * 64;
+  ProfScope ps("ct_blend_bwd_kernel", st, 0.0, 4.0 * n * 5.0);
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(ct_blend_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, s0, s1, mask, g0, g1, gm, n);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_group_rowsum(const float* parts, long mat_stride, int nmat, int rows, int C, int ld, const int* grp, int G, float* out,
+                        int accumulate, hipStream_t st) {
+  if (!parts || !out || nmat <= 0 || rows <= 0 || C <= 0 || ld < 1 || G <= 0) return kErrBadArg;
+  ProfScope ps("group_rowsum_kernel", st, 0.0, 4.0 * nmat * ((double)rows * C + (double)G * C));
+  hipLaunchKernelGGL(group_rowsum_kernel, dim3((C + 255) / 256, G, nmat), dim3(256), 0, st, parts, mat_stride, rows, C, ld, grp, G, out,
+                     accumulate);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
 
 int launch_ct_reg_forward(const float* adj, const float* graph, const float* uni, float* part, float ckl, float cgs, float cpt,
                           int B, int N, hipStream_t st) {

@@ -1234,7 +1234,7 @@ class GroupLinear(Function):
     """y[b, m, s*N + n] = sum_k x[b, m, k] * W_s[group_s[b]][n][koff_s + k] + bias_s[group_s[b]][n] on blocks of 64 rows per
     sample (csrc/glinear.hip).  x [B,64,K]; spec: per segment (koff, group) with group an int32 [B] tensor or None (everybody
     uses matrix 0); wb: per segment the bank W [G,N,ldw >= koff+K] and its bias [G,N] or None.  Several segments may name the
-    same bank (autograd adds their gradients)."""
+    same bank: its gradient then arrives once, at the first of them."""
 
     @staticmethod
     def forward(ctx, x, K, N, spec, *wb):
@@ -1255,6 +1255,10 @@ class GroupLinear(Function):
             Ws.append(W)
             bs.append(b)
             gs.append(grp)
+        for s in range(nseg):            # segments of one bank share one gradient tensor (backward): one bias bank per weight bank
+            for t in range(s):
+                if Ws[t].data_ptr() == Ws[s].data_ptr() and bs[t] is not None and bs[s] is not None and bs[t].data_ptr() != bs[s].data_ptr():
+                    raise RuntimeError("GroupLinear: segments that name the same weight bank must name the same bias bank")
         y = torch.empty((B, 64, nseg * N), dtype=torch.float32, device=x.device)
         ctx.host = (
             (C.c_void_p * nseg)(*[W.data_ptr() + 4 * spec[s][0] for s, W in enumerate(Ws)]),
@@ -1286,20 +1290,33 @@ class GroupLinear(Function):
             dx = torch.empty_like(x)
             native.call("ctvae_glinear_dgrad", g.data_ptr(), nseg * N, nseg, N, h[0], h[1], h[2], h[5], dx.data_ptr(), K, K, B)
         ws = native.workspace(x.device)
-        grads = []
+        # Segments that name the SAME bank (the discoverers' first layers: columns 0..D-1 / D..2D-1, matrix 0 for everybody and
+        # matrix 1 + action per sample) write into ONE gradient tensor per bank, zero-filled once and accumulated into by each
+        # segment's launch; the first segment's input slot carries it, the others return None.  (As separate tensors autograd
+        # added them: a fill per segment and an add per extra segment over 5 MB each.)
+        grads = [None] * (2 * nseg)
+        shared = {}
         for s in range(nseg):
             W = Ws[s]
             G = W.shape[0]
-            dW = db = None
-            if ctx.needs_input_grad[4 + 2 * s]:
-                Gk = G if gs[s] is not None else 1        # no group ids: only matrix 0 is used, the other rows of the bank get zeros
-                full = koffs[s] == 0 and W.shape[2] == K and Gk == G
-                dW = torch.empty_like(W, memory_format=torch.contiguous_format) if full else torch.zeros_like(W, memory_format=torch.contiguous_format)
-                if has_b[s]:
-                    db = torch.empty((G, N), dtype=torch.float32, device=x.device) if Gk == G else torch.zeros((G, N), dtype=torch.float32, device=x.device)
-                native.call("ctvae_glinear_wgrad", x.data_ptr(), K, K, g.data_ptr(), nseg * N, s * N, N, native.ptr(gs[s]), Gk, B,
-                            dW.data_ptr() + 4 * koffs[s], dW.stride(1), native.ptr(db), 0, ws.data_ptr(), ws.numel() * 4)
-            grads += [dW, db]
+            if not ctx.needs_input_grad[4 + 2 * s]:
+                continue
+            key = (W.data_ptr(), tuple(W.shape), tuple(W.stride()))
+            ent = shared.get(key)
+            if ent is None:
+                dW = torch.zeros_like(W, memory_format=torch.contiguous_format)
+                db = torch.zeros((G, N), dtype=torch.float32, device=x.device) if any(
+                    has_b[t] for t in range(nseg) if Ws[t].data_ptr() == W.data_ptr()) else None
+                ent = shared[key] = (dW, db)
+                grads[2 * s] = dW
+                if db is not None:           # the bias gradient goes to the first segment of this bank that has a bias input
+                    t = next(t for t in range(nseg) if Ws[t].data_ptr() == W.data_ptr() and has_b[t])
+                    grads[2 * t + 1] = db
+            dW, db = ent
+            Gk = G if gs[s] is not None else 1        # no group ids: only matrix 0 is used
+            native.call("ctvae_glinear_wgrad", x.data_ptr(), K, K, g.data_ptr(), nseg * N, s * N, N, native.ptr(gs[s]), Gk, B,
+                        dW.data_ptr() + 4 * koffs[s], dW.stride(1), native.ptr(db) if has_b[s] else None, 1, ws.data_ptr(),
+                        ws.numel() * 4)
         return (dx, None, None, None) + tuple(grads)
 
 
@@ -1342,16 +1359,18 @@ class PairScores(Function):
         p, d = uv.data_ptr(), d_uv.data_ptr()
         native.call("ctvae_pair_mlp_backward", p, p + 4 * H, ld, w2.data_ptr(), out[0].data_ptr(), g[0].data_ptr(), d, d + 4 * H, ld,
                     dw2p[0].data_ptr(), db2p[0].data_ptr(), B, 64, H, PairMLP.SLOPE, 0, None)
-        sel = torch.zeros((G, B), dtype=torch.float32, device=uv.device)
-        sel[0] = 1.0
-        parts = torch.cat([dw2p[0], db2p[0].unsqueeze(1)], 1)                      # [B, H+1]
-        dbank = sel @ parts                                                        # rows of the bank: discoverer 0 <- every sample
+        # per-sample partials -> rows of the scorer bank: discoverer 0 takes every sample, discoverer grp[b] sample b (in order,
+        # no atomics; as torch ops this was one_hot^T @ parts plus the fills / casts / cats around it)
+        dw2 = torch.empty((G, H), dtype=torch.float32, device=uv.device)
+        db2 = torch.empty((G,), dtype=torch.float32, device=uv.device)
+        native.call("ctvae_group_rowsum", dw2p[0].data_ptr(), 0, 1, B, H, H, None, G, dw2.data_ptr(), 0)
+        native.call("ctvae_group_rowsum", db2p[0].data_ptr(), 0, 1, B, 1, 1, None, G, db2.data_ptr(), 0)
         if nd == 2:
             native.call("ctvae_pair_mlp_backward", p + 8 * H, p + 12 * H, ld, w2.data_ptr(), out[1].data_ptr(), g[1].data_ptr(),
                         d + 8 * H, d + 12 * H, ld, dw2p[1].data_ptr(), db2p[1].data_ptr(), B, 64, H, PairMLP.SLOPE, 1, grp.data_ptr())
-            sel_a = torch.nn.functional.one_hot(grp.long(), G).to(torch.float32).t()         # [G,B]
-            dbank = dbank + sel_a @ torch.cat([dw2p[1], db2p[1].unsqueeze(1)], 1)
-        return d_uv, dbank[:, :H].contiguous(), dbank[:, H].contiguous(), None, None
+            native.call("ctvae_group_rowsum", dw2p[1].data_ptr(), 0, 1, B, H, H, grp.data_ptr(), G, dw2.data_ptr(), 1)
+            native.call("ctvae_group_rowsum", db2p[1].data_ptr(), 0, 1, B, 1, 1, grp.data_ptr(), G, db2.data_ptr(), 1)
+        return d_uv, dw2, db2, None, None
 
 
 class GATLayer(Function):
@@ -1400,9 +1419,9 @@ class GATLayer(Function):
                     parts[0].data_ptr(), parts[1].data_ptr(), parts[2].data_ptr(), native.ptr(dadj), 0, B, Hs, C, slope, act)
         if head_map is None:
             red = parts.view(3, B, Hs * C).sum(1).view(3, H, C)
-        else:   # per-head sums of the per-(sample, slot) partials as one small GEMM (deterministic, no atomics)
-            sel = torch.nn.functional.one_hot(head_map.view(-1).long(), H).to(torch.float32)      # [B*Hs, H]
-            red = torch.matmul(sel.t().unsqueeze(0), parts)                                        # [3, H, C]
+        else:   # per-head sums of the per-(sample, slot) partials, in row order (deterministic, no atomics): one launch
+            red = torch.empty((3, H, C), dtype=torch.float32, device=dev)
+            native.call("ctvae_group_rowsum", parts.data_ptr(), B * Hs * C, 3, B * Hs, C, C, head_map.data_ptr(), H, red.data_ptr(), 0)
         return d_xlr, dadj, red[2], red[1], red[0].reshape(-1), None, None, None, None, None
 
 
@@ -1519,6 +1538,32 @@ class CTMask(Function):
         native.call("ctvae_ct_mask_backward", x.data_ptr(), action.data_ptr(), pe.data_ptr(), native.ptr(keep), ctx.scale,
                     inter.data_ptr(), psoft[0].data_ptr(), psoft[2].data_ptr(), g.data_ptr(), B, S, D, A, dWp.data_ptr(), dbp.data_ptr())
         return None, None, None, None, None, dWp.sum(0).t(), dbp.sum(0), None
+
+
+class MaskBlend(Function):
+    """adj = s[0] * (1 - mask) + s[1] * mask (CausalTransition._compute_adj, ct_mcq_vae.py:153): s [2,B,64,64] the scores of
+    discoverer 0 and of each sample's own discoverer (PairScores), mask [B,64,1]; one launch each way (csrc/ctmisc.hip)."""
+
+    @staticmethod
+    def forward(ctx, s, mask):
+        _req_cuda(s, mask)
+        s, mask = _c(s), _c(mask)
+        if s.dim() != 4 or s.shape[0] != 2 or s.shape[-1] != 64 or mask.numel() * 64 != s[0].numel():
+            raise RuntimeError("MaskBlend: needs s [2,B,64,64] and one mask value per row of 64")
+        out = torch.empty_like(s[0])
+        native.call("ctvae_ct_blend_forward", s[0].data_ptr(), s[1].data_ptr(), mask.data_ptr(), out.data_ptr(), mask.numel())
+        ctx.save_for_backward(s, mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        s, mask = ctx.saved_tensors
+        g = _c(g)
+        gs = torch.empty_like(s)
+        gm = torch.empty_like(mask)
+        native.call("ctvae_ct_blend_backward", g.data_ptr(), s[0].data_ptr(), s[1].data_ptr(), mask.data_ptr(), gs[0].data_ptr(),
+                    gs[1].data_ptr(), gm.data_ptr(), mask.numel())
+        return gs, gm
 
 
 class CTSample(Function):

@@ -37,7 +37,7 @@ class DeviceNoise:
     def draw(self, tag, shape, p=0.0, device=None):
         dev = device if device is not None else self.device
         if tag.endswith("_dropout"):
-            return (torch.rand(shape, device=dev) >= p).to(torch.float32)
+            return torch.empty(shape, device=dev, dtype=torch.float32).bernoulli_(1.0 - p)      # one launch (was rand, >=, cast)
         if tag.endswith("_gumbel"):
             return torch.empty(shape, device=dev, dtype=torch.float32).exponential_()
         if tag.endswith("_noise"):
@@ -294,6 +294,16 @@ class CausalTransition(nn.Module):
         p = (one_hot_latent * inter).sum(dim=-1)               # [B,S]
         return sample_bernoulli_st(p, "mask_gumbel").unsqueeze(-1)
 
+    def _action_group(self, action):
+        """1 + argmax(action) as int32 [B]: the discoverer / head a sample's action selects (ct_mcq_vae.py:147, 224); formed once
+        per action tensor (three launches) and reused by the adjacency and the transition of the same forward."""
+        c = getattr(self, "_grp_cache", None)
+        if c is not None and c[0] is action and c[1] == action._version:
+            return c[2]
+        grp = (torch.argmax(action, dim=-1) + 1).to(torch.int32)
+        self._grp_cache = (action, action._version, grp)
+        return grp
+
     def _sample_bernoulli(self, adjacency):
         return sample_bernoulli_st(adjacency, "adj_gumbel")
 
@@ -307,10 +317,10 @@ class CausalTransition(nn.Module):
             if mask is None:
                 uv = K.GroupLinear.apply(latent, D, Hd, ((0, None), (D, None)), W1, None, W1, b1)
                 return K.PairScores.apply(uv, w2, b2, None, Hd)[0]
-            grp = (torch.argmax(action, dim=-1) + 1).to(torch.int32)
+            grp = self._action_group(action)
             uv = K.GroupLinear.apply(latent, D, Hd, ((0, None), (D, None), (0, grp), (D, grp)), W1, None, W1, b1, W1, None, W1, b1)
             s = K.PairScores.apply(uv, w2, b2, grp, Hd)
-            return s[0] * (1 - mask) + s[1] * mask
+            return K.MaskBlend.apply(s, mask)                       # s[0] * (1 - mask) + s[1] * mask
         no_inter = self._pair_coeffs(self.graph_discovers[0], latent)
         if mask is None:
             return no_inter
@@ -360,7 +370,7 @@ class CausalTransition(nn.Module):
             latent = latent + _draw("exo_noise", latent.shape, device=latent.device)
         elif self.noise == "endo":
             _draw("endo_noise", (B, D), device=latent.device)      # the draw the reference makes for its isolated noise node
-        slots = [None] if mask is None else [None, action.argmax(dim=-1).to(torch.int32) + 1]      # head 0 (, head 1 + action)
+        slots = [None] if mask is None else [None, self._action_group(action)]      # head 0 (, head 1 + action)
         y = self.graph_transitioner.forward_fused(latent, adjacency, slots).view(B, S, len(slots), D)
         if D <= 64:
             return K.BlendSoftmax.apply(y, mask)          # head blend + softmax in one launch (csrc/ctmisc.hip)
@@ -413,9 +423,15 @@ class CausalTransition(nn.Module):
         return [F.softmin(torch.stack(dist, 1), dim=-1), torch.zeros((), device=latent.device), {}]
 
     # ---- losses / metrics (ct_mcq_vae.py:297-333) --------------------------------------------------
-    def latent_loss(self, latent, latent_y):
+    def latent_loss(self, latent, latent_y, target_inds=None):
+        """target_inds (int64, one index per (b, h, w) row of latent_y in that order): the arg-max of latent_y where the caller
+        already holds it -- CTMCQVAE builds latent_y as the one-hot of exactly these indices, so it skips both the one-hot
+        and its arg-max (latent_y may then be None)."""
         lat = latent.permute(0, 2, 3, 1).reshape(-1, latent.size(1))        # a view when latent is [B,S,D] memory (forward*)
-        tgt = latent_y.detach().permute(0, 2, 3, 1).reshape(-1, latent_y.size(1)).argmax(dim=-1)
+        if target_inds is not None:
+            tgt = target_inds.reshape(-1)
+        else:
+            tgt = latent_y.detach().permute(0, 2, 3, 1).reshape(-1, latent_y.size(1)).argmax(dim=-1)
         if lat.is_cuda and lat.size(1) <= 64:
             return K.LatentCE.apply(lat, tgt)             # clamp + log + cross-entropy in one launch (csrc/ctmisc.hip)
         return F.cross_entropy(lat.clamp(min=1e-4).log(), tgt)

@@ -93,6 +93,14 @@ class CTMCQVAE(BaseVAE):
         x = x.reshape((latents_shape[0], self.codebooks, latents_shape[2], latents_shape[3], self.num_embeddings))
         return torch.argmax(x, dim=-1)
 
+    def _const(self, v, dev):
+        """0-dim constant on the device, made once (a torch.full per step and constant is a launch each)."""
+        c = self.__dict__.setdefault("_consts", {})
+        t = c.get((v, dev))
+        if t is None:
+            t = c[(v, dev)] = torch.full((), float(v), device=dev)
+        return t
+
     # -- modes (ct_mcq_vae.py:501-591) --------------------------------------------------------------------
     def forward_base(self, input: Tensor, **kwargs) -> List[Tensor]:
         latents = self.encode(input)[0]
@@ -100,13 +108,13 @@ class CTMCQVAE(BaseVAE):
         shape = latents.shape
         one_hot = self.ct_preprocess(encoding_inds, shape)
         ct_encodings, ct_reg, *ct_metrics = self.ct_layer(one_hot)
-        ct_loss = ct_reg + self.ct_layer.latent_loss(ct_encodings, one_hot)
+        ct_loss = ct_reg + self.ct_layer.latent_loss(ct_encodings, one_hot, target_inds=encoding_inds)
         ct_inds = self.ct_postprocess(ct_encodings, shape)
         q, vq_loss = self.vq_layer.compute_latents(latents, encoding_inds if self.skip_transition else ct_inds)
         dev = input.device
         return [self.decode(q), input, vq_loss, ct_loss,
-                {**{"causal_acc": torch.full((), 0.0, device=dev), "causal_nodir_acc": torch.full((), 0.0, device=dev),
-                    "mode": "base", "mode_id": torch.full((), 0.0, device=dev)}, **ct_metrics[0]}]
+                {**{"causal_acc": self._const(0.0, dev), "causal_nodir_acc": self._const(0.0, dev),
+                    "mode": "base", "mode_id": self._const(0.0, dev)}, **ct_metrics[0]}]
 
     def _encode_xy(self, input, input_y):
         """latents of x (autograd), code indices of x and of y."""
@@ -128,13 +136,14 @@ class CTMCQVAE(BaseVAE):
         shape = latents.shape
         one_hot = self.ct_preprocess(encoding_inds, shape)
         ct_encodings, ct_reg, *ct_metrics = self.ct_layer.forward_action(one_hot, action)
-        ct_loss = ct_reg + self.ct_layer.latent_loss(ct_encodings, self.ct_preprocess(inds_y, shape))
+        # the target is the one-hot of inds_y (ct_preprocess): its arg-max are the indices themselves
+        ct_loss = ct_reg + self.ct_layer.latent_loss(ct_encodings, None, target_inds=inds_y)
         ct_inds = self.ct_postprocess(ct_encodings, shape)
         q, _ = self.vq_layer.compute_latents(latents, encoding_inds if self.skip_transition else ct_inds)
         dev = input.device
-        return [self.decode(q), input_y, torch.full((), 0.0, device=dev), ct_loss,
-                {**{"causal_acc": torch.full((), 0.0, device=dev), "causal_nodir_acc": torch.full((), 0.0, device=dev),
-                    "mode": "action", "mode_id": torch.full((), 1.0, device=dev)}, **ct_metrics[0]}]
+        return [self.decode(q), input_y, self._const(0.0, dev), ct_loss,
+                {**{"causal_acc": self._const(0.0, dev), "causal_nodir_acc": self._const(0.0, dev),
+                    "mode": "action", "mode_id": self._const(1.0, dev)}, **ct_metrics[0]}]
 
     def forward_causal(self, input: Tensor, input_y: Tensor, action: Tensor = None, **kwargs) -> List[Tensor]:
         lat_x, enc_x, enc_y = self._encode_xy(input, input_y)      # the indices cut the graph: no encoder backward in this mode
@@ -144,8 +153,8 @@ class CTMCQVAE(BaseVAE):
         nodir = self.ct_layer.causal_undirected_accuracy(recons_action, action)
         acc = self.ct_layer.causal_accuracy(recons_action, action)
         dev = input.device
-        return [recons_action, action, torch.full((), 0.0, device=dev), ct_reg.to(dev),
-                {**{"causal_acc": acc, "causal_nodir_acc": nodir, "mode": "causal", "mode_id": torch.full((), 2.0, device=dev)},
+        return [recons_action, action, self._const(0.0, dev), ct_reg.to(dev),
+                {**{"causal_acc": acc, "causal_nodir_acc": nodir, "mode": "causal", "mode_id": self._const(2.0, dev)},
                  **ct_metrics[0]}]
 
     FORWARD_MODES = {"base": forward_base, "action": forward_action, "causal": forward_causal}

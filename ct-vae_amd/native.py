@@ -42,6 +42,9 @@ SIGNATURES = {
     "ctvae_ct_latent_ce_backward": [_fp, _fp, _fp, _fp, _l, _i, _vp],
     "ctvae_ct_mask_forward": [_fp, _fp, _fp, _fp, _f, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _vp],
     "ctvae_ct_mask_backward": [_fp, _fp, _fp, _fp, _f, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _vp],
+    "ctvae_ct_blend_forward": [_fp, _fp, _fp, _fp, _l, _vp],
+    "ctvae_ct_blend_backward": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _l, _vp],
+    "ctvae_group_rowsum": [_fp, _l, _i, _i, _i, _i, _fp, _i, _fp, _i, _vp],
     "ctvae_ct_sample_forward": [_fp, _fp, _fp, _fp, _fp, _l, _vp],
     "ctvae_ct_sample_backward": [_fp, _fp, _fp, _fp, _fp, _fp, _l, _vp],
     "ctvae_glinear_forward": [_fp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _fp, _i, _i, _vp],

@@ -222,6 +222,19 @@ size_t ctvae_glinear_wgrad_ws_bytes(int G, int N, int K);
 int ctvae_glinear_wgrad(const float* x, int ldx, int K, const float* dy, int ldy, int col0, int N, const int32_t* group, int G,
                         int B, float* dW, int ldo, float* dbias, int accumulate, float* ws, size_t ws_bytes, void* stream);
 
+/* CausalTransition._compute_adj's blend (ct_mcq_vae.py:153): out[r, j] = s0[r, j] * (1 - mask[r]) + s1[r, j] * mask[r] for
+ * `rows` = B*64 rows of 64 targets (s0: discoverer 0's scores, s1: the action's discoverer, mask: the intervention mask per
+ * (sample, source node)); backward: g0 = g * (1 - mask), g1 = g * mask, g_mask[r] = sum_j g * (s1 - s0). */
+int ctvae_ct_blend_forward(const float* s0, const float* s1, const float* mask, float* out, long rows, void* stream);
+int ctvae_ct_blend_backward(const float* g, const float* s0, const float* s1, const float* mask, float* g0, float* g1, float* g_mask,
+                            long rows, void* stream);
+/* Per-sample partial gradients into the rows of a parameter bank, in row order (deterministic, no atomics):
+ * out[z][g][c] (+)= sum_{r < rows, group[r] == g} parts[z*mat_stride + r*ld + c], z < nmat, g < G, c < C; group == NULL: every
+ * row belongs to group 0.  Replaces the one_hot(group)^T @ parts products behind the scorer rows of graph_discovers
+ * (ct_mcq_vae.py:147-151) and the per-head vectors of the last GATv2Conv (:224-226). */
+int ctvae_group_rowsum(const float* parts, long mat_stride, int nmat, int rows, int C, int ld, const int32_t* group, int G, float* out,
+                       int accumulate, void* stream);
+
 /* forward_action's regulariser (ct_mcq_vae.py:275): beta * adjacency_KL_loss(adj) + delta * graph_size_loss(graph) + epsilon *
  * positive_trial_loss(adj) (:314-323) on adj, graph [B,64,64] with the uniform draws of the KL target [B,4096] given
  * (torch.rand in :316).  forward writes part4 [B][4] = {KL_b, ||graph_b||_F, ||prod_j(1 - adj_b[i,j])||_2,
