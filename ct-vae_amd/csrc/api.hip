@@ -69,6 +69,10 @@ int launch_ct_blend_backward(const float* g, const float* s0, const float* s1, c
                              long rows, hipStream_t st);
 int launch_group_rowsum(const float* parts, long mat_stride, int nmat, int rows, int C, int ld, const int* grp, int G, float* out,
                         int accumulate, hipStream_t st);
+int launch_ct_posenc_forward(const float* x, const float* pe, const float* keep, float scale, float* out, long n, int sd,
+                             hipStream_t st);
+int launch_ct_posenc_backward(const float* g, const float* keep, float scale, float* gx, long n, hipStream_t st);
+int launch_one_hot(const long long* inds, long n, int N, float* out, hipStream_t st);
 int launch_ct_sample_forward(const float* p, const float* expo, float* out, float* soft, float* weighted, long n, hipStream_t st);
 int launch_ct_sample_backward(const float* gs, const float* gw, const float* p, const float* soft, const float* sample, float* gp,
                               long n, hipStream_t st);
@@ -459,6 +463,19 @@ int ctvae_ct_blend_forward(const float* s0, const float* s1, const float* mask, 
 int ctvae_ct_blend_backward(const float* g, const float* s0, const float* s1, const float* mask, float* g0, float* g1, float* g_mask,
                             long rows, void* stream) {
   return launch_ct_blend_backward(g, s0, s1, mask, g0, g1, g_mask, rows, (hipStream_t)stream);
+}
+
+int ctvae_ct_posenc_forward(const float* x, const float* pe, const float* keep, float scale, float* out, long n, int sd,
+                            void* stream) {
+  return launch_ct_posenc_forward(x, pe, keep, scale, out, n, sd, (hipStream_t)stream);
+}
+
+int ctvae_ct_posenc_backward(const float* g, const float* keep, float scale, float* g_x, long n, void* stream) {
+  return launch_ct_posenc_backward(g, keep, scale, g_x, n, (hipStream_t)stream);
+}
+
+int ctvae_one_hot(const int64_t* inds, long n, int N, float* out, void* stream) {
+  return launch_one_hot((const long long*)inds, n, N, out, (hipStream_t)stream);
 }
 
 int ctvae_group_rowsum(const float* parts, long mat_stride, int nmat, int rows, int C, int ld, const int32_t* group, int G, float* out,

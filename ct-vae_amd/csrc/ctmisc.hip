@@ -404,6 +404,36 @@ __global__ __launch_bounds__(256) void ct_blend_bwd_kernel(const float* __restri
   }
 }
 
+// PositionalEncoding.forward (ct_mcq_vae.py:33-38): out = (x + pe[s]) * keep * scale, keep the dropout mask (NULL: eval /
+// p = 0) -- one launch instead of add, mul, mul; backward g * keep * scale
+__global__ __launch_bounds__(256) void ct_posenc_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pe,
+                                                           const float* __restrict__ keep, float scale, float* __restrict__ out,
+                                                           long n4, int sd4) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[i] + reinterpret_cast<const f32x4*>(pe)[i % sd4];
+    if (keep != nullptr) v = v * reinterpret_cast<const f32x4*>(keep)[i] * scale;
+    reinterpret_cast<f32x4*>(out)[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void ct_posenc_bwd_kernel(const float* __restrict__ g, const float* __restrict__ keep, float scale,
+                                                           float* __restrict__ gx, long n4) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+    reinterpret_cast<f32x4*>(gx)[i] = reinterpret_cast<const f32x4*>(g)[i] * reinterpret_cast<const f32x4*>(keep)[i] * scale;
+}
+
+// F.one_hot(inds, N).float() (CTMCQVAE.ct_preprocess, ct_mcq_vae.py:472-480) in one launch (fill, scatter, cast as torch ops)
+__global__ __launch_bounds__(256) void one_hot_kernel(const long long* __restrict__ inds, long n, int N4, float* __restrict__ out) {
+  const long stride = (long)gridDim.x * 256, tot = n * N4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += stride) {
+    const long r = i / N4;
+    const int c = (int)(i - r * N4) * 4, k = (int)inds[r];
+    reinterpret_cast<f32x4*>(out)[i] = f32x4{k == c ? 1.f : 0.f, k == c + 1 ? 1.f : 0.f, k == c + 2 ? 1.f : 0.f, k == c + 3 ? 1.f : 0.f};
+  }
+}
+
 // out[z][g][c] (+)= sum over the rows r (in order) with grp[r] == g of parts[z][r][c]: per-sample partial gradients gathered
 // into the rows of a parameter bank (scorer rows of the discoverers, per-head vectors of the last GATv2 layer) without
 // atomics -- one thread owns an output element and walks the rows.  grp == NULL: every row belongs to group 0.
@@ -446,6 +476,37 @@ int launch_ct_blend_backward(const float* g, const float* s0, const float* s1, c
   long blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(ct_blend_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, s0, s1, mask, g0, g1, gm, n);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_ct_posenc_forward(const float* x, const float* pe, const float* keep, float scale, float* out, long n, int sd,
+                             hipStream_t st) {
+  if (!x || !pe || !out || n <= 0 || sd <= 0 || (n & 3) || (sd & 3) || n % sd) return kErrBadArg;
+  ProfScope ps("ct_posenc_fwd_kernel", st, 0.0, 4.0 * n * (keep ? 3.0 : 2.0));
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(ct_posenc_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, pe, keep, scale, out, n / 4, sd / 4);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_ct_posenc_backward(const float* g, const float* keep, float scale, float* gx, long n, hipStream_t st) {
+  if (!g || !keep || !gx || n <= 0 || (n & 3)) return kErrBadArg;
+  ProfScope ps("ct_posenc_bwd_kernel", st, 0.0, 4.0 * n * 3.0);
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(ct_posenc_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, keep, scale, gx, n / 4);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_one_hot(const long long* inds, long n, int N, float* out, hipStream_t st) {
+  if (!inds || !out || n <= 0 || N <= 0 || (N & 3)) return kErrBadArg;
+  ProfScope ps("one_hot_kernel", st, 0.0, 8.0 * n + 4.0 * n * N);
+  long blocks = (n * (N / 4) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(one_hot_kernel, dim3((unsigned)blocks), dim3(256), 0, st, inds, n, N / 4, out);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }

@@ -503,6 +503,7 @@ class ConvAct(Function):
             (y,), (y_aux,) = _with_aux(x, _c(aux), run)
             ctx.save_for_backward(x, y if spec.act != ACT_NONE else None)
             ctx.mark_non_differentiable(y_aux)
+            ctx.set_materialize_grads(False)        # else backward is handed a zero-filled tensor for y_aux: a fill per layer
             return y, y_aux
         if add is None and ctx.needs_input_grad[0]:
             n = wino_filter_floats(spec, x.shape[0], x.shape[1], x.shape[2], native.workspace(x.device).numel())
@@ -514,6 +515,8 @@ class ConvAct(Function):
 
     @staticmethod
     def backward(ctx, g_y, *_g_aux):
+        if g_y is None:
+            return (None,) * 6
         spec = ctx.spec
         x, y = ctx.saved_tensors
         g_y = _c(g_y)
@@ -566,6 +569,7 @@ class ResBlock(Function):
             (h, out), (_h_aux, out_aux) = _with_aux(x, _c(aux), run)
             ctx.save_for_backward(x, h, out if spec1.act != ACT_NONE else None)
             ctx.mark_non_differentiable(out_aux)
+            ctx.set_materialize_grads(False)
             return out, out_aux
         h = conv_forward_raw(x, w3, None, spec3, wino_out=ctx.wino_u)
         out = conv_forward_raw(h, w1, None, spec1, x)
@@ -574,6 +578,8 @@ class ResBlock(Function):
 
     @staticmethod
     def backward(ctx, g_out, *_g_aux):
+        if g_out is None:
+            return (None,) * 6
         spec3, spec1 = ctx.specs
         w3, w1 = ctx.w
         x, h, out = ctx.saved_tensors
@@ -782,6 +788,7 @@ class ActFn(Function):
             (out,), (out_aux,) = _with_aux(x, _c(aux), run)
             ctx.save_for_backward(out)
             ctx.mark_non_differentiable(out_aux)
+            ctx.set_materialize_grads(False)
             return out, out_aux
         out = run(x)
         ctx.save_for_backward(out)
@@ -789,6 +796,8 @@ class ActFn(Function):
 
     @staticmethod
     def backward(ctx, g, *_g_aux):
+        if g is None:
+            return None, None, None
         (out,) = ctx.saved_tensors
         return act_backward_raw(_c(g), out, ctx.act), None, None
 
@@ -1303,10 +1312,15 @@ class GroupLinear(Function):
                 continue
             key = (W.data_ptr(), tuple(W.shape), tuple(W.stride()))
             ent = shared.get(key)
+            users = [t for t in range(nseg) if Ws[t].data_ptr() == W.data_ptr() and ctx.needs_input_grad[4 + 2 * t]]
+            # a bank with one user that covers it completely is written, not accumulated into: no zero fill
+            whole = len(users) == 1 and koffs[s] == 0 and W.shape[2] == K and (gs[s] is not None or G == 1)
             if ent is None:
-                dW = torch.zeros_like(W, memory_format=torch.contiguous_format)
-                db = torch.zeros((G, N), dtype=torch.float32, device=x.device) if any(
-                    has_b[t] for t in range(nseg) if Ws[t].data_ptr() == W.data_ptr()) else None
+                alloc = torch.empty_like if whole else torch.zeros_like
+                dW = alloc(W, memory_format=torch.contiguous_format)
+                db = None
+                if any(has_b[t] for t in users):
+                    db = (torch.empty if whole else torch.zeros)((G, N), dtype=torch.float32, device=x.device)
                 ent = shared[key] = (dW, db)
                 grads[2 * s] = dW
                 if db is not None:           # the bias gradient goes to the first segment of this bank that has a bias input
@@ -1315,8 +1329,8 @@ class GroupLinear(Function):
             dW, db = ent
             Gk = G if gs[s] is not None else 1        # no group ids: only matrix 0 is used
             native.call("ctvae_glinear_wgrad", x.data_ptr(), K, K, g.data_ptr(), nseg * N, s * N, N, native.ptr(gs[s]), Gk, B,
-                        dW.data_ptr() + 4 * koffs[s], dW.stride(1), native.ptr(db) if has_b[s] else None, 1, ws.data_ptr(),
-                        ws.numel() * 4)
+                        dW.data_ptr() + 4 * koffs[s], dW.stride(1), native.ptr(db) if has_b[s] else None, 0 if whole else 1,
+                        ws.data_ptr(), ws.numel() * 4)
         return (dx, None, None, None) + tuple(grads)
 
 
@@ -1538,6 +1552,46 @@ class CTMask(Function):
         native.call("ctvae_ct_mask_backward", x.data_ptr(), action.data_ptr(), pe.data_ptr(), native.ptr(keep), ctx.scale,
                     inter.data_ptr(), psoft[0].data_ptr(), psoft[2].data_ptr(), g.data_ptr(), B, S, D, A, dWp.data_ptr(), dbp.data_ptr())
         return None, None, None, None, None, dWp.sum(0).t(), dbp.sum(0), None
+
+
+class PosEncode(Function):
+    """(x + pe) * keep * scale: PositionalEncoding.forward (ct_mcq_vae.py:33-38) with the dropout mask given; x [B,S,D],
+    pe [S,D], keep [B,S,D] or None."""
+
+    @staticmethod
+    def forward(ctx, x, pe, keep, scale):
+        _req_cuda(x, pe)
+        x, pe = _c(x), _c(pe)
+        keep = _c(keep) if keep is not None else None
+        if x.numel() % pe.numel() or pe.numel() % 4 or (keep is not None and keep.shape != x.shape):
+            raise RuntimeError("PosEncode: shapes")
+        out = torch.empty_like(x)
+        native.call("ctvae_ct_posenc_forward", x.data_ptr(), pe.data_ptr(), native.ptr(keep), float(scale), out.data_ptr(), x.numel(),
+                    pe.numel())
+        ctx.save_for_backward(keep)
+        ctx.scale = float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (keep,) = ctx.saved_tensors
+        if keep is None:
+            return g, None, None, None
+        g = _c(g)
+        gx = torch.empty_like(g)
+        native.call("ctvae_ct_posenc_backward", g.data_ptr(), keep.data_ptr(), ctx.scale, gx.data_ptr(), g.numel())
+        return gx, None, None, None
+
+
+def one_hot_f32(inds, N):
+    """F.one_hot(inds, N).float() in one launch; inds int64 (any shape) -> [..., N] float32."""
+    _req_cuda(inds)
+    inds = _c(inds)
+    if inds.dtype != torch.int64 or N % 4:
+        return torch.nn.functional.one_hot(inds, N).to(torch.float32)
+    out = torch.empty(tuple(inds.shape) + (N,), dtype=torch.float32, device=inds.device)
+    native.call("ctvae_one_hot", inds.data_ptr(), inds.numel(), N, out.data_ptr())
+    return out
 
 
 class MaskBlend(Function):

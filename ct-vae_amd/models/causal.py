@@ -74,6 +74,10 @@ class PositionalEncoding(nn.Module):
         self.register_buffer('pe', pe)
 
     def forward(self, x: Tensor, tag: str = "pos_dropout") -> Tensor:       # x [B, S, D]
+        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and (x.size(1) * x.size(2)) % 4 == 0 and self.pe.device == x.device:
+            drop = self.training and self.p > 0.0                            # one launch (csrc/ctmisc.hip)
+            keep = _draw(tag, x.shape, self.p, x.device) if drop else None
+            return K.PosEncode.apply(x, self.pe[:x.size(1), 0], keep, 1.0 / (1.0 - self.p) if drop else 1.0)
         y = x + self.pe[:x.size(1), 0].to(x.device).unsqueeze(0)
         if not self.training or self.p == 0.0:
             return y

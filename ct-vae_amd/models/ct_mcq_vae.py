@@ -83,7 +83,7 @@ class CTMCQVAE(BaseVAE):
     # -- index <-> one-hot formatting around the causal layer (ct_mcq_vae.py:472-496) -------------------
     def ct_preprocess(self, x: Tensor, latents_shape) -> Tensor:
         """[B,K,H,W] int64 -> one-hot float [B, N, K*H, W]"""
-        oh = F.one_hot(x, num_classes=self.num_embeddings).to(dtype=torch.float32)          # [B,K,H,W,N]
+        oh = K.one_hot_f32(x, self.num_embeddings) if x.is_cuda else F.one_hot(x, num_classes=self.num_embeddings).to(dtype=torch.float32)   # [B,K,H,W,N]
         oh = oh.view((latents_shape[0], self.codebooks * latents_shape[2], latents_shape[3], self.num_embeddings))
         return oh.permute(0, 3, 1, 2)
 

@@ -44,6 +44,9 @@ SIGNATURES = {
     "ctvae_ct_mask_backward": [_fp, _fp, _fp, _fp, _f, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _vp],
     "ctvae_ct_blend_forward": [_fp, _fp, _fp, _fp, _l, _vp],
     "ctvae_ct_blend_backward": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _l, _vp],
+    "ctvae_ct_posenc_forward": [_fp, _fp, _fp, _f, _fp, _l, _i, _vp],
+    "ctvae_ct_posenc_backward": [_fp, _fp, _f, _fp, _l, _vp],
+    "ctvae_one_hot": [_fp, _l, _i, _fp, _vp],
     "ctvae_group_rowsum": [_fp, _l, _i, _i, _i, _i, _fp, _i, _fp, _i, _vp],
     "ctvae_ct_sample_forward": [_fp, _fp, _fp, _fp, _fp, _l, _vp],
     "ctvae_ct_sample_backward": [_fp, _fp, _fp, _fp, _fp, _fp, _l, _vp],

@@ -228,6 +228,13 @@ int ctvae_glinear_wgrad(const float* x, int ldx, int K, const float* dy, int ldy
 int ctvae_ct_blend_forward(const float* s0, const float* s1, const float* mask, float* out, long rows, void* stream);
 int ctvae_ct_blend_backward(const float* g, const float* s0, const float* s1, const float* mask, float* g0, float* g1, float* g_mask,
                             long rows, void* stream);
+/* PositionalEncoding.forward (ct_mcq_vae.py:33-38) on n = B*S*D elements, sd = S*D (the table pe [S][D] repeats per sample):
+ * out = (x + pe) * keep * scale with keep the dropout mask (NULL: no dropout) and scale = 1/(1-p); backward g * keep * scale. */
+int ctvae_ct_posenc_forward(const float* x, const float* pe, const float* keep, float scale, float* out, long n, int sd,
+                            void* stream);
+int ctvae_ct_posenc_backward(const float* g, const float* keep, float scale, float* g_x, long n, void* stream);
+/* F.one_hot(inds, N).float() (CTMCQVAE.ct_preprocess, ct_mcq_vae.py:472-480): out [n][N], N % 4 == 0. */
+int ctvae_one_hot(const int64_t* inds, long n, int N, float* out, void* stream);
 /* Per-sample partial gradients into the rows of a parameter bank, in row order (deterministic, no atomics):
  * out[z][g][c] (+)= sum_{r < rows, group[r] == g} parts[z*mat_stride + r*ld + c], z < nmat, g < G, c < C; group == NULL: every
  * row belongs to group 0.  Replaces the one_hot(group)^T @ parts products behind the scorer rows of graph_discovers
