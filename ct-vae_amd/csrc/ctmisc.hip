@@ -436,23 +436,41 @@ __global__ __launch_bounds__(256) void one_hot_kernel(const long long* __restric
 
 // out[z][g][c] (+)= sum over the rows r (in order) with grp[r] == g of parts[z][r][c]: per-sample partial gradients gathered
 // into the rows of a parameter bank (scorer rows of the discoverers, per-head vectors of the last GATv2 layer) without
-// atomics -- one thread owns an output element and walks the rows.  grp == NULL: every row belongs to group 0.
+// atomics -- four lanes own an output element, walk the rows in a fixed interleave and meet in a fixed order.  grp == NULL: every
+// row belongs to group 0.
 __global__ __launch_bounds__(256) void group_rowsum_kernel(const float* __restrict__ parts, long mat_stride, int rows, int C, int ld,
                                                           const int* __restrict__ grp, int G, float* __restrict__ out,
                                                           int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y, z = blockIdx.z;
-  if (c >= C) return;
-  const float* p = parts + (long)z * mat_stride + c;
+  // 64 columns x 4 row lanes per workgroup: lane q walks rows q, q+4, ... with eight loads in flight (every row is loaded,
+  // rows of other groups are dropped by a select: no divergent branch around the load), the four lanes meet in a fixed order
+  __shared__ float sm[4][64];
+  const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl, g = blockIdx.y, z = blockIdx.z;
+  const bool cok = c < C;
+  const float* p = parts + (long)z * mat_stride + (cok ? c : 0);
   float acc = 0.f;
-  if (grp == nullptr) {
-    if (g == 0)
-      for (int r = 0; r < rows; ++r) acc += p[(long)r * ld];
-  } else {
-    for (int r = 0; r < rows; ++r)
-      if (grp[r] == g) acc += p[(long)r * ld];
+  if (grp != nullptr || g == 0) {
+    int r = q;
+    for (; r + 28 < rows; r += 32) {
+      float v[8];
+      int k[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        v[u] = p[(long)(r + 4 * u) * ld];
+        k[u] = grp != nullptr ? grp[r + 4 * u] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += k[u] == g ? v[u] : 0.f;
+    }
+    for (; r < rows; r += 4) acc += (grp != nullptr ? grp[r] : 0) == g ? p[(long)r * ld] : 0.f;
   }
-  float* o = out + ((long)z * G + g) * C + c;
-  *o = accumulate ? *o + acc : acc;
+  sm[q][cl] = acc;
+  __syncthreads();
+  if (q == 0 && cok) {
+    const float t = ((sm[0][cl] + sm[1][cl]) + sm[2][cl]) + sm[3][cl];
+    float* o = out + ((long)z * G + g) * C + c;
+    *o = accumulate ? *o + t : t;
+  }
 }
 
 }  // namespace
@@ -515,7 +533,7 @@ int launch_group_rowsum(const float* parts, long mat_stride, int nmat, int rows,
                         int accumulate, hipStream_t st) {
   if (!parts || !out || nmat <= 0 || rows <= 0 || C <= 0 || ld < 1 || G <= 0) return kErrBadArg;
   ProfScope ps("group_rowsum_kernel", st, 0.0, 4.0 * nmat * ((double)rows * C + (double)G * C));
-  hipLaunchKernelGGL(group_rowsum_kernel, dim3((C + 255) / 256, G, nmat), dim3(256), 0, st, parts, mat_stride, rows, C, ld, grp, G, out,
+  hipLaunchKernelGGL(group_rowsum_kernel, dim3((C + 63) / 64, G, nmat), dim3(256), 0, st, parts, mat_stride, rows, C, ld, grp, G, out,
                      accumulate);
   CTVAE_LAUNCH_CHECK();
   return 0;

@@ -1313,8 +1313,10 @@ class GroupLinear(Function):
             key = (W.data_ptr(), tuple(W.shape), tuple(W.stride()))
             ent = shared.get(key)
             users = [t for t in range(nseg) if Ws[t].data_ptr() == W.data_ptr() and ctx.needs_input_grad[4 + 2 * t]]
-            # a bank with one user that covers it completely is written, not accumulated into: no zero fill
-            whole = len(users) == 1 and koffs[s] == 0 and W.shape[2] == K and (gs[s] is not None or G == 1)
+            # a segment that covers its bank completely (all columns, every group) WRITES it: when that is the bank's first
+            # user -- with its bias, if the bank has one -- there is no zero fill; everybody after it accumulates
+            whole = (ent is None and koffs[s] == 0 and W.shape[2] == K and (gs[s] is not None or G == 1)
+                     and (has_b[s] or not any(has_b[t] for t in users)))
             if ent is None:
                 alloc = torch.empty_like if whole else torch.zeros_like
                 dW = alloc(W, memory_format=torch.contiguous_format)
