@@ -17,6 +17,7 @@
 // Weights always live in HBM as [tap][Ci_layer][Co_layer] (the packed layout behind the
 // PyTorch-shaped parameter views).
 #pragma once
+#include <cstdlib>
 
 #if defined(__HIPCC__)
 #define CTVAE_HD __host__ __device__ __forceinline__
@@ -67,6 +68,16 @@ CTVAE_HD int scatter_pix(const ConvGeom& g, int cls, int b, int qy, int qx) {
   return (b * g.sH + qy * g.os + g.py[cls]) * g.sW + qx * g.os + g.px[cls];
 }
 
+// diagnostic: CTVAE_TAP_ORDER=0 keeps the plain (ky, kx) tap order of strided gathers
+inline bool tap_order_grouped() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return true;
+#else
+  static const int v = [] { const char* e = getenv("CTVAE_TAP_ORDER"); return e ? atoi(e) : 1; }();
+  return v != 0;
+#endif
+}
+
 // ---- host-side builders -------------------------------------------------------------------
 // kind: 0 conv fwd, 1 convT fwd, 2 conv dgrad, 3 convT dgrad.
 // (B,H,W,Ci) is the LAYER's input tensor, Co the layer's output channels; k,s,p,op the layer's
@@ -102,8 +113,21 @@ inline int build_geom(ConvGeom& g, int kind, int B, int H, int W, int Ci, int Co
     g.py[0] = g.px[0] = 0;
     if (k * k > kMaxTaps) return -1;
     int n = 0;
-    for (int ky = 0; ky < k; ++ky)
-      for (int kx = 0; kx < k; ++kx) g.taps[0][n++] = Tap{ky - p, kx - p, ky * k + kx};
+    if (s == 2 && tap_order_grouped()) {
+      // Stride 2: taps whose offsets have the same parity read the SAME rows / columns of the gathered tensor, one output
+      // pixel apart (ky = 0 and ky = 2 of a 3x3 both read the odd rows).  In plain (ky, kx) order a workgroup comes back to a
+      // row several K chunks later -- with ~128 workgroups per L2 that is past the L2's capacity on the large tensors and the
+      // row is fetched again (PMC: final_layer.0's data gradient fetched 2.1 x its 134 MB operand).  Grouped by parity the
+      // re-read follows at once and hits the L2.  The weights follow their tap (wtap), results differ only in summation order.
+      for (int qy = 0; qy < 2; ++qy)
+        for (int qx = 0; qx < 2; ++qx)
+          for (int ky = 0; ky < k; ++ky)
+            for (int kx = 0; kx < k; ++kx)
+              if ((((ky - p) & 1) == (qy ^ 1)) && (((kx - p) & 1) == (qx ^ 1))) g.taps[0][n++] = Tap{ky - p, kx - p, ky * k + kx};
+    } else {
+      for (int ky = 0; ky < k; ++ky)
+        for (int kx = 0; kx < k; ++kx) g.taps[0][n++] = Tap{ky - p, kx - p, ky * k + kx};
+    }
     g.ntaps[0] = n;
   } else {
     // scattered index o = q*s + par; contributions from gathered i with o = i*s - p + ky  =>  i = q + (par + p - ky)/s
