@@ -56,7 +56,9 @@ class _GraphedTrainStep:
     def _body(self):
         exp = self.exp
         exp.model.zero_grad()
-        results = exp.forward(self.x, labels=None, **self.static, **self.const)
+        opts = {**self.static, **self.const}
+        labels = opts.pop("labels", None)         # ConditionalVAE reads them (cvae.py:123); a static buffer like every tensor option
+        results = exp.forward(self.x, labels=labels, **opts)
         losses = exp.model.loss_function(*results, M_N=exp.params['kld_weight'], optimizer_idx=0, batch_idx=0)
         K.backward(losses['loss'])
         if exp.ddp is None:
@@ -185,6 +187,8 @@ class VAEXperiment:
                 real_img, _labels, kwargs = self._unpack(batch)
                 # graph_safe = False: the model's step depends on host state that changes per call (e.g. BetaVAE type 'B':
                 # the capacity C follows the loss-call counter), so a captured step would freeze it
+                if getattr(self.model, 'uses_labels', False) and torch.is_tensor(_labels):
+                    kwargs = {**kwargs, "labels": _labels.to(real_img.device)}      # part of the step's signature and inputs
                 key = _graph_key(real_img, kwargs) if (self.params.get('hipgraph', True) and real_img.is_cuda
                                                        and getattr(self.model, 'graph_safe', True)) else None
                 if key is not None:

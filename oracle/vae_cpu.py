@@ -131,6 +131,17 @@ def infovae_loss(recons, x, z, mu, log_var, prior_z, M_N, alpha, beta, reg_weigh
     return {"loss": loss, "Reconstruction_Loss": rl, "MMD": mmd, "KLD": -kld}
 
 
+def cvae_forward(sd, x, labels, e, training=True, new_buffers=None, img_size=64):
+    """ConditionalVAE.forward (cvae.py:122-130) with the Gaussian noise injected -> [recons, input, mu, log_var]; the loss is
+    VanillaVAE's (cvae.py:132-146 == vanilla_loss)."""
+    y = labels.float()
+    plane = F.linear(y, sd["embed_class.weight"], sd["embed_class.bias"]).view(-1, img_size, img_size).unsqueeze(1)
+    data = F.conv2d(x, sd["embed_data.weight"], sd["embed_data.bias"])
+    mu, log_var = vanilla_encode(sd, torch.cat([data, plane], dim=1), training, new_buffers)
+    z = vanilla_reparameterize(mu, log_var, e)
+    return [vanilla_decode(sd, torch.cat([z, y], dim=1), training, new_buffers), x, mu, log_var]
+
+
 def joint_forward(sd, x, e, u, temp, training=True, new_buffers=None, eps=1e-7):
     """JointVAE.forward (joint_vae.py:110-170) with both noises injected -> [recons, input, q, mu, log_var]."""
     h = x

@@ -144,6 +144,29 @@ def joint_specs():
     return out
 
 
+CVAE_CFG = dict(in_channels=3, num_classes=40, latent_dim=128)
+
+
+def cvae_specs():
+    """state_dict keys/shapes of ConditionalVAE(**CVAE_CFG) (cvae.py:10-79): the label embeddings first, a 4-channel first conv,
+    decoder_input widened by num_classes."""
+    f32 = torch.float32
+    out = [("embed_class.weight", (4096, 40), f32), ("embed_class.bias", (4096,), f32),
+           ("embed_data.weight", (3, 3, 1, 1), f32), ("embed_data.bias", (3,), f32)]
+    for k, sh, dt in vanilla_specs():
+        if k == "encoder.0.0.weight":
+            sh = (32, 4, 3, 3)
+        if k == "decoder_input.weight":
+            sh = (2048, 128 + 40)
+        out.append((k, sh, dt))
+    return out
+
+
+def cvae_labels(seed, B, Q=40):
+    """CelebA-style attribute vectors: independent 0/1 entries."""
+    return (torch.rand(B, Q, generator=torch.Generator().manual_seed(seed + 4)) < 0.3).float()
+
+
 def joint_uniform(seed, B, Q=40):
     return torch.rand(B, Q, generator=torch.Generator().manual_seed(seed + 2))
 

@@ -439,6 +439,7 @@ ZOO = [("VanillaVAE", dict(in_channels=3, latent_dim=128)),
        ("InfoVAE", dict(in_channels=3, latent_dim=128, reg_weight=110, kernel_type="imq", alpha=-9.0, beta=10.5)),
        ("DIPVAE", dict(in_channels=3, latent_dim=128, lambda_diag=0.05, lambda_offdiag=0.1)),
        ("JointVAE", dict(H.JOINT_CFG)),
+       ("ConditionalVAE", dict(H.CVAE_CFG)),
        ("CategoricalVAE", dict(in_channels=3, latent_dim=64, categorical_dim=40, temperature=0.5, alpha=1.0)),
        ("VQVAE", dict(in_channels=3, embedding_dim=64, num_embeddings=512, img_size=64, beta=0.25)),
        ("MCQVAE", dict(in_channels=3, embedding_dim=128, hidden_dims=[64, 128, 256], num_embeddings=64, img_size=64, codebooks=4, beta=0.25))]
@@ -454,7 +455,8 @@ def test_every_registered_model_trains_through_the_harness(dev, name, cfg):
     torch.manual_seed(3)
     m = vae_models[name](**{k: (list(v) if isinstance(v, list) else v) for k, v in cfg.items()}, name=name).to(dev).train()
     before = m.flat_params.clone()
-    batches = [(filler.synthetic_batch(900 + i, 8)[0].to(dev), torch.zeros(8, device=dev)) for i in range(6)]
+    labels = (lambda i: H.cvae_labels(900 + i, 8).to(dev)) if name == "ConditionalVAE" else (lambda i: torch.zeros(8, device=dev))
+    batches = [(filler.synthetic_batch(900 + i, 8)[0].to(dev), labels(i)) for i in range(6)]
     exp = VAEXperiment(m, {"LR": 0.0005, "weight_decay": 0.0, "scheduler_gamma": 0.95, "kld_weight": 0.00025, "hipgraph": True})
     exp.fit(lambda: iter(batches), lambda: iter(batches[:2]), max_epochs=1)
     torch.cuda.synchronize()
@@ -465,9 +467,10 @@ def test_every_registered_model_trains_through_the_harness(dev, name, cfg):
     assert torch.isfinite(after).all() and (after != before).float().mean().item() > 0.9   # codebook rows no latent selected keep a zero gradient
     m.eval()
     with torch.no_grad():
-        assert m.generate(batches[0][0]).shape == (8, 3, 64, 64)
+        extra = {"labels": batches[0][1]} if name == "ConditionalVAE" else {}
+        assert m.generate(batches[0][0], **extra).shape == (8, 3, 64, 64)
         try:
-            assert m.sample(4, dev).shape == (4, 3, 64, 64)
+            assert m.sample(4, dev, **({"labels": batches[0][1][:4]} if extra else {})).shape == (4, 3, 64, 64)
         except Warning:        # the reference's "sampler is not implemented" for the quantised models (vq_vae.py, mcq_vae.py)
             assert name in ("VQVAE", "MCQVAE")
 
@@ -549,3 +552,40 @@ def test_vqvae_vs_golden(dev, golden):
         H.assert_cks_close(H.cks(p.grad), g["gradcks." + k], rtol=2e-3, atol=2e-5, what=k)
     with pytest.raises(Warning):
         m.sample(2, dev)
+
+
+def test_conditional_vae_vs_golden(dev, golden):
+    """ConditionalVAE against the reference's own cvae.py fixture: means, log-variances, reconstruction, loss dict, every
+    gradient (the label embeddings, the 4-channel first conv and the widened decoder_input included)."""
+    from ctvae_amd.models import vae_models
+    g = golden("cvae_b4")
+    seed = int(g["seed"])
+    m = vae_models["ConditionalVAE"](**H.CVAE_CFG)
+    m.load_state_dict(filler.fill_state(H.cvae_specs(), seed + 1))
+    m = m.to(dev).train()
+    x, e = filler.synthetic_batch(seed, 4)
+    labels = H.cvae_labels(seed, 4).to(dev)
+    out = m(x.to(dev), eps=e.to(dev), labels=labels)
+    np.testing.assert_allclose(out[2].detach().cpu().numpy(), g["mu"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(out[3].detach().cpu().numpy(), g["log_var"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(out[0].detach()[:, :, ::8, ::8].cpu().numpy(), g["recons_sub"], atol=TOL, rtol=0)
+    losses = m.loss_function(*out, M_N=float(g["M_N"]))
+    for k, v in losses.items():
+        want = float(g["loss." + k])
+        assert abs(float(v.detach()) - want) <= TOL * max(1.0, abs(want)), (k, float(v.detach()), want)
+    m.zero_grad()
+    losses["loss"].backward()
+    # gradients that reach the image side pass back through five BatchNorm layers at B = 4: differently ordered fp32 sums are
+    # amplified there (1.5e-5 on values of 1e-3); same absolute allowance as the checksums below
+    np.testing.assert_allclose(m.embed_data.weight.grad.cpu().numpy(), g["grad.embed_data.weight"], atol=2e-5, rtol=2e-3)
+    np.testing.assert_allclose(m.embed_data.bias.grad.cpu().numpy(), g["grad.embed_data.bias"], atol=2e-5, rtol=2e-3)
+    np.testing.assert_allclose(m.embed_class.bias.grad[::16].cpu().numpy(), g["grad.embed_class.bias_sub"], atol=2e-6, rtol=2e-3)
+    np.testing.assert_allclose(m.decoder_input.weight.grad[::64, 128:].cpu().numpy(), g["grad.decoder_input.weight_labelcols"],
+                               atol=1e-6, rtol=2e-3)
+    for k, p in m.named_parameters():
+        H.assert_cks_close(H.cks(p.grad), g["gradcks." + k], rtol=2e-3, atol=2e-5, what=k)
+    for k, b in m.named_buffers():
+        if "running" in k:
+            H.assert_cks_close(H.cks(b), g["buf." + k], rtol=1e-4, atol=1e-5, what=k)
+    assert m.sample(3, dev, labels=labels[:3]).shape == (3, 3, 64, 64)
+    assert m.generate(x.to(dev), labels=labels).shape == (4, 3, 64, 64)

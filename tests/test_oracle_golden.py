@@ -283,3 +283,25 @@ def test_vqvae_forward_loss_grads(golden):
     for k, gr in grads.items():
         H.assert_cks_close(H.cks(gr), g["gradcks." + k.replace("vq_layer.quantizers.0.embedding", "vq_layer.embedding")],
                            rtol=1e-3, atol=1e-5, what=k)
+
+
+def test_conditional_vae_forward_loss_grads(golden):
+    """ConditionalVAE (label as an extra input plane and next to z): oracle against the reference's own cvae.py fixture."""
+    g = golden("cvae_b4")
+    seed = int(g["seed"])
+    sd = O.leafify(filler.fill_state(H.cvae_specs(), seed + 1))
+    x, e = filler.synthetic_batch(seed, 4)
+    res = O.cvae_forward(sd, x, H.cvae_labels(seed, 4), e, True, {})
+    np.testing.assert_allclose(res[2].detach().numpy(), g["mu"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(res[3].detach().numpy(), g["log_var"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(res[0].detach()[:, :, ::8, ::8].numpy(), g["recons_sub"], atol=TOL, rtol=0)
+    losses = O.vanilla_loss(*res, float(g["M_N"]))
+    for k, v in losses.items():
+        want = float(g["loss." + k])
+        assert abs(v.item() - want) <= TOL * max(1.0, abs(want)), k
+    losses["loss"].backward()
+    np.testing.assert_allclose(sd["embed_data.weight"].grad.numpy(), g["grad.embed_data.weight"], atol=1e-6, rtol=1e-3)
+    np.testing.assert_allclose(sd["decoder_input.weight"].grad[::64, 128:].numpy(), g["grad.decoder_input.weight_labelcols"], atol=1e-6, rtol=1e-3)
+    for k, v in sd.items():
+        if v.requires_grad:
+            H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
