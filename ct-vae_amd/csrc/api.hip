@@ -313,6 +313,14 @@ int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* 
       return kErrBadArg;
     }
   }
+  {   // how much of the chip the data gradient fills on its own: the weight gradient that shares its launch is sized to match
+    TapGemmPlan pl;
+    tapgemm_plan(gd, half_floats, pl);
+    ctx.dgrad_wgs = (long)pl.mtiles * pl.ntiles * gd.ncls * (pl.splitk > 1 ? pl.splitk : 1);
+    int kmax = 0;
+    for (int c = 0; c < gd.ncls; ++c) kmax = gd.ntaps[c] * gd.gC / KC > kmax ? gd.ntaps[c] * gd.gC / KC : kmax;
+    ctx.dgrad_chunks = pl.splitk > 1 ? (kmax + pl.splitk - 1) / pl.splitk : kmax;
+  }
   const InXform xf{in_scale, in_shift, in_act};
   const DyXform dyx{dy_bn_y, dy_bn_coef, gy_out, dy_bn_act};
   int rc = launch_wgrad(gw, x, dy, dw, dbias, ws, half_bytes, accumulate, st, &xf, &dyx);

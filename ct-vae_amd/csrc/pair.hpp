@@ -16,6 +16,8 @@ namespace ctvae {
 
 struct PairCtx {
   bool haveA = false, haveB = false;
+  long dgrad_wgs = 0;          // workgroups of the data gradient and K chunks of its longest one (planned before the weight
+  int dgrad_chunks = 0;        // gradient is sized)
   TapGemmArgs A;
   unsigned gxA = 0, gyA = 0, gzA = 0;
   double flopsA = 0, bytesA = 0;

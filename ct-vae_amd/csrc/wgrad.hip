@@ -466,7 +466,17 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
   const size_t ws_floats = ws_bytes / sizeof(float);
   // 128x128 tiles hold two workgroups per CU (64 accumulator + 134 other registers): one resident round, and half the
   // partial slabs for the reduce pass
-  static const int tgt_small = [] { const char* e = getenv("CTVAE_WGRAD_WGS"); return e ? atoi(e) : 768; }();   // diagnostic override
+  // grid-size target of the pixel split: 1024 workgroups; 768 for a weight gradient that shares its launch (ctvae_conv_backward)
+  // with a data gradient of fewer than 1024 LONG workgroups (>= 12 K chunks: VanillaVAE's stride-2 3x3 layers) -- together
+  // about one resident round, the coarser slices end with the data gradient and write fewer slabs.  Next to short
+  // data-gradient workgroups (the 1x1 convs of the residual stacks, 8 chunks) or a data gradient that is a round or more by
+  // itself (the 4x4 convs of MCQ / CT-MCQ-VAE) the finer split wins.  One target everywhere, 768 / 1024: VanillaVAE bs=256
+  // 1.719 / 1.723 ms, MCQVAE bs=256 7.65 / 7.53 ms, CT-MCQ-VAE 128 pairs 7.19 / 7.15 ms.
+  static const int tgt_env = [] { const char* e = getenv("CTVAE_WGRAD_WGS"); return e ? atoi(e) : 0; }();   // diagnostic override
+  const PairCtx* pcw = pair_ctx();
+  const bool will_pair = pcw != nullptr && !pcw->haveB && xvec && dvec && !narrow && !big;
+  const bool coarse = will_pair && pcw->dgrad_wgs > 0 && pcw->dgrad_wgs < 1024 && pcw->dgrad_chunks >= 12;
+  const int tgt_small = tgt_env ? tgt_env : (coarse ? 768 : 1024);
   const int S = choose_splits(g, KT, NT, ws_floats, big ? 512 : tgt_small);
   if (wgrad_workspace_floats(g, S) > ws_floats) return kErrWorkspace;
   a.S = S;
