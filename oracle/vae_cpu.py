@@ -8,8 +8,9 @@ leg of ``bench.py``.
 Parity status: PINNED.  ``tests/golden/*.npz`` were produced by importing the reference's own
 unmodified ``models/{types_,base,vanilla_vae,vq_vae,mcq_vae}.py`` in the build container
 (``oracle/gen_golden.py``) and ``tests/test_oracle_golden.py`` checks every function below against
-them.  Exception: ``CausalTransition`` (ct_mcq_vae.py:42-333) depends on torch_geometric 2.2.0,
-which is absent -> that part is restated in ``oracle/causal_cpu.py`` and is "parity unpinned".
+them.  ``CausalTransition`` / ``CTMCQVAE`` (ct_mcq_vae.py:42-620) are restated in ``oracle/causal_cpu.py`` and pinned by
+``oracle/gen_ct_golden.py`` (the reference's own module with an empty stub for the absent torch_geometric 2.2.0 and a test
+double for its GATv2Conv); only the arithmetic inside GATv2Conv is "parity unpinned" (see that file's header).
 
 Everything here works on an ordered ``state_dict``-shaped mapping ``sd`` whose keys and PyTorch
 layouts equal the reference's (Conv2d [Co,Ci,kh,kw], ConvTranspose2d [Ci,Co,kh,kw], Linear
