@@ -64,6 +64,8 @@ int launch_ct_mask_forward(const float* x, const float* action, const float* pe,
 int launch_ct_mask_backward(const float* x, const float* action, const float* pe, const float* keep, float scale,
                             const float* inter, const float* p, const float* soft, const float* g, int B, int S, int D, int A,
                             float* dWp, float* dbp, hipStream_t st);
+int launch_swd_forward(const float* z, const float* prior, const float* proj, int N, int D, int S, float p, float weight, float* out,
+                       float* grad_z, float* ws, size_t ws_bytes, hipStream_t st);
 int launch_ct_blend_forward(const float* s0, const float* s1, const float* mask, float* out, long rows, hipStream_t st);
 int launch_ct_blend_backward(const float* g, const float* s0, const float* s1, const float* mask, float* g0, float* g1, float* gm,
                              long rows, hipStream_t st);
@@ -594,6 +596,23 @@ int ctvae_loss_backward(const float* recons, const float* x, const float* g_loss
   if (!recons || !x || !g_loss || !g_recons || n <= 0 || !mu || !logvar || !g_mu || !g_logvar || B <= 0 || L <= 0) return kErrBadArg;
   return launch_loss_backward(recons, x, g_loss, g_recons, n, logcosh_alpha, mu, mu_rs, logvar, lv_rs, g_mu, g_logvar, B, L, M_N,
                               (hipStream_t)stream, recons_act);
+}
+
+int ctvae_l2l1_loss_forward(const float* recons, const float* x, long n, const float* extra, float* out4, float* ws, size_t ws_bytes,
+                            void* stream) {
+  if (!recons || !x || !out4 || !ws || n <= 0) return kErrBadArg;
+  return launch_loss_forward(recons, x, n, nullptr, 0, nullptr, 0, 0, 0, 0.f, extra, out4, ws, ws_bytes, (hipStream_t)stream, -1.f);
+}
+
+int ctvae_l2l1_backward(const float* recons, const float* x, const float* g_loss, float* g_recons, long n, int recons_act,
+                        void* stream) {
+  if (!recons || !x || !g_loss || !g_recons || n <= 0) return kErrBadArg;
+  return launch_mse_backward(recons, x, g_loss, g_recons, n, (hipStream_t)stream, -1.f, recons_act);
+}
+
+int ctvae_swd_forward(const float* z, const float* prior, const float* proj, int N, int D, int S, float p, float weight, float* out,
+                      float* grad_z, float* ws, size_t ws_bytes, void* stream) {
+  return launch_swd_forward(z, prior, proj, N, D, S, p, weight, out, grad_z, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int ctvae_logcosh_loss_forward(const float* recons, const float* x, long n, float alpha, const float* mu, long mu_rs,

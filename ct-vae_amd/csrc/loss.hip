@@ -16,12 +16,14 @@ constexpr int kLossBlocks = 1024;
 template <int MODE>
 __device__ __forceinline__ float recon_term(float d, float alpha) {
   if constexpr (MODE == 0) return d * d;
+  else if constexpr (MODE == 2) return d * d + fabsf(d);          // F.mse_loss + F.l1_loss (swae.py:121-122) in one pass
   else return alpha * d + logf(1.f + expf(-2.f * alpha * d));
 }
 // its derivative: 2 t  resp.  alpha (1 - e) / (1 + e), e = exp(-2 alpha t)   (= alpha tanh(alpha t))
 template <int MODE>
 __device__ __forceinline__ float recon_term_grad(float d, float alpha) {
   if constexpr (MODE == 0) return 2.f * d;
+  else if constexpr (MODE == 2) return 2.f * d + (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));      // torch: sign(0) = 0
   else {
     const float e = expf(-2.f * alpha * d);
     return e < 3.0e38f ? alpha * (1.f - e) / (1.f + e) : -alpha;
@@ -162,6 +164,8 @@ int launch_loss_forward(const float* r, const float* x, long n, const float* mu,
   ProfScope ps("mse_partial_kernel", st, 0.0, 8.0 * (double)n);
   if (logcosh_alpha > 0.f)
     hipLaunchKernelGGL(mse_partial_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, r, x, ws, n4, n, mu, mu_rs, lv, lv_rs, B, L, logcosh_alpha);
+  else if (logcosh_alpha < 0.f)      // internal code for the squared + absolute error term (ctvae_l2l1_loss_forward)
+    hipLaunchKernelGGL(mse_partial_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, r, x, ws, n4, n, mu, mu_rs, lv, lv_rs, B, L, 0.f);
   else
     hipLaunchKernelGGL(mse_partial_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, r, x, ws, n4, n, mu, mu_rs, lv, lv_rs, B, L, 0.f);
   }
@@ -183,6 +187,9 @@ int launch_mse_backward(const float* r, const float* x, const float* go, float* 
   if (logcosh_alpha > 0.f)   // d/dt of (alpha t + log(1 + e^{-2 alpha t}) - log 2) / alpha = tanh(alpha t)
     hipLaunchKernelGGL(mse_bwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, r, x, go, gr, n4, n,
                        (float)(1.0 / ((double)n * logcosh_alpha)), logcosh_alpha, ract);
+  else if (logcosh_alpha < 0.f)
+    hipLaunchKernelGGL(mse_bwd_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, r, x, go, gr, n4, n, (float)(1.0 / (double)n), 0.f,
+                       ract);
   else
     hipLaunchKernelGGL(mse_bwd_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, r, x, go, gr, n4, n, (float)(1.0 / (double)n), 0.f,
                        ract);

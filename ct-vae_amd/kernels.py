@@ -912,7 +912,8 @@ class VAELoss(Function):
 
     @staticmethod
     def forward(ctx, recons, x, mu, logvar, extra, M_N, logcosh_alpha=0.0):
-        """logcosh_alpha > 0: the reconstruction term is LogCoshVAE's (logcosh_vae.py:141-150) instead of the MSE."""
+        """logcosh_alpha > 0: the reconstruction term is LogCoshVAE's (logcosh_vae.py:141-150) instead of the MSE;
+        logcosh_alpha == L2L1 (-1): SWAE's F.mse_loss + F.l1_loss (swae.py:121-125), no KL term."""
         _req_cuda(recons, x)
         recons, x = _c(recons), _c(x)
         if recons.shape != x.shape:
@@ -925,7 +926,12 @@ class VAELoss(Function):
             B, L = mu.shape
         else:
             mu_, lv_, mrs, lrs, B, L = None, None, 0, 0, 0, 0
-        if logcosh_alpha > 0.0:
+        if logcosh_alpha < 0.0:
+            if mu is not None:
+                raise RuntimeError("l2 + l1 reconstruction term: no KL term")
+            native.call("ctvae_l2l1_loss_forward", recons.data_ptr(), x.data_ptr(), recons.numel(), native.ptr(extra), out.data_ptr(),
+                        ws.data_ptr(), ws.numel() * 4)
+        elif logcosh_alpha > 0.0:
             if extra is not None:
                 raise RuntimeError("log-cosh loss: no extra term")
             native.call("ctvae_logcosh_loss_forward", recons.data_ptr(), x.data_ptr(), recons.numel(), float(logcosh_alpha),
@@ -960,7 +966,10 @@ class VAELoss(Function):
                         ctx.logcosh_alpha, mu_.data_ptr(), mrs, lv_.data_ptr(), lrs, g_mu.data_ptr(), g_lv.data_ptr(), B, L, M_N, ract)
         else:
             if want_r:
-                if ctx.logcosh_alpha > 0.0:
+                if ctx.logcosh_alpha < 0.0:
+                    native.call("ctvae_l2l1_backward", recons.data_ptr(), x.data_ptr(), g_loss.data_ptr(), g_r.data_ptr(), recons.numel(),
+                                ract)
+                elif ctx.logcosh_alpha > 0.0:
                     native.call("ctvae_logcosh_backward", recons.data_ptr(), x.data_ptr(), g_loss.data_ptr(), g_r.data_ptr(),
                                 recons.numel(), ctx.logcosh_alpha, ract)
                 else:
@@ -1093,6 +1102,35 @@ class MMD(Function):
     def backward(ctx, g_mmd, *_unused):
         (grad,) = ctx.saved_tensors
         return (grad * g_mmd if g_mmd is not None else None), None, None, None, None, None, None
+
+
+L2L1 = -1.0      # VAELoss(..., logcosh_alpha=L2L1): squared + absolute error
+
+
+class SWD(Function):
+    """Sliced Wasserstein distance of SWAE.compute_swd (swae.py:150-178): z, prior [N,D]; proj [S,D] unit directions; p the
+    exponent; weight = reg_weight.  One launch projects, sorts both sets per direction and leaves d swd / d z (csrc/swd.hip)."""
+
+    @staticmethod
+    def forward(ctx, z, prior, proj, p, weight):
+        _req_cuda(z, prior, proj)
+        z, prior, proj = _c(z), _c(prior), _c(proj)
+        if z.dim() != 2 or z.shape != prior.shape or proj.dim() != 2 or proj.shape[1] != z.shape[1]:
+            raise RuntimeError("swd: z / prior must be [N,D] of one shape and proj [S,D]")
+        N, D = z.shape
+        S = proj.shape[0]
+        out = torch.empty(1, dtype=torch.float32, device=z.device)
+        grad = torch.empty_like(z)
+        ws = native.workspace(z.device)
+        native.call("ctvae_swd_forward", z.data_ptr(), prior.data_ptr(), proj.data_ptr(), N, D, S, float(p), float(weight),
+                    out.data_ptr(), grad.data_ptr(), ws.data_ptr(), ws.numel() * 4)
+        ctx.save_for_backward(grad)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None, None
 
 
 class DIPLoss(Function):

@@ -376,6 +376,20 @@ int ctvae_iw_loss_backward(const float* recons, const float* x, long n, int R, i
                            int L, float M_N, const float* coef, const float* g_loss, float* g_recons, float* g_mu,
                            float* g_logvar, void* stream);
 
+/* SWAE's reconstruction term F.mse_loss + F.l1_loss (swae.py:121-125) in one pass: out4 = {loss, rl, 0, 0} with
+ * rl = mean((r-x)^2) + mean(|r-x|), loss = rl (+ extra[0]); backward g_recons = g_loss[0] * (2 t + sign(t)) / n * act'(recons)
+ * (recons_act as in ctvae_mse_backward). */
+int ctvae_l2l1_loss_forward(const float* recons, const float* x, long n, const float* extra, float* out4, float* ws, size_t ws_bytes,
+                            void* stream);
+int ctvae_l2l1_backward(const float* recons, const float* x, const float* g_loss, float* g_recons, long n, int recons_act,
+                        void* stream);
+/* Sliced Wasserstein distance of SWAE (swae.py:150-178) between z and prior draws [N][D] (N <= 1024, D <= 512, D % 4 == 0) along
+ * the S unit directions proj [S][D]: out[0] = weight * mean_{s,r} (sort_r(z . w_s) - sort_r(prior . w_s))^p (torch.sort + pow + mean
+ * in the reference); grad_z [N][D] receives d out / d z (the backward pass scales it by the incoming gradient).
+ * ws: >= 4 * (S + N*S) bytes. */
+int ctvae_swd_forward(const float* z, const float* prior, const float* proj, int N, int D, int S, float p, float weight, float* out,
+                      float* grad_z, float* ws, size_t ws_bytes, void* stream);
+
 /* Maximum-mean-discrepancy regulariser of WAE_MMD / InfoVAE (wae_mmd.py:120-203, info_vae.py:150-229) between the latent
  * codes z [N][D] and prior draws [N][D] (D <= 512):  out4 = {mmd, K(p,p), K(z,z), K(p,z)},
  * mmd = w_pp*K(p,p) + w_zz*K(z,z) - 2*w_pz*K(p,z);  kind 0 (imq): K(a,b) = sum_{i != j} c / (eps + c + |a_i - b_j|^2),

@@ -121,6 +121,17 @@ def wae_loss(recons, x, z, prior_z, reg_weight, kernel_type, z_var=2.0):
     return {"loss": rl + mmd, "Reconstruction_Loss": rl, "MMD": mmd}
 
 
+def swae_loss(recons, x, z, prior_z, proj, reg_weight, p=2.0):
+    """swae.py:109-126,150-178 with the prior draws and the unit directions proj [S, D] injected."""
+    B = x.size(0)
+    w = reg_weight / (B * (B - 1))
+    lat, pri = z.matmul(proj.t()), prior_z.matmul(proj.t())                  # [N, S]
+    w_dist = torch.sort(lat.t(), dim=1)[0] - torch.sort(pri.t(), dim=1)[0]
+    swd = w * w_dist.pow(p).mean()
+    rl = F.mse_loss(recons, x) + F.l1_loss(recons, x)
+    return {"loss": rl + swd, "Reconstruction_Loss": rl, "SWD": swd}
+
+
 def infovae_loss(recons, x, z, mu, log_var, prior_z, M_N, alpha, beta, reg_weight, kernel_type, z_var=2.0):
     """info_vae.py:128-148,218-229."""
     B = x.size(0)

@@ -144,6 +144,17 @@ def joint_specs():
     return out
 
 
+SWAE_CFG = dict(in_channels=3, latent_dim=128, reg_weight=100, wasserstein_deg=2.0, num_projections=200, projection_dist="normal")
+
+
+def swae_draws(seed, B, L=128, S=200):
+    """(prior draws [B,L], unit directions [S,L]) -- the rule oracle/gen_swae_golden.py injects."""
+    g = torch.Generator().manual_seed(seed + 5)
+    prior = torch.randn(B, L, generator=g)
+    r = torch.randn(S, L, generator=g)
+    return prior, r / r.norm(dim=1).view(-1, 1)
+
+
 CVAE_CFG = dict(in_channels=3, num_classes=40, latent_dim=128)
 
 

@@ -440,6 +440,7 @@ ZOO = [("VanillaVAE", dict(in_channels=3, latent_dim=128)),
        ("DIPVAE", dict(in_channels=3, latent_dim=128, lambda_diag=0.05, lambda_offdiag=0.1)),
        ("JointVAE", dict(H.JOINT_CFG)),
        ("ConditionalVAE", dict(H.CVAE_CFG)),
+       ("SWAE", dict(H.SWAE_CFG)),
        ("CategoricalVAE", dict(in_channels=3, latent_dim=64, categorical_dim=40, temperature=0.5, alpha=1.0)),
        ("VQVAE", dict(in_channels=3, embedding_dim=64, num_embeddings=512, img_size=64, beta=0.25)),
        ("MCQVAE", dict(in_channels=3, embedding_dim=128, hidden_dims=[64, 128, 256], num_embeddings=64, img_size=64, codebooks=4, beta=0.25))]
@@ -589,3 +590,48 @@ def test_conditional_vae_vs_golden(dev, golden):
             H.assert_cks_close(H.cks(b), g["buf." + k], rtol=1e-4, atol=1e-5, what=k)
     assert m.sample(3, dev, labels=labels[:3]).shape == (3, 3, 64, 64)
     assert m.generate(x.to(dev), labels=labels).shape == (4, 3, 64, 64)
+
+
+def test_swae_vs_golden(dev, golden):
+    """SWAE against the reference's own swae.py fixture: codes, loss dict (mse + l1, SWD), every gradient; the SWD kernel
+    (projections + per-direction sort + rank-wise power) against the torch expression at other batch sizes and exponents."""
+    from ctvae_amd import kernels as K
+    from ctvae_amd.models import vae_models
+    g = golden("swae_b8")
+    seed, B = int(g["seed"]), int(g["B"])
+    m = vae_models["SWAE"](**H.SWAE_CFG)
+    m.load_state_dict(filler.fill_state(H.wae_specs(), seed + 1))
+    m = m.to(dev).train()
+    x, _ = filler.synthetic_batch(seed, B)
+    out = m(x.to(dev))
+    np.testing.assert_allclose(out[2].detach().cpu().numpy(), g["z"], atol=TOL, rtol=0)
+    prior, proj = H.swae_draws(seed, B)
+    losses = m.loss_function(*out, M_N=0.00025, prior_z=prior.to(dev), proj=proj.to(dev))
+    for k, v in losses.items():
+        want = float(g["loss." + k])
+        assert abs(float(v.detach()) - want) <= TOL * max(1.0, abs(want)), (k, float(v.detach()), want)
+    m.zero_grad()
+    losses["loss"].backward()
+    np.testing.assert_allclose(m.fc_z.bias.grad.cpu().numpy(), g["grad.fc_z.bias"], atol=2e-6, rtol=2e-3)
+    np.testing.assert_allclose(m.final_layer._modules["3"].bias.grad.cpu().numpy(), g["grad.final_layer.3.bias"], atol=2e-6, rtol=2e-3)
+    for k, p in m.named_parameters():
+        H.assert_cks_close(H.cks(p.grad), g["gradcks." + k], rtol=2e-3, atol=2e-5, what=k)
+    assert m.sample(3, dev).shape == (3, 3, 64, 64)
+    # the distance kernel alone: odd batch sizes (padding of the bitonic network), p = 2 and p = 4, default draws run
+    gen = torch.Generator().manual_seed(3)
+    for N, S, p in ((37, 50, 2.0), (256, 200, 2.0), (64, 16, 4.0), (1000, 8, 2.0)):
+        z = torch.randn(N, 128, generator=gen).to(dev).requires_grad_(True)
+        pr = torch.randn(N, 128, generator=gen).to(dev)
+        r = torch.randn(S, 128, generator=gen)
+        pj = (r / r.norm(dim=1).view(-1, 1)).to(dev)
+        got = K.SWD.apply(z, pr, pj, p, 0.7)
+        got.backward()
+        z2 = z.detach().clone().requires_grad_(True)
+        wd = torch.sort(z2.matmul(pj.t()).t(), dim=1)[0] - torch.sort(pr.matmul(pj.t()).t(), dim=1)[0]
+        ref = 0.7 * wd.pow(p).mean()
+        ref.backward()
+        assert abs(float(got) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref))), (N, S, p, float(got), float(ref))
+        # two samples whose projections on some direction agree to rounding may swap ranks between the two dot-product orders;
+        # the swap moves their gradients by the gap of their rank partners: compare in the L2 sense, not element by element
+        assert float((z.grad - z2.grad).norm() / z2.grad.norm()) <= 2e-3, (N, S, p)
+    assert torch.isfinite(m.loss_function(*m(x.to(dev)), M_N=0.00025)["loss"])

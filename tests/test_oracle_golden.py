@@ -305,3 +305,24 @@ def test_conditional_vae_forward_loss_grads(golden):
     for k, v in sd.items():
         if v.requires_grad:
             H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
+
+
+def test_swae_forward_loss_grads(golden):
+    """SWAE (WAE's network, mse + l1 + sliced Wasserstein distance): oracle against the reference's own swae.py fixture with the
+    prior draws and the projection directions injected."""
+    g = golden("swae_b8")
+    seed, B = int(g["seed"]), int(g["B"])
+    sd = O.leafify(filler.fill_state(H.wae_specs(), seed + 1))
+    x, _ = filler.synthetic_batch(seed, B)
+    res = O.wae_forward(sd, x, True, {})
+    np.testing.assert_allclose(res[2].detach().numpy(), g["z"], atol=TOL, rtol=0)
+    prior, proj = H.swae_draws(seed, B)
+    losses = O.swae_loss(*res, prior, proj, 100, 2.0)
+    for k, v in losses.items():
+        want = float(g["loss." + k])
+        assert abs(v.item() - want) <= TOL * max(1.0, abs(want)), (k, v.item(), want)
+    losses["loss"].backward()
+    np.testing.assert_allclose(sd["fc_z.bias"].grad.numpy(), g["grad.fc_z.bias"], atol=1e-6, rtol=1e-3)
+    for k, v in sd.items():
+        if v.requires_grad:
+            H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
