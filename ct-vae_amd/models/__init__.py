@@ -14,6 +14,7 @@ from .dip_vae import DIPVAE
 from .joint_vae import JointVAE
 from .cvae import ConditionalVAE
 from .swae import SWAE
+from .twostage_vae import TwoStageVAE
 
 # Aliases (models/__init__.py:29-32)
 VAE = VanillaVAE
@@ -34,6 +35,7 @@ vae_models = {
     'InfoVAE': InfoVAE,       # VanillaVAE's network, beta*mse + (1-alpha)*KL + MMD (info_vae.py)
     'DIPVAE': DIPVAE,         # VanillaVAE's network, sum-reduced objective + DIP-II covariance regulariser (dip_vae.py)
     'JointVAE': JointVAE,     # VanillaVAE's stacks, Gaussian + one categorical latent, capacity objective (joint_vae.py)
+    'TwoStageVAE': TwoStageVAE,   # VanillaVAE's step; the second-stage MLPs are parameter holders, as in the reference (twostage_vae.py)
     'SWAE': SWAE,             # WAE_MMD's network, mse + l1 + sliced Wasserstein distance (swae.py)
     'ConditionalVAE': ConditionalVAE,   # VanillaVAE's stacks, the label as an extra input plane and next to z (cvae.py)
     'CategoricalVAE': CategoricalVAE,   # VanillaVAE's stacks around a Gumbel-softmax categorical latent (cat_vae.py)

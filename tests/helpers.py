@@ -144,6 +144,26 @@ def joint_specs():
     return out
 
 
+def twostage_specs(hidden2=(1024, 1024), L=128):
+    """state_dict keys/shapes of TwoStageVAE(in_channels=3, latent_dim=128) (twostage_vae.py:10-101): VanillaVAE's, then the
+    second-stage MLPs (Linear + BatchNorm1d per block), fc_mu2 / fc_var2, and the mirrored decoder2."""
+    f32, i64 = torch.float32, torch.int64
+    out = list(vanilla_specs())
+
+    def mlp(name, dims_in, dims_out):
+        for i, (a, b) in enumerate(zip(dims_in, dims_out)):
+            out.extend([(f"{name}.{i}.0.weight", (b, a), f32), (f"{name}.{i}.0.bias", (b,), f32),
+                        (f"{name}.{i}.1.weight", (b,), f32), (f"{name}.{i}.1.bias", (b,), f32),
+                        (f"{name}.{i}.1.running_mean", (b,), f32), (f"{name}.{i}.1.running_var", (b,), f32),
+                        (f"{name}.{i}.1.num_batches_tracked", (), i64)])
+    h = list(hidden2)
+    mlp("encoder2", [L] + h[:-1], h)
+    out.extend([("fc_mu2.weight", (L, h[-1]), f32), ("fc_mu2.bias", (L,), f32), ("fc_var2.weight", (L, h[-1]), f32), ("fc_var2.bias", (L,), f32)])
+    h.reverse()
+    mlp("decoder2", [L] + h[:-1], h)
+    return out
+
+
 SWAE_CFG = dict(in_channels=3, latent_dim=128, reg_weight=100, wasserstein_deg=2.0, num_projections=200, projection_dist="normal")
 
 

@@ -326,3 +326,27 @@ def test_swae_forward_loss_grads(golden):
     for k, v in sd.items():
         if v.requires_grad:
             H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
+
+
+def test_twostage_vae_is_the_first_stage(golden):
+    """TwoStageVAE: the reference's step uses the first stage only -- the oracle's VanillaVAE functions on the first-stage keys
+    reproduce the fixture of the reference's own twostage_vae.py; key order / shapes of the whole state_dict as recorded."""
+    g = golden("twostage_b2")
+    seed = int(g["seed"])
+    specs = H.twostage_specs()
+    assert [k for k, _, _ in specs] == list(g["keys"]) and [str(tuple(sh)) for _, sh, _ in specs] == list(g["shapes"])
+    sd = O.leafify(filler.fill_state(specs, seed + 1))
+    x, e = filler.synthetic_batch(seed, 2)
+    res = O.vanilla_forward(sd, x, e, True, {})
+    np.testing.assert_allclose(res[2].detach().numpy(), g["mu"], atol=TOL, rtol=0)
+    losses = O.vanilla_loss(*res, float(g["M_N"]))
+    for k, v in losses.items():
+        assert abs(v.item() - float(g["loss." + k])) <= TOL * max(1.0, abs(float(g["loss." + k]))), k
+    losses["loss"].backward()
+    no_grad = set(g["no_grad"])
+    assert no_grad == {k for k, v in sd.items() if v.requires_grad and k.split(".")[0] in ("encoder2", "fc_mu2", "fc_var2", "decoder2")}
+    for k, v in sd.items():
+        if v.requires_grad and k not in no_grad:
+            H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
+        elif v.requires_grad:
+            assert v.grad is None
