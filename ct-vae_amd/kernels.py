@@ -1106,6 +1106,40 @@ class MMD(Function):
 
 L2L1 = -1.0      # VAELoss(..., logcosh_alpha=L2L1): squared + absolute error
 
+_kl_dummy = {}
+
+
+class GaussKL(Function):
+    """mean_b(-0.5 * sum_d(1 + logvar - mu^2 - exp(logvar))): the Gaussian KL term on its own (hvae.py:213-222 forms three of
+    them) through the loss kernels: reconstruction operands of four zeros, M_N = 1, so out = {kld, 0, kld, -kld}."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar):
+        _req_cuda(mu, logvar)
+        mu_, mrs = _rows(mu)
+        lv_, lrs = _rows(logvar)
+        B, L = mu.shape
+        z4 = _kl_dummy.get(mu.device)
+        if z4 is None:
+            z4 = _kl_dummy[mu.device] = torch.zeros(4, dtype=torch.float32, device=mu.device)
+        out = torch.empty(4, dtype=torch.float32, device=mu.device)
+        ws = native.workspace(mu.device)
+        native.call("ctvae_loss_forward", z4.data_ptr(), z4.data_ptr(), 4, mu_.data_ptr(), mrs, lv_.data_ptr(), lrs, B, L, 1.0, None,
+                    out.data_ptr(), ws.data_ptr(), ws.numel() * 4)
+        ctx.save_for_backward(mu_, lv_)
+        ctx.meta = (mrs, lrs, B, L)
+        return out[2].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        mu_, lv_ = ctx.saved_tensors
+        mrs, lrs, B, L = ctx.meta
+        g = _c(g.reshape(1))
+        g_mu = torch.empty((B, L), dtype=torch.float32, device=mu_.device)
+        g_lv = torch.empty((B, L), dtype=torch.float32, device=mu_.device)
+        native.call("ctvae_kl_backward", mu_.data_ptr(), mrs, lv_.data_ptr(), lrs, g.data_ptr(), g_mu.data_ptr(), g_lv.data_ptr(), B, L, 1.0)
+        return g_mu, g_lv
+
 
 class SWD(Function):
     """Sliced Wasserstein distance of SWAE.compute_swd (swae.py:150-178): z, prior [N,D]; proj [S,D] unit directions; p the

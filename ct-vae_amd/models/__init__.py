@@ -15,6 +15,7 @@ from .joint_vae import JointVAE
 from .cvae import ConditionalVAE
 from .swae import SWAE
 from .twostage_vae import TwoStageVAE
+from .hvae import HVAE
 
 # Aliases (models/__init__.py:29-32)
 VAE = VanillaVAE
@@ -36,6 +37,7 @@ vae_models = {
     'DIPVAE': DIPVAE,         # VanillaVAE's network, sum-reduced objective + DIP-II covariance regulariser (dip_vae.py)
     'JointVAE': JointVAE,     # VanillaVAE's stacks, Gaussian + one categorical latent, capacity objective (joint_vae.py)
     'TwoStageVAE': TwoStageVAE,   # VanillaVAE's step; the second-stage MLPs are parameter holders, as in the reference (twostage_vae.py)
+    'HVAE': HVAE,             # two latent levels, the second encoder conditioned on z2; three Gaussian-KL terms (hvae.py)
     'SWAE': SWAE,             # WAE_MMD's network, mse + l1 + sliced Wasserstein distance (swae.py)
     'ConditionalVAE': ConditionalVAE,   # VanillaVAE's stacks, the label as an extra input plane and next to z (cvae.py)
     'CategoricalVAE': CategoricalVAE,   # VanillaVAE's stacks around a Gumbel-softmax categorical latent (cat_vae.py)

@@ -121,6 +121,45 @@ def wae_loss(recons, x, z, prior_z, reg_weight, kernel_type, z_var=2.0):
     return {"loss": rl + mmd, "Reconstruction_Loss": rl, "MMD": mmd}
 
 
+def _conv_stack(sd, pfx, h, training, new_buffers, n_layers=5):
+    for i in range(n_layers):
+        h = F.conv2d(h, sd[f"{pfx}.{i}.0.weight"], sd[f"{pfx}.{i}.0.bias"], stride=2, padding=1)
+        h = _bn_lrelu(sd, f"{pfx}.{i}.1", h, training, new_buffers)
+    return torch.flatten(h, start_dim=1)
+
+
+def hvae_forward(sd, x, e1, e2, training=True, new_buffers=None, img_size=64):
+    """HVAE.forward (hvae.py:112-199) with both Gaussian draws injected (e2 for z2, which is drawn first; e1 for z1)
+    -> [recons, input, z1_mu, z1_log_var, z2_mu, z2_log_var, z1, z2]."""
+    lin = lambda name, t: F.linear(t, sd[name + ".weight"], sd[name + ".bias"])
+    f2 = _conv_stack(sd, "encoder_z2_layers", x, training, new_buffers)
+    z2_mu, z2_lv = lin("fc_z2_mu", f2), lin("fc_z2_var", f2)
+    z2 = vanilla_reparameterize(z2_mu, z2_lv, e2)
+    plane = lin("embed_z2_code", z2).view(-1, img_size, img_size).unsqueeze(1)
+    data = F.conv2d(x, sd["embed_data.weight"], sd["embed_data.bias"])
+    f1 = _conv_stack(sd, "encoder_z1_layers", torch.cat([data, plane], dim=1), training, new_buffers)
+    z1_mu, z1_lv = lin("fc_z1_mu", f1), lin("fc_z1_var", f1)
+    z1 = vanilla_reparameterize(z1_mu, z1_lv, e1)
+    h = torch.cat([lin("debed_z1_code", z1), lin("debed_z2_code", z2)], dim=1).view(-1, 512, 2, 2)
+    for i in range(4):
+        h = F.conv_transpose2d(h, sd[f"decoder.{i}.0.weight"], sd[f"decoder.{i}.0.bias"], stride=2, padding=1, output_padding=1)
+        h = _bn_lrelu(sd, f"decoder.{i}.1", h, training, new_buffers)
+    h = F.conv_transpose2d(h, sd["final_layer.0.weight"], sd["final_layer.0.bias"], stride=2, padding=1, output_padding=1)
+    h = _bn_lrelu(sd, "final_layer.1", h, training, new_buffers)
+    recons = torch.tanh(F.conv2d(h, sd["final_layer.3.weight"], sd["final_layer.3.bias"], padding=1))
+    return [recons, x, z1_mu, z1_lv, z2_mu, z2_lv, z1, z2]
+
+
+def hvae_loss(sd, recons, x, z1_mu, z1_lv, z2_mu, z2_lv, z1, z2, M_N):
+    """hvae.py:201-229 (the keys as the reference spells them)."""
+    p_mu = F.linear(z2, sd["recons_z1_mu.weight"], sd["recons_z1_mu.bias"])
+    p_lv = F.linear(z2, sd["recons_z1_log_var.weight"], sd["recons_z1_log_var.bias"])
+    kl = lambda m, l: torch.mean(-0.5 * torch.sum(1 + l - m ** 2 - l.exp(), dim=1), dim=0)
+    kld_loss = -(kl(z1 - p_mu, p_lv) - kl(z1_mu, z1_lv) - kl(z2_mu, z2_lv))
+    rl = F.mse_loss(recons, x)
+    return {"loss": rl + M_N * kld_loss, "Reconstruction Loss": rl, "KLD": -kld_loss}
+
+
 def swae_loss(recons, x, z, prior_z, proj, reg_weight, p=2.0):
     """swae.py:109-126,150-178 with the prior draws and the unit directions proj [S, D] injected."""
     B = x.size(0)

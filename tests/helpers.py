@@ -144,6 +144,46 @@ def joint_specs():
     return out
 
 
+def hvae_specs(L1=64, L2=64):
+    """state_dict keys/shapes of HVAE(in_channels=3, latent1_dim=64, latent2_dim=64) in the reference's order (hvae.py:24-104)."""
+    f32, i64 = torch.float32, torch.int64
+    out = []
+
+    def bn(p, c):
+        out.extend([(p + ".weight", (c,), f32), (p + ".bias", (c,), f32), (p + ".running_mean", (c,), f32),
+                    (p + ".running_var", (c,), f32), (p + ".num_batches_tracked", (), i64)])
+
+    def lin(p, o, i):
+        out.extend([(p + ".weight", (o, i), f32), (p + ".bias", (o,), f32)])
+
+    def stack(p, ci):
+        for i, c in enumerate([32, 64, 128, 256, 512]):
+            out.extend([(f"{p}.{i}.0.weight", (c, ci, 3, 3), f32), (f"{p}.{i}.0.bias", (c,), f32)])
+            bn(f"{p}.{i}.1", c)
+            ci = c
+    stack("encoder_z2_layers", 3)
+    lin("fc_z2_mu", L2, 2048); lin("fc_z2_var", L2, 2048)
+    lin("embed_z2_code", 4096, L2)
+    out.extend([("embed_data.weight", (3, 3, 1, 1), f32), ("embed_data.bias", (3,), f32)])
+    stack("encoder_z1_layers", 4)
+    lin("fc_z1_mu", L1, 2048); lin("fc_z1_var", L1, 2048)
+    lin("recons_z1_mu", L1, L2); lin("recons_z1_log_var", L1, L2)
+    lin("debed_z1_code", 1024, L1); lin("debed_z2_code", 1024, L2)
+    hd = [512, 256, 128, 64, 32]
+    for i in range(4):
+        out.extend([(f"decoder.{i}.0.weight", (hd[i], hd[i + 1], 3, 3), f32), (f"decoder.{i}.0.bias", (hd[i + 1],), f32)])
+        bn(f"decoder.{i}.1", hd[i + 1])
+    out.extend([("final_layer.0.weight", (32, 32, 3, 3), f32), ("final_layer.0.bias", (32,), f32)])
+    bn("final_layer.1", 32)
+    out.extend([("final_layer.3.weight", (3, 32, 3, 3), f32), ("final_layer.3.bias", (3,), f32)])
+    return out
+
+
+def hvae_noise(seed, B, L1=64, L2=64):
+    g = torch.Generator().manual_seed(seed + 6)
+    return torch.randn(B, L1, generator=g), torch.randn(B, L2, generator=g)
+
+
 def twostage_specs(hidden2=(1024, 1024), L=128):
     """state_dict keys/shapes of TwoStageVAE(in_channels=3, latent_dim=128) (twostage_vae.py:10-101): VanillaVAE's, then the
     second-stage MLPs (Linear + BatchNorm1d per block), fc_mu2 / fc_var2, and the mirrored decoder2."""

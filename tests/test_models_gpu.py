@@ -442,6 +442,7 @@ ZOO = [("VanillaVAE", dict(in_channels=3, latent_dim=128)),
        ("ConditionalVAE", dict(H.CVAE_CFG)),
        ("SWAE", dict(H.SWAE_CFG)),
        ("TwoStageVAE", dict(in_channels=3, latent_dim=128)),
+       ("HVAE", dict(in_channels=3, latent1_dim=64, latent2_dim=64, pseudo_input_size=128)),
        ("CategoricalVAE", dict(in_channels=3, latent_dim=64, categorical_dim=40, temperature=0.5, alpha=1.0)),
        ("VQVAE", dict(in_channels=3, embedding_dim=64, num_embeddings=512, img_size=64, beta=0.25)),
        ("MCQVAE", dict(in_channels=3, embedding_dim=128, hidden_dims=[64, 128, 256], num_embeddings=64, img_size=64, codebooks=4, beta=0.25))]
@@ -675,3 +676,33 @@ def test_twostage_vae_vs_golden(dev, golden):
     for k, p in m.named_parameters():
         if k in no_grad:
             assert torch.equal(p.detach(), before[k]), k
+
+
+def test_hvae_vs_golden(dev, golden):
+    """HVAE against the reference's own hvae.py fixture: both levels' posterior means, z1, reconstruction, loss dict (the three
+    Gaussian-KL terms through the KL kernels), every gradient."""
+    from ctvae_amd.models import vae_models
+    g = golden("hvae_b4")
+    seed, B = int(g["seed"]), int(g["B"])
+    m = vae_models["HVAE"](in_channels=3, latent1_dim=64, latent2_dim=64, pseudo_input_size=128)
+    assert list(m.state_dict().keys()) == list(g["keys"])
+    m.load_state_dict(filler.fill_state(H.hvae_specs(), seed + 1))
+    m = m.to(dev).train()
+    x, _ = filler.synthetic_batch(seed, B)
+    e1, e2 = H.hvae_noise(seed, B)
+    out = m(x.to(dev), eps=e1.to(dev), eps2=e2.to(dev))
+    np.testing.assert_allclose(out[2].detach().cpu().numpy(), g["z1_mu"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(out[4].detach().cpu().numpy(), g["z2_mu"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(out[6].detach().cpu().numpy(), g["z1"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(out[0].detach()[:, :, ::8, ::8].cpu().numpy(), g["recons_sub"], atol=TOL, rtol=0)
+    losses = m.loss_function(*out, M_N=float(g["M_N"]))
+    for k, v in losses.items():
+        want = float(g["loss." + k])
+        assert abs(float(v.detach()) - want) <= TOL * max(1.0, abs(want)), (k, float(v.detach()), want)
+    m.zero_grad()
+    losses["loss"].backward()
+    np.testing.assert_allclose(m.recons_z1_mu.bias.grad.cpu().numpy(), g["grad.recons_z1_mu.bias"], atol=1e-7, rtol=2e-3)
+    np.testing.assert_allclose(m.fc_z2_var.bias.grad.cpu().numpy(), g["grad.fc_z2_var.bias"], atol=2e-6, rtol=2e-3)
+    for k, p in m.named_parameters():
+        H.assert_cks_close(H.cks(p.grad), g["gradcks." + k], rtol=2e-3, atol=2e-5, what=k)
+    assert m.sample(3, dev).shape == (3, 3, 64, 64)

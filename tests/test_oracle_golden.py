@@ -350,3 +350,28 @@ def test_twostage_vae_is_the_first_stage(golden):
             H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
         elif v.requires_grad:
             assert v.grad is None
+
+
+def test_hvae_forward_loss_grads(golden):
+    """HVAE (two latent levels, second encoder conditioned on z2, three Gaussian-KL terms): oracle against the reference's own
+    hvae.py fixture with both noise draws injected."""
+    g = golden("hvae_b4")
+    seed, B = int(g["seed"]), int(g["B"])
+    specs = H.hvae_specs()
+    assert [k for k, _, _ in specs] == list(g["keys"])
+    sd = O.leafify(filler.fill_state(specs, seed + 1))
+    x, _ = filler.synthetic_batch(seed, B)
+    e1, e2 = H.hvae_noise(seed, B)
+    res = O.hvae_forward(sd, x, e1, e2, True, {})
+    np.testing.assert_allclose(res[2].detach().numpy(), g["z1_mu"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(res[4].detach().numpy(), g["z2_mu"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(res[6].detach().numpy(), g["z1"], atol=TOL, rtol=0)
+    losses = O.hvae_loss(sd, *res, float(g["M_N"]))
+    for k, v in losses.items():
+        want = float(g["loss." + k])
+        assert abs(v.item() - want) <= TOL * max(1.0, abs(want)), (k, v.item(), want)
+    losses["loss"].backward()
+    np.testing.assert_allclose(sd["recons_z1_mu.bias"].grad.numpy(), g["grad.recons_z1_mu.bias"], atol=1e-7, rtol=1e-3)
+    for k, v in sd.items():
+        if v.requires_grad:
+            H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
