@@ -303,6 +303,64 @@ __global__ __launch_bounds__(256) void vq_bwd_codebook_pos_kernel(const float* _
   }
 }
 
+// The same for wide codebook slices (32 < Dc <= 128: CT-MCQ-VAE's single 128-wide codebook): a whole wave owns a position per
+// step (lane = d and d + 64) and a table per wave, sAcc[wave][k][128] -- 4 x K x 128 floats, 128 KB at K = 64.  The
+// scan-per-code kernel above took 82 us on that model's 8192 positions.
+__global__ __launch_bounds__(256) void vq_bwd_codebook_posw_kernel(const float* __restrict__ gvq, const float* __restrict__ lat,
+                                                                   const float* __restrict__ cb,
+                                                                   const long long* __restrict__ inds, float* __restrict__ part,
+                                                                   int P, int D, int K, int Dc, int C, int HW, int Ps) {
+  extern __shared__ float vq_smem[];
+  float* sAcc = vq_smem;                               // [4][K][128]
+  float* sCnt = sAcc + 4 * K * 128;                    // [4][K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = blockIdx.y;
+  for (int e = tid; e < 4 * K * 128 + 4 * K; e += 256) vq_smem[e] = 0.f;
+  __syncthreads();
+  float* tAcc = sAcc + (size_t)wave * K * 128;
+  float* tCnt = sCnt + wave * K;
+  const int p_lo = blockIdx.x * Ps;
+  const int p_hi = p_lo + Ps < P ? p_lo + Ps : P;
+  constexpr int U = 4;                                 // positions in flight per wave
+  for (int base = p_lo + wave; base < p_hi; base += 4 * U) {
+    int kk[U];
+    float v0[U], v1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = base + 4 * u;
+      kk[u] = -1;
+      v0[u] = v1[u] = 0.f;
+      if (p < p_hi) {
+        const int b = p / HW, hw = p - b * HW;
+        kk[u] = (int)inds[((size_t)b * C + i) * HW + hw];
+        if (lane < Dc) v0[u] = lat[(size_t)p * D + i + lane];
+        if (lane + 64 < Dc) v1[u] = lat[(size_t)p * D + i + lane + 64];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (kk[u] >= 0) {                                // uniform over the wave
+        tAcc[kk[u] * 128 + lane] += v0[u];
+        tAcc[kk[u] * 128 + 64 + lane] += v1[u];
+        if (lane == 0) tCnt[kk[u]] += 1.f;
+      }
+    }
+  }
+  __syncthreads();
+  const float sc = (gvq != nullptr ? gvq[0] : 0.f) * 2.f / ((float)P * (float)Dc);
+  for (int e = tid; e < K * Dc; e += 256) {
+    const int k = e / Dc, dd = e - k * Dc;
+    float sx = 0.f, c = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      sx += sAcc[((size_t)t * K + k) * 128 + dd];
+      c += sCnt[t * K + k];
+    }
+    const size_t o = ((size_t)i * K + k) * Dc + dd;
+    part[(size_t)blockIdx.x * ((size_t)C * K * Dc) + o] = sc * (c * cb[o] - sx);
+  }
+}
+
 __global__ __launch_bounds__(256) void vq_cb_reduce_kernel(const float* __restrict__ part, float* __restrict__ dcb, int n, int S,
                                                           int accumulate) {
   const int o = blockIdx.x * 256 + threadIdx.x;
@@ -392,6 +450,31 @@ int launch_vq_backward(const float* gq, const float* gvq, const float* lat, cons
         }
         ProfScope ps("vq_bwd_codebook_pos_kernel", st, 0.0, 4.0 * (double)P * D + 8.0 * (double)P * C + 4.0 * S * n_all);
         hipLaunchKernelGGL(vq_bwd_codebook_pos_kernel, dim3(S, C), dim3(256), smem, st, gvq, lat, cb, inds, ws, P, D, K, Dc, C,
+                           HW, Ps);
+        CTVAE_LAUNCH_CHECK();
+        hipLaunchKernelGGL(vq_cb_reduce_kernel, dim3(ceil_div((int)n_all, 256)), dim3(256), 0, st, ws, dcb, (int)n_all, S,
+                           accumulate);
+        CTVAE_LAUNCH_CHECK();
+        return 0;
+      }
+    }
+    if (Dc <= 128 && (size_t)(4 * K * 128 + 4 * K) * sizeof(float) <= 150 * 1024 && ws != nullptr) {
+      // wide slices: a wave per position, a table per wave; ~64 positions per workgroup
+      int S = ceil_div(P, 64);
+      if (S > 512) S = 512;
+      while (S > 1 && (size_t)S * n_all > ws_bytes / sizeof(float)) --S;
+      if ((size_t)S * n_all <= ws_bytes / sizeof(float)) {
+        const int Ps = ceil_div(P, S);
+        S = ceil_div(P, Ps);
+        const size_t smem = ((size_t)4 * K * 128 + 4 * K) * sizeof(float);
+        static bool attr_set_w = false;
+        if (!attr_set_w) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vq_bwd_codebook_posw_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          attr_set_w = true;
+        }
+        ProfScope ps("vq_bwd_codebook_posw_kernel", st, 0.0, 4.0 * (double)P * D + 8.0 * (double)P * C + 4.0 * S * n_all);
+        hipLaunchKernelGGL(vq_bwd_codebook_posw_kernel, dim3(S, C), dim3(256), smem, st, gvq, lat, cb, inds, ws, P, D, K, Dc, C,
                            HW, Ps);
         CTVAE_LAUNCH_CHECK();
         hipLaunchKernelGGL(vq_cb_reduce_kernel, dim3(ceil_div((int)n_all, 256)), dim3(256), 0, st, ws, dcb, (int)n_all, S,
