@@ -37,6 +37,8 @@ int launch_bn_backward(const float* ga, const float* beta, const float* y, int R
                        const float* save_mean, const float* save_invstd, int act, float* gy, float* dgamma, float* dbeta,
                        int accumulate, float* ws, size_t ws_bytes, const float* part_in, int part_rows, hipStream_t st,
                        float* coef_out = nullptr, const float* coef_in = nullptr);
+int launch_wino_filters_batch(int n, const float* const* W, float* const* Uf, float* const* Ub, const int* Ci, const int* Co,
+                              hipStream_t st);
 bool upconv_wgrad_supported(const ConvGeom& g);
 int launch_permute(const float* in, float* out, int B, int C, int P, int to_nhwc, hipStream_t st);
 int launch_gat_score(int mode, const float* xl, const float* xr, const float* attr, const float* we, const float* att, float* out,
@@ -153,19 +155,25 @@ size_t ctvae_workspace_bytes(void) { return (size_t)256 << 20; }
 
 int ctvae_conv_forward(int kind, const float* x, const float* w, const float* bias, const float* add, float* y, int B,
                        int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int act, const float* in_scale,
-                       const float* in_shift, int in_act, float* wino_dgrad_filters_out, float* ws, size_t ws_bytes,
-                       void* stream) {
+                       const float* in_shift, int in_act, float* wino_dgrad_filters_out, const float* wino_fwd_filters, float* ws,
+                       size_t ws_bytes, void* stream) {
   if (!x || !w || !y || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
   if ((in_scale != nullptr) != (in_shift != nullptr)) return kErrBadArg;
   ConvGeom g;
   if (build_geom(g, kind == CTVAE_CONV ? 0 : 1, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
-  if (wino_dgrad_filters_out != nullptr &&
+  if ((wino_dgrad_filters_out != nullptr || wino_fwd_filters != nullptr) &&
       !ctvae_conv_wino_filter_floats(kind, B, H, W, Ci, Co, k, stride, pad, out_pad, ws_bytes))
     return kErrBadArg;
   const InXform xf{in_scale, in_shift, in_act};
-  const WinoFilters wf{nullptr, wino_dgrad_filters_out};
+  // wino_fwd_filters: both filter sets were made ahead of time (ctvae_wino_filters_batch): no transform launch here
+  const WinoFilters wf{wino_fwd_filters, wino_fwd_filters != nullptr ? nullptr : wino_dgrad_filters_out};
   return launch_tapgemm(g, x, w, bias, add, nullptr, 0, y, act, nullptr, ws, ws_bytes / sizeof(float), (hipStream_t)stream,
                         nullptr, &xf, &wf);
+}
+
+int ctvae_wino_filters_batch(int n, const float* const* w, float* const* fwd_filters, float* const* dgrad_filters, const int* Ci,
+                             const int* Co, void* stream) {
+  return launch_wino_filters_batch(n, w, fwd_filters, dgrad_filters, Ci, Co, (hipStream_t)stream);
 }
 
 size_t ctvae_conv_wino_filter_floats(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,

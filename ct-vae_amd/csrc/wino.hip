@@ -125,11 +125,10 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 // workgroup = a 32 ci x 32 co tile of W ([9][Ci][Co], tap = ky*3+kx): 128-byte coalesced tap loads, the 16 transformed
 // values of every (ci,co) go through LDS, and both layouts leave as 1-KB contiguous runs of 16-byte stores.
 constexpr int W2_LD = 33;
-__global__ __launch_bounds__(256) void wino_weight2_kernel(const float* __restrict__ Wp, float* __restrict__ Uf,
-                                                           float* __restrict__ Ub, int Ci, int Co) {
-  extern __shared__ __attribute__((aligned(16))) float sW2[];     // [16][32 ci][W2_LD]
+__device__ __forceinline__ void wino_weight2_body(const float* __restrict__ Wp, float* __restrict__ Uf, float* __restrict__ Ub,
+                                                  int Ci, int Co, int bx, int by, float* sW2) {
   const int tid = threadIdx.x;
-  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int ci0 = bx * 32, co0 = by * 32;
   {
     const int co_l = tid & 31;
 #pragma unroll
@@ -174,6 +173,28 @@ __global__ __launch_bounds__(256) void wino_weight2_kernel(const float* __restri
     for (int k = 0; k < 4; ++k) v[k] = src[x_l * W2_LD + 8 * o + 4 * half + k];
     *reinterpret_cast<f32x4*>(Ub + fo * fs + ((long)(co0 / 8 + o) * Ci + ci0 + x_l) * 8 + 4 * half) = v;
   }
+}
+
+__global__ __launch_bounds__(256) void wino_weight2_kernel(const float* __restrict__ Wp, float* __restrict__ Uf,
+                                                           float* __restrict__ Ub, int Ci, int Co) {
+  extern __shared__ __attribute__((aligned(16))) float sW2[];     // [16][32 ci][W2_LD]
+  wino_weight2_body(Wp, Uf, Ub, Ci, Co, blockIdx.x, blockIdx.y, sW2);
+}
+
+// Every Winograd layer's filter transform of a training step in ONE launch (blockIdx.z = layer): the weights only change
+// at the optimizer step, and thirteen 7-us launches of 8 x 8 workgroups each are mostly launch floor.
+constexpr int kWinoBatchMax = 32;
+struct WinoBatch {
+  const float* W[kWinoBatchMax];
+  float* Uf[kWinoBatchMax];
+  float* Ub[kWinoBatchMax];
+  int Ci[kWinoBatchMax], Co[kWinoBatchMax];
+};
+__global__ __launch_bounds__(256) void wino_weight2_batch_kernel(const WinoBatch t) {
+  extern __shared__ __attribute__((aligned(16))) float sW2[];
+  const int l = blockIdx.z;
+  if ((int)blockIdx.x * 32 >= t.Ci[l] || (int)blockIdx.y * 32 >= t.Co[l]) return;
+  wino_weight2_body(t.W[l], t.Uf[l], t.Ub[l], t.Ci[l], t.Co[l], blockIdx.x, blockIdx.y, sW2);
 }
 
 // ---- the GEMM --------------------------------------------------------------------------------------------------
@@ -1131,6 +1152,35 @@ bool wino_supported(const ConvGeom& g, size_t ws_floats) {
 
 // filters_ready: this launch's transformed filters (what an earlier forward launch left in its bwd_out) -> no transform.
 // bwd_out (forward launches only): also write the data gradient's filter set there, in the same transform launch.
+int launch_wino_filters_batch(int n, const float* const* W, float* const* Uf, float* const* Ub, const int* Ci, const int* Co,
+                              hipStream_t st) {
+  if (n <= 0 || !W || !Uf || !Ub || !Ci || !Co) return kErrBadArg;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_weight2_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
+  for (int l0 = 0; l0 < n; l0 += kWinoBatchMax) {
+    WinoBatch t{};
+    const int m = n - l0 < kWinoBatchMax ? n - l0 : kWinoBatchMax;
+    int gx = 0, gy = 0;
+    double bytes = 0;
+    for (int l = 0; l < m; ++l) {
+      if (!W[l0 + l] || !Uf[l0 + l] || !Ub[l0 + l] || Ci[l0 + l] % 32 || Co[l0 + l] % 32 || Ci[l0 + l] <= 0 || Co[l0 + l] <= 0)
+        return kErrBadArg;
+      t.W[l] = W[l0 + l]; t.Uf[l] = Uf[l0 + l]; t.Ub[l] = Ub[l0 + l]; t.Ci[l] = Ci[l0 + l]; t.Co[l] = Co[l0 + l];
+      gx = t.Ci[l] / 32 > gx ? t.Ci[l] / 32 : gx;
+      gy = t.Co[l] / 32 > gy ? t.Co[l] / 32 : gy;
+      bytes += 4.0 * (9.0 + 32.0) * t.Ci[l] * t.Co[l];
+    }
+    ProfScope ps("wino_weight2_batch_kernel", st, 0.0, bytes);
+    hipLaunchKernelGGL(wino_weight2_batch_kernel, dim3(gx, gy, m), dim3(256), (size_t)16 * 32 * W2_LD * 4, st, t);
+    CTVAE_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 int launch_wino_conv(const ConvGeom& g, const float* X, const float* Wp, const float* bias, float* Y, int act, float* ws,
                      size_t ws_floats, hipStream_t st, const float* filters_ready, float* bwd_out, const float* add) {
   WTaps wt;

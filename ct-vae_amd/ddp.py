@@ -28,6 +28,8 @@ class GradBucketAllReduce:
     # C3: parameters (and buffers) from rank 0 once at construction
     def broadcast_parameters(self, src=0):
         dist.broadcast(self.model.flat_params, src, group=self.pg)
+        from . import kernels as K
+        K.bump_param_epoch()                 # cached Winograd filters were made from the old values
         for b in self.model.buffers():
             if b.is_floating_point():
                 dist.broadcast(b, src, group=self.pg)

@@ -69,6 +69,7 @@ class _GraphedTrainStep:
         return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in losses.items()}
 
     def run(self, real_img, kwargs=None):
+        exp = self.exp
         K.stage_batch(self.x, real_img)
         for k, t in self.static.items():
             t.copy_(kwargs[k], non_blocking=True)
@@ -80,11 +81,12 @@ class _GraphedTrainStep:
             self.graph = g
         if self.graph is not None:
             self.graph.replay()
+            if exp.ddp is None:
+                K.bump_param_epoch()       # the replayed Adam launch changed the parameters behind Python's back
             losses = self.losses
         else:
             losses = self._body()
         self.seen += 1
-        exp = self.exp
         if exp.ddp is not None:
             exp.ddp.all_reduce()
             exp.optimizer.step(grad_scale=exp.ddp.grad_scale)

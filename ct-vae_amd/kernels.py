@@ -79,9 +79,10 @@ def wino_filter_floats(spec: ConvSpec, B, H, W, ws_numel) -> int:
     return n
 
 
-def conv_forward_raw(x, w, b, spec: ConvSpec, add=None, act=None, in_coef=None, in_act=ACT_NONE, wino_out=None):
+def conv_forward_raw(x, w, b, spec: ConvSpec, add=None, act=None, in_coef=None, in_act=ACT_NONE, wino_out=None, wino_ready=None):
     """in_coef [2][Ci]: read act_in(x*scale+shift) instead of x (lazy BatchNorm apply, image-side layers only).
-    wino_out: buffer of wino_filter_floats() floats that receives the data gradient's Winograd filters."""
+    wino_out: buffer of wino_filter_floats() floats that receives the data gradient's Winograd filters.
+    wino_ready: the forward's transformed filters, made ahead of time for the current weights (WinoFilterCache)."""
     B, H, W, _ = x.shape
     ho, wo = spec.out_hw(H, W)
     y = torch.empty((B, ho, wo, spec.co), dtype=torch.float32, device=x.device)
@@ -90,8 +91,76 @@ def conv_forward_raw(x, w, b, spec: ConvSpec, add=None, act=None, in_coef=None, 
     sh = in_coef.data_ptr() + 4 * spec.ci if in_coef is not None else None
     native.call("ctvae_conv_forward", spec.kind, x.data_ptr(), w.data_ptr(), native.ptr(b), native.ptr(add), y.data_ptr(),
                 B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, spec.act if act is None else act,
-                sc, sh, in_act, native.ptr(wino_out), ws.data_ptr(), ws.numel() * 4)
+                sc, sh, in_act, native.ptr(wino_out), native.ptr(wino_ready), ws.data_ptr(), ws.numel() * 4)
     return y
+
+
+# ---------------------------------------------------------------------------------------------------
+# Winograd filters of a whole step in one launch
+# ---------------------------------------------------------------------------------------------------
+_param_epoch = [0]
+
+
+def bump_param_epoch():
+    """Parameters may have changed by means torch does not see (the Adam kernel writes through raw pointers), or a new step
+    begins (zero_grad): transformed filters made before this are not trusted any more."""
+    _param_epoch[0] += 1
+
+
+class _WinoFilterCache:
+    """Both transformed filter sets of every 3x3 stride-1 layer that runs Winograd, refreshed by ONE launch per training step
+    (ctvae_wino_filters_batch) instead of a launch per layer: the first Winograd layer of a forward pass that finds its
+    entry stale (another parameter epoch -- see bump_param_epoch -- or another tensor version) refreshes EVERY registered
+    entry whose weight is alive.  Used only for forward passes that will be differentiated (training); anything else keeps the
+    per-layer transform.  Entries die with their weight (weak references)."""
+
+    def __init__(self):
+        self.entries = {}          # id(weight) -> dict(ref, uf, ub, epoch, version, ci, co)
+
+    def filters(self, w, spec, n_floats):
+        """(forward filters, data-gradient filters) valid for w as it is now."""
+        e = self.entries.get(id(w))
+        if e is None or e["ref"]() is not w or e["uf"].numel() != n_floats or e["uf"].device != w.device:
+            e = self.entries[id(w)] = dict(ref=weakref.ref(w), uf=torch.empty(n_floats, dtype=torch.float32, device=w.device),
+                                           ub=torch.empty(n_floats, dtype=torch.float32, device=w.device), epoch=-1, version=-1,
+                                           ci=spec.ci, co=spec.co)
+        if e["epoch"] != _param_epoch[0] or e["version"] != w._version:
+            self.refresh(w.device)
+        return e["uf"], e["ub"]
+
+    def refresh(self, device):
+        import ctypes as C
+        live = []
+        for k in list(self.entries):
+            e = self.entries[k]
+            w = e["ref"]()
+            if w is None:
+                del self.entries[k]
+            elif w.device == device and (e["epoch"] != _param_epoch[0] or e["version"] != w._version):
+                live.append((e, w))
+        if not live:
+            return
+        n = len(live)
+        native.call("ctvae_wino_filters_batch", n, (C.c_void_p * n)(*[w.data_ptr() for _, w in live]),
+                    (C.c_void_p * n)(*[e["uf"].data_ptr() for e, _ in live]), (C.c_void_p * n)(*[e["ub"].data_ptr() for e, _ in live]),
+                    (C.c_int * n)(*[e["ci"] for e, _ in live]), (C.c_int * n)(*[e["co"] for e, _ in live]))
+        for e, w in live:
+            e["epoch"], e["version"] = _param_epoch[0], w._version
+
+
+wino_cache = _WinoFilterCache()
+_WINO_BATCH = os.environ.get("CTVAE_NO_WINO_BATCH", "0") != "1"     # diagnostic: one filter-transform launch per layer
+
+
+def _wino_filters_for(ctx_needs_grad, w, spec, B, H, W_):
+    """(ready forward filters or None, buffer for / holding the data-gradient filters or None) for a Winograd layer."""
+    n = wino_filter_floats(spec, B, H, W_, native.workspace(w.device).numel()) if ctx_needs_grad else 0
+    if not n:
+        return None, None
+    if _WINO_BATCH and spec.ci % 32 == 0 and spec.co % 32 == 0:
+        uf, ub = wino_cache.filters(w, spec, n)
+        return uf, ub
+    return None, torch.empty(n, dtype=torch.float32, device=w.device)
 
 
 def conv_dgrad_raw(dy, w, spec: ConvSpec, in_hw, add=None, mask=None, mask_act=ACT_NONE, wino_filters=None):
@@ -491,25 +560,21 @@ class ConvAct(Function):
                 raise RuntimeError("ConvAct: companion rows and a residual operand together are not supported")
             rows = adjacent_rows(x, _c(aux))
             Bt = rows.shape[0] if rows is not None else x.shape[0]
-            if ctx.needs_input_grad[0]:
-                n = wino_filter_floats(spec, Bt, x.shape[1], x.shape[2], native.workspace(x.device).numel())
-                if n:
-                    ctx.wino_u = torch.empty(n, dtype=torch.float32, device=x.device)
+            ready, ctx.wino_u = _wino_filters_for(ctx.needs_input_grad[0], w, spec, Bt, x.shape[1], x.shape[2])
             first = [True]
 
             def run(t):
-                wo, first[0] = (ctx.wino_u if first[0] else None), False
-                return conv_forward_raw(t, w, b, spec, None, wino_out=wo)
+                wo, first[0] = (ctx.wino_u if (first[0] and ready is None) else None), False
+                return conv_forward_raw(t, w, b, spec, None, wino_out=wo, wino_ready=ready)
             (y,), (y_aux,) = _with_aux(x, _c(aux), run)
             ctx.save_for_backward(x, y if spec.act != ACT_NONE else None)
             ctx.mark_non_differentiable(y_aux)
             ctx.set_materialize_grads(False)        # else backward is handed a zero-filled tensor for y_aux: a fill per layer
             return y, y_aux
-        if add is None and ctx.needs_input_grad[0]:
-            n = wino_filter_floats(spec, x.shape[0], x.shape[1], x.shape[2], native.workspace(x.device).numel())
-            if n:
-                ctx.wino_u = torch.empty(n, dtype=torch.float32, device=x.device)
-        y = conv_forward_raw(x, w, b, spec, add_c, wino_out=ctx.wino_u)
+        ready = None
+        if add is None:
+            ready, ctx.wino_u = _wino_filters_for(ctx.needs_input_grad[0], w, spec, x.shape[0], x.shape[1], x.shape[2])
+        y = conv_forward_raw(x, w, b, spec, add_c, wino_out=None if ready is not None else ctx.wino_u, wino_ready=ready)
         ctx.save_for_backward(x, y if spec.act != ACT_NONE else None)
         return y
 
@@ -555,23 +620,20 @@ class ResBlock(Function):
         ctx.w = (w3, w1)
         rows = adjacent_rows(x, _c(aux)) if aux is not None else None
         Bt = rows.shape[0] if rows is not None else x.shape[0]
-        if ctx.needs_input_grad[0]:
-            n = wino_filter_floats(spec3, Bt, x.shape[1], x.shape[2], native.workspace(x.device).numel())
-            if n:
-                ctx.wino_u = torch.empty(n, dtype=torch.float32, device=x.device)
+        ready, ctx.wino_u = _wino_filters_for(ctx.needs_input_grad[0], w3, spec3, Bt, x.shape[1], x.shape[2])
         if aux is not None:
             first = [True]
 
             def run(t):
-                wo, first[0] = (ctx.wino_u if first[0] else None), False
-                h_ = conv_forward_raw(t, w3, None, spec3, wino_out=wo)
+                wo, first[0] = (ctx.wino_u if (first[0] and ready is None) else None), False
+                h_ = conv_forward_raw(t, w3, None, spec3, wino_out=wo, wino_ready=ready)
                 return h_, conv_forward_raw(h_, w1, None, spec1, t)
             (h, out), (_h_aux, out_aux) = _with_aux(x, _c(aux), run)
             ctx.save_for_backward(x, h, out if spec1.act != ACT_NONE else None)
             ctx.mark_non_differentiable(out_aux)
             ctx.set_materialize_grads(False)
             return out, out_aux
-        h = conv_forward_raw(x, w3, None, spec3, wino_out=ctx.wino_u)
+        h = conv_forward_raw(x, w3, None, spec3, wino_out=None if ready is not None else ctx.wino_u, wino_ready=ready)
         out = conv_forward_raw(h, w1, None, spec1, x)
         ctx.save_for_backward(x, h, out if spec1.act != ACT_NONE else None)
         return out
@@ -1812,5 +1874,6 @@ class VQLookup(Function):
 # ---------------------------------------------------------------------------------------------------
 def adam_step(flat_params, flat_grads, exp_avg, exp_avg_sq, state, grad_scale=1.0):
     _req_cuda(flat_params, flat_grads)
+    bump_param_epoch()
     native.call("ctvae_adam_step", flat_params.data_ptr(), flat_grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
                 state.data_ptr(), flat_params.numel(), float(grad_scale))

@@ -252,6 +252,8 @@ class FlatParamMixin:
         attached, AccumulateGrad adds into it with one tiny launch per parameter (62 per CT-MCQ-VAE step); detached,
         autograd just hands the tensor over and gather_torch_grads() moves all of them into the flat buffer with one
         multi-tensor copy."""
+        from .. import kernels as _K
+        _K.bump_param_epoch()          # a new step: transformed Winograd filters are remade once for all layers (kernels.wino_cache)
         if getattr(self, "_flat_grads", None) is not None:
             self._flat_grads.zero_()
             for p, _ in getattr(self, "_torch_grad_views", ()):

@@ -47,11 +47,19 @@ size_t ctvae_workspace_bytes(void); /* scratch size that is sufficient for every
  * wino_dgrad_filters_out (may be NULL): for a layer whose forward AND data gradient run Winograd
  * (ctvae_conv_wino_filter_floats() > 0, that many floats), the forward's filter-transform launch also leaves the data
  * gradient's transformed filters there; hand them to ctvae_conv_dgrad of the same layer and weights (one transform
- * launch per layer and step instead of two). */
+ * launch per layer and step instead of two).
+ * wino_fwd_filters (may be NULL; same size): the forward's own transformed filters made ahead of time by
+ * ctvae_wino_filters_batch for the CURRENT weights -- no transform launch at all in this call. */
 int ctvae_conv_forward(int kind, const float* x, const float* w, const float* bias, const float* add, float* y, int B,
                        int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int act, const float* in_scale,
-                       const float* in_shift, int in_act, float* wino_dgrad_filters_out, float* ws, size_t ws_bytes,
-                       void* stream);
+                       const float* in_shift, int in_act, float* wino_dgrad_filters_out, const float* wino_fwd_filters, float* ws,
+                       size_t ws_bytes, void* stream);
+/* Both Winograd filter sets (forward / data gradient, ctvae_conv_wino_filter_floats() floats each) of n 3x3 stride-1 layers
+ * in ONE launch: w[l] = the layer's packed weights [9][Ci][Co], Ci, Co multiples of 32.  The residual stacks of MCQ-VAE /
+ * CT-MCQ-VAE have 13 / 14 such layers (vq_vae.py:57-70 via mcq_vae.py:182-216); their weights change once per optimizer step.
+ * w, fwd_filters, dgrad_filters, Ci, Co: HOST arrays of n entries (device pointers / ints). */
+int ctvae_wino_filters_batch(int n, const float* const* w, float* const* fwd_filters, float* const* dgrad_filters, const int* Ci,
+                             const int* Co, void* stream);
 size_t ctvae_conv_wino_filter_floats(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
                                      size_t ws_bytes);
 int ctvae_conv_input_transform_supported(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad,

@@ -706,3 +706,43 @@ def test_hvae_vs_golden(dev, golden):
     for k, p in m.named_parameters():
         H.assert_cks_close(H.cks(p.grad), g["gradcks." + k], rtol=2e-3, atol=2e-5, what=k)
     assert m.sample(3, dev).shape == (3, 3, 64, 64)
+
+
+def test_winograd_filter_cache_follows_the_parameters(dev, monkeypatch):
+    """The per-step batched Winograd filter transform (kernels.wino_cache) must never serve filters of older weights: after
+    optimizer steps (raw-pointer updates: parameter epoch), after an in-place edit through torch (tensor version) and after
+    load_state_dict, a training-mode forward equals -- bit for bit -- the forward of a fresh model holding the same parameters
+    with the cache switched off (one transform launch per layer, the round-1 path)."""
+    from ctvae_amd import kernels as K
+    from ctvae_amd.models import vae_models
+    from ctvae_amd.optim import FlatAdam
+    cfg = dict(in_channels=3, embedding_dim=128, hidden_dims=[64, 128, 256], num_embeddings=64, img_size=64, codebooks=4, beta=0.25)
+    B = 128
+    x = filler.synthetic_batch(31, B)[0].to(dev)
+
+    def fresh_forward(src):
+        monkeypatch.setattr(K, "_WINO_BATCH", False)
+        m2 = vae_models["MCQVAE"](**{k: (list(v) if isinstance(v, list) else v) for k, v in cfg.items()}).to(dev).train()
+        m2.load_state_dict(src.state_dict())
+        out = m2(x)[0].detach().clone()
+        monkeypatch.setattr(K, "_WINO_BATCH", True)
+        return out
+
+    torch.manual_seed(5)
+    m = vae_models["MCQVAE"](**{k: (list(v) if isinstance(v, list) else v) for k, v in cfg.items()}).to(dev).train()
+    opt = FlatAdam(m, lr=1e-3)
+    n_before = len(K.wino_cache.entries)
+    for _ in range(2):
+        m.zero_grad()
+        out = m(x)
+        K.backward(m.loss_function(*out, M_N=0.00025)["loss"])
+        opt.step()
+    assert len(K.wino_cache.entries) > n_before, "the Winograd layers did not register with the cache"
+    assert torch.equal(m(x)[0].detach(), fresh_forward(m)), "stale filters after optimizer steps"
+    with torch.no_grad():
+        for p in m.encoder[4].resblock.parameters():
+            p.mul_(1.25)
+    assert torch.equal(m(x)[0].detach(), fresh_forward(m)), "stale filters after an in-place edit"
+    sd = {k: (v * 0.9 if v.is_floating_point() and v.dim() == 4 else v) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    assert torch.equal(m(x)[0].detach(), fresh_forward(m)), "stale filters after load_state_dict"
