@@ -731,13 +731,14 @@ def test_winograd_filter_cache_follows_the_parameters(dev, monkeypatch):
     torch.manual_seed(5)
     m = vae_models["MCQVAE"](**{k: (list(v) if isinstance(v, list) else v) for k, v in cfg.items()}).to(dev).train()
     opt = FlatAdam(m, lr=1e-3)
-    n_before = len(K.wino_cache.entries)
     for _ in range(2):
         m.zero_grad()
         out = m(x)
         K.backward(m.loss_function(*out, M_N=0.00025)["loss"])
         opt.step()
-    assert len(K.wino_cache.entries) > n_before, "the Winograd layers did not register with the cache"
+    w3 = m.encoder[4].resblock._modules["0"].weight
+    e = K.wino_cache.entries.get(id(w3))
+    assert e is not None and e["ref"]() is w3, "the Winograd layers did not register with the cache"
     assert torch.equal(m(x)[0].detach(), fresh_forward(m)), "stale filters after optimizer steps"
     with torch.no_grad():
         for p in m.encoder[4].resblock.parameters():
