@@ -66,6 +66,11 @@ int launch_ct_mask_forward(const float* x, const float* action, const float* pe,
 int launch_ct_mask_backward(const float* x, const float* action, const float* pe, const float* keep, float scale,
                             const float* inter, const float* p, const float* soft, const float* g, int B, int S, int D, int A,
                             float* dWp, float* dbp, hipStream_t st);
+int launch_vamp_forward(const float* z, const float* mu, const float* lv, const float* pmu, const float* plv, int B, int D, int K,
+                        float* out3, float* wgt, float* ws, size_t ws_bytes, hipStream_t st);
+int launch_vamp_backward(const float* z, const float* mu, const float* lv, const float* pmu, const float* plv, const float* wgt,
+                         const float* g, int B, int D, int K, float* dz, float* dmu, float* dlv, float* dpmu, float* dplv,
+                         hipStream_t st);
 int launch_swd_forward(const float* z, const float* prior, const float* proj, int N, int D, int S, float p, float weight, float* out,
                        float* grad_z, float* ws, size_t ws_bytes, hipStream_t st);
 int launch_ct_blend_forward(const float* s0, const float* s1, const float* mask, float* out, long rows, hipStream_t st);
@@ -616,6 +621,18 @@ int ctvae_l2l1_backward(const float* recons, const float* x, const float* g_loss
                         void* stream) {
   if (!recons || !x || !g_loss || !g_recons || n <= 0) return kErrBadArg;
   return launch_mse_backward(recons, x, g_loss, g_recons, n, (hipStream_t)stream, -1.f, recons_act);
+}
+
+int ctvae_vamp_kl_forward(const float* z, const float* mu, const float* logvar, const float* prior_mu, const float* prior_logvar,
+                          int B, int D, int K, float* out3, float* weights, float* ws, size_t ws_bytes, void* stream) {
+  return launch_vamp_forward(z, mu, logvar, prior_mu, prior_logvar, B, D, K, out3, weights, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int ctvae_vamp_kl_backward(const float* z, const float* mu, const float* logvar, const float* prior_mu, const float* prior_logvar,
+                           const float* weights, const float* g_kld, int B, int D, int K, float* g_z, float* g_mu, float* g_logvar,
+                           float* g_prior_mu, float* g_prior_logvar, void* stream) {
+  return launch_vamp_backward(z, mu, logvar, prior_mu, prior_logvar, weights, g_kld, B, D, K, g_z, g_mu, g_logvar, g_prior_mu,
+                              g_prior_logvar, (hipStream_t)stream);
 }
 
 int ctvae_swd_forward(const float* z, const float* prior, const float* proj, int N, int D, int S, float p, float weight, float* out,

@@ -1203,6 +1203,39 @@ class GaussKL(Function):
         return g_mu, g_lv
 
 
+class VampKL(Function):
+    """VampVAE's KL term (vampvae.py:140-171): -(E_log_p - E_log_q) with the VampPrior mixture over the K pseudo-input
+    posteriors.  z, mu, logvar [B,D]; prior_mu, prior_logvar [K,D].  csrc/vamp.hip, both directions."""
+
+    @staticmethod
+    def forward(ctx, z, mu, logvar, pmu, plv):
+        _req_cuda(z, mu, logvar, pmu, plv)
+        z, mu, logvar, pmu, plv = (_c(t) for t in (z, mu, logvar, pmu, plv))
+        B, D = z.shape
+        Kc = pmu.shape[0]
+        if mu.shape != z.shape or logvar.shape != z.shape or pmu.shape != (Kc, D) or plv.shape != (Kc, D):
+            raise RuntimeError("vamp kl: shapes")
+        out = torch.empty(3, dtype=torch.float32, device=z.device)
+        wgt = torch.empty((B, Kc), dtype=torch.float32, device=z.device)
+        ws = native.workspace(z.device)
+        native.call("ctvae_vamp_kl_forward", z.data_ptr(), mu.data_ptr(), logvar.data_ptr(), pmu.data_ptr(), plv.data_ptr(), B, D, Kc,
+                    out.data_ptr(), wgt.data_ptr(), ws.data_ptr(), ws.numel() * 4)
+        ctx.save_for_backward(z, mu, logvar, pmu, plv, wgt)
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        z, mu, logvar, pmu, plv, wgt = ctx.saved_tensors
+        B, D = z.shape
+        Kc = pmu.shape[0]
+        g = _c(g.reshape(1))
+        dz, dmu, dlv = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
+        dpm, dpl = torch.empty_like(pmu), torch.empty_like(pmu)
+        native.call("ctvae_vamp_kl_backward", z.data_ptr(), mu.data_ptr(), logvar.data_ptr(), pmu.data_ptr(), plv.data_ptr(),
+                    wgt.data_ptr(), g.data_ptr(), B, D, Kc, dz.data_ptr(), dmu.data_ptr(), dlv.data_ptr(), dpm.data_ptr(), dpl.data_ptr())
+        return dz, dmu, dlv, dpm, dpl
+
+
 class SWD(Function):
     """Sliced Wasserstein distance of SWAE.compute_swd (swae.py:150-178): z, prior [N,D]; proj [S,D] unit directions; p the
     exponent; weight = reg_weight.  One launch projects, sorts both sets per direction and leaves d swd / d z (csrc/swd.hip)."""

@@ -391,6 +391,16 @@ int ctvae_l2l1_loss_forward(const float* recons, const float* x, long n, const f
                             void* stream);
 int ctvae_l2l1_backward(const float* recons, const float* x, const float* g_loss, float* g_recons, long n, int recons_act,
                         void* stream);
+/* VampPrior KL term of VampVAE (vampvae.py:140-171): z, mu, logvar [B][D] (contiguous), prior_mu / prior_logvar [K][D] (the
+ * encoder on the K pseudo-inputs, K <= 512): out3 = {kld, E_log_p, E_log_q} with E_log_q = mean_b sum_d -0.5 (lv + (z-mu)^2) /
+ * e^lv, E_log_p = mean_b logsumexp_k (sum_d -0.5 (plv_k + (z - pmu_k)^2) / e^plv_k - log K), kld = -(E_log_p - E_log_q);
+ * weights [B][K] receives softmax_k of the component scores for the backward call (g_kld: one float on the device).
+ * ws: >= 8*B bytes. */
+int ctvae_vamp_kl_forward(const float* z, const float* mu, const float* logvar, const float* prior_mu, const float* prior_logvar,
+                          int B, int D, int K, float* out3, float* weights, float* ws, size_t ws_bytes, void* stream);
+int ctvae_vamp_kl_backward(const float* z, const float* mu, const float* logvar, const float* prior_mu, const float* prior_logvar,
+                           const float* weights, const float* g_kld, int B, int D, int K, float* g_z, float* g_mu, float* g_logvar,
+                           float* g_prior_mu, float* g_prior_logvar, void* stream);
 /* Sliced Wasserstein distance of SWAE (swae.py:150-178) between z and prior draws [N][D] (N <= 1024, D <= 512, D % 4 == 0) along
  * the S unit directions proj [S][D]: out[0] = weight * mean_{s,r} (sort_r(z . w_s) - sort_r(prior . w_s))^p (torch.sort + pow + mean
  * in the reference); grad_z [N][D] receives d out / d z (the backward pass scales it by the incoming gradient).

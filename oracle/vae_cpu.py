@@ -160,6 +160,19 @@ def hvae_loss(sd, recons, x, z1_mu, z1_lv, z2_mu, z2_lv, z1, z2, M_N):
     return {"loss": rl + M_N * kld_loss, "Reconstruction Loss": rl, "KLD": -kld_loss}
 
 
+def vamp_loss(sd, recons, x, mu, log_var, z, M_N, K, training=True, new_buffers=None):
+    """vampvae.py:126-172: the pseudo-inputs go through the same encoder (train mode: their own batch statistics)."""
+    pseudo = torch.clamp(F.linear(torch.eye(K), sd["embed_pseudo.0.weight"], sd["embed_pseudo.0.bias"]), 0.0, 1.0)
+    prior_mu, prior_lv = vanilla_encode(sd, pseudo.view(-1, x.size(1), x.size(2), x.size(3)), training, new_buffers)
+    rl = F.mse_loss(recons, x)
+    e_log_q = torch.mean(torch.sum(-0.5 * (log_var + (z - mu) ** 2) / log_var.exp(), dim=1), dim=0)
+    e_log_p = torch.sum(-0.5 * (prior_lv.unsqueeze(0) + (z.unsqueeze(1) - prior_mu.unsqueeze(0)) ** 2) / prior_lv.unsqueeze(0).exp(),
+                        dim=2) - torch.log(torch.tensor(K).float())
+    e_log_p = torch.mean(torch.logsumexp(e_log_p, dim=1), dim=0)
+    kld = -(e_log_p - e_log_q)
+    return {"loss": rl + M_N * kld, "Reconstruction_Loss": rl, "KLD": -kld}
+
+
 def swae_loss(recons, x, z, prior_z, proj, reg_weight, p=2.0):
     """swae.py:109-126,150-178 with the prior draws and the unit directions proj [S, D] injected."""
     B = x.size(0)

@@ -184,6 +184,11 @@ def hvae_noise(seed, B, L1=64, L2=64):
     return torch.randn(B, L1, generator=g), torch.randn(B, L2, generator=g)
 
 
+def vamp_specs(K=50):
+    """state_dict keys/shapes of VampVAE(in_channels=3, latent_dim=128): VanillaVAE's, then embed_pseudo.0 (vampvae.py:73-75)."""
+    return list(vanilla_specs()) + [("embed_pseudo.0.weight", (12288, K), torch.float32), ("embed_pseudo.0.bias", (12288,), torch.float32)]
+
+
 def twostage_specs(hidden2=(1024, 1024), L=128):
     """state_dict keys/shapes of TwoStageVAE(in_channels=3, latent_dim=128) (twostage_vae.py:10-101): VanillaVAE's, then the
     second-stage MLPs (Linear + BatchNorm1d per block), fc_mu2 / fc_var2, and the mirrored decoder2."""

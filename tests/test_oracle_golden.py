@@ -375,3 +375,32 @@ def test_hvae_forward_loss_grads(golden):
     for k, v in sd.items():
         if v.requires_grad:
             H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
+
+
+def _vamp_state(seed):
+    sd = filler.fill_state(H.vamp_specs(), seed + 1)
+    sd["embed_pseudo.0.bias"] = sd["embed_pseudo.0.bias"] + 0.5      # as oracle/gen_vamp_golden.py: the Hardtanh gets all three regimes
+    return sd
+
+
+def test_vamp_vae_forward_loss_grads(golden):
+    """VampVAE (VampPrior over K pseudo-inputs encoded by the same network): oracle against the reference's own vampvae.py
+    fixture."""
+    g = golden("vamp_b4")
+    seed, B = int(g["seed"]), int(g["B"])
+    assert [k for k, _, _ in H.vamp_specs()] == list(g["keys"])
+    sd = O.leafify(_vamp_state(seed))
+    x, e = filler.synthetic_batch(seed, B)
+    res = O.vanilla_forward(sd, x, e, True, {})
+    z = O.vanilla_reparameterize(res[2], res[3], e)
+    np.testing.assert_allclose(res[2].detach().numpy(), g["mu"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(z.detach().numpy(), g["z"], atol=TOL, rtol=0)
+    losses = O.vamp_loss(sd, *res, z, float(g["M_N"]), 50, True, {})
+    for k, v in losses.items():
+        want = float(g["loss." + k])
+        assert abs(v.item() - want) <= TOL * max(1.0, abs(want)), (k, v.item(), want)
+    losses["loss"].backward()
+    np.testing.assert_allclose(sd["embed_pseudo.0.bias"].grad[::64].numpy(), g["grad.embed_pseudo.0.bias_sub"], atol=1e-9, rtol=2e-3)
+    for k, v in sd.items():
+        if v.requires_grad:
+            H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
