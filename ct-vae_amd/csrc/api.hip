@@ -66,6 +66,10 @@ int launch_ct_mask_forward(const float* x, const float* action, const float* pe,
 int launch_ct_mask_backward(const float* x, const float* action, const float* pe, const float* keep, float scale,
                             const float* inter, const float* p, const float* soft, const float* g, int B, int S, int D, int A,
                             float* dWp, float* dbp, hipStream_t st);
+int launch_tc_forward(const float* z, const float* mu, const float* lv, const float* liw, int B, int D, float* out3, float* lse_s,
+                      float* lse_d, float* ws, size_t ws_bytes, hipStream_t st);
+int launch_tc_backward(const float* z, const float* mu, const float* lv, const float* liw, const float* lse_s, const float* lse_d,
+                       const float* g3, int B, int D, float* dz, float* dmu, float* dlv, hipStream_t st);
 int launch_vamp_forward(const float* z, const float* mu, const float* lv, const float* pmu, const float* plv, int B, int D, int K,
                         float* out3, float* wgt, float* ws, size_t ws_bytes, hipStream_t st);
 int launch_vamp_backward(const float* z, const float* mu, const float* lv, const float* pmu, const float* plv, const float* wgt,
@@ -621,6 +625,16 @@ int ctvae_l2l1_backward(const float* recons, const float* x, const float* g_loss
                         void* stream) {
   if (!recons || !x || !g_loss || !g_recons || n <= 0) return kErrBadArg;
   return launch_mse_backward(recons, x, g_loss, g_recons, n, (hipStream_t)stream, -1.f, recons_act);
+}
+
+int ctvae_tc_forward(const float* z, const float* mu, const float* logvar, const float* log_iw, int B, int D, float* out3, float* lse_s,
+                     float* lse_d, float* ws, size_t ws_bytes, void* stream) {
+  return launch_tc_forward(z, mu, logvar, log_iw, B, D, out3, lse_s, lse_d, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int ctvae_tc_backward(const float* z, const float* mu, const float* logvar, const float* log_iw, const float* lse_s, const float* lse_d,
+                      const float* g3, int B, int D, float* g_z, float* g_mu, float* g_logvar, void* stream) {
+  return launch_tc_backward(z, mu, logvar, log_iw, lse_s, lse_d, g3, B, D, g_z, g_mu, g_logvar, (hipStream_t)stream);
 }
 
 int ctvae_vamp_kl_forward(const float* z, const float* mu, const float* logvar, const float* prior_mu, const float* prior_logvar,

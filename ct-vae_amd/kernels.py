@@ -1203,6 +1203,41 @@ class GaussKL(Function):
         return g_mu, g_lv
 
 
+class TCDecomp(Function):
+    """(mi, tc, kld) of BetaTCVAE's KL decomposition (betatc_vae.py:128-199; csrc/tcvae.hip): z, mu, logvar [B,D] (D <= 32),
+    log_iw [B,B] the log importance weights.  All three outputs carry gradient."""
+
+    @staticmethod
+    def forward(ctx, z, mu, logvar, log_iw):
+        _req_cuda(z, mu, logvar, log_iw)
+        z, mu, logvar, log_iw = (_c(t) for t in (z, mu, logvar, log_iw))
+        B, D = z.shape
+        if mu.shape != z.shape or logvar.shape != z.shape or tuple(log_iw.shape) != (B, B):
+            raise RuntimeError("tc decomposition: shapes")
+        out = torch.empty(3, dtype=torch.float32, device=z.device)
+        lse_s = torch.empty(B, dtype=torch.float32, device=z.device)
+        lse_d = torch.empty((B, D), dtype=torch.float32, device=z.device)
+        ws = native.workspace(z.device)
+        native.call("ctvae_tc_forward", z.data_ptr(), mu.data_ptr(), logvar.data_ptr(), log_iw.data_ptr(), B, D, out.data_ptr(),
+                    lse_s.data_ptr(), lse_d.data_ptr(), ws.data_ptr(), ws.numel() * 4)
+        ctx.save_for_backward(z, mu, logvar, log_iw, lse_s, lse_d)
+        ctx.set_materialize_grads(False)
+        return out.unbind(0)
+
+    @staticmethod
+    def backward(ctx, g_mi, g_tc, g_kld):
+        z, mu, logvar, log_iw, lse_s, lse_d = ctx.saved_tensors
+        if g_mi is None and g_tc is None and g_kld is None:
+            return None, None, None, None
+        zero = torch.zeros((), dtype=torch.float32, device=z.device)
+        g3 = torch.stack([(g if g is not None else zero).reshape(()).to(torch.float32) for g in (g_mi, g_tc, g_kld)])
+        B, D = z.shape
+        dz, dmu, dlv = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
+        native.call("ctvae_tc_backward", z.data_ptr(), mu.data_ptr(), logvar.data_ptr(), log_iw.data_ptr(), lse_s.data_ptr(),
+                    lse_d.data_ptr(), g3.data_ptr(), B, D, dz.data_ptr(), dmu.data_ptr(), dlv.data_ptr())
+        return dz, dmu, dlv, None
+
+
 class VampKL(Function):
     """VampVAE's KL term (vampvae.py:140-171): -(E_log_p - E_log_q) with the VampPrior mixture over the K pseudo-input
     posteriors.  z, mu, logvar [B,D]; prior_mu, prior_logvar [K,D].  csrc/vamp.hip, both directions."""

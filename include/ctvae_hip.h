@@ -391,6 +391,16 @@ int ctvae_l2l1_loss_forward(const float* recons, const float* x, long n, const f
                             void* stream);
 int ctvae_l2l1_backward(const float* recons, const float* x, const float* g_loss, float* g_recons, long n, int recons_act,
                         void* stream);
+/* BetaTCVAE's decomposition of the KL term (betatc_vae.py:128-199) on z, mu, logvar [B][D] (D <= 32, 2 <= B <= 4096) with the
+ * log importance weights log_iw [B][B] of minibatch stratified sampling (:176-184): M[i,j,d] = log N(z_i[d]; mu_j[d], e^lv_j[d]) +
+ * log_iw[i,j]; log_q_z = logsumexp_j sum_d M, log_prod = sum_d logsumexp_j M, log_q_zx / log_p_z the sample's own and the
+ * standard normal log density; out3 = {mi, tc, kld} = means of (log_q_zx - log_q_z, log_q_z - log_prod, log_prod - log_p_z).
+ * lse_s [B], lse_d [B][D] keep the logsumexps for the backward call; g3: d loss / d {mi, tc, kld} (3 floats on the device).
+ * ws: >= 16*B bytes. */
+int ctvae_tc_forward(const float* z, const float* mu, const float* logvar, const float* log_iw, int B, int D, float* out3, float* lse_s,
+                     float* lse_d, float* ws, size_t ws_bytes, void* stream);
+int ctvae_tc_backward(const float* z, const float* mu, const float* logvar, const float* log_iw, const float* lse_s, const float* lse_d,
+                      const float* g3, int B, int D, float* g_z, float* g_mu, float* g_logvar, void* stream);
 /* VampPrior KL term of VampVAE (vampvae.py:140-171): z, mu, logvar [B][D] (contiguous), prior_mu / prior_logvar [K][D] (the
  * encoder on the K pseudo-inputs, K <= 512): out3 = {kld, E_log_p, E_log_q} with E_log_q = mean_b sum_d -0.5 (lv + (z-mu)^2) /
  * e^lv, E_log_p = mean_b logsumexp_k (sum_d -0.5 (plv_k + (z - pmu_k)^2) / e^plv_k - log K), kld = -(E_log_p - E_log_q);

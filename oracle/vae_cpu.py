@@ -160,6 +160,49 @@ def hvae_loss(sd, recons, x, z1_mu, z1_lv, z2_mu, z2_lv, z1, z2, M_N):
     return {"loss": rl + M_N * kld_loss, "Reconstruction Loss": rl, "KLD": -kld_loss}
 
 
+def betatc_forward(sd, x, e):
+    """BetaTCVAE.forward (betatc_vae.py:84-126) with the Gaussian draws injected -> [recons, input, mu, log_var, z]."""
+    h = x
+    for i in range(4):
+        h = F.leaky_relu(F.conv2d(h, sd[f"encoder.{i}.0.weight"], sd[f"encoder.{i}.0.bias"], stride=2, padding=1), LEAKY)
+    f = F.linear(torch.flatten(h, start_dim=1), sd["fc.weight"], sd["fc.bias"])
+    mu, lv = F.linear(f, sd["fc_mu.weight"], sd["fc_mu.bias"]), F.linear(f, sd["fc_var.weight"], sd["fc_var.bias"])
+    z = vanilla_reparameterize(mu, lv, e)
+    h = F.linear(z, sd["decoder_input.weight"], sd["decoder_input.bias"]).view(-1, 32, 4, 4)
+    for i in range(3):
+        h = F.leaky_relu(F.conv_transpose2d(h, sd[f"decoder.{i}.0.weight"], sd[f"decoder.{i}.0.bias"], stride=2, padding=1,
+                                            output_padding=1), LEAKY)
+    h = F.leaky_relu(F.conv_transpose2d(h, sd["final_layer.0.weight"], sd["final_layer.0.bias"], stride=2, padding=1, output_padding=1), LEAKY)
+    recons = torch.tanh(F.conv2d(h, sd["final_layer.2.weight"], sd["final_layer.2.bias"], padding=1))
+    return [recons, x, mu, lv, z]
+
+
+def betatc_loss(recons, x, mu, log_var, z, M_N, num_iter, anneal_steps, alpha, beta, gamma):
+    """betatc_vae.py:142-205; num_iter = the counter value AFTER this (training) call's increment."""
+    import math
+
+    def logn(v, m, l):
+        return -0.5 * (math.log(2 * math.pi) + l) - 0.5 * ((v - m) ** 2 * torch.exp(-l))
+    B, D = z.shape
+    rl = F.mse_loss(recons, x, reduction='sum')
+    log_q_zx = logn(z, mu, log_var).sum(dim=1)
+    log_p_z = logn(z, torch.zeros_like(z), torch.zeros_like(z)).sum(dim=1)
+    mat = logn(z.view(B, 1, D), mu.view(1, B, D), log_var.view(1, B, D))
+    N = (1 / M_N) * B
+    strat = (N - B + 1) / (N * (B - 1))
+    iw = torch.full((B, B), 1 / (B - 1))
+    iw.view(-1)[::B] = 1 / N
+    iw.view(-1)[1::B] = strat
+    iw[B - 2, 0] = strat
+    mat = mat + iw.log().view(B, B, 1)
+    log_q_z = torch.logsumexp(mat.sum(2), dim=1)
+    log_prod = torch.logsumexp(mat, dim=1).sum(1)
+    mi, tc, kld = (log_q_zx - log_q_z).mean(), (log_q_z - log_prod).mean(), (log_prod - log_p_z).mean()
+    anneal = min(num_iter / anneal_steps, 1)
+    return {"loss": rl / B + alpha * mi + beta * tc + anneal * gamma * kld, "Reconstruction_Loss": rl, "KLD": kld, "TC_Loss": tc,
+            "MI_Loss": mi}
+
+
 def vamp_loss(sd, recons, x, mu, log_var, z, M_N, K, training=True, new_buffers=None):
     """vampvae.py:126-172: the pseudo-inputs go through the same encoder (train mode: their own batch statistics)."""
     pseudo = torch.clamp(F.linear(torch.eye(K), sd["embed_pseudo.0.weight"], sd["embed_pseudo.0.bias"]), 0.0, 1.0)

@@ -184,6 +184,26 @@ def hvae_noise(seed, B, L1=64, L2=64):
     return torch.randn(B, L1, generator=g), torch.randn(B, L2, generator=g)
 
 
+BETATC_CFG = dict(in_channels=3, latent_dim=10, anneal_steps=10000, alpha=1., beta=6., gamma=1.)
+
+
+def betatc_specs(L=10):
+    """state_dict keys/shapes of BetaTCVAE(**BETATC_CFG) (betatc_vae.py:12-82)."""
+    f32 = torch.float32
+    out, ci = [], 3
+    for i in range(4):
+        out.extend([(f"encoder.{i}.0.weight", (32, ci, 4, 4), f32), (f"encoder.{i}.0.bias", (32,), f32)])
+        ci = 32
+    out.extend([("fc.weight", (256, 512), f32), ("fc.bias", (256,), f32), ("fc_mu.weight", (L, 256), f32), ("fc_mu.bias", (L,), f32),
+                ("fc_var.weight", (L, 256), f32), ("fc_var.bias", (L,), f32),
+                ("decoder_input.weight", (512, L), f32), ("decoder_input.bias", (512,), f32)])
+    for i in range(3):
+        out.extend([(f"decoder.{i}.0.weight", (32, 32, 3, 3), f32), (f"decoder.{i}.0.bias", (32,), f32)])
+    out.extend([("final_layer.0.weight", (32, 32, 3, 3), f32), ("final_layer.0.bias", (32,), f32),
+                ("final_layer.2.weight", (3, 32, 3, 3), f32), ("final_layer.2.bias", (3,), f32)])
+    return out
+
+
 def vamp_specs(K=50):
     """state_dict keys/shapes of VampVAE(in_channels=3, latent_dim=128): VanillaVAE's, then embed_pseudo.0 (vampvae.py:73-75)."""
     return list(vanilla_specs()) + [("embed_pseudo.0.weight", (12288, K), torch.float32), ("embed_pseudo.0.bias", (12288,), torch.float32)]

@@ -444,6 +444,7 @@ ZOO = [("VanillaVAE", dict(in_channels=3, latent_dim=128)),
        ("TwoStageVAE", dict(in_channels=3, latent_dim=128)),
        ("HVAE", dict(in_channels=3, latent1_dim=64, latent2_dim=64, pseudo_input_size=128)),
        ("VampVAE", dict(in_channels=3, latent_dim=128)),
+       ("BetaTCVAE", dict(H.BETATC_CFG)),
        ("CategoricalVAE", dict(in_channels=3, latent_dim=64, categorical_dim=40, temperature=0.5, alpha=1.0)),
        ("VQVAE", dict(in_channels=3, embedding_dim=64, num_embeddings=512, img_size=64, beta=0.25)),
        ("MCQVAE", dict(in_channels=3, embedding_dim=128, hidden_dims=[64, 128, 256], num_embeddings=64, img_size=64, codebooks=4, beta=0.25))]
@@ -801,3 +802,55 @@ def test_vamp_vae_vs_golden(dev, golden):
         assert abs(float(got) - float(ref)) <= 2e-5 * max(1.0, abs(float(ref))), (Bk, D, Kc, float(got), float(ref))
         for a, b2 in zip(t + pr, t2 + p2):
             torch.testing.assert_close(a.grad, b2.grad, rtol=2e-4, atol=2e-5 * float(b2.grad.abs().max()))
+
+
+def test_betatc_vae_vs_golden(dev, golden):
+    """BetaTCVAE against the reference's own betatc_vae.py fixture: codes, reconstruction, two consecutive loss dicts (anneal
+    counter), every gradient; the decomposition kernel against the torch expression on other shapes."""
+    from ctvae_amd import kernels as K
+    from ctvae_amd.models import vae_models
+    g = golden("betatc_b8")
+    seed, B = int(g["seed"]), int(g["B"])
+    m = vae_models["BetaTCVAE"](**H.BETATC_CFG)
+    assert list(m.state_dict().keys()) == list(g["keys"])
+    m.load_state_dict(filler.fill_state(H.betatc_specs(), seed + 1))
+    m = m.to(dev).train()
+    x, e = filler.synthetic_batch(seed, B, latent_dim=10)
+    out = m(x.to(dev), eps=e.to(dev))
+    np.testing.assert_allclose(out[2].detach().cpu().numpy(), g["mu"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(out[4].detach().cpu().numpy(), g["z"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(out[0].detach()[:, :, ::8, ::8].cpu().numpy(), g["recons_sub"], atol=TOL, rtol=0)
+    l1 = m.loss_function(*out, M_N=float(g["M_N"]))
+    m.zero_grad()
+    l1["loss"].backward()
+    with torch.no_grad():
+        l2 = m.loss_function(*out, M_N=float(g["M_N"]))
+    for call, l in (("call1", l1), ("call2", l2)):
+        for k, v in l.items():
+            want = float(g[f"{call}.{k}"])
+            assert abs(float(v.detach()) - want) <= TOL * max(1.0, abs(want)), (call, k, float(v.detach()), want)
+    np.testing.assert_allclose(m.fc_var.bias.grad.cpu().numpy(), g["grad.fc_var.bias"], atol=2e-4, rtol=2e-3)
+    np.testing.assert_allclose(m.fc_mu.bias.grad.cpu().numpy(), g["grad.fc_mu.bias"], atol=2e-4, rtol=2e-3)
+    for k, p in m.named_parameters():
+        H.assert_cks_close(H.cks(p.grad), g["gradcks." + k], rtol=2e-3, atol=2e-3, what=k)     # sum-reduced objective: gradients of O(1e2)
+    assert m.sample(3, dev).shape == (3, 3, 64, 64)
+    gen = torch.Generator().manual_seed(12)
+    import math
+    for Bk, D in ((8, 10), (64, 10), (300, 32), (5, 1)):
+        t = [torch.randn(Bk, D, generator=gen).to(dev).requires_grad_(True) for _ in range(3)]
+        liw = torch.log(torch.rand(Bk, Bk, generator=gen) * 0.1 + 1e-3).to(dev)
+        mi, tc, kld = K.TCDecomp.apply(*t, liw)
+        (1.5 * mi + 6.0 * tc + 0.3 * kld).backward()
+        zz, mm, ll = [v.detach().clone().requires_grad_(True) for v in t]
+
+        def logn(v, a, b):
+            return -0.5 * (math.log(2 * math.pi) + b) - 0.5 * ((v - a) ** 2 * torch.exp(-b))
+        mat = logn(zz.view(Bk, 1, D), mm.view(1, Bk, D), ll.view(1, Bk, D)) + liw.view(Bk, Bk, 1)
+        lqz, lprod = torch.logsumexp(mat.sum(2), dim=1), torch.logsumexp(mat, dim=1).sum(1)
+        lqzx, lpz = logn(zz, mm, ll).sum(1), logn(zz, torch.zeros_like(zz), torch.zeros_like(zz)).sum(1)
+        r = ((lqzx - lqz).mean(), (lqz - lprod).mean(), (lprod - lpz).mean())
+        (1.5 * r[0] + 6.0 * r[1] + 0.3 * r[2]).backward()
+        for a, b2 in zip((mi, tc, kld), r):
+            assert abs(float(a.detach()) - float(b2.detach())) <= 2e-5 * max(1.0, abs(float(b2.detach()))), (Bk, D)
+        for a, b2 in zip(t, (zz, mm, ll)):
+            torch.testing.assert_close(a.grad, b2.grad, rtol=3e-4, atol=3e-5 * float(b2.grad.abs().max()))

@@ -404,3 +404,31 @@ def test_vamp_vae_forward_loss_grads(golden):
     for k, v in sd.items():
         if v.requires_grad:
             H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
+
+
+def test_betatc_vae_forward_loss_grads(golden):
+    """BetaTCVAE (own conv net without BatchNorm; mutual information / total correlation / dimension-wise KL from the [B,B,D]
+    log-density matrix with stratified importance weights): oracle against the reference's own betatc_vae.py fixture, two
+    consecutive loss calls (anneal counter)."""
+    g = golden("betatc_b8")
+    seed, B = int(g["seed"]), int(g["B"])
+    specs = H.betatc_specs()
+    assert [k for k, _, _ in specs] == list(g["keys"])
+    sd = O.leafify(filler.fill_state(specs, seed + 1))
+    x, e = filler.synthetic_batch(seed, B, latent_dim=10)
+    res = O.betatc_forward(sd, x, e)
+    np.testing.assert_allclose(res[2].detach().numpy(), g["mu"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(res[4].detach().numpy(), g["z"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(res[0].detach()[:, :, ::8, ::8].numpy(), g["recons_sub"], atol=TOL, rtol=0)
+    c = H.BETATC_CFG
+    for call, it in (("call1", 1), ("call2", 2)):
+        l = O.betatc_loss(*res, float(g["M_N"]), it, c["anneal_steps"], c["alpha"], c["beta"], c["gamma"])
+        for k, v in l.items():
+            want = float(g[f"{call}.{k}"])
+            assert abs(v.item() - want) <= TOL * max(1.0, abs(want)), (call, k, v.item(), want)
+        if it == 1:
+            l["loss"].backward()
+    np.testing.assert_allclose(sd["fc_var.bias"].grad.numpy(), g["grad.fc_var.bias"], atol=1e-5, rtol=1e-3)
+    for k, v in sd.items():
+        if v.requires_grad:
+            H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-4, what=k)
