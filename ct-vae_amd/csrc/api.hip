@@ -66,6 +66,14 @@ int launch_ct_mask_forward(const float* x, const float* action, const float* pe,
 int launch_ct_mask_backward(const float* x, const float* action, const float* pe, const float* keep, float scale,
                             const float* inter, const float* p, const float* soft, const float* g, int B, int S, int D, int A,
                             float* dWp, float* dbp, hipStream_t st);
+int launch_gamma_reparam_forward(const float* alpha, const float* beta, const float* zhat, float shape_b, float* z, long n, hipStream_t st);
+int launch_gamma_reparam_backward(const float* g, const float* alpha, const float* beta, const float* zhat, float shape_b, float* ga,
+                                  float* gb, long n, hipStream_t st);
+int launch_gamma_kl_forward(const float* alpha, const float* beta, int B, int D, float prior_alpha, float prior_beta, float* out,
+                            float* ws, size_t ws_bytes, hipStream_t st);
+int launch_gamma_kl_backward(const float* g, const float* alpha, const float* beta, int B, int D, float prior_alpha, float prior_beta,
+                             float* ga, float* gb, hipStream_t st);
+int launch_sigmoid(const float* x_or_g, const float* y, float* out, long n, int backward, hipStream_t st);
 int launch_tc_forward(const float* z, const float* mu, const float* lv, const float* liw, int B, int D, float* out3, float* lse_s,
                       float* lse_d, float* ws, size_t ws_bytes, hipStream_t st);
 int launch_tc_backward(const float* z, const float* mu, const float* lv, const float* liw, const float* lse_s, const float* lse_d,
@@ -625,6 +633,32 @@ int ctvae_l2l1_backward(const float* recons, const float* x, const float* g_loss
                         void* stream) {
   if (!recons || !x || !g_loss || !g_recons || n <= 0) return kErrBadArg;
   return launch_mse_backward(recons, x, g_loss, g_recons, n, (hipStream_t)stream, -1.f, recons_act);
+}
+
+int ctvae_gamma_reparam_forward(const float* alpha, const float* beta, const float* zhat, float gamma_shape, float* z, long n,
+                                void* stream) {
+  return launch_gamma_reparam_forward(alpha, beta, zhat, gamma_shape, z, n, (hipStream_t)stream);
+}
+
+int ctvae_gamma_reparam_backward(const float* g_z, const float* alpha, const float* beta, const float* zhat, float gamma_shape,
+                                 float* g_alpha, float* g_beta, long n, void* stream) {
+  return launch_gamma_reparam_backward(g_z, alpha, beta, zhat, gamma_shape, g_alpha, g_beta, n, (hipStream_t)stream);
+}
+
+int ctvae_gamma_kl_forward(const float* alpha, const float* beta, int B, int D, float prior_alpha, float prior_beta, float* out,
+                           float* ws, size_t ws_bytes, void* stream) {
+  return launch_gamma_kl_forward(alpha, beta, B, D, prior_alpha, prior_beta, out, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int ctvae_gamma_kl_backward(const float* g_kld, const float* alpha, const float* beta, int B, int D, float prior_alpha,
+                            float prior_beta, float* g_alpha, float* g_beta, void* stream) {
+  return launch_gamma_kl_backward(g_kld, alpha, beta, B, D, prior_alpha, prior_beta, g_alpha, g_beta, (hipStream_t)stream);
+}
+
+int ctvae_sigmoid_forward(const float* x, float* y, long n, void* stream) { return launch_sigmoid(x, nullptr, y, n, 0, (hipStream_t)stream); }
+
+int ctvae_sigmoid_backward(const float* g, const float* y, float* g_x, long n, void* stream) {
+  return launch_sigmoid(g, y, g_x, n, 1, (hipStream_t)stream);
 }
 
 int ctvae_tc_forward(const float* z, const float* mu, const float* logvar, const float* log_iw, int B, int D, float* out3, float* lse_s,

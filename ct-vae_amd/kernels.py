@@ -1203,6 +1203,79 @@ class GaussKL(Function):
         return g_mu, g_lv
 
 
+class GammaReparam(Function):
+    """z = h(alpha + Bs, h^-1(alpha + Bs, zhat)) / beta: GammaVAE.reparameterize (gamma_vae.py:108-149) with the draw
+    zhat ~ Gamma(alpha + Bs, 1) given.  csrc/gamma.hip."""
+
+    @staticmethod
+    def forward(ctx, alpha, beta, zhat, shape_b):
+        _req_cuda(alpha, beta, zhat)
+        alpha, beta, zhat = _c(alpha), _c(beta), _c(zhat)
+        z = torch.empty_like(alpha)
+        native.call("ctvae_gamma_reparam_forward", alpha.data_ptr(), beta.data_ptr(), zhat.data_ptr(), float(shape_b), z.data_ptr(),
+                    alpha.numel())
+        ctx.save_for_backward(alpha, beta, zhat)
+        ctx.shape_b = float(shape_b)
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        alpha, beta, zhat = ctx.saved_tensors
+        g = _c(g)
+        ga, gb = torch.empty_like(alpha), torch.empty_like(alpha)
+        native.call("ctvae_gamma_reparam_backward", g.data_ptr(), alpha.data_ptr(), beta.data_ptr(), zhat.data_ptr(), ctx.shape_b,
+                    ga.data_ptr(), gb.data_ptr(), alpha.numel())
+        return ga, gb, None, None
+
+
+class GammaKL(Function):
+    """mean_b sum_d [I(c,d,c,d) - I(1/alpha, beta, c, d)], c = 1/prior_alpha, d = prior_beta (gamma_vae.py:151-171)."""
+
+    @staticmethod
+    def forward(ctx, alpha, beta, prior_alpha, prior_beta):
+        _req_cuda(alpha, beta)
+        alpha, beta = _c(alpha), _c(beta)
+        B, D = alpha.shape
+        out = torch.empty(1, dtype=torch.float32, device=alpha.device)
+        ws = native.workspace(alpha.device)
+        native.call("ctvae_gamma_kl_forward", alpha.data_ptr(), beta.data_ptr(), B, D, float(prior_alpha), float(prior_beta),
+                    out.data_ptr(), ws.data_ptr(), ws.numel() * 4)
+        ctx.save_for_backward(alpha, beta)
+        ctx.prior = (float(prior_alpha), float(prior_beta))
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        alpha, beta = ctx.saved_tensors
+        B, D = alpha.shape
+        g = _c(g.reshape(1))
+        ga, gb = torch.empty_like(alpha), torch.empty_like(alpha)
+        native.call("ctvae_gamma_kl_backward", g.data_ptr(), alpha.data_ptr(), beta.data_ptr(), B, D, ctx.prior[0], ctx.prior[1],
+                    ga.data_ptr(), gb.data_ptr())
+        return ga, gb, None, None
+
+
+class Sigmoid(Function):
+    """nn.Sigmoid behind GammaVAE's final conv (gamma_vae.py:78) as an elementwise pair."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _req_cuda(x)
+        x = _c(x)
+        y = torch.empty_like(x)
+        native.call("ctvae_sigmoid_forward", x.data_ptr(), y.data_ptr(), x.numel())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = _c(g)
+        gx = torch.empty_like(y)
+        native.call("ctvae_sigmoid_backward", g.data_ptr(), y.data_ptr(), gx.data_ptr(), y.numel())
+        return gx
+
+
 class TCDecomp(Function):
     """(mi, tc, kld) of BetaTCVAE's KL decomposition (betatc_vae.py:128-199; csrc/tcvae.hip): z, mu, logvar [B,D] (D <= 32),
     log_iw [B,B] the log importance weights.  All three outputs carry gradient."""

@@ -18,6 +18,7 @@ from .twostage_vae import TwoStageVAE
 from .hvae import HVAE
 from .vampvae import VampVAE
 from .betatc_vae import BetaTCVAE
+from .gamma_vae import GammaVAE
 
 # Aliases (models/__init__.py:29-32)
 VAE = VanillaVAE
@@ -39,6 +40,7 @@ vae_models = {
     'DIPVAE': DIPVAE,         # VanillaVAE's network, sum-reduced objective + DIP-II covariance regulariser (dip_vae.py)
     'JointVAE': JointVAE,     # VanillaVAE's stacks, Gaussian + one categorical latent, capacity objective (joint_vae.py)
     'TwoStageVAE': TwoStageVAE,   # VanillaVAE's step; the second-stage MLPs are parameter holders, as in the reference (twostage_vae.py)
+    'GammaVAE': GammaVAE,     # VanillaVAE's stacks, Gamma latents (shape-augmentation reparameterisation, Gamma KL), Sigmoid output (gamma_vae.py)
     'BetaTCVAE': BetaTCVAE,   # own small conv net (no BatchNorm), total-correlation decomposition of the KL term (betatc_vae.py)
     'VampVAE': VampVAE,       # VanillaVAE's network, VampPrior over K learned pseudo-inputs (vampvae.py)
     'HVAE': HVAE,             # two latent levels, the second encoder conditioned on z2; three Gaussian-KL terms (hvae.py)

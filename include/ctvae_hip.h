@@ -391,6 +391,21 @@ int ctvae_l2l1_loss_forward(const float* recons, const float* x, long n, const f
                             void* stream);
 int ctvae_l2l1_backward(const float* recons, const float* x, const float* g_loss, float* g_recons, long n, int recons_act,
                         void* stream);
+/* GammaVAE (gamma_vae.py:108-193).  Reparameterisation by shape augmentation with the draw zhat ~ Gamma(alpha + gamma_shape, 1)
+ * given: z = h(a, h^-1(a, zhat)) / beta, a = alpha + gamma_shape (:108-149); backward g_alpha (both partials, as autograd forms
+ * them), g_beta.  KL of the Gamma posteriors to the Gamma(prior_alpha, prior_beta) prior as the reference writes it (:151-171),
+ * out[0] = mean_b sum_d; g_kld one float on the device.  The final layer's nn.Sigmoid (:78) as an elementwise pair
+ * (n % 4 == 0).  ws: >= 4*B bytes. */
+int ctvae_gamma_reparam_forward(const float* alpha, const float* beta, const float* zhat, float gamma_shape, float* z, long n,
+                                void* stream);
+int ctvae_gamma_reparam_backward(const float* g_z, const float* alpha, const float* beta, const float* zhat, float gamma_shape,
+                                 float* g_alpha, float* g_beta, long n, void* stream);
+int ctvae_gamma_kl_forward(const float* alpha, const float* beta, int B, int D, float prior_alpha, float prior_beta, float* out,
+                           float* ws, size_t ws_bytes, void* stream);
+int ctvae_gamma_kl_backward(const float* g_kld, const float* alpha, const float* beta, int B, int D, float prior_alpha,
+                            float prior_beta, float* g_alpha, float* g_beta, void* stream);
+int ctvae_sigmoid_forward(const float* x, float* y, long n, void* stream);
+int ctvae_sigmoid_backward(const float* g, const float* y, float* g_x, long n, void* stream);
 /* BetaTCVAE's decomposition of the KL term (betatc_vae.py:128-199) on z, mu, logvar [B][D] (D <= 32, 2 <= B <= 4096) with the
  * log importance weights log_iw [B][B] of minibatch stratified sampling (:176-184): M[i,j,d] = log N(z_i[d]; mu_j[d], e^lv_j[d]) +
  * log_iw[i,j]; log_q_z = logsumexp_j sum_d M, log_prod = sum_d logsumexp_j M, log_q_zx / log_p_z the sample's own and the

@@ -160,6 +160,37 @@ def hvae_loss(sd, recons, x, z1_mu, z1_lv, z2_mu, z2_lv, z1, z2, M_N):
     return {"loss": rl + M_N * kld_loss, "Reconstruction Loss": rl, "KLD": -kld_loss}
 
 
+def gamma_forward(sd, x, zhat, shape_b=8.0, training=True, new_buffers=None):
+    """GammaVAE.forward (gamma_vae.py:93-149) with the Gamma(alpha + B, 1) draw injected -> [recons, input, alpha, beta]."""
+    h = x
+    for i in range(5):
+        h = F.conv2d(h, sd[f"encoder.{i}.0.weight"], sd[f"encoder.{i}.0.bias"], stride=2, padding=1)
+        h = _bn_lrelu(sd, f"encoder.{i}.1", h, training, new_buffers)
+    flat = torch.flatten(h, start_dim=1)
+    alpha = torch.softmax(F.linear(flat, sd["fc_mu.0.weight"], sd["fc_mu.0.bias"]), dim=1)
+    beta = torch.softmax(F.linear(flat, sd["fc_var.0.weight"], sd["fc_var.0.bias"]), dim=1)
+    a = alpha + shape_b
+    eps = torch.sqrt(9. * a - 3.) * ((zhat / (a - 1. / 3.)) ** (1. / 3.) - 1.)
+    z = (a - 1. / 3.) * (1 + eps / torch.sqrt(9. * a - 3.)) ** 3 / beta
+    h = F.linear(z, sd["decoder_input.0.weight"], sd["decoder_input.0.bias"]).view(-1, 512, 2, 2)
+    for i in range(4):
+        h = F.conv_transpose2d(h, sd[f"decoder.{i}.0.weight"], sd[f"decoder.{i}.0.bias"], stride=2, padding=1, output_padding=1)
+        h = _bn_lrelu(sd, f"decoder.{i}.1", h, training, new_buffers)
+    h = F.conv_transpose2d(h, sd["final_layer.0.weight"], sd["final_layer.0.bias"], stride=2, padding=1, output_padding=1)
+    h = _bn_lrelu(sd, "final_layer.1", h, training, new_buffers)
+    return [torch.sigmoid(F.conv2d(h, sd["final_layer.3.weight"], sd["final_layer.3.bias"], padding=1)), x, alpha, beta]
+
+
+def gamma_loss(recons, x, alpha, beta, prior_alpha=2.0, prior_beta=1.0):
+    """gamma_vae.py:151-199."""
+    def I(a, b, c, d):
+        return -c * d / a - b * torch.log(a) - torch.lgamma(b) + (b - 1) * (torch.digamma(d) + torch.log(c))
+    c, d = 1 / torch.tensor([prior_alpha]), torch.tensor([prior_beta])
+    kld = torch.sum(I(c, d, c, d) - I(1 / alpha, beta, c, d), dim=1)
+    rl = torch.mean(F.mse_loss(recons, x, reduction='none'), dim=(1, 2, 3))
+    return {"loss": torch.mean(rl + kld, dim=0)}
+
+
 def betatc_forward(sd, x, e):
     """BetaTCVAE.forward (betatc_vae.py:84-126) with the Gaussian draws injected -> [recons, input, mu, log_var, z]."""
     h = x

@@ -184,6 +184,19 @@ def hvae_noise(seed, B, L1=64, L2=64):
     return torch.randn(B, L1, generator=g), torch.randn(B, L2, generator=g)
 
 
+def gamma_specs(L=128):
+    """state_dict keys/shapes of GammaVAE(in_channels=3, latent_dim=128): VanillaVAE's with the Linear layers under Sequential
+    child "0" (gamma_vae.py:43-49)."""
+    ren = {"fc_mu.": "fc_mu.0.", "fc_var.": "fc_var.0.", "decoder_input.": "decoder_input.0."}
+    out = []
+    for k, sh, dt in vanilla_specs():
+        for a, b in ren.items():
+            if k.startswith(a):
+                k = b + k[len(a):]
+        out.append((k, sh, dt))
+    return out
+
+
 BETATC_CFG = dict(in_channels=3, latent_dim=10, anneal_steps=10000, alpha=1., beta=6., gamma=1.)
 
 

@@ -432,3 +432,26 @@ def test_betatc_vae_forward_loss_grads(golden):
     for k, v in sd.items():
         if v.requires_grad:
             H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-4, what=k)
+
+
+def test_gamma_vae_forward_loss_grads(golden):
+    """GammaVAE (softmax heads, shape-augmentation reparameterisation of an injected Gamma draw, Gamma KL with lgamma / digamma,
+    Sigmoid output): oracle against the reference's own gamma_vae.py fixture."""
+    g = golden("gamma_b4")
+    seed, B = int(g["seed"]), int(g["B"])
+    specs = H.gamma_specs()
+    assert [k for k, _, _ in specs] == list(g["keys"])
+    sd = O.leafify(filler.fill_state(specs, seed + 1))
+    x, _ = filler.synthetic_batch(seed, B)
+    res = O.gamma_forward(sd, x, torch.from_numpy(g["zhat"]), 8.0, True, {})
+    np.testing.assert_allclose(res[2].detach().numpy(), g["alpha"], atol=1e-6, rtol=1e-4)
+    np.testing.assert_allclose(res[3].detach().numpy(), g["beta"], atol=1e-6, rtol=1e-4)
+    np.testing.assert_allclose(res[0].detach()[:, :, ::8, ::8].numpy(), g["recons_sub"], atol=TOL, rtol=0)
+    losses = O.gamma_loss(*res)
+    want = float(g["loss.loss"])
+    assert abs(losses["loss"].item() - want) <= TOL * max(1.0, abs(want)), (losses["loss"].item(), want)
+    losses["loss"].backward()
+    np.testing.assert_allclose(sd["fc_var.0.bias"].grad.numpy(), g["grad.fc_var.0.bias"], atol=1e-6, rtol=1e-3)
+    for k, v in sd.items():
+        if v.requires_grad:
+            H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
