@@ -66,6 +66,10 @@ int launch_ct_mask_forward(const float* x, const float* action, const float* pe,
 int launch_ct_mask_backward(const float* x, const float* action, const float* pe, const float* keep, float scale,
                             const float* inter, const float* p, const float* soft, const float* g, int B, int S, int D, int A,
                             float* dWp, float* dbp, hipStream_t st);
+int launch_ladder_forward(const float* mu_e, const float* lv_e, const float* mu_t, const float* lv_t, const float* eps, int B, int D,
+                          float* z, float* kl, hipStream_t st);
+int launch_ladder_backward(const float* gz, const float* gkl, const float* mu_e, const float* lv_e, const float* mu_t, const float* lv_t,
+                           const float* eps, int B, int D, float* g_mu_e, float* g_lv_e, float* g_mu_t, float* g_lv_t, hipStream_t st);
 int launch_gamma_reparam_forward(const float* alpha, const float* beta, const float* zhat, float shape_b, float* z, long n, hipStream_t st);
 int launch_gamma_reparam_backward(const float* g, const float* alpha, const float* beta, const float* zhat, float shape_b, float* ga,
                                   float* gb, long n, hipStream_t st);
@@ -633,6 +637,18 @@ int ctvae_l2l1_backward(const float* recons, const float* x, const float* g_loss
                         void* stream) {
   if (!recons || !x || !g_loss || !g_recons || n <= 0) return kErrBadArg;
   return launch_mse_backward(recons, x, g_loss, g_recons, n, (hipStream_t)stream, -1.f, recons_act);
+}
+
+int ctvae_ladder_merge_forward(const float* mu_e, const float* logvar_e, const float* mu_t, const float* logvar_t, const float* eps,
+                               int B, int D, float* z, float* kl, void* stream) {
+  return launch_ladder_forward(mu_e, logvar_e, mu_t, logvar_t, eps, B, D, z, kl, (hipStream_t)stream);
+}
+
+int ctvae_ladder_merge_backward(const float* g_z, const float* g_kl, const float* mu_e, const float* logvar_e, const float* mu_t,
+                                const float* logvar_t, const float* eps, int B, int D, float* g_mu_e, float* g_logvar_e,
+                                float* g_mu_t, float* g_logvar_t, void* stream) {
+  return launch_ladder_backward(g_z, g_kl, mu_e, logvar_e, mu_t, logvar_t, eps, B, D, g_mu_e, g_logvar_e, g_mu_t, g_logvar_t,
+                                (hipStream_t)stream);
 }
 
 int ctvae_gamma_reparam_forward(const float* alpha, const float* beta, const float* zhat, float gamma_shape, float* z, long n,

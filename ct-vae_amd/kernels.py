@@ -1203,6 +1203,37 @@ class GaussKL(Function):
         return g_mu, g_lv
 
 
+class LadderMerge(Function):
+    """(z, kl) of one LVAE rung (lvae.py:166-204; csrc/ladder.hip): merge of the bottom-up (mu_e, lv_e) and top-down (mu_t, lv_t)
+    Gaussians, reparameterised sample with eps, kl [B] between the merged and the bottom-up Gaussian."""
+
+    @staticmethod
+    def forward(ctx, mu_e, lv_e, mu_t, lv_t, eps):
+        _req_cuda(mu_e, lv_e, mu_t, lv_t, eps)
+        mu_e, lv_e, mu_t, lv_t, eps = (_c(t) for t in (mu_e, lv_e, mu_t, lv_t, eps))
+        B, D = mu_e.shape
+        z = torch.empty_like(mu_e)
+        kl = torch.empty(B, dtype=torch.float32, device=mu_e.device)
+        native.call("ctvae_ladder_merge_forward", mu_e.data_ptr(), lv_e.data_ptr(), mu_t.data_ptr(), lv_t.data_ptr(), eps.data_ptr(),
+                    B, D, z.data_ptr(), kl.data_ptr())
+        ctx.save_for_backward(mu_e, lv_e, mu_t, lv_t, eps)
+        ctx.set_materialize_grads(False)
+        return z, kl
+
+    @staticmethod
+    def backward(ctx, gz, gkl):
+        mu_e, lv_e, mu_t, lv_t, eps = ctx.saved_tensors
+        if gz is None and gkl is None:
+            return (None,) * 5
+        B, D = mu_e.shape
+        gz = _c(gz) if gz is not None else None
+        gkl = _c(gkl) if gkl is not None else None
+        outs = [torch.empty_like(mu_e) for _ in range(4)]
+        native.call("ctvae_ladder_merge_backward", native.ptr(gz), native.ptr(gkl), mu_e.data_ptr(), lv_e.data_ptr(), mu_t.data_ptr(),
+                    lv_t.data_ptr(), eps.data_ptr(), B, D, *[o.data_ptr() for o in outs])
+        return outs[0], outs[1], outs[2], outs[3], None
+
+
 class GammaReparam(Function):
     """z = h(alpha + Bs, h^-1(alpha + Bs, zhat)) / beta: GammaVAE.reparameterize (gamma_vae.py:108-149) with the draw
     zhat ~ Gamma(alpha + Bs, 1) given.  csrc/gamma.hip."""

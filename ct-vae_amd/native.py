@@ -81,6 +81,8 @@ SIGNATURES = {
     "ctvae_iw_loss_backward": [_fp, _fp, _l, _i, _i, _fp, _fp, _i, _f, _fp, _fp, _fp, _fp, _fp, _vp],
     "ctvae_l2l1_loss_forward": [_fp, _fp, _l, _fp, _fp, _fp, _sz, _vp],
     "ctvae_l2l1_backward": [_fp, _fp, _fp, _fp, _l, _i, _vp],
+    "ctvae_ladder_merge_forward": [_fp, _fp, _fp, _fp, _fp, _i, _i, _fp, _fp, _vp],
+    "ctvae_ladder_merge_backward": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp, _fp, _fp, _fp, _vp],
     "ctvae_gamma_reparam_forward": [_fp, _fp, _fp, _f, _fp, _l, _vp],
     "ctvae_gamma_reparam_backward": [_fp, _fp, _fp, _fp, _f, _fp, _fp, _l, _vp],
     "ctvae_gamma_kl_forward": [_fp, _fp, _i, _i, _f, _f, _fp, _fp, _sz, _vp],

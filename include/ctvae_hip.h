@@ -391,6 +391,14 @@ int ctvae_l2l1_loss_forward(const float* recons, const float* x, long n, const f
                             void* stream);
 int ctvae_l2l1_backward(const float* recons, const float* x, const float* g_loss, float* g_recons, long n, int recons_act,
                         void* stream);
+/* One rung of LVAE's top-down pass (lvae.py:166-204) on [B][D] tensors: merge_gauss of the bottom-up (mu_e, logvar_e) and the
+ * top-down (mu_t, logvar_t) Gaussians, z = eps * exp(logvar/2) + mu of the merged one, kl[b] = sum_d compute_kl_divergence(merged,
+ * bottom-up) as the reference writes it.  Backward: g_z [B][D] and / or g_kl [B] -> gradients of the four inputs. */
+int ctvae_ladder_merge_forward(const float* mu_e, const float* logvar_e, const float* mu_t, const float* logvar_t, const float* eps,
+                               int B, int D, float* z, float* kl, void* stream);
+int ctvae_ladder_merge_backward(const float* g_z, const float* g_kl, const float* mu_e, const float* logvar_e, const float* mu_t,
+                                const float* logvar_t, const float* eps, int B, int D, float* g_mu_e, float* g_logvar_e,
+                                float* g_mu_t, float* g_logvar_t, void* stream);
 /* GammaVAE (gamma_vae.py:108-193).  Reparameterisation by shape augmentation with the draw zhat ~ Gamma(alpha + gamma_shape, 1)
  * given: z = h(a, h^-1(a, zhat)) / beta, a = alpha + gamma_shape (:108-149); backward g_alpha (both partials, as autograd forms
  * them), g_beta.  KL of the Gamma posteriors to the Gamma(prior_alpha, prior_beta) prior as the reference writes it (:151-171),

@@ -160,6 +160,45 @@ def hvae_loss(sd, recons, x, z1_mu, z1_lv, z2_mu, z2_lv, z1, z2, M_N):
     return {"loss": rl + M_N * kld_loss, "Reconstruction Loss": rl, "KLD": -kld_loss}
 
 
+def lvae_forward(sd, x, eps, latent_dims=(4, 8, 16, 32, 128), training=True, new_buffers=None):
+    """LVAE.forward (lvae.py:137-222) with the Gaussian draws injected (eps[0]: top latent; eps[1:]: the rungs, top-down)
+    -> [recons, input, kl_div [B]]."""
+    n = len(latent_dims)
+    h, post = x, []
+    for i in range(n):
+        h = F.conv2d(h, sd[f"encoders.{i}.encoder.0.weight"], sd[f"encoders.{i}.encoder.0.bias"], stride=2, padding=1)
+        h = _bn_lrelu(sd, f"encoders.{i}.encoder.1", h, training, new_buffers)
+        f = torch.flatten(h, start_dim=1)
+        post.append((F.linear(f, sd[f"encoders.{i}.encoder_mu.weight"], sd[f"encoders.{i}.encoder_mu.bias"]),
+                     F.linear(f, sd[f"encoders.{i}.encoder_var.weight"], sd[f"encoders.{i}.encoder_var.bias"])))
+    mu, lv = post.pop()
+    z = vanilla_reparameterize(mu, lv, eps[0])
+    post.reverse()
+    kl_div = 0
+    for i in range(n - 1):
+        mu_e, lv_e = post[i]
+        p = f"ladders.{i}"
+        d = F.linear(z, sd[p + ".decode.0.weight"], sd[p + ".decode.0.bias"])
+        rm, rv = sd[p + ".decode.1.running_mean"].detach().clone(), sd[p + ".decode.1.running_var"].detach().clone()
+        d = F.batch_norm(d, rm, rv, sd[p + ".decode.1.weight"], sd[p + ".decode.1.bias"], training, BN_MOMENTUM, BN_EPS)
+        if training and new_buffers is not None:
+            new_buffers[p + ".decode.1.running_mean"], new_buffers[p + ".decode.1.running_var"] = rm, rv
+        mu_t = F.linear(d, sd[p + ".fc_mu.weight"], sd[p + ".fc_mu.bias"])
+        lv_t = F.linear(d, sd[p + ".fc_var.weight"], sd[p + ".fc_var.bias"])
+        p1, p2 = 1. / (lv_e.exp() + 1e-7), 1. / (lv_t.exp() + 1e-7)
+        mu_m, lv_m = (mu_e * p1 + mu_t * p2) / (p1 + p2), torch.log(1. / (p1 + p2))
+        z = vanilla_reparameterize(mu_m, lv_m, eps[1 + i])
+        kl = (lv_e - lv_m) + (lv_m.exp() + (mu_m - mu_e) ** 2) / (2 * lv_e.exp()) - 0.5
+        kl_div = kl_div + torch.sum(kl, dim=-1)
+    return [vanilla_decode(sd, z, training, new_buffers), x, kl_div]
+
+
+def lvae_loss(recons, x, kl_div, M_N):
+    """lvae.py:224-244."""
+    rl, kld = F.mse_loss(recons, x), torch.mean(kl_div, dim=0)
+    return {"loss": rl + M_N * kld, "Reconstruction_Loss": rl, "KLD": -kld}
+
+
 def gamma_forward(sd, x, zhat, shape_b=8.0, training=True, new_buffers=None):
     """GammaVAE.forward (gamma_vae.py:93-149) with the Gamma(alpha + B, 1) draw injected -> [recons, input, alpha, beta]."""
     h = x

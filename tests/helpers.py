@@ -184,6 +184,16 @@ def hvae_noise(seed, B, L1=64, L2=64):
     return torch.randn(B, L1, generator=g), torch.randn(B, L2, generator=g)
 
 
+LVAE_CFG = dict(in_channels=3, latent_dims=[4, 8, 16, 32, 128], hidden_dims=[32, 64, 128, 256, 512])
+
+
+def lvae_noise(seed, B, latent_dims=(4, 8, 16, 32, 128)):
+    """[top latent draw, then one per rung top-down] -- the order LVAE.forward consumes them (lvae.py:170-222)."""
+    g = torch.Generator().manual_seed(seed + 8)
+    dims = [latent_dims[-1]] + [latent_dims[i - 1] for i in range(len(latent_dims) - 1, 0, -1)]
+    return [torch.randn(B, d, generator=g) for d in dims]
+
+
 def gamma_specs(L=128):
     """state_dict keys/shapes of GammaVAE(in_channels=3, latent_dim=128): VanillaVAE's with the Linear layers under Sequential
     child "0" (gamma_vae.py:43-49)."""

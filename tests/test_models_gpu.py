@@ -446,6 +446,7 @@ ZOO = [("VanillaVAE", dict(in_channels=3, latent_dim=128)),
        ("VampVAE", dict(in_channels=3, latent_dim=128)),
        ("BetaTCVAE", dict(H.BETATC_CFG)),
        ("GammaVAE", dict(in_channels=3, latent_dim=128, gamma_shape=8., prior_shape=2., prior_rate=1.)),
+       ("LVAE", dict(H.LVAE_CFG)),
        ("CategoricalVAE", dict(in_channels=3, latent_dim=64, categorical_dim=40, temperature=0.5, alpha=1.0)),
        ("VQVAE", dict(in_channels=3, embedding_dim=64, num_embeddings=512, img_size=64, beta=0.25)),
        ("MCQVAE", dict(in_channels=3, embedding_dim=128, hidden_dims=[64, 128, 256], num_embeddings=64, img_size=64, codebooks=4, beta=0.25))]
@@ -905,3 +906,51 @@ def test_gamma_vae_vs_golden(dev, golden):
     torch.testing.assert_close(be.grad, b2.grad, rtol=2e-4, atol=1e-4 * float(b2.grad.abs().max()))
     # d z / d alpha cancels analytically; what is left on both sides is rounding, compare through the KL part's scale
     assert float((al.grad - a2.grad).abs().max()) <= 1e-3 * max(1.0, float(a2.grad.abs().max()))
+
+
+def test_lvae_vs_golden(dev, golden):
+    """LVAE against the reference's own lvae.py fixture: per-sample KL of the four rungs, reconstruction, loss dict, every
+    gradient, BatchNorm1d / BatchNorm2d running statistics; the rung kernel against the torch expressions."""
+    from ctvae_amd import kernels as K
+    from ctvae_amd.models import vae_models
+    g = golden("lvae_b4")
+    seed, B = int(g["seed"]), int(g["B"])
+    m = vae_models["LVAE"](**{k: (list(v) if isinstance(v, list) else v) for k, v in H.LVAE_CFG.items()})
+    assert list(m.state_dict().keys()) == list(g["keys"])
+    m.load_state_dict(filler.fill_state(filler.specs_of(m), seed + 1))
+    m = m.to(dev).train()
+    x, _ = filler.synthetic_batch(seed, B)
+    out = m(x.to(dev), eps=[e.to(dev) for e in H.lvae_noise(seed, B)])
+    np.testing.assert_allclose(out[2].detach().cpu().numpy(), g["kl_div"], atol=2e-3, rtol=2e-4)
+    np.testing.assert_allclose(out[0].detach()[:, :, ::8, ::8].cpu().numpy(), g["recons_sub"], atol=TOL, rtol=0)
+    losses = m.loss_function(*out, M_N=float(g["M_N"]))
+    for k, v in losses.items():
+        want = float(g["loss." + k])
+        assert abs(float(v.detach()) - want) <= TOL * max(1.0, abs(want)), (k, float(v.detach()), want)
+    m.zero_grad()
+    losses["loss"].backward()
+    np.testing.assert_allclose(m.ladders[0].fc_var.bias.grad.cpu().numpy(), g["grad.ladders.0.fc_var.bias"], atol=2e-7, rtol=2e-3)
+    np.testing.assert_allclose(m.encoders[2].encoder_mu.bias.grad.cpu().numpy(), g["grad.encoders.2.encoder_mu.bias"], atol=2e-7, rtol=2e-3)
+    for k, p in m.named_parameters():
+        H.assert_cks_close(H.cks(p.grad), g["gradcks." + k], rtol=2e-3, atol=2e-5, what=k)
+    for k, b in m.named_buffers():
+        if "running" in k:
+            H.assert_cks_close(H.cks(b), g["buf." + k], rtol=1e-4, atol=1e-5, what=k)
+    assert m.sample(3, dev).shape == (3, 3, 64, 64)
+    gen = torch.Generator().manual_seed(2)
+    t = [torch.randn(9, 20, generator=gen).to(dev).requires_grad_(True) for _ in range(4)]
+    e = torch.randn(9, 20, generator=gen).to(dev)
+    wz, wk = torch.randn(9, 20, generator=gen).to(dev), torch.randn(9, generator=gen).to(dev)
+    z, kl = K.LadderMerge.apply(*t, e)
+    ((z * wz).sum() + (kl * wk).sum()).backward()
+    t2 = [v.detach().clone().requires_grad_(True) for v in t]
+    mu_e, lv_e, mu_t, lv_t = t2
+    p1, p2 = 1. / (lv_e.exp() + 1e-7), 1. / (lv_t.exp() + 1e-7)
+    mu_m, lv_m = (mu_e * p1 + mu_t * p2) / (p1 + p2), torch.log(1. / (p1 + p2))
+    zr = e * torch.exp(0.5 * lv_m) + mu_m
+    klr = torch.sum((lv_e - lv_m) + (lv_m.exp() + (mu_m - mu_e) ** 2) / (2 * lv_e.exp()) - 0.5, dim=-1)
+    ((zr * wz).sum() + (klr * wk).sum()).backward()
+    torch.testing.assert_close(z, zr, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(kl, klr, rtol=1e-5, atol=1e-4)
+    for a, b2 in zip(t, t2):
+        torch.testing.assert_close(a.grad, b2.grad, rtol=2e-4, atol=2e-5 * float(b2.grad.abs().max()))

@@ -455,3 +455,27 @@ def test_gamma_vae_forward_loss_grads(golden):
     for k, v in sd.items():
         if v.requires_grad:
             H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
+
+
+def test_lvae_forward_loss_grads(golden):
+    """LVAE (ladder VAE: per-level heads bottom-up; precision merge, sample and KL per rung top-down): oracle against the
+    reference's own lvae.py fixture with all five noise draws injected."""
+    from ctvae_amd.models import vae_models
+    g = golden("lvae_b4")
+    seed, B = int(g["seed"]), int(g["B"])
+    specs = filler.specs_of(vae_models["LVAE"](**{k: (list(v) if isinstance(v, list) else v) for k, v in H.LVAE_CFG.items()}))
+    assert [k for k, _, _ in specs] == list(g["keys"])           # the product mirrors the reference's state_dict, key for key
+    sd = O.leafify(filler.fill_state(specs, seed + 1))
+    x, _ = filler.synthetic_batch(seed, B)
+    res = O.lvae_forward(sd, x, H.lvae_noise(seed, B), training=True, new_buffers={})
+    np.testing.assert_allclose(res[2].detach().numpy(), g["kl_div"], atol=1e-3, rtol=1e-4)
+    np.testing.assert_allclose(res[0].detach()[:, :, ::8, ::8].numpy(), g["recons_sub"], atol=TOL, rtol=0)
+    losses = O.lvae_loss(*res, float(g["M_N"]))
+    for k, v in losses.items():
+        want = float(g["loss." + k])
+        assert abs(v.item() - want) <= TOL * max(1.0, abs(want)), (k, v.item(), want)
+    losses["loss"].backward()
+    np.testing.assert_allclose(sd["ladders.0.fc_var.bias"].grad.numpy(), g["grad.ladders.0.fc_var.bias"], atol=1e-7, rtol=1e-3)
+    for k, v in sd.items():
+        if v.requires_grad:
+            H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
