@@ -40,6 +40,12 @@ int launch_bn_backward(const float* ga, const float* beta, const float* y, int R
 int launch_wino_filters_batch(int n, const float* const* W, float* const* Uf, float* const* Ub, const int* Ci, const int* Co,
                               hipStream_t st);
 bool upconv_wgrad_supported(const ConvGeom& g);
+bool img_conv_supported(const ConvGeom& g);
+int launch_img_backward_fused(const ConvGeom& g, const float* dY, const float* W, float* dX, const BnBwdFuse* bnb, float* ws,
+                              float** part_out, float** pbias_out, int* nparts, bool want_bias, hipStream_t st);
+size_t img_backward_fused_ws_floats(const ConvGeom& g);
+int wgrad_finish_slabs(const float* part, float* dW, long n, int nparts, const float* pbias, float* dbias, long nb, int accumulate,
+                       hipStream_t st);
 int launch_permute(const float* in, float* out, int B, int C, int P, int to_nhwc, hipStream_t st);
 int launch_gat_score(int mode, const float* xl, const float* xr, const float* attr, const float* we, const float* att, float* out,
                      int B, int N, int H, int C, float slope, hipStream_t st);
@@ -151,6 +157,23 @@ int launch_vq_backward(const float* gq, const float* gvq, const float* lat, cons
 
 using namespace ctvae;
 
+// `kind` of the conv entry points: CTVAE_CONV / CTVAE_CONVT, for CTVAE_CONV optionally | CTVAE_W_CI_TAP (weights stored
+// [Ci][tap][Co]: the block of a Linear layer over torch.flatten(NCHW), run as a k x k convolution on the NHWC tensor)
+static bool conv_kind_ok(int kind) {
+  const int base = kind & ~CTVAE_W_CI_TAP;
+  return base == CTVAE_CONV || (base == CTVAE_CONVT && !(kind & CTVAE_W_CI_TAP));
+}
+// gkind0: 0 for the forward / weight-gradient geometry, 2 for the data gradient's
+static int conv_geom(ConvGeom& g, int kind, int gkind0, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad) {
+  const int rc = build_geom(g, gkind0 + ((kind & ~CTVAE_W_CI_TAP) == CTVAE_CONV ? 0 : 1), B, H, W, Ci, Co, k, stride, pad, out_pad);
+  if (rc) return rc;
+  if (kind & CTVAE_W_CI_TAP) {
+    g.wts = Co;
+    g.wrs = k * k * Co;
+  }
+  return 0;
+}
+
 extern "C" {
 
 const char* ctvae_version(void) { return "0.1.0"; }
@@ -178,10 +201,10 @@ int ctvae_conv_forward(int kind, const float* x, const float* w, const float* bi
                        int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int act, const float* in_scale,
                        const float* in_shift, int in_act, float* wino_dgrad_filters_out, const float* wino_fwd_filters, float* ws,
                        size_t ws_bytes, void* stream) {
-  if (!x || !w || !y || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
+  if (!x || !w || !y || !conv_kind_ok(kind)) return kErrBadArg;
   if ((in_scale != nullptr) != (in_shift != nullptr)) return kErrBadArg;
   ConvGeom g;
-  if (build_geom(g, kind == CTVAE_CONV ? 0 : 1, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
+  if (conv_geom(g, kind, 0, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
   if ((wino_dgrad_filters_out != nullptr || wino_fwd_filters != nullptr) &&
       !ctvae_conv_wino_filter_floats(kind, B, H, W, Ci, Co, k, stride, pad, out_pad, ws_bytes))
     return kErrBadArg;
@@ -209,9 +232,9 @@ size_t ctvae_conv_wino_filter_floats(int kind, int B, int H, int W, int Ci, int 
 
 int ctvae_conv_input_transform_supported(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad,
                                          int out_pad) {
-  if (kind != CTVAE_CONV && kind != CTVAE_CONVT) return 0;
+  if (!conv_kind_ok(kind)) return 0;
   ConvGeom g;
-  if (build_geom(g, kind == CTVAE_CONV ? 0 : 1, B, H, W, Ci, Co, k, stride, pad, out_pad)) return 0;
+  if (conv_geom(g, kind, 0, B, H, W, Ci, Co, k, stride, pad, out_pad)) return 0;
   return (thin_forward_supported(g) && thin_wgrad_supported(g)) ? 1 : 0;
 }
 
@@ -221,13 +244,13 @@ int ctvae_conv_bn_act_forward(int kind, const float* x, const float* w, const fl
                               float* scale_shift_out, int64_t* num_batches_tracked, int B, int H, int W, int Ci, int Co, int k,
                               int stride, int pad, int out_pad, float* ws, size_t ws_bytes, void* stream) {
   long long* nbt = (long long*)num_batches_tracked;
-  if (!x || !w || !gamma || !beta || !y || !ws || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
+  if (!x || !w || !gamma || !beta || !y || !ws || !conv_kind_ok(kind)) return kErrBadArg;
   if (!a_out && !scale_shift_out) return kErrBadArg;   // either materialise a or hand out the coefficients
   if (training && (!save_mean || !save_invstd)) return kErrBadArg;
   if (!training && (!running_mean || !running_var)) return kErrBadArg;
   if (Co % 4 != 0) return kErrBadArg;
   ConvGeom g;
-  if (build_geom(g, kind == CTVAE_CONV ? 0 : 1, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
+  if (conv_geom(g, kind, 0, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
   const size_t wsf = ws_bytes / sizeof(float);
   TapGemmPlan plan;
   tapgemm_plan(g, wsf, plan);
@@ -250,9 +273,9 @@ int ctvae_conv_bn_act_forward(int kind, const float* x, const float* w, const fl
 int ctvae_conv_dgrad(int kind, const float* dy, const float* w, const float* add, const float* mask, int mask_act,
                      float* dx, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
                      const float* wino_filters, float* ws, size_t ws_bytes, void* stream) {
-  if (!dy || !w || !dx || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
+  if (!dy || !w || !dx || !conv_kind_ok(kind)) return kErrBadArg;
   ConvGeom g;
-  if (build_geom(g, kind == CTVAE_CONV ? 2 : 3, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
+  if (conv_geom(g, kind, 2, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
   if (wino_filters != nullptr && !ctvae_conv_wino_filter_floats(kind, B, H, W, Ci, Co, k, stride, pad, out_pad, ws_bytes))
     return kErrBadArg;
   const WinoFilters wf{wino_filters, nullptr};
@@ -262,9 +285,9 @@ int ctvae_conv_dgrad(int kind, const float* dy, const float* w, const float* add
 
 int ctvae_conv_dgrad_bn_rows(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
                              size_t ws_bytes) {
-  if (kind != CTVAE_CONV && kind != CTVAE_CONVT) return 0;
+  if (!conv_kind_ok(kind)) return 0;
   ConvGeom g;
-  if (build_geom(g, kind == CTVAE_CONV ? 2 : 3, B, H, W, Ci, Co, k, stride, pad, out_pad)) return 0;
+  if (conv_geom(g, kind, 2, B, H, W, Ci, Co, k, stride, pad, out_pad)) return 0;
   return tapgemm_bnb_rows(g, ws_bytes / sizeof(float));
 }
 
@@ -273,10 +296,10 @@ int ctvae_conv_dgrad_bn(int kind, const float* dy, const float* w, const float* 
                         const float* bn_y, const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
                         const float* bn_beta, int bn_act, float* bn_part, int bn_part_rows, float* ws, size_t ws_bytes,
                         void* stream) {
-  if (!dy || !w || !dx || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
+  if (!dy || !w || !dx || !conv_kind_ok(kind)) return kErrBadArg;
   if (!bn_y || !bn_mean || !bn_invstd || !bn_gamma || !bn_beta || !bn_part) return kErrBadArg;
   ConvGeom g;
-  if (build_geom(g, kind == CTVAE_CONV ? 2 : 3, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
+  if (conv_geom(g, kind, 2, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
   const int rows = tapgemm_bnb_rows(g, ws_bytes / sizeof(float));
   if (rows <= 0 || rows != bn_part_rows) return kErrBadArg;
   if (img_dgrad_supported(g) && (add != nullptr || mask != nullptr)) return kErrBadArg;   // image kernel has no add/mask
@@ -289,11 +312,11 @@ int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float
                      int Co, int k, int stride, int pad, int out_pad, int accumulate, const float* in_scale,
                      const float* in_shift, int in_act, const float* dy_bn_y, const float* dy_bn_coef, int dy_bn_act,
                      float* gy_out, float* ws, size_t ws_bytes, void* stream) {
-  if (!x || !dy || !dw || !ws || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
+  if (!x || !dy || !dw || !ws || !conv_kind_ok(kind)) return kErrBadArg;
   if ((in_scale != nullptr) != (in_shift != nullptr)) return kErrBadArg;
   if ((dy_bn_y != nullptr) != (dy_bn_coef != nullptr) || (dy_bn_y != nullptr) != (gy_out != nullptr)) return kErrBadArg;
   ConvGeom g;
-  if (build_geom(g, kind == CTVAE_CONV ? 0 : 1, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
+  if (conv_geom(g, kind, 0, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
   const InXform xf{in_scale, in_shift, in_act};
   const DyXform dyx{dy_bn_y, dy_bn_coef, gy_out, dy_bn_act};
   return launch_wgrad(g, x, dy, dw, dbias, ws, ws_bytes, accumulate, (hipStream_t)stream, &xf, &dyx);
@@ -301,9 +324,9 @@ int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float
 
 int ctvae_conv_backward_bn_rows(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
                                 size_t ws_bytes) {
-  if (kind != CTVAE_CONV && kind != CTVAE_CONVT) return 0;
+  if (!conv_kind_ok(kind)) return 0;
   ConvGeom g;
-  if (build_geom(g, kind == CTVAE_CONV ? 2 : 3, B, H, W, Ci, Co, k, stride, pad, out_pad)) return 0;
+  if (conv_geom(g, kind, 2, B, H, W, Ci, Co, k, stride, pad, out_pad)) return 0;
   PairCtx ctx;                      // plan as ctvae_conv_backward does
   pair_ctx() = &ctx;
   const int rows = tapgemm_bnb_rows(g, ((ws_bytes / 2) & ~(size_t)255) / sizeof(float));
@@ -319,7 +342,7 @@ int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* 
                         const float* in_scale, const float* in_shift, int in_act,
                         const float* dy_bn_y, const float* dy_bn_coef, int dy_bn_act, float* gy_out, float* ws, size_t ws_bytes,
                         void* stream) {
-  if (!x || !dy || !w || !dw || !dx || !ws || (kind != CTVAE_CONV && kind != CTVAE_CONVT)) return kErrBadArg;
+  if (!x || !dy || !w || !dw || !dx || !ws || !conv_kind_ok(kind)) return kErrBadArg;
   const bool bn = bn_part != nullptr;
   if (bn_coef_out != nullptr && !bn) return kErrBadArg;
   if ((bn_dgamma != nullptr) != (bn_dbeta != nullptr) || (bn_dgamma != nullptr && bn_coef_out == nullptr)) return kErrBadArg;
@@ -327,8 +350,8 @@ int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* 
   if ((dy_bn_y != nullptr) != (dy_bn_coef != nullptr) || (dy_bn_y != nullptr) != (gy_out != nullptr)) return kErrBadArg;
   if (bn && (!bn_y || !bn_mean || !bn_invstd || !bn_gamma || !bn_beta)) return kErrBadArg;
   ConvGeom gw, gd;
-  if (build_geom(gw, kind == CTVAE_CONV ? 0 : 1, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
-  if (build_geom(gd, kind == CTVAE_CONV ? 2 : 3, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
+  if (conv_geom(gw, kind, 0, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
+  if (conv_geom(gd, kind, 2, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
   // the two GEMMs run concurrently: each gets its own half of the workspace
   const size_t half_bytes = (ws_bytes / 2) & ~(size_t)255, half_floats = half_bytes / sizeof(float);
   float* ws_d = ws + half_floats;
@@ -354,13 +377,27 @@ int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* 
   }
   const InXform xf{in_scale, in_shift, in_act};
   const DyXform dyx{dy_bn_y, dy_bn_coef, gy_out, dy_bn_act};
-  int rc = launch_wgrad(gw, x, dy, dw, dbias, ws, half_bytes, accumulate, st, &xf, &dyx);
-  if (!rc) {
+  // diagnostic: CTVAE_IMG_BWD_FUSED=0 keeps the picture-side conv's weight gradient and data gradient as two kernels
+  static const int img_fused = [] { const char* e = getenv("CTVAE_IMG_BWD_FUSED"); return e ? atoi(e) : 1; }();
+  int rc;
+  if (img_fused && bn && x == bn_y && in_scale != nullptr && in_act == bn_act && mask == nullptr && dy_bn_y == nullptr &&
+      img_conv_supported(gw) && img_dgrad_supported(gd) && img_backward_fused_ws_floats(gd) <= half_floats) {
+    // picture-side conv behind BatchNorm + activation (final_layer.1-3): the data gradient's pass over y also forms the
+    // weight gradient (image.hip img_bwd_fused_kernel) -- x of the weight gradient is act(BN(y)), which that pass computes
+    float *part = nullptr, *pb = nullptr;
+    int np = 0;
+    const BnBwdFuse f{bn_y, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_act, bn_part};
+    rc = launch_img_backward_fused(gd, dy, w, dx, &f, ws, &part, &pb, &np, dbias != nullptr, st);
+    if (!rc) rc = wgrad_finish_slabs(part, dw, 9L * 32 * 3, np, pb, dbias, 3L, accumulate, st);
+  } else {
+    rc = launch_wgrad(gw, x, dy, dw, dbias, ws, half_bytes, accumulate, st, &xf, &dyx);
+    if (!rc) {
     const WinoFilters wf{wino_filters, nullptr};
     const BnBwdFuse f{bn_y, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_act, bn_part};
     // dy_bn_*: dy was g_a of the BatchNorm behind this layer; the weight-gradient kernel left g_y in gy_out for the data gradient
-    rc = launch_tapgemm(gd, gy_out != nullptr ? gy_out : dy, w, nullptr, nullptr, mask, mask_act, dx, ACT_NONE, nullptr, ws_d,
-                        half_floats, st, bn ? &f : nullptr, nullptr, &wf);
+      rc = launch_tapgemm(gd, gy_out != nullptr ? gy_out : dy, w, nullptr, nullptr, mask, mask_act, dx, ACT_NONE, nullptr, ws_d,
+                          half_floats, st, bn ? &f : nullptr, nullptr, &wf);
+    }
   }
   pair_ctx() = nullptr;
   if (rc) return rc;
@@ -373,9 +410,9 @@ int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* 
 }
 
 int ctvae_conv_wgrad_bn_apply_supported(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad) {
-  if (kind != CTVAE_CONV && kind != CTVAE_CONVT) return 0;
+  if (!conv_kind_ok(kind)) return 0;
   ConvGeom g;
-  if (build_geom(g, kind == CTVAE_CONV ? 0 : 1, B, H, W, Ci, Co, k, stride, pad, out_pad)) return 0;
+  if (conv_geom(g, kind, 0, B, H, W, Ci, Co, k, stride, pad, out_pad)) return 0;
   return upconv_wgrad_supported(g) ? 1 : 0;
 }
 

@@ -43,6 +43,8 @@ struct ConvGeom {
   int ncls;
   int wCi, wCo;     // weight storage [ntaps_total][wCi][wCo]
   int wT;           // 0: Wmat[t][c][n] = W[t][c][n] (c<wCi,n<wCo); 1: Wmat[t][c][n] = W[t][n][c] (c<wCo,n<wCi)
+  int wts, wrs;     // element W[t][r][j] sits at t*wts + r*wrs + j floats: (wCi*wCo, wCo) for the packed [tap][Ci][Co] layout,
+                    // (wCo, ntaps*wCo) for [Ci][tap][Co] -- a Linear layer over torch.flatten(NCHW) read as a k x k convolution
   int ntaps[kMaxCls];
   int py[kMaxCls], px[kMaxCls];
   Tap taps[kMaxCls][kMaxTaps];
@@ -63,6 +65,8 @@ CTVAE_HD int gather_pix(const ConvGeom& g, int b, int qy, int qx, const Tap& t) 
   if ((unsigned)iy >= (unsigned)g.gH || (unsigned)ix >= (unsigned)g.gW) return -1;
   return (b * g.gH + iy) * g.gW + ix;
 }
+
+CTVAE_HD bool packed_weights(const ConvGeom& g) { return g.wrs == g.wCo && g.wts == g.wCi * g.wCo; }
 
 CTVAE_HD int scatter_pix(const ConvGeom& g, int cls, int b, int qy, int qx) {
   return (b * g.sH + qy * g.os + g.py[cls]) * g.sW + qx * g.os + g.px[cls];
@@ -97,6 +101,8 @@ inline int build_geom(ConvGeom& g, int kind, int B, int H, int W, int Ci, int Co
   g.B = B;
   g.wCi = Ci;
   g.wCo = Co;
+  g.wts = Ci * Co;
+  g.wrs = Co;
   const bool fwd = (kind == 0 || kind == 1);
   g.wT = fwd ? 0 : 1;
   // "conv-like" geometry: gather with stride, scatter dense.  "convT-like": gather dense, scatter strided.

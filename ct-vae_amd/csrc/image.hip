@@ -518,6 +518,140 @@ __global__ __launch_bounds__(256, 4) void img_dgrad_kernel(const ImgArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The whole backward of the picture-side conv behind a BatchNorm + activation (vanilla_vae.py:71-74, final_layer.1-3) in
+// ONE pass over y: img_dgrad_kernel with its BatchNorm-backward sums, plus the weight gradient.  The data gradient already
+// holds, per lane, y[pixel(r, lh)][ci = li] for the 16 pixels r of its 32-pixel row block -- which is the A operand
+// (M = ci, K = pixel) of  dW[t][ci][co] = sum_p a[p][ci] * g[p + off_t][co]  as it stands, and the B operand g[p + off_t][co]
+// (N = j = 3t + co) sits in the staged gradient patch.  16 more MFMAs per row block into one accumulator per wave replace
+// img_wgrad_kernel's own pass over the 134 MB activation (VanillaVAE bs = 256: 67 us).  a = act(gamma * xhat + beta) is the value
+// the BatchNorm-backward sums need anyway.  Slabs out[blockIdx.x][wtap*32 + ci][co] and bias partials pbias[blockIdx.x][co] like
+// img_wgrad_kernel; all merges in a fixed order.
+__global__ __launch_bounds__(256, 4) void img_bwd_fused_kernel(const ImgArgs a, float* __restrict__ wpart, float* __restrict__ wpbias) {
+  __shared__ __attribute__((aligned(16))) float sG[NP * 4];
+  __shared__ __attribute__((aligned(16))) float sR[4 * 32 * 32];   // end of the launch: the 4 waves' dW accumulators
+  __shared__ float sS[4 * C * 2];
+  __shared__ float sB[4 * NO];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rG = rsrc(a.dY, (long)a.B * a.H * a.W * NO * 4);
+  const long obytes = (long)a.B * a.H * a.W * C * 4;
+  const __amdgpu_buffer_rsrc_t rO = rsrc(a.out, obytes);
+  const __amdgpu_buffer_rsrc_t rY = rsrc(a.bn_y, obytes);
+
+  int koff[14];
+  float bw[14];
+#pragma unroll
+  for (int s = 0; s < 14; ++s) {
+    const int k0 = 2 * s, k1 = 2 * s + 1;
+    const int t0 = k0 / 3, c0 = k0 % 3, t1 = (k1 < NJ ? k1 : 0) / 3, c1 = (k1 < NJ ? k1 : 0) % 3;
+    const int o0 = (a.tdy[t0] * PW + a.tdx[t0]) * 4 + c0, o1 = (a.tdy[t1] * PW + a.tdx[t1]) * 4 + c1;
+    const float w0 = a.Wt[(a.twt[t0] * C + li) * NO + c0];
+    const float w1 = k1 < NJ ? a.Wt[(a.twt[t1] * C + li) * NO + c1] : 0.f;
+    koff[s] = lh ? (k1 < NJ ? o1 : 0) : o0;
+    bw[s] = lh ? w1 : w0;
+  }
+  // weight gradient: lane column j = li = 3t + co (columns 27..31 are computed from a valid address and dropped)
+  const int jj = li < NJ ? li : NJ - 1;
+  const int t_l = jj / 3, co_l = jj - 3 * t_l;
+  const int wlane = ((1 + tap_dy(a, t_l)) * PW + (1 + tap_dx(a, t_l)) + 4 * lh) * 4 + co_l;
+  const float bmean = a.bn_mean[li], binv = a.bn_invstd[li], bgm = a.bn_gamma[li], bbt = a.bn_beta[li];
+  float s1 = 0.f, s2 = 0.f;
+  float bs[NO] = {0.f, 0.f, 0.f};
+  f32x16 wacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) wacc[r] = 0.f;
+
+  float gq[2][NO];
+  auto g_load = [&](const TileXY& t) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pp = tid + 256 * j;
+      const int py = (pp * 241) >> 13, px = pp - py * PW;
+      const int iy = t.y0 - 1 + py, ix = t.x0 - 1 + px;
+      const bool ok = pp < NP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      const unsigned off = ok ? (unsigned)(((t.b * a.H + iy) * a.W + ix) * NO) * 4u : kOOBi;
+#pragma unroll
+      for (int n = 0; n < NO; ++n) gq[j][n] = ld1(rG, ok ? off + 4u * n : kOOBi);
+    }
+  };
+  int tile = blockIdx.x;
+  TileXY cur = tile_xy(a, tile < a.ntiles ? tile : 0);
+  if (tile < a.ntiles) g_load(cur);
+  for (; tile < a.ntiles; tile += gridDim.x) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pp = tid + 256 * j;
+      if (pp < NP) {
+        const int py = (pp * 241) >> 13, px = pp - py * PW;
+        const bool inner = py >= 1 && py <= TH && px >= 1 && px <= TW;     // the tile itself: counted once for d bias
+#pragma unroll
+        for (int n = 0; n < NO; ++n) {
+          sG[pp * 4 + n] = gq[j][n];
+          bs[n] += inner ? gq[j][n] : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    const TileXY nxt = tile_xy(a, next < a.ntiles ? next : 0);
+    if (next < a.ntiles) g_load(nxt);
+#pragma unroll 1
+    for (int i = 0; i < 2; ++i) {
+      const int ly = wave + 4 * i;   // tile row = one 32-pixel MFMA block
+      const unsigned rowoff = (unsigned)(((cur.b * a.H + cur.y0 + ly) * a.W + cur.x0) * C + li) * 4u;
+      float yv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) yv[r] = ld1(rY, rowoff + (unsigned)((8 * (r >> 2) + 4 * lh + (r & 3)) * C) * 4u);
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* gp = &sG[((ly + 1) * PW + li + 1) * 4];
+#pragma unroll
+      for (int s = 0; s < 14; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gp[koff[s]], bw[s], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st1(rO, rowoff + (unsigned)((8 * (r >> 2) + 4 * lh + (r & 3)) * C) * 4u, acc[r]);
+      const float* gw = &sG[ly * PW * 4 + wlane];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float xh = (yv[r] - bmean) * binv;
+        const float av = act_fwd(bgm * xh + bbt, a.bn_act);
+        const float g1 = acc[r] * act_bwd_from_out(av, a.bn_act);
+        s1 += g1;
+        s2 += g1 * xh;
+        wacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, gw[(8 * (r >> 2) + (r & 3)) * 4], wacc, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    cur = nxt;
+  }
+  s1 += __shfl_xor(s1, 32, 64);
+  s2 += __shfl_xor(s2, 32, 64);
+  if (lh == 0) {
+    sS[(wave * C + li) * 2] = s1;
+    sS[(wave * C + li) * 2 + 1] = s2;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sR[(wave * 32 + 8 * (r >> 2) + 4 * lh + (r & 3)) * 32 + li] = wacc[r];
+  float bwv[NO];
+#pragma unroll
+  for (int n = 0; n < NO; ++n) bwv[n] = wave_sum(bs[n]);
+  if (lane == 0)
+#pragma unroll
+    for (int n = 0; n < NO; ++n) sB[wave * NO + n] = bwv[n];
+  __syncthreads();
+  if (tid < C * 2) {
+    const float v = ((sS[tid] + sS[C * 2 + tid]) + sS[2 * C * 2 + tid]) + sS[3 * C * 2 + tid];
+    a.bn_part[(long)blockIdx.x * C * 2 + tid] = v;
+  }
+  for (int e = tid; e < C * NJ; e += 256) {
+    const int ci = e / NJ, j = e - ci * NJ;
+    const float v = ((sR[(0 * 32 + ci) * 32 + j] + sR[(1 * 32 + ci) * 32 + j]) + sR[(2 * 32 + ci) * 32 + j]) + sR[(3 * 32 + ci) * 32 + j];
+    const int t = j / 3, co = j - 3 * t;
+    wpart[((long)blockIdx.x * (NT * C) + tap_wt(a, t) * C + ci) * NO + co] = v;
+  }
+  if (wpbias != nullptr && tid < NO) wpbias[(long)blockIdx.x * NO + tid] = ((sB[tid] + sB[NO + tid]) + sB[2 * NO + tid]) + sB[3 * NO + tid];
+}
+
 // =====================================================================================================================
 // Picture-side stride-2 convolution 3 -> 32 channels (vanilla_vae.py:28-29, encoder.0: Conv2d(3, 32, 3, stride 2, pad 1)).
 // Same idea with the roles swapped: K = (tap, input channel) = 27, N = 32 output channels, the 3-channel patch
@@ -751,13 +885,13 @@ void fill(ImgArgs& a, const ConvGeom& g) {
 }  // namespace
 
 // forward / wgrad geometry (build_geom kind 0): 32 -> 3 channels
-bool img_conv_supported(const ConvGeom& g) { return g.wT == 0 && g.gC == C && g.sC == NO && g.wCi == C && g.wCo == NO && taps_ok(g); }
+bool img_conv_supported(const ConvGeom& g) { return packed_weights(g) && g.wT == 0 && g.gC == C && g.sC == NO && g.wCi == C && g.wCo == NO && taps_ok(g); }
 // dgrad geometry (kind 2): gathers the 3-channel gradient, scatters 32 channels
-bool img_dgrad_supported(const ConvGeom& g) { return g.wT == 1 && g.gC == NO && g.sC == C && g.wCi == C && g.wCo == NO && taps_ok(g); }
+bool img_dgrad_supported(const ConvGeom& g) { return packed_weights(g) && g.wT == 1 && g.gC == NO && g.sC == C && g.wCi == C && g.wCo == NO && taps_ok(g); }
 
 // encoder.0 geometry (kind 0, stride 2): gathers 3 channels with is = 2, scatters 32
 bool img_enc_supported(const ConvGeom& g) {
-  if (g.wT != 0 || g.gC != NO || g.sC != C || g.wCi != NO || g.wCo != C) return false;
+  if (!packed_weights(g) || g.wT != 0 || g.gC != NO || g.sC != C || g.wCi != NO || g.wCo != C) return false;
   if (g.ncls != 1 || g.is != 2 || g.os != 1 || g.ntaps[0] != NT) return false;
   if (g.gH != 2 * g.sH || g.gW != 2 * g.sW || g.sH % TH != 0 || g.sW % TW != 0) return false;
   for (int t = 0; t < NT; ++t) {
@@ -856,6 +990,28 @@ int launch_img_wgrad(const ConvGeom& g, const float* X, const float* dY, float* 
   *nparts = nwg;
   return 0;
 }
+
+// img_dgrad (with the BatchNorm-backward sums of bnb) + img_wgrad of the SAME layer in one launch: x of the weight gradient
+// is a = act(BN(bnb->y)).  Slabs [parts][9*32][3] (+ bias partials [parts][3]) into ws, parts = img_dgrad_rows(g).
+int launch_img_backward_fused(const ConvGeom& g, const float* dY, const float* W, float* dX, const BnBwdFuse* bnb, float* ws,
+                              float** part_out, float** pbias_out, int* nparts, bool want_bias, hipStream_t st) {
+  ImgArgs a{};
+  fill(a, g);
+  a.dY = dY; a.Wt = W; a.out = dX;
+  a.bn_y = bnb->y; a.bn_mean = bnb->mean; a.bn_invstd = bnb->invstd; a.bn_gamma = bnb->gamma; a.bn_beta = bnb->beta;
+  a.bn_act = bnb->act; a.bn_part = bnb->part;
+  const int nwg = img_dgrad_rows(g);
+  float* part = ws;
+  float* pb = want_bias ? ws + (size_t)nwg * NT * C * NO : nullptr;
+  ProfScope ps("img_bwd_fused_kernel", st, 4.0 * a.ntiles * TH * TW * NT * C * NO, 4.0 * a.ntiles * TH * TW * (C * 2 + NO));
+  hipLaunchKernelGGL(img_bwd_fused_kernel, dim3(nwg), dim3(256), 0, st, a, part, pb);
+  CTVAE_LAUNCH_CHECK();
+  *part_out = part;
+  *pbias_out = pb;
+  *nparts = nwg;
+  return 0;
+}
+size_t img_backward_fused_ws_floats(const ConvGeom& g) { return (size_t)img_dgrad_rows(g) * (NT * C * NO + NO); }
 
 int launch_img_dgrad(const ConvGeom& g, const float* dY, const float* W, float* dX, const BnBwdFuse* bnb, hipStream_t st) {
   ImgArgs a{};

@@ -168,8 +168,8 @@ __global__ __launch_bounds__(256) void tapgemm_masked_kernel(const TapGemmArgs a
           int n = n0 + 4 * nq;
           bool ok = n < a.N;
           if constexpr (AVEC) {
-            const unsigned wbase = (unsigned)((tp.wtap * g.wCi + ci0) * g.wCo);   // wave-uniform
-            const unsigned off = ok ? wbase + (unsigned)(kr * g.wCo + n) : 0u;
+            const unsigned wbase = (unsigned)(tp.wtap * g.wts + ci0 * g.wrs);   // wave-uniform
+            const unsigned off = ok ? wbase + (unsigned)(kr * g.wrs + n) : 0u;
             f32x4 v = *reinterpret_cast<const f32x4*>(a.W + off);
             if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
             rb[j] = v;
@@ -177,9 +177,9 @@ __global__ __launch_bounds__(256) void tapgemm_masked_kernel(const TapGemmArgs a
             int k = c * KC + kr;
             int wt = sTab[(k & 63) * 4 + 3];
             ok = ok && (k < Ktot);
-            long row = (long)wt * g.wCi + sTab[(k & 63) * 4 + 2];
+            long row = (long)wt * g.wts + (long)sTab[(k & 63) * 4 + 2] * g.wrs;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(a.W + row * g.wCo + n);
+            if (ok) v = *reinterpret_cast<const f32x4*>(a.W + row + n);
             rb[j] = v;
           }
         }
@@ -192,14 +192,14 @@ __global__ __launch_bounds__(256) void tapgemm_masked_kernel(const TapGemmArgs a
           long row;
           bool ok = n < a.N;
           if constexpr (AVEC) {
-            row = (long)tp.wtap * g.wCi + ci0 + kr;
+            row = (long)tp.wtap * g.wts + (long)(ci0 + kr) * g.wrs;
           } else {
             int k = c * KC + kr;
             int wt = sTab[(k & 63) * 4 + 3];
             ok = ok && (k < Ktot);
-            row = (long)wt * g.wCi + sTab[(k & 63) * 4 + 2];
+            row = (long)wt * g.wts + (long)sTab[(k & 63) * 4 + 2] * g.wrs;
           }
-          rbs[j] = ok ? a.W[row * g.wCo + n] : 0.f;
+          rbs[j] = ok ? a.W[row + n] : 0.f;
         }
       }
     } else {
@@ -211,8 +211,8 @@ __global__ __launch_bounds__(256) void tapgemm_masked_kernel(const TapGemmArgs a
           int nr = (tid >> 3) + 32 * j;
           int n = n0 + nr;
           const bool ok = n < a.N;
-          const unsigned wbase = (unsigned)(tp.wtap * g.wCi * g.wCo + ci0);      // wave-uniform
-          const unsigned off = ok ? wbase + (unsigned)(n * g.wCo + 4 * kq) : 0u;
+          const unsigned wbase = (unsigned)(tp.wtap * g.wts + ci0);      // wave-uniform
+          const unsigned off = ok ? wbase + (unsigned)(n * g.wrs + 4 * kq) : 0u;
           f32x4 v = *reinterpret_cast<const f32x4*>(a.W + off);
           if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
           rb[j] = v;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void tapgemm_masked_kernel(const TapGemmArgs a
         for (int j = 0; j < B_S; ++j) {
           int nr = (tid >> 5) + 8 * j;
           int n = n0 + nr;
-          rbs[j] = (kok && n < a.N) ? a.W[((long)wt * g.wCi + n) * g.wCo + cc] : 0.f;
+          rbs[j] = (kok && n < a.N) ? a.W[(long)wt * g.wts + (long)n * g.wrs + cc] : 0.f;
         }
       }
     }
@@ -593,7 +593,9 @@ void tapgemm_plan(const ConvGeom& g, size_t ws_floats, TapGemmPlan& p) {
   static const int pair_maxwgs = [] { const char* e = getenv("CTVAE_PAIR_SK_MAXWGS"); return e ? atoi(e) : 384; }();
   const bool paired = pair_ctx() != nullptr && g.wT != 0;
   const int tgt = paired ? pair_target : sk_target, maxw = paired ? pair_maxwgs : sk_maxwgs;
-  if (avec && bvec && (N % 4) == 0 && wgs < maxw && nch_min >= 8) {
+  // paired with a reduction of fewer than 16 chunks (K < 512: the Linear heads' data gradient): splitting saves ~1 us of a
+  // launch the weight gradient fills anyway and would cost the fused BatchNorm-backward sums of the layer below
+  if (avec && bvec && (N % 4) == 0 && wgs < maxw && nch_min >= (paired ? 16 : 8)) {
     int sk = (int)((tgt + wgs - 1) / wgs);
     if (sk > nch_min / 4) sk = nch_min / 4;
     if (sk > 16) sk = 16;

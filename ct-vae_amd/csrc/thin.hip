@@ -212,7 +212,7 @@ static int max_taps(const ConvGeom& g) {
 }
 
 static bool thin_shape_ok(const ConvGeom& g) {
-  if (g.wT != 0 || g.sC != 3) return false;
+  if (!packed_weights(g) || g.wT != 0 || g.sC != 3) return false;
   if (!(g.gC == 32 || g.gC == 64)) return false;
   const int TH = 8, TW = g.gC == 32 ? 32 : 16;
   if (g.Qh % TH != 0 || g.Qw % TW != 0) return false;

@@ -410,7 +410,7 @@ constexpr size_t kUpFwdSmem = (size_t)(NP * LDA + NT * C * C) * 4;   // 79 632 B
 
 // forward geometry (build_geom kind 1) of a 32 -> 32 channel, k3 s2 p1 op1 transposed convolution
 bool upconv_supported(const ConvGeom& g) {
-  if (g.wT != 0 || g.gC != C || g.sC != C || g.wCi != C || g.wCo != C) return false;
+  if (!packed_weights(g) || g.wT != 0 || g.gC != C || g.sC != C || g.wCi != C || g.wCo != C) return false;
   if (g.is != 1 || g.os != 2 || g.ncls != NCLS) return false;
   if (g.sH != 2 * g.gH || g.sW != 2 * g.gW || g.gH % TH != 0 || g.gW % TW != 0) return false;
   int total = 0;

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void upimg_fwd_kernel(UpImgArgs a) {
 
 // ConvTranspose2d(64 -> 3, k4 s2 p1) forward geometry (kind 1): 4 parity classes x 4 taps, 2 x 2 input neighbourhood
 bool upimg_supported(const ConvGeom& g) {
-  if (g.wT != 0 || g.is != 1 || g.os != 2 || g.ncls != 4 || g.gC != 64 || g.sC != 3) return false;
+  if (!packed_weights(g) || g.wT != 0 || g.is != 1 || g.os != 2 || g.ncls != 4 || g.gC != 64 || g.sC != 3) return false;
   if (g.gH % UTH || g.gW % UTW || g.sH != 2 * g.gH || g.sW != 2 * g.gW) return false;
   for (int c = 0; c < 4; ++c) {
     if (g.ntaps[c] != 4 || g.py[c] != c / 2 || g.px[c] != c % 2) return false;

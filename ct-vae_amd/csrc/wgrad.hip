@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     int k = kt0 + wk * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
     if (k < Ktot && col < N) {
       int t = k / gC, c = k - t * gC;
-      int wrow = g.taps[cls][t].wtap * gC + c;
+      int wrow = g.taps[cls][t].wtap * (g.wts / g.wCo) + c * (g.wrs / g.wCo);   // row of the [rows][N] weight block (geom.hpp wts / wrs)
       a.part[((long)split * a.rows_total + wrow) * N + col] = acc[r];
     }
   }
@@ -355,6 +355,12 @@ static int finish_reduce(const float* p1, float* d1, long n1, int S1, long st1, 
   else launch_reduce(p1, d1, n1, S1, st1, accumulate, st);
   CTVAE_LAUNCH_CHECK();
   return 0;
+}
+
+// for a kernel outside this file that produced weight-gradient slabs (image.hip img_bwd_fused_kernel)
+int wgrad_finish_slabs(const float* part, float* dW, long n, int nparts, const float* pbias, float* dbias, long nb, int accumulate,
+                       hipStream_t st) {
+  return finish_reduce(part, dW, n, nparts, n, pbias, dbias, nb, nparts, nb, accumulate, st);
 }
 
 size_t wgrad_workspace_floats(const ConvGeom& g, int S) {

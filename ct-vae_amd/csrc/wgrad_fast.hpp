@@ -204,10 +204,11 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, int lgQw, in
         const int k0 = kt0 + (wk * TK + i) * 32 + 8 * q4 + 4 * lh;      // 4 consecutive k rows: same tap when gC % 4 == 0
         if (k0 < Ktot && col < N) {
           const int t = lgC >= 0 ? (k0 >> lgC) : (k0 / gC);
-          const int wrow0 = g.taps[cls][t].wtap * gC + (k0 - t * gC);
+          const int wcr = g.wrs / g.wCo;                                   // rows between consecutive channels (geom.hpp wts / wrs)
+          const int wrow0 = g.taps[cls][t].wtap * (g.wts / g.wCo) + (k0 - t * gC) * wcr;
           float* dst = a.part + ((long)split * a.rows_total + wrow0) * N + col;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) dst[(long)q * N] = acc[i][j][4 * q4 + q];
+          for (int q = 0; q < 4; ++q) dst[(long)q * wcr * N] = acc[i][j][4 * q4 + q];
         }
       }
     }

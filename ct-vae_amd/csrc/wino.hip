@@ -1090,7 +1090,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
 
 // 3x3, stride 1, "same" padding, one class: effective tap table (ky' = dy + 1, kx' = dx + 1) or false
 bool wino_taps(const ConvGeom& g, WTaps& wt) {
-  if (g.is != 1 || g.os != 1 || g.ncls != 1 || g.ntaps[0] != 9 || g.gH != g.sH || g.gW != g.sW) return false;
+  if (!packed_weights(g) || g.is != 1 || g.os != 1 || g.ncls != 1 || g.ntaps[0] != 9 || g.gH != g.sH || g.gW != g.sW) return false;
   bool seen[9] = {};
   for (int t = 0; t < 9; ++t) {
     const Tap& tp = g.taps[0][t];

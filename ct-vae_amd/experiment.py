@@ -55,12 +55,13 @@ class _GraphedTrainStep:
 
     def _body(self):
         exp = self.exp
-        exp.model.zero_grad()
+        exp.model.zero_grad(lazy=True)            # no fill launch: first writers overwrite, settle_grads() fills what nobody wrote
         opts = {**self.static, **self.const}
         labels = opts.pop("labels", None)         # ConditionalVAE reads them (cvae.py:123); a static buffer like every tensor option
         results = exp.forward(self.x, labels=labels, **opts)
         losses = exp.model.loss_function(*results, M_N=exp.params['kld_weight'], optimizer_idx=0, batch_idx=0)
         K.backward(losses['loss'])
+        exp.model.settle_grads()                  # inside the capture: the fills of unwritten blocks belong to the replayed step
         if exp.ddp is None:
             exp.optimizer.step()
         # detached: a live loss keeps the step's autograd graph -- and with it the AccumulateGrad nodes of the parameters
@@ -203,9 +204,10 @@ class VAEXperiment:
                     self.log_all(losses, batch_size=real_img.size(0), validation=False)
                     self.global_step += 1
                 else:
-                    self.model.zero_grad()
+                    self.model.zero_grad(lazy=True)
                     loss = self.training_step(batch, i)
                     K.backward(loss)
+                    self.model.settle_grads()
                     self.optimizer_step()
                 n += batch[0].size(0)
             if self.scheduler is not None:

@@ -23,6 +23,7 @@ from . import native
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 CONV, CONVT = 0, 1
+CONV_FLAT = CONV | 0x100   # CTVAE_W_CI_TAP: nn.Linear over torch.flatten(NCHW [B,ci,k,k]) run as a k x k conv of the NHWC tensor
 BN_MOMENTUM, BN_EPS = 0.1, 1e-5      # nn.BatchNorm2d defaults (vanilla_vae.py:30)
 
 
@@ -38,7 +39,7 @@ class ConvSpec:
     act: int = ACT_NONE
 
     def out_hw(self, h, w):
-        if self.kind == CONV:
+        if self.kind in (CONV, CONV_FLAT):
             return (h + 2 * self.pad - self.k) // self.stride + 1, (w + 2 * self.pad - self.k) // self.stride + 1
         return ((h - 1) * self.stride - 2 * self.pad + self.k + self.out_pad,
                 (w - 1) * self.stride - 2 * self.pad + self.k + self.out_pad)
@@ -61,7 +62,14 @@ def grad_target(p):
         return p.grad, 0
     if p.grad.stride() != p.stride():
         raise RuntimeError("parameter .grad does not share the packed layout of the parameter")
+    blk = getattr(p, "_grad_block", None)
+    if blk is not None and blk.fresh:      # zero_grad(lazy=True) (models/packing.py): first writer of the block overwrites
+        blk.fresh = False
+        return p.grad, 0
     return p.grad, 1
+
+
+LAZY_ZERO_GRAD = os.environ.get("CTVAE_NO_LAZY_ZERO", "0") != "1"     # diagnostic: zero_grad(lazy=True) fills like zero_grad()
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -124,6 +124,16 @@ class PackedEmbedding(nn.Module):
         return [(self.K * self.D, [(self.weight, 0, (self.K, self.D), (self.D, 1))])]
 
 
+class _GradBlock:
+    """One storage block of the flat gradient buffer, [lo, hi) floats.  ``fresh``: zero_grad(lazy=True) declared the block zero
+    without writing it -- the first kernel that writes the block's gradient overwrites instead of accumulating
+    (kernels.grad_target), and whatever is still fresh when the buffer is read gets its zeros then (settle_grads)."""
+    __slots__ = ("lo", "hi", "fresh")
+
+    def __init__(self, lo, hi):
+        self.lo, self.hi, self.fresh = lo, hi, False
+
+
 class FlatParamMixin:
     """Mixin for nn.Module roots: one flat parameter buffer + one flat gradient buffer."""
 
@@ -173,11 +183,20 @@ class FlatParamMixin:
         gflat = torch.zeros(total, dtype=torch.float32, device=dev)
         off = 0
         self._grad_views = []
+        self._grad_blocks = []
+        self._lazy_zero = False
         with torch.no_grad():
             for n, views in blocks:
                 if n < 0:
                     off = -(-off // -n) * -n
                     continue
+                if views and not any(id(p) in self._torch_param_ids for p, *_ in views):
+                    # written by the HIP gradient kernels, the whole block by one call (a PackedLinearGroup's heads are ONE
+                    # GEMM): its parameters share the lazy-zero flag
+                    blk = _GradBlock(off, off + n)
+                    self._grad_blocks.append(blk)
+                    for p, *_ in views:
+                        p._grad_block = blk
                 for p, o, size, stride in views:
                     v = flat.as_strided(size, stride, off + o)
                     v.copy_(p.detach().to(dev))
@@ -245,8 +264,14 @@ class FlatParamMixin:
             self.flatten_parameters()
         return out
 
-    def zero_grad(self, set_to_none: bool = False):
+    def zero_grad(self, set_to_none: bool = False, lazy: bool = False):
         """Gradients live in the flat buffer: zero it in one memset instead of dropping the views.
+
+        lazy: no memset.  Every block of the buffer is only DECLARED zero: the first gradient kernel that writes a block
+        overwrites it instead of accumulating, and blocks nobody wrote get their zeros when the buffer is next read
+        (settle_grads, called by gather_torch_grads / ``flat_grads`` / FlatAdam.step / the gradient exchange).  In a step
+        where every parameter receives a gradient (VanillaVAE, MCQ-VAE) the 16 MB fill launch disappears.  ``p.grad`` of a
+        parameter that got no gradient is stale until then, which is why this is the training loop's option and not the default.
 
         Parameters of torch-level sub-modules (CausalTransition) get their gradient from autograd: with ``.grad``
         attached, AccumulateGrad adds into it with one tiny launch per parameter (62 per CT-MCQ-VAE step); detached,
@@ -255,15 +280,52 @@ class FlatParamMixin:
         from .. import kernels as _K
         _K.bump_param_epoch()          # a new step: transformed Winograd filters are remade once for all layers (kernels.wino_cache)
         if getattr(self, "_flat_grads", None) is not None:
-            self._flat_grads.zero_()
+            if lazy and _K.LAZY_ZERO_GRAD:
+                for blk in self._grad_blocks:
+                    blk.fresh = True
+                self._lazy_zero = True
+            else:
+                self._flat_grads.zero_()
+                for blk in self._grad_blocks:
+                    blk.fresh = False
+                self._lazy_zero = False
             for p, _ in getattr(self, "_torch_grad_views", ()):
                 p.grad = None
         else:
             super().zero_grad(set_to_none=set_to_none)
 
+    def settle_grads(self):
+        """Write the zeros that zero_grad(lazy=True) only declared, for every block no gradient kernel has written since
+        (and for torch-level parameters autograd produced no gradient for): adjacent ranges share one fill."""
+        if not getattr(self, "_lazy_zero", False):
+            return
+        self._lazy_zero = False
+        ranges = []
+        for blk in self._grad_blocks:
+            if blk.fresh:
+                blk.fresh = False
+                ranges.append((blk.lo, blk.hi))
+        with torch.no_grad():
+            for p, g in getattr(self, "_torch_grad_views", ()):
+                if p.grad is None:
+                    if g.is_contiguous():
+                        ranges.append((g.storage_offset(), g.storage_offset() + g.numel()))
+                    else:
+                        g.zero_()
+            ranges.sort()
+            merged = []
+            for lo, hi in ranges:
+                if merged and lo <= merged[-1][1] + 4:       # alignment gaps hold zeros anyway
+                    merged[-1][1] = max(merged[-1][1], hi)
+                else:
+                    merged.append([lo, hi])
+            for lo, hi in merged:
+                self._flat_grads[lo:hi].zero_()
+
     def gather_torch_grads(self):
         """Move autograd-produced gradients of torch-level parameters into their views of the flat gradient buffer and
-        re-attach the views (call before the optimizer step / gradient exchange)."""
+        re-attach the views (call before the optimizer step / gradient exchange).  Completes a lazy zero_grad first."""
+        self.settle_grads()
         pairs = [(p, g) for p, g in getattr(self, "_torch_grad_views", ()) if p.grad is not None and p.grad is not g]
         if pairs:
             with torch.no_grad():

@@ -29,6 +29,11 @@ extern "C" {
 /* layer kinds */
 #define CTVAE_CONV 0  /* nn.Conv2d / nn.Linear */
 #define CTVAE_CONVT 1 /* nn.ConvTranspose2d */
+/* CTVAE_CONV | CTVAE_W_CI_TAP: the weight block is [Ci][kh*kw][Co] instead of [kh*kw][Ci][Co].  That is the [in][out] block of
+ * an nn.Linear whose input is torch.flatten(h, start_dim=1) of an NCHW tensor h [B,Ci,k,k] (vanilla_vae.py:36-37,87-91: in =
+ * Ci*k*k, feature index ci*k*k + ky*k + kx): with this flag the layer runs as a k x k convolution straight on the NHWC tensor
+ * (forward, data gradient, weight gradient), without the NHWC <-> NCHW copies around the flatten. */
+#define CTVAE_W_CI_TAP 0x100
 
 const char* ctvae_version(void);
 const char* ctvae_arch(void); /* "gfx950" */

@@ -54,7 +54,7 @@ def test_vanilla_step_at_bench_batch_vs_oracle(dev, B):
     torch.cuda.synchronize()
     native.prof_enable(False)
     rep = native.prof_report()
-    want = ["conv_bwd_pair_kernel", "img_fwd_kernel", "img_wgrad_kernel", "img_dgrad_kernel", "img_enc_fwd_kernel",
+    want = ["conv_bwd_pair_kernel", "img_fwd_kernel", "img_bwd_fused_kernel", "img_enc_fwd_kernel",
             "img_enc_wgrad_kernel", "up_fwd_kernel", "up_wgrad_kernel"]
     missing = [k for k in want if not any(r.startswith(k) for r in rep)]
     assert not missing, (missing, sorted(rep))

@@ -81,3 +81,37 @@ def test_geometry_matches_torch(emul, case):
     dw = np.zeros_like(wn)
     assert emul.emul_wgrad(1 if tr else 0, ptr(xn), ptr(gyn), ptr(dw), *args) == 0
     np.testing.assert_allclose(dw, pack_weight(w.grad, tr).numpy(), atol=5e-4, rtol=1e-4)
+
+
+FLAT_CASES = [
+    # (C, k, stride, out): nn.Linear(C*k*k, out) over torch.flatten(h [B,C,k,k], 1), run as a k x k convolution of the NHWC tensor
+    (8, 2, 2, 12),      # vanilla_vae.py:36-37 family (fc_mu | fc_var over [B,512,2,2])
+    (8, 2, 1, 12),
+    (4, 4, 1, 6),       # betatc_vae.py family (Linear over a 4x4 map)
+]
+
+
+@pytest.mark.parametrize("case", FLAT_CASES)
+def test_linear_over_flatten_as_convolution(emul, case):
+    """CTVAE_W_CI_TAP (include/ctvae_hip.h): the Linear layer's [in][out] block read as [Ci][tap][Co]."""
+    C, k, s, out = case
+    B, FLAG = 3, 0x100
+    g = torch.Generator().manual_seed(5)
+    h = torch.randn(B, C, k, k, generator=g).requires_grad_(True)
+    w = torch.randn(out, C * k * k, generator=g).requires_grad_(True)
+    y = F.linear(torch.flatten(h, start_dim=1), w)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    hn = h.detach().permute(0, 2, 3, 1).contiguous().numpy()
+    wn = w.detach().t().contiguous().numpy()                      # packing.PackedLinear memory: [in][out]
+    gyn = gy.contiguous().numpy()
+    args = (B, k, k, C, out, k, s, 0, 0)
+    o = np.zeros((B, 1, 1, out), np.float32)
+    assert emul.emul_tapgemm(0 | FLAG, ptr(hn), ptr(wn), ptr(o), *args) == 0
+    np.testing.assert_allclose(o.reshape(B, out), y.detach().numpy(), atol=2e-4, rtol=1e-4)
+    dx = np.zeros((B, k, k, C), np.float32)
+    assert emul.emul_tapgemm(2 | FLAG, ptr(gyn), ptr(wn), ptr(dx), *args) == 0
+    np.testing.assert_allclose(dx, h.grad.permute(0, 2, 3, 1).numpy(), atol=2e-4, rtol=1e-4)
+    dw = np.zeros_like(wn)
+    assert emul.emul_wgrad(0 | FLAG, ptr(hn), ptr(gyn), ptr(dw), *args) == 0
+    np.testing.assert_allclose(dw, w.grad.t().numpy(), atol=5e-4, rtol=1e-4)

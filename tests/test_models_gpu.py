@@ -485,6 +485,40 @@ def test_every_registered_model_trains_through_the_harness(dev, name, cfg):
             assert name in ("VQVAE", "MCQVAE")
 
 
+@pytest.mark.parametrize("name,cfg", ZOO, ids=[z[0] for z in ZOO])
+def test_lazy_zero_grad_gives_the_same_gradient_buffer(dev, name, cfg):
+    """zero_grad(lazy=True) (models/packing.py: no fill, first writers overwrite, settle_grads() fills the rest) against
+    zero_grad(): the flat gradient buffer after one forward + backward is the same bit for bit, starting from a buffer
+    full of NaN -- so every block is either overwritten completely by its first writer or zero-filled by the settle."""
+    from ctvae_amd.models import vae_models
+    torch.manual_seed(3)
+    m = vae_models[name](**{k: (list(v) if isinstance(v, list) else v) for k, v in cfg.items()}, name=name).to(dev).train()
+    x = filler.synthetic_batch(901, 8)[0].to(dev)
+    labels = H.cvae_labels(901, 8).to(dev) if name == "ConditionalVAE" else torch.zeros(8, device=dev)
+
+    def grads(lazy):
+        torch.manual_seed(11)
+        for mod in m.modules():                      # in-kernel noise: same Philox key and position in both runs
+            if getattr(mod, "_rng_state", None) is not None:
+                mod._rng_state = None
+            if hasattr(mod, "num_iter"):             # annealed loss weights (betatc_vae.py:166, joint_vae.py:195): same step both times
+                mod.num_iter = 0
+        m.gather_torch_grads()
+        for blk in m._grad_blocks:                   # (the alignment gaps between blocks hold zeros and are never written)
+            m._flat_grads[blk.lo:blk.hi] = float("nan")
+        for _, g in m._torch_grad_views:
+            g.fill_(float("nan"))
+        m.zero_grad(lazy=lazy)
+        out = m(x, labels=labels)
+        m.loss_function(*out, M_N=0.00025, optimizer_idx=0, batch_idx=0)["loss"].backward()
+        return m.flat_grads.clone()                  # the property settles / gathers
+
+    want = grads(False)
+    got = grads(True)
+    assert torch.isfinite(want).all()
+    assert torch.equal(got, want), f"{(got != want).sum().item()} of {want.numel()} gradient elements differ"
+
+
 def test_dip_vae_vs_golden(dev, golden):
     """DIPVAE against the reference's own dip_vae.py fixture: loss dict (sums + DIP term) and every parameter gradient."""
     from ctvae_amd.models import vae_models

@@ -89,6 +89,44 @@ def test_conv_family(K, case):
     np.testing.assert_allclose(wp.grad.cpu().numpy(), 2 * g1.cpu().numpy(), atol=TOL * scale, rtol=1e-4)
 
 
+@pytest.mark.parametrize("C,k,s,out,B", [(512, 2, 2, 256, 7), (512, 2, 2, 256, 256), (64, 4, 1, 32, 5), (32, 2, 1, 12, 3)])
+def test_linear_over_flatten_as_convolution(K, C, k, s, out, B):
+    """CONV_FLAT (CTVAE_W_CI_TAP): nn.Linear over torch.flatten(NCHW) as a k x k convolution of the NHWC tensor, reading and
+    writing the Linear layer's own [in][out] weight block; forward, data gradient, weight / bias gradient vs torch."""
+    g = torch.Generator().manual_seed(C + k + out)
+    h = torch.randn(B, C, k, k, generator=g).requires_grad_(True)
+    w = (torch.randn(out, C * k * k, generator=g) / (C * k * k) ** 0.5).requires_grad_(True)
+    b = torch.randn(out, generator=g).requires_grad_(True)
+    y = F.linear(torch.flatten(h, start_dim=1), w, b)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    dev = torch.device("cuda")
+    spec = K.ConvSpec(K.CONV_FLAT, C, out, k, s, 0)
+    hd = h.detach().permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+    wp = torch.nn.Parameter(w.detach().t().contiguous().to(dev).t())          # logical [out, in] over memory [in][out]
+    bp = torch.nn.Parameter(b.detach().to(dev))
+    o = K.ConvAct.apply(hd, wp, bp, None, spec)
+    assert tuple(o.shape) == (B, 1, 1, out)
+    o.backward(gy.view(B, 1, 1, out).to(dev))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(o.detach().cpu().view(B, out).numpy(), y.detach().numpy(), atol=TOL, rtol=1e-4)
+    np.testing.assert_allclose(hd.grad.cpu().permute(0, 3, 1, 2).numpy(), h.grad.numpy(), atol=TOL, rtol=1e-4)
+    scale = max(1.0, float(w.grad.abs().max()))
+    np.testing.assert_allclose(wp.grad.cpu().numpy(), w.grad.numpy(), atol=TOL * scale, rtol=1e-4)
+    np.testing.assert_allclose(bp.grad.cpu().numpy(), b.grad.numpy(), atol=TOL * max(1.0, float(b.grad.abs().max())), rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,C,P", [(5, 3, 64 * 64), (2, 3, 36), (3, 3, 35), (4, 512, 4), (2, 7, 10)])
+def test_permute_both_ways(K, B, C, P):
+    """ctvae_permute (NCHW <-> NHWC copies): the 3-channel quad kernel, and the element-wise one for everything else."""
+    dev = torch.device("cuda")
+    x = torch.randn(B, C, P, generator=torch.Generator().manual_seed(P)).to(dev)
+    nhwc = K.permute_raw(x, B, C, P, True).view(B, P, C)
+    assert torch.equal(nhwc, x.permute(0, 2, 1).contiguous())
+    back = K.permute_raw(nhwc.contiguous(), B, C, P, False).view(B, C, P)
+    assert torch.equal(back, x)
+
+
 @pytest.mark.parametrize("C,R_shape", [(32, (3, 32, 32)), (512, (5, 2, 2)), (64, (2, 16, 16))])
 def test_conv_bn_lrelu(K, C, R_shape):
     """ConvBNAct against conv2d + F.batch_norm(training) + leaky_relu incl. running stats and all gradients."""
@@ -381,7 +419,9 @@ def test_bn_backward_sums_fused_into_dgrad(K, transposed, B, H):
     gx_u, *_rest, rep_u = run(False)
     ws = native.workspace(dev)
     Hin = H * 2 if transposed else H          # input size of the second block
-    rows = native.load().ctvae_conv_dgrad_bn_rows(kind, B, Hin, Hin, C1, C2, 3, s, 1, op, ws.numel() * 4)
+    # the plan of the call backward really makes: the paired launch (ctvae_conv_backward) splits K later than a lone data gradient
+    rows_of = native.load().ctvae_conv_backward_bn_rows if K._PAIR else native.load().ctvae_conv_dgrad_bn_rows
+    rows = rows_of(kind, B, Hin, Hin, C1, C2, 3, s, 1, op, ws.numel() * 4)
     if B >= 32:
         assert rows > 0, "this shape is expected to take the fused path"
     assert rep_u["bn_bwd_partial_kernel"]["count"] == 2
