@@ -546,6 +546,30 @@ def _with_aux(x, aux, fn):
 # ---------------------------------------------------------------------------------------------------
 # conv / linear (+ bias + residual + activation)
 # ---------------------------------------------------------------------------------------------------
+_flat_specs = {}
+
+
+def flatten_linear(h, w, b, out_features):
+    """nn.Linear(C*k*k, out_features) applied to torch.flatten(h_nchw, start_dim=1), for the NHWC tensor h [B,k,k,C] -> [B, out]
+    (vanilla_vae.py:87-91 and every model built on that encoder).  k = 2 with 32-aligned widths: a 2x2 stride-2 convolution
+    straight on the NHWC tensor over the Linear layer's own [in][out] block (CONV_FLAT) -- no layout copies, and the data
+    gradient comes back NHWC with the BatchNorm-backward sums of the layer below in its epilogue.  Anything else: the NCHW copy
+    and a 1x1 GEMM."""
+    B, k, k2, C = h.shape
+    key = (k, k2, C, out_features)
+    spec = _flat_specs.get(key)
+    if spec is None:
+        if k == 2 and k2 == 2 and C % 32 == 0 and out_features % 32 == 0:
+            spec = ConvSpec(CONV_FLAT, C, out_features, 2, 2, 0)
+        else:
+            spec = ConvSpec(CONV, C * k * k2, out_features, 1)
+        _flat_specs[key] = spec
+    if spec.kind == CONV_FLAT:
+        return ConvAct.apply(h, w, b, None, spec).view(B, -1)
+    flat = _ToNCHW.apply(h).view(B, 1, 1, -1)
+    return ConvAct.apply(flat, w, b, None, spec).view(B, -1)
+
+
 class ConvAct(Function):
     """y = act(conv(x, w) + b + add).  Conv2d/ConvTranspose2d/Linear forward, dgrad and wgrad on HIP."""
 

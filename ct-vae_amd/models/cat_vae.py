@@ -60,9 +60,7 @@ class CategoricalVAE(BaseVAE):
         """[B,C,64,64] -> [logits [B, latent_dim, categorical_dim]] (cat_vae.py:90-104)."""
         self.attach_grads()
         h = self.encoder(K.to_nhwc(input))
-        B = h.shape[0]
-        flat = K._ToNCHW.apply(h).view(B, 1, 1, -1)                      # torch.flatten(start_dim=1) on NCHW
-        z = K.ConvAct.apply(flat, self.fc_z.weight, self.fc_z.bias, None, self._head_spec)
+        z = K.flatten_linear(h, self.fc_z.weight, self.fc_z.bias, self._head_spec.co)     # torch.flatten(start_dim=1) on NCHW
         return [z.view(-1, self.latent_dim, self.categorical_dim)]
 
     def decode(self, z: Tensor) -> Tensor:

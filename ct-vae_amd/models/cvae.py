@@ -79,9 +79,7 @@ class ConditionalVAE(BaseVAE):
     def _encode_heads(self, x_nhwc: Tensor) -> Tensor:
         self.attach_grads()
         h = self.encoder(x_nhwc)
-        B = h.shape[0]
-        flat = K._ToNCHW.apply(h).view(B, 1, 1, -1)
-        return K.ConvAct.apply(flat, self.fc_mu.weight, self.fc_mu.bias, None, self._head_spec).view(B, -1)
+        return K.flatten_linear(h, self.fc_mu.weight, self.fc_mu.bias, self._head_spec.co)
 
     def decode(self, z: Tensor) -> Tensor:
         """z: [B, latent_dim + num_classes] (cvae.py:100-105)."""

@@ -77,10 +77,9 @@ class GammaVAE(BaseVAE):
         self.attach_grads()
         h = self.encoder(K.to_nhwc(input))
         B = h.shape[0]
-        flat = K._ToNCHW.apply(h).view(B, 1, 1, -1)
         lm, lv = self.fc_mu._modules["0"], self.fc_var._modules["0"]
-        a = K.ConvAct.apply(flat, lm.weight, lm.bias, None, self._head_spec).view(B, -1)
-        b = K.ConvAct.apply(flat, lv.weight, lv.bias, None, self._head_spec).view(B, -1)
+        a = K.flatten_linear(h, lm.weight, lm.bias, self._head_spec.co)
+        b = K.flatten_linear(h, lv.weight, lv.bias, self._head_spec.co)
         return [torch.softmax(a, dim=1), torch.softmax(b, dim=1)]
 
     def decode(self, z: Tensor) -> Tensor:

@@ -81,9 +81,7 @@ class HVAE(BaseVAE):
 
     def _stack_heads(self, layers, x_nhwc, first_head, spec, L):
         h = layers(x_nhwc)
-        B = h.shape[0]
-        flat = K._ToNCHW.apply(h).view(B, 1, 1, -1)
-        heads = K.ConvAct.apply(flat, first_head.weight, first_head.bias, None, spec).view(B, -1)
+        heads = K.flatten_linear(h, first_head.weight, first_head.bias, spec.co)
         return K.SplitHeads.apply(heads, L)
 
     def reparameterize(self, mu: Tensor, logvar: Tensor, eps: Tensor = None) -> Tensor:

@@ -69,10 +69,9 @@ class JointVAE(BaseVAE):
         self.attach_grads()
         h = self.encoder(K.to_nhwc(input))
         B = h.shape[0]
-        flat = K._ToNCHW.apply(h).view(B, 1, 1, -1)
-        heads = K.ConvAct.apply(flat, self.fc_mu.weight, self.fc_mu.bias, None, self._head_spec).view(B, -1)
+        heads = K.flatten_linear(h, self.fc_mu.weight, self.fc_mu.bias, self._head_spec.co)
         mu, log_var = K.SplitHeads.apply(heads, self.latent_dim)
-        z = K.ConvAct.apply(flat, self.fc_z.weight, self.fc_z.bias, None, self._cat_spec).view(B, -1)
+        z = K.flatten_linear(h, self.fc_z.weight, self.fc_z.bias, self._cat_spec.co)
         return [mu, log_var, z.view(-1, self.categorical_dim)]
 
     def decode(self, z: Tensor) -> Tensor:

@@ -54,9 +54,7 @@ class EncoderBlock(nn.Module):
 
     def forward(self, x):
         h = self.encoder(x)                                            # NHWC
-        B = h.shape[0]
-        flat = K._ToNCHW.apply(h).view(B, 1, 1, -1)
-        heads = K.ConvAct.apply(flat, self.encoder_mu.weight, self.encoder_mu.bias, None, self._spec).view(B, -1)
+        heads = K.flatten_linear(h, self.encoder_mu.weight, self.encoder_mu.bias, self._spec.co)
         mu, log_var = K.SplitHeads.apply(heads, self.latent_dim)
         return [h, mu, log_var]
 

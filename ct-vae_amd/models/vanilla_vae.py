@@ -68,10 +68,6 @@ class VanillaVAE(BaseVAE):
         grp = PackedLinearGroup([self.fc_mu, self.fc_var])
         self.fc_mu._linear_group = grp
         self.fc_var._linear_group = grp
-        # torch.flatten(NCHW [B,512,2,2]) -> Linear == a 2x2 convolution of the NHWC tensor over the same [in][out] weight block
-        # (include/ctvae_hip.h CTVAE_W_CI_TAP): no layout copies around the flatten, and the data gradient arrives NHWC with
-        # encoder.4's BatchNorm-backward sums in its epilogue like that of any other layer
-        self._head_spec = K.ConvSpec(K.CONV_FLAT, hidden_dims[-1], 2 * latent_dim, 2, 2, 0)
 
         self.decoder_input = PackedLinear(latent_dim, hidden_dims[-1] * 4)
         self._dec_in_spec = K.ConvSpec(K.CONV, latent_dim, hidden_dims[-1] * 4, 1)
@@ -101,11 +97,10 @@ class VanillaVAE(BaseVAE):
         """[B,C,64,64] -> [B, 2L]: fc_mu | fc_var of the flattened encoder output as one GEMM."""
         self.attach_grads()
         h = self.encoder(self._input_nhwc(input))                       # [B,2,2,512] NHWC
-        B = h.shape[0]
         if tuple(h.shape[1:3]) != (2, 2):
             raise RuntimeError("VanillaVAE: fc_mu / fc_var take hidden_dims[-1]*4 features, i.e. a 2x2 encoder output "
                                "(64x64 input through 5 stride-2 layers, vanilla_vae.py:36-37)")
-        return K.ConvAct.apply(h, self.fc_mu.weight, self.fc_mu.bias, None, self._head_spec).view(B, -1)
+        return K.flatten_linear(h, self.fc_mu.weight, self.fc_mu.bias, 2 * self.latent_dim)
 
     def encode(self, input: Tensor) -> List[Tensor]:
         """[B,C,64,64] -> [mu [B,L], log_var [B,L]] (vanilla_vae.py:77-92)."""

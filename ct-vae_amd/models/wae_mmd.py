@@ -58,9 +58,7 @@ class WAE_MMD(BaseVAE):
         """[B,C,64,64] -> z [B, latent_dim] (a Tensor, not a list: wae_mmd.py:81-94)."""
         self.attach_grads()
         h = self.encoder(K.to_nhwc(input))
-        B = h.shape[0]
-        flat = K._ToNCHW.apply(h).view(B, 1, 1, -1)
-        return K.ConvAct.apply(flat, self.fc_z.weight, self.fc_z.bias, None, self._head_spec).view(B, -1)
+        return K.flatten_linear(h, self.fc_z.weight, self.fc_z.bias, self._head_spec.co)
 
     def decode(self, z: Tensor) -> Tensor:
         self.attach_grads()
