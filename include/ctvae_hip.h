@@ -122,7 +122,10 @@ int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float
  * the rider commits the parameter gradients itself (+= under bn_accumulate) -- for a caller that applies the coefficients
  * on load (ctvae_conv_wgrad dy_bn_*) and therefore never calls ctvae_bn_backward.
  * in_scale / in_shift / in_act and dy_bn_y / dy_bn_coef / dy_bn_act / gy_out: the weight gradient's options as in
- * ctvae_conv_wgrad (the layers of the final block, vanilla_vae.py:64-75); with gy_out the data gradient reads g_y from it. */
+ * ctvae_conv_wgrad (the layers of the final block, vanilla_vae.py:64-75); with gy_out the data gradient reads g_y from it.
+ * x == bn_y with in_scale / in_shift given (they must then be that BatchNorm's scale / shift, in_act == bn_act) on the 32 -> 3
+ * picture-side conv (vanilla_vae.py:73-74): ONE kernel forms the data gradient, the BatchNorm-backward sums and the weight
+ * gradient in a single pass over y (image.hip img_bwd_fused_kernel). */
 int ctvae_conv_backward_bn_rows(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
                                 size_t ws_bytes);
 int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* w, float* dw, float* dbias, float* dx, int B,
