@@ -40,6 +40,7 @@ int launch_bn_backward(const float* ga, const float* beta, const float* y, int R
 int launch_wino_filters_batch(int n, const float* const* W, float* const* Uf, float* const* Ub, const int* Ci, const int* Co,
                               hipStream_t st);
 bool upconv_wgrad_supported(const ConvGeom& g);
+bool img_enc_supported(const ConvGeom& g);
 bool img_conv_supported(const ConvGeom& g);
 int launch_img_backward_fused(const ConvGeom& g, const float* dY, const float* W, float* dX, const BnBwdFuse* bnb, float* ws,
                               float** part_out, float** pbias_out, int* nparts, bool want_bias, hipStream_t st);
@@ -311,14 +312,17 @@ int ctvae_conv_dgrad_bn(int kind, const float* dy, const float* w, const float* 
 int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float* dbias, int B, int H, int W, int Ci,
                      int Co, int k, int stride, int pad, int out_pad, int accumulate, const float* in_scale,
                      const float* in_shift, int in_act, const float* dy_bn_y, const float* dy_bn_coef, int dy_bn_act,
-                     float* gy_out, float* ws, size_t ws_bytes, void* stream) {
+                     float* gy_out, float* bn_dgamma, float* bn_dbeta, int bn_accumulate, float* ws, size_t ws_bytes,
+                     void* stream) {
   if (!x || !dy || !dw || !ws || !conv_kind_ok(kind)) return kErrBadArg;
   if ((in_scale != nullptr) != (in_shift != nullptr)) return kErrBadArg;
-  if ((dy_bn_y != nullptr) != (dy_bn_coef != nullptr) || (dy_bn_y != nullptr) != (gy_out != nullptr)) return kErrBadArg;
+  if ((dy_bn_y != nullptr) != (dy_bn_coef != nullptr) || (gy_out != nullptr && dy_bn_y == nullptr)) return kErrBadArg;
+  if ((bn_dgamma != nullptr) != (bn_dbeta != nullptr) || (bn_dgamma != nullptr && (dy_bn_y == nullptr || gy_out != nullptr)))
+    return kErrBadArg;
   ConvGeom g;
   if (conv_geom(g, kind, 0, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
   const InXform xf{in_scale, in_shift, in_act};
-  const DyXform dyx{dy_bn_y, dy_bn_coef, gy_out, dy_bn_act};
+  const DyXform dyx{dy_bn_y, dy_bn_coef, gy_out, dy_bn_act, bn_dgamma, bn_dbeta, bn_accumulate};
   return launch_wgrad(g, x, dy, dw, dbias, ws, ws_bytes, accumulate, (hipStream_t)stream, &xf, &dyx);
 }
 
@@ -413,7 +417,8 @@ int ctvae_conv_wgrad_bn_apply_supported(int kind, int B, int H, int W, int Ci, i
   if (!conv_kind_ok(kind)) return 0;
   ConvGeom g;
   if (conv_geom(g, kind, 0, B, H, W, Ci, Co, k, stride, pad, out_pad)) return 0;
-  return upconv_wgrad_supported(g) ? 1 : 0;
+  if (upconv_wgrad_supported(g)) return 1;
+  return img_enc_supported(g) ? 2 : 0;
 }
 
 int ctvae_bn_forward(const float* y, int R, int C, const float* gamma, const float* beta, float* running_mean,

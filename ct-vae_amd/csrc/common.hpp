@@ -74,8 +74,11 @@ struct InXform {
 struct DyXform {
   const float* y;
   const float* coef;
-  float* gy_out;
+  float* gy_out;     // may be null where no data gradient follows (image.hip img_enc_wgrad_kernel)
   int act;
+  float* dgamma = nullptr;   // with gy_out null: the kernel also commits the BatchNorm's parameter gradients (coef rows 5, 6)
+  float* dbeta = nullptr;
+  int bn_accumulate = 0;
 };
 
 // Winograd filter hand-over between a layer's forward launch and its data-gradient launch (wino.hip)

@@ -667,6 +667,13 @@ struct EncArgs {
   float* out;         // fwd: y [B,H,W,32]; wgrad: slabs [nwg][27][32]
   float* pbias;       // wgrad: [nwg][32]
   float* bn_part;     // fwd: [nwg][32][3] (count, mean, M2) of y, may be null
+  // wgrad, optional: dY is g_a of the BatchNorm behind this layer; g_y = k1*g_a*act'(y*scale+shift) + k2*y + k3 is formed on
+  // load from dy_y and dy_coef [7][32] (rows as ctvae_bn_backward coef_out, 5/6 = d gamma / d beta, committed by block 0)
+  const float* dy_y;
+  const float* dy_coef;
+  float* dgamma;
+  float* dbeta;
+  int dy_act, bn_accumulate;
   int act;
   int B, H, W, tiles_y, tiles_x, ntiles;   // H, W: OUTPUT size
   int tdy[NT], tdx[NT], twt[NT];
@@ -798,6 +805,7 @@ __global__ __launch_bounds__(256, 4) void img_enc_fwd_kernel(const EncArgs a) {
 
 // dW[t][ci][co] = sum_q x[2q + off_t][ci] * dy[q][co]: M = co, N = (t,ci), K = output pixels.  dy goes from global memory
 // straight into the MFMA A operand (128 B per pixel), x comes from the LDS patch.
+template <bool FUSED>
 __global__ __launch_bounds__(256, 4) void img_enc_wgrad_kernel(const EncArgs a) {
   __shared__ __attribute__((aligned(16))) float sX[ENP * 4];
   __shared__ __attribute__((aligned(16))) float sR[4 * 32 * 32];
@@ -814,6 +822,15 @@ __global__ __launch_bounds__(256, 4) void img_enc_wgrad_kernel(const EncArgs a) 
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float bsum = 0.f;
 
+  constexpr bool fused = FUSED;
+  const __amdgpu_buffer_rsrc_t rY = rsrc(a.dy_y, fused ? (long)a.B * a.H * a.W * C * 4 : 0);
+  const float k1 = fused ? a.dy_coef[li] : 0.f, k2 = fused ? a.dy_coef[C + li] : 0.f, k3 = fused ? a.dy_coef[2 * C + li] : 0.f;
+  const float ksc = fused ? a.dy_coef[3 * C + li] : 0.f, ksh = fused ? a.dy_coef[4 * C + li] : 0.f;
+  const float nslope = a.dy_act == ACT_LRELU ? kLeaky : (a.dy_act == ACT_RELU ? 0.f : 1.f);   // host admits only these
+  if (fused && blockIdx.x == 0 && tid < C && a.dgamma != nullptr) {
+    a.dgamma[tid] = (a.bn_accumulate ? a.dgamma[tid] : 0.f) + a.dy_coef[5 * C + tid];
+    a.dbeta[tid] = (a.bn_accumulate ? a.dbeta[tid] : 0.f) + a.dy_coef[6 * C + tid];
+  }
   EncPatch pt;
   float dv[2][16];   // this wave's dy operand: rows ly = wave, wave + 4; 16 pixel pairs each
   auto dy_load = [&](const TileXY& t) {
@@ -822,6 +839,16 @@ __global__ __launch_bounds__(256, 4) void img_enc_wgrad_kernel(const EncArgs a) 
       const unsigned rowoff = (unsigned)(((t.b * a.H + t.y0 + wave + 4 * i) * a.W + t.x0) * C + li) * 4u;
 #pragma unroll
       for (int j = 0; j < 16; ++j) dv[i][j] = ld1(rG, rowoff + (unsigned)((2 * j + lh) * C) * 4u);
+      if constexpr (FUSED) {   // BatchNorm-backward apply on load: no data gradient follows this layer, g_y never reaches memory
+        float yv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) yv[j] = ld1(rY, rowoff + (unsigned)((2 * j + lh) * C) * 4u);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const float g1 = (yv[j] * ksc + ksh) > 0.f ? dv[i][j] : dv[i][j] * nslope;
+          dv[i][j] = k1 * g1 + k2 * yv[j] + k3;
+        }
+      }
     }
   };
   int tile = blockIdx.x;
@@ -929,15 +956,22 @@ int launch_img_enc_forward(const ConvGeom& g, const float* X, const float* W, co
 
 // partial slabs [parts][27][32] (+ bias partials [parts][32]) into ws; the caller reduces them
 int launch_img_enc_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, float** part_out, float** pbias_out,
-                         int* nparts, bool want_bias, hipStream_t st) {
+                         int* nparts, bool want_bias, hipStream_t st, const DyXform* dyx) {
   EncArgs a{};
   fill_enc(a, g);
   a.X = X; a.dY = dY;
+  if (dyx != nullptr && dyx->y != nullptr) {
+    if (dyx->gy_out != nullptr || (dyx->act != ACT_NONE && dyx->act != ACT_RELU && dyx->act != ACT_LRELU)) return kErrBadArg;
+    if ((dyx->dgamma != nullptr) != (dyx->dbeta != nullptr)) return kErrBadArg;
+    a.dy_y = dyx->y; a.dy_coef = dyx->coef; a.dy_act = dyx->act;
+    a.dgamma = dyx->dgamma; a.dbeta = dyx->dbeta; a.bn_accumulate = dyx->bn_accumulate;
+  }
   const int nwg = a.ntiles < 512 ? a.ntiles : 512;
   a.out = ws;
   a.pbias = want_bias ? ws + (size_t)nwg * NJ * C : nullptr;
   ProfScope ps("img_enc_wgrad_kernel", st, 2.0 * a.ntiles * TH * TW * NT * C * NO, 4.0 * a.ntiles * TH * TW * (C + 4 * NO));
-  hipLaunchKernelGGL(img_enc_wgrad_kernel, dim3(nwg), dim3(256), 0, st, a);
+  if (a.dy_y != nullptr) hipLaunchKernelGGL(img_enc_wgrad_kernel<true>, dim3(nwg), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(img_enc_wgrad_kernel<false>, dim3(nwg), dim3(256), 0, st, a);
   CTVAE_LAUNCH_CHECK();
   *part_out = a.out;
   *pbias_out = a.pbias;

@@ -396,7 +396,7 @@ int launch_upconv_wgrad(const ConvGeom& g, const float* X, const float* dY, floa
                         int* nparts, bool want_bias, hipStream_t st, const DyXform* dyx);
 bool img_enc_supported(const ConvGeom& g);
 int launch_img_enc_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, float** part_out, float** pbias_out,
-                         int* nparts, bool want_bias, hipStream_t st);
+                         int* nparts, bool want_bias, hipStream_t st, const DyXform* dyx);
 
 bool wino_wgrad_supported(const ConvGeom& g, size_t ws_floats, int* splits);
 int launch_wino_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, size_t ws_floats, int* nparts,
@@ -418,7 +418,11 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
   }
   const bool up = upconv_wgrad_supported(g) && (xf == nullptr || xf->scale == nullptr) &&
                   ws_bytes / sizeof(float) >= (size_t)512 * (9 * 32 * 32 + 32);
-  if (dyx != nullptr && dyx->y != nullptr && !up) return kErrBadArg;   // only the transposed-conv kernel applies BN-backward on load
+  const bool enc = img_enc_supported(g) && (xf == nullptr || xf->scale == nullptr) &&
+                   ws_bytes / sizeof(float) >= (size_t)512 * (27 * 32 + 32);
+  // BN-backward on load: the transposed-conv kernel (writes g_y for the data gradient) and encoder.0's (no data gradient, no g_y)
+  if (dyx != nullptr && dyx->y != nullptr && !up && !(enc && dyx->gy_out == nullptr)) return kErrBadArg;
+  if (dyx != nullptr && dyx->y != nullptr && up && dyx->gy_out == nullptr) return kErrBadArg;
   if (up) {
     float *part = nullptr, *pb = nullptr;
     int np = 0;
@@ -427,10 +431,10 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
     const long n = 9L * 32 * 32;
     return finish_reduce(part, dW, n, np, n, pb, dbias, 32L, np, 32L, accumulate, st);
   }
-  if (img_enc_supported(g) && (xf == nullptr || xf->scale == nullptr) && ws_bytes / sizeof(float) >= (size_t)512 * (27 * 32 + 32)) {
+  if (enc) {
     float *part = nullptr, *pb = nullptr;
     int np = 0;
-    int rc = launch_img_enc_wgrad(g, X, dY, ws, &part, &pb, &np, dbias != nullptr, st);
+    int rc = launch_img_enc_wgrad(g, X, dY, ws, &part, &pb, &np, dbias != nullptr, st, dyx);
     if (rc) return rc;
     const long n = 27L * 32;
     return finish_reduce(part, dW, n, np, n, pb, dbias, 32L, np, 32L, accumulate, st);

@@ -322,9 +322,10 @@ def conv_dgrad_bn_raw(dy, w, spec: ConvSpec, in_hw, link: BNLink):
     return dx
 
 
-def conv_wgrad_raw(x, dy, w_param, b_param, spec: ConvSpec, in_coef=None, in_act=ACT_NONE, dy_bn=None):
+def conv_wgrad_raw(x, dy, w_param, b_param, spec: ConvSpec, in_coef=None, in_act=ACT_NONE, dy_bn=None, bn_commit=None):
     """dy_bn = (y, coef[5][Co], act, gy_out): dy is g_a of the BatchNorm behind this layer; g_y is formed on load and
-    written to gy_out (ctvae_conv_wgrad dy_bn_*)."""
+    written to gy_out (ctvae_conv_wgrad dy_bn_*).  gy_out None + bn_commit = (dgamma, dbeta, accumulate): the layer with no
+    data gradient (encoder.0) -- g_y is never written and the kernel commits the BatchNorm's parameter gradients."""
     B, H, W, _ = x.shape
     ws = native.workspace(x.device)
     gw, acc = grad_target(w_param)
@@ -339,15 +340,17 @@ def conv_wgrad_raw(x, dy, w_param, b_param, spec: ConvSpec, in_coef=None, in_act
             acc = 1
     sc = in_coef.data_ptr() if in_coef is not None else None
     sh = in_coef.data_ptr() + 4 * spec.ci if in_coef is not None else None
-    by, bc, bact, bgy = (dy_bn[0].data_ptr(), dy_bn[1].data_ptr(), dy_bn[2], dy_bn[3].data_ptr()) if dy_bn is not None else (None, None, 0, None)
+    by, bc, bact, bgy = (dy_bn[0].data_ptr(), dy_bn[1].data_ptr(), dy_bn[2], native.ptr(dy_bn[3])) if dy_bn is not None else (None, None, 0, None)
+    cg, cb, cacc = (bn_commit[0].data_ptr(), bn_commit[1].data_ptr(), bn_commit[2]) if bn_commit is not None else (None, None, 0)
     native.call("ctvae_conv_wgrad", spec.kind, x.data_ptr(), dy.data_ptr(), gw.data_ptr(), native.ptr(gb),
                 B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, acc, sc, sh, in_act,
-                by, bc, bact, bgy, ws.data_ptr(), ws.numel() * 4)
+                by, bc, bact, bgy, cg, cb, cacc, ws.data_ptr(), ws.numel() * 4)
 
 
 _PAIR = os.environ.get("CTVAE_NO_PAIR", "0") != "1"     # diagnostic: separate wgrad / dgrad launches
 _BN_RIDER = os.environ.get("CTVAE_NO_BN_RIDER", "0") != "1"   # diagnostic: BatchNorm-backward finalize as its own launch
 _OUT_ACT_LINK = os.environ.get("CTVAE_NO_OUT_ACT_LINK", "0") != "1"   # diagnostic: final Tanh backward as its own launch
+_ENC_BN_ON_LOAD = os.environ.get("CTVAE_NO_ENC_BN_ON_LOAD", "0") != "1"   # diagnostic: encoder.0's BatchNorm-backward apply as its own launch
 
 
 def conv_backward_raw(x, dy, w_param, b_param, spec: ConvSpec, link=None, mask=None, mask_act=ACT_NONE, wino_filters=None,
@@ -728,7 +731,6 @@ class ConvBNAct(Function):
         g_a = _c(g_a)
         B, H, W, C = y.shape
         ws = native.workspace(x.device)
-        g_y = torch.empty_like(y)
         gg, accg = grad_target(gamma)
         gbt, accb = grad_target(beta)
         if accg != accb:
@@ -737,6 +739,12 @@ class ConvBNAct(Function):
         part, rows, coef = ctx.link_out.take(g_a) if ctx.link_out is not None else (None, 0, None)
         if coef is not None:
             part, rows = None, 0         # finalized by the consumer's finishing launch: apply + commit only
+            if not ctx.needs_input_grad[0] and _ENC_BN_ON_LOAD and wgrad_bn_apply_mode(spec, x.shape[0], x.shape[1], x.shape[2]) == 2:
+                # the first layer of the encoder: no data gradient follows, so g_y is only the weight gradient's operand -- formed
+                # on load from (g_a, y, coef); the apply launch and its 33 MB output are not needed
+                conv_wgrad_raw(x, g_a, w, b, spec, dy_bn=(y, coef, ctx.bn_act, None), bn_commit=(gg, gbt, accg))
+                return (None,) * 11
+        g_y = torch.empty_like(y)
         native.call("ctvae_bn_backward", g_a.data_ptr(), beta.data_ptr(), y.data_ptr(), B * H * W, C, gamma.data_ptr(),
                     save_mean.data_ptr(), save_invstd.data_ptr(), ctx.bn_act, g_y.data_ptr(), gg.data_ptr(), gbt.data_ptr(),
                     accg, native.ptr(part), rows, None, native.ptr(coef), ws.data_ptr(), ws.numel() * 4)
@@ -759,13 +767,19 @@ def input_transform_supported(spec: ConvSpec, B, H, W) -> bool:
 _wgrad_bn_ok_cache = {}
 
 
-def wgrad_bn_apply_supported(spec: ConvSpec, B, H, W) -> bool:
-    """Can this layer's weight-gradient kernel apply the BatchNorm backward on load (ctvae_conv_wgrad dy_bn_*)?"""
+def wgrad_bn_apply_mode(spec: ConvSpec, B, H, W) -> int:
+    """ctvae_conv_wgrad_bn_apply_supported: 0 no; 1 the weight-gradient kernel applies the BatchNorm backward on load and writes
+    g_y for the data gradient (final_layer.0); 2 it applies it on load and nothing is written (encoder.0: no data gradient)."""
     key = (spec.kind, B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad)
-    ok = _wgrad_bn_ok_cache.get(key)
-    if ok is None:
-        ok = _wgrad_bn_ok_cache[key] = bool(native.load().ctvae_conv_wgrad_bn_apply_supported(*key))
-    return ok
+    mode = _wgrad_bn_ok_cache.get(key)
+    if mode is None:
+        mode = _wgrad_bn_ok_cache[key] = int(native.load().ctvae_conv_wgrad_bn_apply_supported(*key))
+    return mode
+
+
+def wgrad_bn_apply_supported(spec: ConvSpec, B, H, W) -> bool:
+    """Can this layer's weight-gradient kernel apply the BatchNorm backward on load and hand g_y on (ctvae_conv_wgrad dy_bn_*)?"""
+    return wgrad_bn_apply_mode(spec, B, H, W) == 1
 
 
 class ConvBNActConvAct(Function):

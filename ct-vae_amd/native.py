@@ -22,7 +22,7 @@ SIGNATURES = {
     "ctvae_conv_bn_act_forward": [_i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp] + [_i] * 9
                                  + [_fp, _sz, _vp],
     "ctvae_conv_dgrad": [_i, _fp, _fp, _fp, _fp, _i, _fp] + [_i] * 9 + [_fp, _fp, _sz, _vp],
-    "ctvae_conv_wgrad": [_i, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _sz, _vp],
+    "ctvae_conv_wgrad": [_i, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _fp, _i, _fp, _sz, _vp],
     "ctvae_conv_backward": [_i, _fp, _fp, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _i,
                             _fp, _fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _sz, _vp],
     "ctvae_bn_forward": [_fp, _i, _i, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _fp, _fp, _fp, _fp, _fp, _sz, _vp],

@@ -107,7 +107,8 @@ int ctvae_conv_dgrad_bn(int kind, const float* dy, const float* w, const float* 
 int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float* dbias, int B, int H, int W, int Ci,
                      int Co, int k, int stride, int pad, int out_pad, int accumulate, const float* in_scale,
                      const float* in_shift, int in_act, const float* dy_bn_y, const float* dy_bn_coef, int dy_bn_act,
-                     float* gy_out, float* ws, size_t ws_bytes, void* stream);
+                     float* gy_out, float* bn_dgamma, float* bn_dbeta, int bn_accumulate, float* ws, size_t ws_bytes,
+                     void* stream);
 /* A layer's whole backward pass in one call: weight (+ bias) gradient as ctvae_conv_wgrad(x, dy -> dw, dbias) and data
  * gradient as ctvae_conv_dgrad / ctvae_conv_dgrad_bn(dy, w -> dx; optional mask, Winograd filters, fused BatchNorm-backward
  * sums).  The two GEMMs are independent; when both take their 64x64 tile kernels they are issued as ONE launch
@@ -141,7 +142,11 @@ int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* 
  * activation that follows this layer; the kernel forms g_y = k1*g_a*act'(y*scale+shift) + k2*y + k3 while loading
  * (coef = [5][Co]: k1,k2,k3,scale,shift as written by ctvae_bn_backward coef_out), uses it for dw/dbias and writes it to
  * gy_out for the ctvae_conv_dgrad call that follows: the separate BatchNorm-backward apply pass disappears.
- * Only where ctvae_conv_wgrad_bn_apply_supported() says 1 (the 32->32 transposed conv of the final block). */
+ * Only where ctvae_conv_wgrad_bn_apply_supported() says 1 (the 32->32 transposed conv of the final block).
+ * Where it says 2 (encoder.0, the 3 -> 32 picture-side conv, vanilla_vae.py:25-35 with i = 0: no data gradient follows, the
+ * input is the picture) gy_out must be NULL -- g_y is used for dw/dbias and never written -- coef is the [7][Co] block of
+ * ctvae_conv_backward's bn_coef_out, and bn_dgamma / bn_dbeta (both or none; += under bn_accumulate) receive its rows 5, 6:
+ * the BatchNorm-backward apply launch and its 33 MB output disappear. */
 int ctvae_conv_wgrad_bn_apply_supported(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad,
                                         int out_pad);
 
