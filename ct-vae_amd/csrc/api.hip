@@ -120,6 +120,7 @@ int launch_reparam_fwd(const float* mu, long mu_rs, const float* lv, long lv_rs,
 int launch_reparam_bwd(const float* gz, const float* lv, long lv_rs, const float* eps, float* gmu, float* glv, int B, int L,
                        hipStream_t st);
 int launch_adam(float* p, const float* g, float* m, float* v, float* state, long n, float grad_scale, hipStream_t st);
+size_t adam_state_floats();
 int launch_gumbel_fwd(const float* p, const float* noise, float* out, float* soft, long n, hipStream_t st);
 int launch_gumbel_bwd(const float* go, const float* p, const float* soft, float* gp, long n, hipStream_t st);
 int launch_gumbel_softmax_fwd(const float* z, const float* u, float* s, long rows, int Q, float temp, float eps, hipStream_t st);
@@ -856,6 +857,8 @@ int ctvae_dip_backward(const float* state, const float* g_dip, float* g_mu, floa
   if (!state || !g_dip || !g_mu || !g_logvar || B <= 0 || D <= 0) return kErrBadArg;
   return launch_dip_backward(state, g_dip, g_mu, g_logvar, B, D, (hipStream_t)stream);
 }
+
+size_t ctvae_adam_state_floats(void) { return adam_state_floats(); }
 
 int ctvae_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* state, long n,
                     float grad_scale, void* stream) {

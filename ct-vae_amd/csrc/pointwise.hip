@@ -160,32 +160,81 @@ __global__ __launch_bounds__(256) void gauss_latent_bwd_kernel(const float* __re
 }
 
 // ---- Adam ---------------------------------------------------------------------------------------------
-// state[0]=step (as float), [1]=lr, [2]=beta1, [3]=beta2, [4]=eps, [5]=weight_decay, [6]=beta1^t, [7]=beta2^t
-__global__ void adam_advance_kernel(float* state) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    state[0] += 1.f;
-    state[6] *= state[2];
-    state[7] *= state[3];
-  }
-}
-
+// state[0]=step (as float), [1]=lr, [2]=beta1, [3]=beta2, [4]=eps, [5]=weight_decay, [6]=beta1^t, [7]=beta2^t,
+// [16 + 16k], k = 0..64: ticket counters (bits), zero between launches -- kAdamStateFloats floats in all
+constexpr int kAdamTicketOffset = 16, kAdamMaxWgs = 2048, kAdamStateFloats = kAdamTicketOffset + 16 * (1 + kAdamMaxWgs / 32);
 // torch.optim.Adam (no amsgrad): g += wd*p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// The step counter's advance rides in this launch: every thread forms beta^t of THIS step from the stored beta^(t-1), and the
+// workgroup that finishes last -- every other one has read the state by then -- writes the advanced state back.  With ONE
+// ticket counter the 2048 same-address atomics serialised behind the kernel (19.5 -> 37.7 us, tools/negative), and fewer,
+// fatter workgroups stream slower (512: 27.5 us, 256: 43 us): hence the two-level ticket below.
+template <bool VEC>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, const float* __restrict__ state, long n,
-                                                   float grad_scale) {
+                                                   float* __restrict__ v, float* state, long n, float grad_scale) {
   const float lr = state[1], b1 = state[2], b2 = state[3], eps = state[4], wd = state[5];
-  const float bc1 = 1.f - state[6], bc2 = 1.f - state[7];
+  const float b1t = state[6] * b1, b2t = state[7] * b2;
+  const float bc1 = 1.f - b1t, bc2 = 1.f - b2t;
   const float step_size = lr / bc1, bc2s = sqrtf(bc2);
   const long stride = (long)gridDim.x * 256;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    float pi = p[i];
-    float gi = g[i] * grad_scale + wd * pi;
-    float mi = b1 * m[i] + (1.f - b1) * gi;
-    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  auto upd = [&](float& pi, float gi, float& mi, float& vi) {
+    gi = gi * grad_scale + wd * pi;
+    mi = b1 * mi + (1.f - b1) * gi;
+    vi = b2 * vi + (1.f - b2) * gi * gi;
+    pi = pi - step_size * (mi / (sqrtf(vi) / bc2s + eps));
+  };
+  const long n4 = VEC ? n / 4 : 0;
+  if constexpr (VEC) {   // all four buffers 16-byte aligned: 16-byte accesses, two quads per thread in flight
+    f32x4* p4 = reinterpret_cast<f32x4*>(p);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+    f32x4* m4 = reinterpret_cast<f32x4*>(m);
+    f32x4* v4 = reinterpret_cast<f32x4*>(v);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += 2 * stride) {
+      const long i2 = i + stride;
+      const bool two = i2 < n4;
+      f32x4 pa = p4[i], ga = g4[i], ma = m4[i], va = v4[i];
+      f32x4 pb = two ? p4[i2] : pa, gb = two ? g4[i2] : ga, mb = two ? m4[i2] : ma, vb = two ? v4[i2] : va;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float pq = pa[q], mq = ma[q], vq = va[q];
+        upd(pq, ga[q], mq, vq);
+        pa[q] = pq; ma[q] = mq; va[q] = vq;
+      }
+      m4[i] = ma; v4[i] = va; p4[i] = pa;
+      if (two) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float pq = pb[q], mq = mb[q], vq = vb[q];
+          upd(pq, gb[q], mq, vq);
+          pb[q] = pq; mb[q] = mq; vb[q] = vq;
+        }
+        m4[i2] = mb; v4[i2] = vb; p4[i2] = pb;
+      }
+    }
+  }
+  for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    float pi = p[i], mi = m[i], vi = v[i];
+    upd(pi, g[i], mi, vi);
     m[i] = mi;
     v[i] = vi;
-    p[i] = pi - step_size * (mi / (sqrtf(vi) / bc2s + eps));
+    p[i] = pi;
+  }
+  __syncthreads();   // every thread of this workgroup holds its copy of the state
+  if (threadIdx.x == 0) {
+    // two-level ticket, every counter on its own 64-byte line: 32 workgroups share a first-level counter, the last of each
+    // group takes a ticket of the top-level one (<= 64 groups)
+    unsigned* tk = reinterpret_cast<unsigned*>(state + kAdamTicketOffset);
+    const unsigned grp = blockIdx.x >> 5, ngrp = (gridDim.x + 31) >> 5;
+    const unsigned gsize = gridDim.x - grp * 32 < 32 ? gridDim.x - grp * 32 : 32;
+    if (atomicAdd(tk + 16 * (1 + grp), 1u) == gsize - 1) {
+      atomicExch(tk + 16 * (1 + grp), 0u);
+      if (atomicAdd(tk, 1u) == ngrp - 1) {
+        atomicExch(tk, 0u);
+        state[0] += 1.f;
+        state[6] = b1t;
+        state[7] = b2t;
+      }
+    }
   }
 }
 
@@ -275,11 +324,15 @@ int launch_gumbel_bwd(const float* go, const float* p, const float* soft, float*
   return 0;
 }
 
+size_t adam_state_floats() { return kAdamStateFloats; }
+
 int launch_adam(float* p, const float* g, float* m, float* v, float* state, long n, float grad_scale, hipStream_t st) {
   ProfScope ps("adam_kernel", st, 0.0, 28.0 * (double)n);
-  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, st, state);
-  CTVAE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, st, p, g, m, v, state, n, grad_scale);
+  static const int wgs = [] { const char* e = getenv("CTVAE_ADAM_WGS"); const int w = e ? atoi(e) : 1024; return w > kAdamMaxWgs ? kAdamMaxWgs : w; }();   // diagnostic
+  const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                     reinterpret_cast<uintptr_t>(v)) % 16) == 0;
+  if (vec) hipLaunchKernelGGL(adam_kernel<true>, dim3(grid_for(n / 4, wgs)), dim3(256), 0, st, p, g, m, v, state, n, grad_scale);
+  else hipLaunchKernelGGL(adam_kernel<false>, dim3(grid_for(n, wgs)), dim3(256), 0, st, p, g, m, v, state, n, grad_scale);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }

@@ -2090,6 +2090,18 @@ class VQLookup(Function):
 # ---------------------------------------------------------------------------------------------------
 # flat fused Adam
 # ---------------------------------------------------------------------------------------------------
+def adam_state(head, device):
+    """The device state of ctvae_adam_step: head = [step, lr, beta1, beta2, eps, weight_decay, beta1^step, beta2^step], followed
+    by the kernel's zeroed ticket counters (ctvae_adam_state_floats() floats in all).  On the CPU (the gloo tests run a test
+    double of the kernel): just the head."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return torch.tensor(head, dtype=torch.float32, device=dev)
+    st = torch.zeros(int(native.load().ctvae_adam_state_floats()), dtype=torch.float32, device=dev)
+    st[:8] = torch.tensor(head, dtype=torch.float32)
+    return st
+
+
 def adam_step(flat_params, flat_grads, exp_avg, exp_avg_sq, state, grad_scale=1.0):
     _req_cuda(flat_params, flat_grads)
     bump_param_epoch()

@@ -112,6 +112,7 @@ _RESTYPES = {
     "ctvae_winograd_enable": _c.c_int,
     "ctvae_conv_wino_filter_floats": _c.c_size_t,
     "ctvae_dip_state_floats": _c.c_size_t,
+    "ctvae_adam_state_floats": _c.c_size_t,
     "ctvae_glinear_wgrad_ws_bytes": _c.c_size_t,
     "ctvae_conv_input_transform_supported": _c.c_int,
     "ctvae_conv_wgrad_bn_apply_supported": _c.c_int,

@@ -28,8 +28,7 @@ class FlatAdam:
         n = flat[self.slice].numel()
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=flat.device)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=flat.device)
-        self.state = torch.tensor([0.0, lr, betas[0], betas[1], eps, weight_decay, 1.0, 1.0], dtype=torch.float32,
-                                  device=flat.device)
+        self.state = K.adam_state([0.0, lr, betas[0], betas[1], eps, weight_decay, 1.0, 1.0], flat.device)
         self.lr = lr
 
     def set_lr(self, lr):
@@ -50,7 +49,7 @@ class FlatAdam:
     def load_state_dict(self, sd):
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        self.state.copy_(sd["state"])
+        self.state[:8].copy_(sd["state"][:8])      # (states saved before the ticket word existed have 8 entries)
 
 
 class ExponentialLR:

@@ -472,8 +472,11 @@ int ctvae_dip_forward(const float* mu, long mu_row_stride, const float* logvar, 
                       float lambda_diag, float lambda_offdiag, float* state, void* stream);
 int ctvae_dip_backward(const float* state, const float* g_dip, float* g_mu, float* g_logvar, int B, int D, void* stream);
 
-/* torch.optim.Adam step over one flat buffer (experiment.py:158-160).  state (device, 8 floats):
- * {step, lr, beta1, beta2, eps, weight_decay, beta1^step, beta2^step}; the call advances step. */
+/* torch.optim.Adam step over one flat buffer (experiment.py:158-160).  state (device, ctvae_adam_state_floats() floats, 64-byte
+ * aligned): [0..7] = {step, lr, beta1, beta2, eps, weight_decay, beta1^step, beta2^step}, the rest scratch (ticket counters),
+ * all zero when the caller creates the state.  The call advances step inside its one launch: the workgroup that finishes
+ * last writes the advanced state back. */
+size_t ctvae_adam_state_floats(void);
 int ctvae_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* state, long n,
                     float grad_scale, void* stream);
 

@@ -341,7 +341,7 @@ def test_adam_matches_torch(K):
     opt = torch.optim.Adam([ref], lr=0.005, weight_decay=0.01)
     pd = p0.cuda()
     m, v = torch.zeros_like(pd), torch.zeros_like(pd)
-    state = torch.tensor([0.0, 0.005, 0.9, 0.999, 1e-8, 0.01, 1.0, 1.0], device="cuda")
+    state = K.adam_state([0.0, 0.005, 0.9, 0.999, 1e-8, 0.01, 1.0, 1.0], "cuda")
     for step in range(4):
         gr = torch.randn(n, generator=g)
         ref.grad = gr.clone()
