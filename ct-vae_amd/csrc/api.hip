@@ -121,6 +121,10 @@ int launch_reparam_bwd(const float* gz, const float* lv, long lv_rs, const float
                        hipStream_t st);
 int launch_adam(float* p, const float* g, float* m, float* v, float* state, long n, float grad_scale, hipStream_t st);
 size_t adam_state_floats();
+float* defer_wgrad_ws(float* ws, size_t ws_floats);
+void defer_wgrad_done();
+int defer_begin(float* arena, size_t arena_floats);
+int defer_flush(hipStream_t st);
 int launch_gumbel_fwd(const float* p, const float* noise, float* out, float* soft, long n, hipStream_t st);
 int launch_gumbel_bwd(const float* go, const float* p, const float* soft, float* gp, long n, hipStream_t st);
 int launch_gumbel_softmax_fwd(const float* z, const float* u, float* s, long rows, int Q, float temp, float eps, hipStream_t st);
@@ -324,8 +328,14 @@ int ctvae_conv_wgrad(int kind, const float* x, const float* dy, float* dw, float
   if (conv_geom(g, kind, 0, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
   const InXform xf{in_scale, in_shift, in_act};
   const DyXform dyx{dy_bn_y, dy_bn_coef, gy_out, dy_bn_act, bn_dgamma, bn_dbeta, bn_accumulate};
-  return launch_wgrad(g, x, dy, dw, dbias, ws, ws_bytes, accumulate, (hipStream_t)stream, &xf, &dyx);
+  float* wws = defer_wgrad_ws(ws, ws_bytes / sizeof(float));   // between ctvae_defer_begin / _flush: slabs into the arena
+  const int rc = launch_wgrad(g, x, dy, dw, dbias, wws, ws_bytes, accumulate, (hipStream_t)stream, &xf, &dyx);
+  defer_wgrad_done();
+  return rc;
 }
+
+int ctvae_defer_begin(float* arena, size_t arena_bytes) { return defer_begin(arena, arena_bytes / sizeof(float)); }
+int ctvae_defer_flush(void* stream) { return defer_flush((hipStream_t)stream); }
 
 int ctvae_conv_backward_bn_rows(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
                                 size_t ws_bytes) {
@@ -395,7 +405,10 @@ int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* 
     rc = launch_img_backward_fused(gd, dy, w, dx, &f, ws, &part, &pb, &np, dbias != nullptr, st);
     if (!rc) rc = wgrad_finish_slabs(part, dw, 9L * 32 * 3, np, pb, dbias, 3L, accumulate, st);
   } else {
-    rc = launch_wgrad(gw, x, dy, dw, dbias, ws, half_bytes, accumulate, st, &xf, &dyx);
+    // (a finishing launch that carries the BatchNorm finalize of the layer below stays in the chain: its reduction rides there)
+    float* wws = bn_coef_out == nullptr ? defer_wgrad_ws(ws, half_floats) : ws;
+    rc = launch_wgrad(gw, x, dy, dw, dbias, wws, half_bytes, accumulate, st, &xf, &dyx);
+    defer_wgrad_done();
     if (!rc) {
     const WinoFilters wf{wino_filters, nullptr};
     const BnBwdFuse f{bn_y, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_act, bn_part};

@@ -242,7 +242,11 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradArgs a, int 
 // blocks [0, nb1) serve job 1, the rest job 2.  Two block shapes, both deterministic (fixed summation order):
 //  * few slices (S <= 8): one thread per float4 / float, a plain pass over the slices;
 //  * many slices: 16 split-lanes x 16 element-lanes; lane j sums s = j, j+16, ... , then a fixed shuffle tree
-//    and a 4-wave LDS combine.  With VEC the element lane covers a float4 (64 elements per block).
+//    and a 4-wave LDS combine.  With VEC the element lane covers a float4 (64 elements per block): the most workgroups and
+//    the shortest dependent chain -- the shape for the small jobs that sit in the backward chain;
+//  * many slices of a LARGE gradient (>= kReduceWideItems elements per slice; `small` == 2): 4 split-lanes (the waves) x 64
+//    element-lanes, wave w sums s = w, w+4, ... with eight loads in flight, 4-wave LDS combine in a fixed order -- 1 KB of every
+//    slab per workgroup instead of 256 B (MCQ-VAE's 3x3 layers: 600 MB of slabs per step, 3.5 -> 5.6 TB/s).
 
 template <typename T>
 __device__ __forceinline__ T rzero();
@@ -261,7 +265,7 @@ __device__ __forceinline__ void reduce_small(const ReduceJob& j, int blk, int ac
 }
 
 template <typename T>
-__device__ __forceinline__ void reduce_split(const ReduceJob& j, int blk, int accumulate, T (*sm)[16]) {
+__device__ __forceinline__ void reduce_split(const ReduceJob& j, int blk, int accumulate, T (*sm)[64]) {
   const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const long n = j.n / (long)(sizeof(T) / 4), i = (long)blk * 16 + el;
   T v = rzero<T>();
@@ -290,11 +294,31 @@ __device__ __forceinline__ void reduce_split(const ReduceJob& j, int blk, int ac
   }
 }
 
+template <typename T>
+__device__ __forceinline__ void reduce_wide(const ReduceJob& j, int blk, int accumulate, T (*sm)[64]) {
+  // wave = split lane: wave w sums the slabs w, w+4, ... for 64 consecutive elements (1 KB of every slab per workgroup with
+  // float4 elements), eight loads in flight; the four waves' sums are combined in a fixed order
+  const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const long n = j.n / (long)(sizeof(T) / 4), i = (long)blk * 64 + el;
+  T v = rzero<T>();
+  if (i < n) {
+#pragma unroll 8
+    for (int s = sl; s < j.S; s += 4) v += reinterpret_cast<const T*>(j.part + (long)s * j.stride)[i];
+  }
+  sm[sl][el] = v;
+  __syncthreads();
+  if (sl == 0 && i < n) {
+    T t = ((sm[0][el] + sm[1][el]) + sm[2][el]) + sm[3][el];
+    T* d = reinterpret_cast<T*>(j.dst) + i;
+    *d = accumulate ? (*d + t) : t;
+  }
+}
+
 // blocks [0, nb1) job 1, [nb1, nb12) job 2, [nb12, nb123) the split-K finish of the paired data gradient (sk.nblk blocks, may be
 // 0), [nb123, ...) the BatchNorm-backward finalize of the layer below (bf.C blocks, may be 0)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(ReduceJob j1, ReduceJob j2, int nb1, int accumulate, SplitKJob sk, int nb12,
                                                               BnFinJob bf, int nb123) {
-  __shared__ f32x4 sm[4][16];
+  __shared__ f32x4 sm[4][64];
   if ((int)blockIdx.x >= nb123) {
     bn_bwd_finalize_body(bf, (int)blockIdx.x - nb123, reinterpret_cast<double*>(&sm[0][0]));
     return;
@@ -306,21 +330,25 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(ReduceJob j1, Redu
   const bool second = (int)blockIdx.x >= nb1;
   const ReduceJob j = second ? j2 : j1;
   const int blk = second ? blockIdx.x - nb1 : blockIdx.x;
-  if (j.small) {
+  if (j.small == 1) {
     if (j.vec) reduce_small<f32x4>(j, blk, accumulate);
     else reduce_small<float>(j, blk, accumulate);
+  } else if (j.small == 2) {
+    if (j.vec) reduce_wide<f32x4>(j, blk, accumulate, sm);
+    else reduce_wide<float>(j, blk, accumulate, reinterpret_cast<float(*)[64]>(sm));
   } else {
     if (j.vec) reduce_split<f32x4>(j, blk, accumulate, sm);
-    else reduce_split<float>(j, blk, accumulate, reinterpret_cast<float(*)[16]>(sm));
+    else reduce_split<float>(j, blk, accumulate, reinterpret_cast<float(*)[64]>(sm));
   }
 }
 
 static int reduce_job_blocks(ReduceJob& j) {
   if (j.n <= 0 || j.S <= 0) return 0;
   j.vec = ((j.n & 3) == 0 && (j.stride & 3) == 0 && (((uintptr_t)j.part | (uintptr_t)j.dst) & 15) == 0) ? 1 : 0;
-  j.small = j.S <= 8 ? 1 : 0;
   const long items = j.vec ? j.n / 4 : j.n;
-  return (int)(j.small ? (items + 255) / 256 : (items + 15) / 16);
+  static const long wide_items = [] { const char* e = getenv("CTVAE_REDUCE_WIDE_ITEMS"); return e ? atol(e) : 65536L; }();   // diagnostic
+  j.small = j.S <= 8 ? 1 : (items >= wide_items ? 2 : 0);
+  return (int)(j.small == 1 ? (items + 255) / 256 : (j.small == 2 ? (items + 63) / 64 : (items + 15) / 16));
 }
 
 static void launch_reduce2(const float* p1, float* d1, long n1, int S1, long st1, const float* p2, float* d2, long n2, int S2,
@@ -336,10 +364,147 @@ static void launch_reduce(const float* part, float* dst, long n, int S, long str
   launch_reduce2(part, dst, n, S, stride, nullptr, nullptr, 0, 0, 0, accumulate, st);
 }
 
+// ---- deferred slab reductions (ctvae_defer_begin / ctvae_defer_flush) -------------------------------------------------------
+// A parameter gradient is not read before the optimizer step, so the slab reduction behind a weight-gradient kernel need not sit
+// in the backward chain: between ctvae_defer_begin and ctvae_defer_flush the weight-gradient kernels write their slabs into the
+// caller's arena (each call behind the previous one's slabs) and the reductions are only recorded; the flush runs all of them
+// in one or two launches.  MCQ-VAE / CT-MCQ-VAE: 33 finishing launches of ~19 MB each per step become one pass over 630 MB.
+// Calls whose finishing launch carries a BatchNorm-backward finalize keep it (VanillaVAE's: that launch is in the chain anyway).
+constexpr int kDeferJobsPerLaunch = 24;
+struct DeferTable {
+  ReduceJob j[kDeferJobsPerLaunch];
+  int acc[kDeferJobsPerLaunch];
+  int blk0[kDeferJobsPerLaunch + 1];
+  int n;
+};
+struct DeferJob {
+  ReduceJob j;
+  int acc, nb;
+};
+struct DeferCtx {
+  bool active = false;
+  float* base = nullptr;
+  size_t floats = 0, off = 0;
+  float* cur = nullptr;       // arena workspace handed to the weight-gradient call that is running (null: not deferring this call)
+  size_t cur_floats = 0;
+  std::vector<DeferJob> jobs;
+  double bytes = 0;
+};
+// process-wide, not thread-local: loss.backward() runs the gradient kernels' launchers on autograd's device thread while the
+// thread that called ctvae_defer_begin waits for it -- one deferral at a time per process (one GPU per process, one stream)
+static DeferCtx& defer_ctx() {
+  static DeferCtx c;
+  return c;
+}
+
+__global__ __launch_bounds__(256) void reduce_multi_kernel(const DeferTable t) {
+  __shared__ f32x4 sm[4][64];
+  int k = 0;
+  while (k + 1 < t.n && (int)blockIdx.x >= t.blk0[k + 1]) ++k;   // workgroup-uniform
+  const ReduceJob j = t.j[k];
+  const int blk = blockIdx.x - t.blk0[k], accumulate = t.acc[k];
+  if (j.small == 1) {
+    if (j.vec) reduce_small<f32x4>(j, blk, accumulate);
+    else reduce_small<float>(j, blk, accumulate);
+  } else if (j.small == 2) {
+    if (j.vec) reduce_wide<f32x4>(j, blk, accumulate, sm);
+    else reduce_wide<float>(j, blk, accumulate, reinterpret_cast<float(*)[64]>(sm));
+  } else {
+    if (j.vec) reduce_split<f32x4>(j, blk, accumulate, sm);
+    else reduce_split<float>(j, blk, accumulate, reinterpret_cast<float(*)[64]>(sm));
+  }
+}
+
+// workspace of the weight-gradient call that follows: a slice of the arena while deferring (and there is room), else ws
+float* defer_wgrad_ws(float* ws, size_t ws_floats) {
+  DeferCtx& d = defer_ctx();
+  d.cur = nullptr;
+  if (!d.active || d.floats - d.off < ws_floats) return ws;
+  d.cur = d.base + d.off;
+  d.cur_floats = ws_floats;
+  return d.cur;
+}
+void defer_wgrad_done() { defer_ctx().cur = nullptr; }
+
+int defer_begin(float* arena, size_t arena_floats) {
+  DeferCtx& d = defer_ctx();
+  if (d.active || arena == nullptr) return kErrBadArg;
+  d.active = true;
+  d.base = arena; d.floats = arena_floats; d.off = 0; d.cur = nullptr;
+  d.jobs.clear();
+  d.bytes = 0;
+  return 0;
+}
+
+static int defer_run_pending(DeferCtx& d, hipStream_t st);
+
+int defer_flush(hipStream_t st) {
+  DeferCtx& d = defer_ctx();
+  if (!d.active) return kErrBadArg;
+  d.active = false;
+  d.cur = nullptr;
+  return defer_run_pending(d, st);
+}
+
+static int defer_run_pending(DeferCtx& d, hipStream_t st) {
+  for (size_t i0 = 0; i0 < d.jobs.size(); i0 += kDeferJobsPerLaunch) {
+    DeferTable t{};
+    int nb = 0;
+    double bytes = 0;
+    t.n = (int)(d.jobs.size() - i0 < (size_t)kDeferJobsPerLaunch ? d.jobs.size() - i0 : (size_t)kDeferJobsPerLaunch);
+    for (int k = 0; k < t.n; ++k) {
+      const DeferJob& dj = d.jobs[i0 + k];
+      t.j[k] = dj.j; t.acc[k] = dj.acc; t.blk0[k] = nb;
+      nb += dj.nb;
+      bytes += 4.0 * (double)(dj.j.S + 1) * dj.j.n;
+    }
+    t.blk0[t.n] = nb;
+    if (nb == 0) continue;
+    ProfScope ps("reduce_multi_kernel", st, 0.0, bytes);
+    hipLaunchKernelGGL(reduce_multi_kernel, dim3(nb), dim3(256), 0, st, t);
+    CTVAE_LAUNCH_CHECK();
+  }
+  d.jobs.clear();
+  return 0;
+}
+
+// record one call's reductions instead of running them; false: this call is not being deferred (or must not be)
+static bool defer_record(const float* p1, float* d1, long n1, int S1, long st1, const float* p2, float* d2, long n2, int S2, long st2,
+                         int accumulate, hipStream_t st) {
+  DeferCtx& d = defer_ctx();
+  if (!d.active) return false;
+  // a second writer of a gradient that has a recorded reduction (a layer used twice in one pass): keep their order -- the
+  // recorded ones run now, this one after them as usual
+  for (const DeferJob& dj : d.jobs)
+    if (dj.j.dst == d1 || (d2 != nullptr && dj.j.dst == d2)) {
+      defer_run_pending(d, st);
+      return false;
+    }
+  if (d.cur == nullptr) return false;
+  const float* lo = d.cur;
+  const float* hi = d.cur + d.cur_floats;
+  if (p1 < lo || p1 + (size_t)S1 * st1 > hi) return false;                       // slabs are not in the arena slice
+  if (p2 != nullptr && d2 != nullptr && (p2 < lo || p2 + (size_t)S2 * st2 > hi)) return false;
+  const float* end = p1 + (size_t)S1 * st1;
+  ReduceJob j1{p1, d1, n1, S1, st1, 0, 0};
+  const int nb1 = reduce_job_blocks(j1);
+  if (nb1 > 0) d.jobs.push_back(DeferJob{j1, accumulate, nb1});
+  if (p2 != nullptr && d2 != nullptr) {
+    ReduceJob j2{p2, d2, n2, S2, st2, 0, 0};
+    const int nb2 = reduce_job_blocks(j2);
+    if (nb2 > 0) d.jobs.push_back(DeferJob{j2, accumulate, nb2});
+    if (p2 + (size_t)S2 * st2 > end) end = p2 + (size_t)S2 * st2;
+  }
+  d.off = ((size_t)(end - d.base) + 63) & ~(size_t)63;                          // the next call's slice starts behind these slabs
+  d.cur = nullptr;
+  return true;
+}
+
 // Slab reduction behind a weight-gradient kernel: issued now, or -- inside ctvae_conv_backward -- recorded so that it shares
 // the call's ONE finishing launch with the data gradient's split-K sum and the BatchNorm-backward finalize (pair.hpp)
 static int finish_reduce(const float* p1, float* d1, long n1, int S1, long st1, const float* p2, float* d2, long n2, int S2, long st2,
                          int accumulate, hipStream_t st) {
+  if (defer_record(p1, d1, n1, S1, st1, p2, d2, n2, S2, st2, accumulate, st)) return 0;
   if (PairCtx* pc = pair_ctx(); pc != nullptr && !pc->haveRed) {
     pc->j1 = ReduceJob{p1, d1, n1, S1, st1, 0, 0};
     pc->j2 = (p2 != nullptr && d2 != nullptr) ? ReduceJob{p2, d2, n2, S2, st2, 0, 0} : ReduceJob{nullptr, nullptr, 0, 0, 0, 0, 0};

@@ -1478,14 +1478,33 @@ class DIPLoss(Function):
 _ones = {}
 
 
+_DEFER_REDUCE = os.environ.get("CTVAE_NO_DEFER_REDUCE", "0") != "1"   # diagnostic: every slab reduction in the backward chain
+_DEFER_ARENA_BYTES = int(os.environ.get("CTVAE_DEFER_ARENA_MB", "2048")) << 20
+_defer_arena = {}
+
+
 def backward(loss):
     """``loss.backward()`` with the root gradient taken from a cached ones tensor: autograd otherwise fills a fresh
-    ``ones_like(loss)`` on every call (one launch per step; the harness and bench.py call this)."""
+    ``ones_like(loss)`` on every call (one launch per step; the harness and bench.py call this).
+
+    The slab reductions behind the weight-gradient kernels are deferred to the end of the pass (ctvae_defer_begin / _flush:
+    their slabs go into a 2 GB arena, one launch reduces all of them) -- a parameter gradient is complete when this returns."""
     key = (loss.device, loss.dtype, tuple(loss.shape))
     one = _ones.get(key)
     if one is None:
         one = _ones[key] = torch.ones_like(loss)
-    loss.backward(gradient=one)
+    if not (_DEFER_REDUCE and loss.is_cuda):
+        loss.backward(gradient=one)
+        return
+    arena = _defer_arena.get(loss.device)
+    if arena is None:
+        arena = _defer_arena[loss.device] = torch.empty(_DEFER_ARENA_BYTES // 4, dtype=torch.float32, device=loss.device)
+    lib = native.load()
+    native.check(lib.ctvae_defer_begin(arena.data_ptr(), arena.numel() * 4), "ctvae_defer_begin")
+    try:
+        loss.backward(gradient=one)
+    finally:
+        native.check(lib.ctvae_defer_flush(native.stream_ptr()), "ctvae_defer_flush")
 
 
 class PairMLP(Function):

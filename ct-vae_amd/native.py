@@ -98,6 +98,8 @@ SIGNATURES = {
     "ctvae_dip_forward": [_fp, _l, _fp, _l, _i, _i, _f, _f, _fp, _vp],
     "ctvae_dip_backward": [_fp, _fp, _fp, _fp, _i, _i, _vp],
     "ctvae_adam_step": [_fp, _fp, _fp, _fp, _fp, _l, _f, _vp],
+    "ctvae_defer_begin": [_fp, _sz],
+    "ctvae_defer_flush": [_vp],
 }
 _RESTYPES = {
     "ctvae_version": _c.c_char_p,

@@ -472,6 +472,17 @@ int ctvae_dip_forward(const float* mu, long mu_row_stride, const float* logvar, 
                       float lambda_diag, float lambda_offdiag, float* state, void* stream);
 int ctvae_dip_backward(const float* state, const float* g_dip, float* g_mu, float* g_logvar, int B, int D, void* stream);
 
+/* Deferred slab reductions.  A parameter gradient is not read before the optimizer step, so the finishing launch behind a
+ * weight-gradient kernel (the deterministic reduction of its per-slice partial dW slabs) need not sit in the backward chain.
+ * Between ctvae_defer_begin and ctvae_defer_flush (one deferral at a time per process; the calls in between may come from
+ * another thread, as autograd's do), ctvae_conv_wgrad / ctvae_conv_backward write their slabs
+ * into `arena` (each call behind the previous call's slabs; a call that finds less than its workspace size left, or whose
+ * finishing launch carries a BatchNorm finalize, or that writes a gradient an earlier deferred call wrote, runs as usual)
+ * and only record the reduction; ctvae_defer_flush issues all of them in one launch per 24 jobs.  dw / dbias of the deferred
+ * calls are valid only after the flush.  `arena` must stay untouched in between. */
+int ctvae_defer_begin(float* arena, size_t arena_bytes);
+int ctvae_defer_flush(void* stream);
+
 /* torch.optim.Adam step over one flat buffer (experiment.py:158-160).  state (device, ctvae_adam_state_floats() floats, 64-byte
  * aligned): [0..7] = {step, lr, beta1, beta2, eps, weight_decay, beta1^step, beta2^step}, the rest scratch (ticket counters),
  * all zero when the caller creates the state.  The call advances step inside its one launch: the workgroup that finishes

@@ -519,6 +519,42 @@ def test_lazy_zero_grad_gives_the_same_gradient_buffer(dev, name, cfg):
     assert torch.equal(got, want), f"{(got != want).sum().item()} of {want.numel()} gradient elements differ"
 
 
+@pytest.mark.parametrize("name", ["VanillaVAE", "MCQVAE", "VQVAE", "BetaTCVAE", "ConditionalVAE"])
+def test_deferred_slab_reductions_give_the_same_gradients(dev, name):
+    """kernels.backward (ctvae_defer_begin / _flush: the weight-gradient slabs go into an arena, ONE launch reduces all of
+    them at the end of the pass) against loss.backward() (every reduction behind its kernel): the same bits."""
+    from ctvae_amd import kernels as K
+    from ctvae_amd.models import vae_models
+    cfg = dict(next(c for n, c in ZOO if n == name))
+    torch.manual_seed(3)
+    m = vae_models[name](**{k: (list(v) if isinstance(v, list) else v) for k, v in cfg.items()}, name=name).to(dev).train()
+    x = filler.synthetic_batch(902, 16)[0].to(dev)
+    labels = H.cvae_labels(902, 16).to(dev) if name == "ConditionalVAE" else torch.zeros(16, device=dev)
+
+    def grads(deferred):
+        torch.manual_seed(11)
+        for mod in m.modules():
+            if getattr(mod, "_rng_state", None) is not None:
+                mod._rng_state = None
+            if hasattr(mod, "num_iter"):
+                mod.num_iter = 0
+        m.zero_grad()
+        out = m(x, labels=labels)
+        loss = m.loss_function(*out, M_N=0.00025, optimizer_idx=0, batch_idx=0)["loss"]
+        if deferred:
+            K.backward(loss)
+        else:
+            loss.backward()
+        return m.flat_grads.clone()
+
+    want = grads(False)
+    got = grads(True)
+    assert K._DEFER_REDUCE and torch.isfinite(want).all() and want.abs().max() > 0
+    assert torch.equal(got, want), f"{(got != want).sum().item()} of {want.numel()} gradient elements differ"
+    again = grads(True)                      # the arena and the job list are clean after a flush
+    assert torch.equal(again, want)
+
+
 def test_dip_vae_vs_golden(dev, golden):
     """DIPVAE against the reference's own dip_vae.py fixture: loss dict (sums + DIP term) and every parameter gradient."""
     from ctvae_amd.models import vae_models
