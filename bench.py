@@ -241,15 +241,15 @@ def run_workload(wl, args, ctx, want_kernels=False):
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         if split is not None:
-            with torch.cuda.graph(graph):
+            with kernels_mod.capture_graph(graph):
                 stage1()
             graph2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph2, pool=graph.pool()):
+            with kernels_mod.capture_graph(graph2, pool=graph.pool()):
                 split.stage2()
                 if not multi:
                     opt.step()
         else:
-            with torch.cuda.graph(graph):
+            with kernels_mod.capture_graph(graph):
                 local_step()
 
     def step(i):

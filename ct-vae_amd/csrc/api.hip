@@ -405,8 +405,9 @@ int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* 
     rc = launch_img_backward_fused(gd, dy, w, dx, &f, ws, &part, &pb, &np, dbias != nullptr, st);
     if (!rc) rc = wgrad_finish_slabs(part, dw, 9L * 32 * 3, np, pb, dbias, 3L, accumulate, st);
   } else {
-    // (a finishing launch that carries the BatchNorm finalize of the layer below stays in the chain: its reduction rides there)
-    float* wws = bn_coef_out == nullptr ? defer_wgrad_ws(ws, half_floats) : ws;
+    // (a finishing launch that carries the BatchNorm finalize of the layer below stays in the chain, without the reduction)
+    static const int defer_bn = [] { const char* e = getenv("CTVAE_DEFER_WITH_BN_RIDER"); return e ? atoi(e) : 0; }();   // diagnostic: 1.615 vs 1.611 ms (VanillaVAE)
+    float* wws = (bn_coef_out == nullptr || defer_bn) ? defer_wgrad_ws(ws, half_floats) : ws;
     rc = launch_wgrad(gw, x, dy, dw, dbias, wws, half_bytes, accumulate, st, &xf, &dyx);
     defer_wgrad_done();
     if (!rc) {

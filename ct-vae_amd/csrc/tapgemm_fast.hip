@@ -174,7 +174,7 @@ int pair_flush(PairCtx& c, hipStream_t st) {
     const int rc = launch_wgrad_fast_recorded(c, st);
     if (rc) return rc;
   }
-  if (c.haveRed) {            // slab reduction, with the data gradient's split-K finish (and the BatchNorm-backward finalize of
+  if (c.haveRed || (c.haveSK && c.haveBF)) {   // slab reduction, with the data gradient's split-K finish (and the BatchNorm-backward finalize of
     const int rc = launch_finish_recorded(c, st);   // the layer below) as extra blocks of the same launch
     if (rc) return rc;
   } else {

@@ -77,7 +77,7 @@ class _GraphedTrainStep:
         if self.graph is None and self.seen >= self.WARM:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with K.capture_graph(g):
                 self.losses = self._body()
             self.graph = g
         if self.graph is not None:

@@ -1478,6 +1478,32 @@ class DIPLoss(Function):
 _ones = {}
 
 
+class capture_graph:
+    """``torch.cuda.graph(g, **kw)`` with Python's cyclic garbage collector switched off for the duration of the capture.
+    torch collects once before it begins the capture; a collection that the capture's own allocations trigger in the middle
+    can destroy device objects of an earlier owner (another model's graphs and pools) while the stream is capturing -- under
+    the capture's global mode that is an illegal call, and it ends in ``Fatal Python error: Aborted`` from a destructor."""
+
+    def __init__(self, graph, **kwargs):
+        self._cm = torch.cuda.graph(graph, **kwargs)
+        self._was = False
+
+    def __enter__(self):
+        import gc
+        self._was = gc.isenabled()
+        r = self._cm.__enter__()      # synchronizes, collects, empties the cache, begins the capture
+        gc.disable()
+        return r
+
+    def __exit__(self, *exc):
+        import gc
+        try:
+            return self._cm.__exit__(*exc)
+        finally:
+            if self._was:
+                gc.enable()
+
+
 _DEFER_REDUCE = os.environ.get("CTVAE_NO_DEFER_REDUCE", "0") != "1"   # diagnostic: every slab reduction in the backward chain
 _DEFER_ARENA_BYTES = int(os.environ.get("CTVAE_DEFER_ARENA_MB", "2048")) << 20
 _defer_arena = {}

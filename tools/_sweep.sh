@@ -1,12 +1,9 @@
 set -e
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_models_gpu.py tests/test_ops_gpu.py -m gpu -x -q -k "deferred or conv_family or lazy" > gpurun_out/t_def.log 2>&1 || { tail -20 gpurun_out/t_def.log; exit 1; }
+python -m pytest tests/test_models_gpu.py tests/test_ops_gpu.py tests/test_bench_sizes_gpu.py -m gpu -x -q > gpurun_out/t_def.log 2>&1 || { tail -20 gpurun_out/t_def.log; exit 1; }
 tail -2 gpurun_out/t_def.log
-for w in 65536 262144 100000000; do
-  echo "wide_items $w"
-  CTVAE_REDUCE_WIDE_ITEMS=$w python bench.py --no-cpu-baseline > gpurun_out/b_w_$w.json 2>/dev/null
+for w in 1 0 1 0; do
+  echo "defer with bn rider $w"
+  CTVAE_DEFER_WITH_BN_RIDER=$w python bench.py --no-cpu-baseline --no-configs > gpurun_out/b_w_$w.json 2>/dev/null
   python tools/show_bench.py gpurun_out/b_w_$w.json 0
 done
-echo "no defer"
-CTVAE_NO_DEFER_REDUCE=1 python bench.py --no-cpu-baseline > gpurun_out/b_nodefer.json 2>/dev/null
-python tools/show_bench.py gpurun_out/b_nodefer.json 0
