@@ -293,6 +293,123 @@ __global__ __launch_bounds__(256, 3) void img_fwd_kernel(const ImgArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The same forward with the 32-channel operand going from global memory STRAIGHT into the MFMA A registers: lane (pixel li,
+// half lh) of a 32-pixel block loads channels [16 lh, 16 lh + 16) of its patch pixel with four 16-byte loads (two lanes cover
+// the pixel's 128 bytes), applies the lazy BatchNorm + activation in registers, and the K steps pair channel s with channel
+// 16 + s (the B registers are permuted to match).  No staging of the patch in LDS, no prefetch buffer in registers: LDS holds
+// only Z (340 x 29 floats = 39 KB), so FOUR workgroups fit a CU (img_fwd_kernel: 51 KB and 162 VGPRs -> three), and a wave's
+// next block is in flight while it multiplies the current one.
+constexpr int LDZ2 = 29;   // odd: the pixel-per-lane gather reads are conflict-free; 4 x 340 x 29 x 4 B = 157.8 KB per CU
+__global__ __launch_bounds__(256, 4) void img_fwd2_kernel(const ImgArgs a) {
+  __shared__ float sZ[NP * LDZ2];
+  __shared__ __attribute__((aligned(16))) float sSS[2 * C];   // BatchNorm scale | shift of the lazy apply
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rX = rsrc(a.X, (long)a.B * a.H * a.W * C * 4);
+  const __amdgpu_buffer_rsrc_t rO = rsrc(a.out, (long)a.B * a.H * a.W * NO * 4);
+
+  // B operand, resident for the whole launch: step s multiplies channel 16 lh + s: breg[s] = W'[ci = 16 lh + s][j = li]
+  float breg[16];
+  {
+    const int t = li / 3, co = li - 3 * t;
+    const int wt = tap_wt(a, t);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) breg[s] = li < NJ ? a.Wt[(wt * C + 16 * lh + s) * NO + co] : 0.f;
+  }
+  const bool xform = a.scale != nullptr;
+  if (xform && tid < 2 * C) sSS[tid] = tid < C ? a.scale[tid] : a.shift[tid - C];   // read per block: 32 registers less
+  float bias_r[NO];
+#pragma unroll
+  for (int n = 0; n < NO; ++n) bias_r[n] = a.bias != nullptr ? a.bias[n] : 0.f;
+  int zoff[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) zoff[t] = (a.tdy[t] * PW + a.tdx[t]) * LDZ2 + 3 * t;
+
+  // the wave's blocks of 32 patch pixels: mt = wave, wave + 4, wave + 8 (the last exists for waves 0..2: 11 blocks of 340 + 12)
+  int ppy[3], ppx[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int pp = (wave + 4 * i) * 32 + li;
+    ppy[i] = (pp * 241) >> 13;
+    ppx[i] = pp - ppy[i] * PW;
+    if (pp >= NP) ppy[i] = -1000;     // beyond the patch: never inside the image
+  }
+  auto blk_load = [&](const TileXY& t, int i, f32x4 (&v)[4]) -> bool {
+    const int iy = t.y0 - 1 + ppy[i], ix = t.x0 - 1 + ppx[i];
+    const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    const unsigned off = ok ? (unsigned)(((t.b * a.H + iy) * a.W + ix) * C + 16 * lh) * 4u : kOOBi;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = ld4(rX, ok ? off + 16u * q : kOOBi);
+    return ok;
+  };
+  auto blk_mma = [&](int i, const f32x4 (&v)[4], bool ok) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 x4 = v[q];
+      if (xform) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(&sSS[16 * lh + 4 * q]);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(&sSS[C + 16 * lh + 4 * q]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x4[k] = ok ? act_fwd(x4[k] * sc[k] + sh[k], a.in_act) : 0.f;     // zero padding stays zero
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x4[k], breg[4 * q + k], acc, 0, 0, 0);
+    }
+    const int mt = wave + 4 * i;
+    if (li < NJ) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mt * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+        if (row < NP) sZ[row * LDZ2 + li] = acc[r];
+      }
+    }
+  };
+  const int nblk = wave < 3 ? 3 : 2;
+  __syncthreads();   // sSS
+  // all of a tile's blocks are requested one tile ahead: the loads of tile t + 1 go out before tile t's gather phase
+  f32x4 va[4], vb[4], vc[4];
+  bool oka = false, okb = false, okc = false;
+  int tile = blockIdx.x;
+  TileXY cur = tile_xy(a, tile < a.ntiles ? tile : 0);
+  if (tile < a.ntiles) {
+    oka = blk_load(cur, 0, va);
+    okb = blk_load(cur, 1, vb);
+    if (nblk == 3) okc = blk_load(cur, 2, vc);
+  }
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    const TileXY nxt = tile_xy(a, next < a.ntiles ? next : 0);
+    blk_mma(0, va, oka);
+    blk_mma(1, vb, okb);
+    if (nblk == 3) blk_mma(2, vc, okc);
+    __syncthreads();
+    if (next < a.ntiles) {
+      oka = blk_load(nxt, 0, va);
+      okb = blk_load(nxt, 1, vb);
+      if (nblk == 3) okc = blk_load(nxt, 2, vc);
+    }
+    {   // gather: one thread per output pixel
+      const int ly = tid >> 5, lx = tid & 31;
+      const float* z = sZ + ((ly + 1) * PW + lx + 1) * LDZ2;
+      float o[NO];
+#pragma unroll
+      for (int n = 0; n < NO; ++n) o[n] = bias_r[n];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int n = 0; n < NO; ++n) o[n] += z[zoff[t] + n];
+      const unsigned off = (unsigned)(((cur.b * a.H + cur.y0 + ly) * a.W + cur.x0 + lx) * NO) * 4u;
+#pragma unroll
+      for (int n = 0; n < NO; ++n) st1(rO, off + 4u * n, act_fwd(o[n], a.act));
+    }
+    __syncthreads();   // Z consumed before the next tile's blocks land
+    cur = nxt;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // partial dW slab per workgroup: out[blockIdx.x][wtap*32 + ci][co]; bias partial pbias[blockIdx.x][co]
 __global__ __launch_bounds__(256) void img_wgrad_kernel(const ImgArgs a) {
   __shared__ __attribute__((aligned(16))) float sA[NPP * LDA];
@@ -999,8 +1116,15 @@ int launch_img_forward(const ConvGeom& g, const float* X, const float* W, const 
   fill(a, g);
   a.X = X; a.Wt = W; a.bias = bias; a.out = S; a.act = act;
   if (xf != nullptr && xf->scale != nullptr) { a.scale = xf->scale; a.shift = xf->shift; a.in_act = xf->act; }
-  const int nwg = a.ntiles < kImgFwdWgs ? a.ntiles : kImgFwdWgs;
+  static const int v2 = env_int("CTVAE_IMG_FWD2", 1), wgs2 = env_int("CTVAE_IMG_FWD2_WGS", 1024);   // diagnostic
   ProfScope ps("img_fwd_kernel", st, 2.0 * a.ntiles * TH * TW * NT * C * NO, 4.0 * a.ntiles * TH * TW * (C + NO));
+  if (v2) {   // A operand straight from global memory, four workgroups per CU
+    const int nwg = a.ntiles < wgs2 ? a.ntiles : wgs2;
+    hipLaunchKernelGGL(img_fwd2_kernel, dim3(nwg), dim3(256), 0, st, a);
+    CTVAE_LAUNCH_CHECK();
+    return 0;
+  }
+  const int nwg = a.ntiles < kImgFwdWgs ? a.ntiles : kImgFwdWgs;
   hipLaunchKernelGGL(img_fwd_kernel, dim3(nwg), dim3(256), 0, st, a);
   CTVAE_LAUNCH_CHECK();
   return 0;
