@@ -121,6 +121,10 @@ int launch_reparam_bwd(const float* gz, const float* lv, long lv_rs, const float
                        hipStream_t st);
 int launch_adam(float* p, const float* g, float* m, float* v, float* state, long n, float grad_scale, hipStream_t st);
 size_t adam_state_floats();
+int launch_ssim_forward(const float* a, const float* b, const float* window, float* part, float* loss, float* coef, int B, int C, int H,
+                        int W, const float* weights, hipStream_t st);
+int launch_ssim_backward(const float* a, const float* b, const float* window, const float* coef, const float* g_loss, float* g_a, int B,
+                         int C, int H, int W, hipStream_t st);
 float* defer_wgrad_ws(float* ws, size_t ws_floats);
 void defer_wgrad_done();
 int defer_begin(float* arena, size_t arena_floats);
@@ -873,6 +877,16 @@ int ctvae_dip_backward(const float* state, const float* g_dip, float* g_mu, floa
 }
 
 size_t ctvae_adam_state_floats(void) { return adam_state_floats(); }
+
+size_t ctvae_mssim_part_floats(int B, int C) { return (size_t)5 * B * C * 2; }
+int ctvae_mssim_forward(const float* a, const float* b, const float* window, const float* weights, float* part, float* loss,
+                        float* coef, int B, int C, int H, int W, void* stream) {
+  return launch_ssim_forward(a, b, window, part, loss, coef, B, C, H, W, weights, (hipStream_t)stream);
+}
+int ctvae_mssim_backward(const float* a, const float* b, const float* window, const float* coef, const float* g_loss, float* g_a,
+                         int B, int C, int H, int W, void* stream) {
+  return launch_ssim_backward(a, b, window, coef, g_loss, g_a, B, C, H, W, (hipStream_t)stream);
+}
 
 int ctvae_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* state, long n,
                     float grad_scale, void* stream) {

@@ -2135,6 +2135,55 @@ class VQLookup(Function):
 # ---------------------------------------------------------------------------------------------------
 # flat fused Adam
 # ---------------------------------------------------------------------------------------------------
+_mssim_host = None
+
+
+def _mssim_host_arrays():
+    """(window, weights) as HOST float arrays for ctvae_mssim_*: the window exactly as the reference builds it
+    (mssim_vae.py:203-206: exp(+(x - 5)^2 / (2 * 1.5^2)) in float32, normalised), the level weights of mssim_vae.py:252."""
+    global _mssim_host
+    if _mssim_host is None:
+        import ctypes
+        from math import exp
+        k = torch.tensor([exp((x - 11 // 2) ** 2 / (2 * 1.5 ** 2)) for x in range(11)])
+        k = (k / k.sum()).float()
+        win = (ctypes.c_float * 11)(*[float(v) for v in k])
+        wts = (ctypes.c_float * 5)(0.0448, 0.2856, 0.3001, 0.2363, 0.1333)
+        _mssim_host = (win, wts)
+    return _mssim_host
+
+
+class MSSIMLoss(Function):
+    """MSSIM.forward (mssim_vae.py:250-279) of NHWC pictures [B,64,64,C]: 1 - prod of the level powers, five SSIM levels with
+    the reference's 11-tap window; the gradient goes to the first picture only (the second is the input image)."""
+
+    @staticmethod
+    def forward(ctx, recons, target):
+        _req_cuda(recons, target)
+        r, x = _c(recons), _c(target)
+        B, H, W, C = r.shape
+        if tuple(x.shape) != (B, H, W, C) or H != 64 or W != 64:
+            raise RuntimeError("MSSIMLoss: NHWC pictures of 64 x 64 pixels (five levels down to 4 x 4, mssim_vae.py:255-266)")
+        win, wts = _mssim_host_arrays()
+        lib = native.load()
+        part = torch.empty(int(lib.ctvae_mssim_part_floats(B, C)), dtype=torch.float32, device=r.device)
+        out = torch.empty(11, dtype=torch.float32, device=r.device)          # [0] loss, [1..10] per-level coefficients
+        native.call("ctvae_mssim_forward", r.data_ptr(), x.data_ptr(), win, wts, part.data_ptr(), out.data_ptr(),
+                    out.data_ptr() + 4, B, C, H, W)
+        ctx.save_for_backward(r, x, out)
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        r, x, out = ctx.saved_tensors
+        B, H, W, C = r.shape
+        win, _ = _mssim_host_arrays()
+        g_r = torch.empty_like(r)
+        native.call("ctvae_mssim_backward", r.data_ptr(), x.data_ptr(), win, out.data_ptr() + 4, _c(g).data_ptr(), g_r.data_ptr(),
+                    B, C, H, W)
+        return g_r, None
+
+
 def adam_state(head, device):
     """The device state of ctvae_adam_step: head = [step, lr, beta1, beta2, eps, weight_decay, beta1^step, beta2^step], followed
     by the kernel's zeroed ticket counters (ctvae_adam_state_floats() floats in all).  On the CPU (the gloo tests run a test

@@ -19,6 +19,7 @@ from .hvae import HVAE
 from .vampvae import VampVAE
 from .betatc_vae import BetaTCVAE
 from .gamma_vae import GammaVAE
+from .mssim_vae import MSSIMVAE
 from .lvae import LVAE
 
 # Aliases (models/__init__.py:29-32)
@@ -42,6 +43,7 @@ vae_models = {
     'JointVAE': JointVAE,     # VanillaVAE's stacks, Gaussian + one categorical latent, capacity objective (joint_vae.py)
     'TwoStageVAE': TwoStageVAE,   # VanillaVAE's step; the second-stage MLPs are parameter holders, as in the reference (twostage_vae.py)
     'LVAE': LVAE,             # ladder VAE: per-level heads bottom-up, merge / sample / KL per rung top-down (lvae.py)
+    'MSSIMVAE': MSSIMVAE,     # VanillaVAE's network, multi-scale SSIM reconstruction loss (mssim_vae.py)
     'GammaVAE': GammaVAE,     # VanillaVAE's stacks, Gamma latents (shape-augmentation reparameterisation, Gamma KL), Sigmoid output (gamma_vae.py)
     'BetaTCVAE': BetaTCVAE,   # own small conv net (no BatchNorm), total-correlation decomposition of the KL term (betatc_vae.py)
     'VampVAE': VampVAE,       # VanillaVAE's network, VampPrior over K learned pseudo-inputs (vampvae.py)

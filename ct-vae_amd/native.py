@@ -98,6 +98,8 @@ SIGNATURES = {
     "ctvae_dip_forward": [_fp, _l, _fp, _l, _i, _i, _f, _f, _fp, _vp],
     "ctvae_dip_backward": [_fp, _fp, _fp, _fp, _i, _i, _vp],
     "ctvae_adam_step": [_fp, _fp, _fp, _fp, _fp, _l, _f, _vp],
+    "ctvae_mssim_forward": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp],
+    "ctvae_mssim_backward": [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp],
     "ctvae_defer_begin": [_fp, _sz],
     "ctvae_defer_flush": [_vp],
 }
@@ -115,6 +117,7 @@ _RESTYPES = {
     "ctvae_conv_wino_filter_floats": _c.c_size_t,
     "ctvae_dip_state_floats": _c.c_size_t,
     "ctvae_adam_state_floats": _c.c_size_t,
+    "ctvae_mssim_part_floats": _c.c_size_t,
     "ctvae_glinear_wgrad_ws_bytes": _c.c_size_t,
     "ctvae_conv_input_transform_supported": _c.c_int,
     "ctvae_conv_wgrad_bn_apply_supported": _c.c_int,

@@ -472,6 +472,17 @@ int ctvae_dip_forward(const float* mu, long mu_row_stride, const float* logvar, 
                       float lambda_diag, float lambda_offdiag, float* state, void* stream);
 int ctvae_dip_backward(const float* state, const float* g_dip, float* g_mu, float* g_logvar, int B, int D, void* stream);
 
+/* MSSIMVAE's reconstruction loss (mssim_vae.py:182-279): 1 - prod_{i<4} (mcs_i^w_i * mssim_4^w_4) over five levels of SSIM with the
+ * reference's 11-tap window (2x2 average pooling between levels), for NHWC pictures a (the reconstruction) and b [B,64,64,C].
+ * window [11] and weights [5]: HOST arrays (the window as the reference builds it: exp(+(x-5)^2 / 4.5), normalised).
+ * part: ctvae_mssim_part_floats(B, C) floats of scratch; loss [1]; coef [10]: d loss / d (element of the ssim / cs map) per
+ * level, which ctvae_mssim_backward reads.  Backward: g_a [B,64,64,C] = g_loss[0] * d loss / d a. */
+size_t ctvae_mssim_part_floats(int B, int C);
+int ctvae_mssim_forward(const float* a, const float* b, const float* window, const float* weights, float* part, float* loss,
+                        float* coef, int B, int C, int H, int W, void* stream);
+int ctvae_mssim_backward(const float* a, const float* b, const float* window, const float* coef, const float* g_loss, float* g_a,
+                         int B, int C, int H, int W, void* stream);
+
 /* Deferred slab reductions.  A parameter gradient is not read before the optimizer step, so the finishing launch behind a
  * weight-gradient kernel (the deterministic reduction of its per-slice partial dW slabs) need not sit in the backward chain.
  * Between ctvae_defer_begin and ctvae_defer_flush (one deferral at a time per process; the calls in between may come from

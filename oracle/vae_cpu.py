@@ -583,3 +583,54 @@ def adam_steps(params, grads_fn, n_steps, lr, weight_decay=0.0, gamma=None):
             p.grad = g.clone()
         opt.step()
     return [p.detach() for p in ps]
+
+
+# ---- MSSIMVAE (mssim_vae.py:182-279) ------------------------------------------------------------------------------
+MSSIM_WEIGHTS = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)
+
+
+def mssim_window(window_size=11, sigma=1.5):
+    """mssim_vae.py:203-206: NOT a Gaussian -- the exponent is +x^2 / (2 sigma^2) (no minus sign), normalised to sum 1."""
+    import math
+    k = torch.tensor([math.exp((x - window_size // 2) ** 2 / (2 * sigma ** 2)) for x in range(window_size)])
+    return k / k.sum()
+
+
+def mssim_ssim(img1, img2, window_size=11):
+    """mssim_vae.py:214-248 with size_average=True -> (mean ssim map, mean contrast-sensitivity map)."""
+    C = img1.shape[1]
+    w1 = mssim_window(window_size).unsqueeze(1)
+    window = w1.mm(w1.t()).float().unsqueeze(0).unsqueeze(0).expand(C, 1, window_size, window_size).contiguous()
+    pad = window_size // 2
+    mu1 = F.conv2d(img1, window, padding=pad, groups=C)
+    mu2 = F.conv2d(img2, window, padding=pad, groups=C)
+    s11 = F.conv2d(img1 * img1, window, padding=pad, groups=C) - mu1 * mu1
+    s22 = F.conv2d(img2 * img2, window, padding=pad, groups=C) - mu2 * mu2
+    s12 = F.conv2d(img1 * img2, window, padding=pad, groups=C) - mu1 * mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    v1, v2 = 2.0 * s12 + C2, s11 + s22 + C2
+    cs = torch.mean(v1 / v2)
+    ssim = torch.mean(((2 * mu1 * mu2 + C1) * v1) / ((mu1 * mu1 + mu2 * mu2 + C1) * v2))
+    return ssim, cs
+
+
+def mssim_loss(img1, img2, window_size=11):
+    """MSSIM.forward (mssim_vae.py:250-279): five levels, 2x2 average pooling between them;
+    output = prod(pow1[:-1] * pow2[-1]) -- the last level's ssim power multiplies EACH of the four contrast powers."""
+    weights = torch.tensor(MSSIM_WEIGHTS)
+    ms, mc = [], []
+    for _ in range(len(MSSIM_WEIGHTS)):
+        s, c = mssim_ssim(img1, img2, window_size)
+        ms.append(s)
+        mc.append(c)
+        img1, img2 = F.avg_pool2d(img1, (2, 2)), F.avg_pool2d(img2, (2, 2))
+    ms, mc = torch.stack(ms), torch.stack(mc)
+    pow1, pow2 = mc ** weights, ms ** weights
+    return 1 - torch.prod(pow1[:-1] * pow2[-1])
+
+
+def mssimvae_loss(recons, x, mu, log_var, M_N):
+    """MSSIMVAE.loss_function (mssim_vae.py:130-152)."""
+    rl = mssim_loss(recons, x)
+    kld = torch.mean(-0.5 * torch.sum(1 + log_var - mu ** 2 - log_var.exp(), dim=1), dim=0)
+    return {"loss": rl + M_N * kld, "Reconstruction_Loss": rl, "KLD": -kld}

@@ -367,3 +367,15 @@ def ct_codes(seed, B, S=64, D=64):
 def ct_w(seed, i, shape):
     """Deterministic cotangent number i of the CT fixtures (oracle/gen_ct_golden.py uses the same rule)."""
     return torch.randn(tuple(shape), generator=torch.Generator().manual_seed(int(seed) * 31 + 7 + int(i)))
+
+
+def zoo_prepare(name, model, x):
+    """Per-model adjustment of the ZOO smoke tests' random model and batch.  MSSIMVAE: the reference's loss takes fractional
+    powers of the level means (mssim_vae.py:274-276), which are NaN -- there as here -- when a mean is negative, e.g. for a
+    randomly initialised network whose output is uncorrelated with the picture; a positive output bias and bright pictures keep
+    the luminance term of every level positive."""
+    if name == "MSSIMVAE":
+        with torch.no_grad():
+            model.final_layer._modules["3"].bias.fill_(1.0)
+        return (0.6 + 0.2 * x).clamp(-1.0, 1.0)
+    return x

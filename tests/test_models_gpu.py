@@ -404,6 +404,41 @@ def test_logcosh_vae_vs_golden(dev, golden):
         H.assert_cks_close(H.cks(p.grad), g["gradcks." + k], rtol=2e-3, atol=2e-5, what=k)
 
 
+def test_mssim_loss_kernel_vs_golden(dev, golden):
+    """csrc/ssim.hip on its own against the pair recorded from the reference's MSSIM module: value and full gradient."""
+    from ctvae_amd import kernels as K
+    g = golden("mssim_b4")
+    a = torch.from_numpy(g["pair.a"]).permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+    b = torch.from_numpy(g["pair.b"]).permute(0, 2, 3, 1).contiguous().to(dev)
+    val = K.MSSIMLoss.apply(a, b)
+    assert abs(float(val.detach()) - float(g["pair.loss"])) <= 2e-6, (float(val.detach()), float(g["pair.loss"]))
+    (3.0 * val).backward()
+    want = 3.0 * np.transpose(g["pair.grad_a"], (0, 2, 3, 1))
+    np.testing.assert_allclose(a.grad.cpu().numpy(), want, atol=2e-7 * max(1.0, float(np.abs(want).max()) / 1e-3), rtol=2e-3)
+
+
+def test_mssim_vae_vs_golden(dev, golden):
+    """MSSIMVAE against the reference's own mssim_vae.py fixture: loss dict and every parameter gradient."""
+    from ctvae_amd.models import vae_models
+    g = golden("mssim_b4")
+    seed = int(g["seed"])
+    m = vae_models["MSSIMVAE"](in_channels=3, latent_dim=128)
+    assert list(m.state_dict().keys()) == list(g["keys"])
+    m.load_state_dict(filler.fill_state(H.vanilla_specs(), seed + 1))
+    m = m.to(dev).train()
+    x, eps = filler.synthetic_batch(seed, 4)
+    out = m(x.to(dev), eps=eps.to(dev))
+    np.testing.assert_allclose(out[2].detach().cpu().numpy(), g["mu"], atol=TOL, rtol=0)
+    losses = m.loss_function(*out, M_N=float(g["M_N"]))
+    losses["loss"].backward()
+    for k in ("loss", "Reconstruction_Loss", "KLD"):
+        want = float(g["loss." + k])
+        assert abs(float(losses[k].detach()) - want) <= TOL * max(1.0, abs(want)), (k, float(losses[k].detach()), want)
+    np.testing.assert_allclose(m.fc_mu.bias.grad.cpu().numpy(), g["grad.fc_mu.bias"], atol=1e-5, rtol=2e-3)
+    for k, p in m.named_parameters():
+        H.assert_cks_close(H.cks(p.grad), g["gradcks." + k], rtol=2e-3, atol=2e-5, what=k)
+
+
 @pytest.mark.parametrize("tag", ["wae_imq", "wae_rbf", "infovae"])
 def test_mmd_models_vs_golden(dev, golden, tag):
     """WAE_MMD (imq / rbf) and InfoVAE against the reference's own fixtures: latent codes, loss dict (incl. the MMD term),
@@ -446,6 +481,7 @@ ZOO = [("VanillaVAE", dict(in_channels=3, latent_dim=128)),
        ("VampVAE", dict(in_channels=3, latent_dim=128)),
        ("BetaTCVAE", dict(H.BETATC_CFG)),
        ("GammaVAE", dict(in_channels=3, latent_dim=128, gamma_shape=8., prior_shape=2., prior_rate=1.)),
+       ("MSSIMVAE", dict(in_channels=3, latent_dim=128)),
        ("LVAE", dict(H.LVAE_CFG)),
        ("CategoricalVAE", dict(in_channels=3, latent_dim=64, categorical_dim=40, temperature=0.5, alpha=1.0)),
        ("VQVAE", dict(in_channels=3, embedding_dim=64, num_embeddings=512, img_size=64, beta=0.25)),
@@ -461,9 +497,9 @@ def test_every_registered_model_trains_through_the_harness(dev, name, cfg):
     from ctvae_amd.models import vae_models
     torch.manual_seed(3)
     m = vae_models[name](**{k: (list(v) if isinstance(v, list) else v) for k, v in cfg.items()}, name=name).to(dev).train()
-    before = m.flat_params.clone()
     labels = (lambda i: H.cvae_labels(900 + i, 8).to(dev)) if name == "ConditionalVAE" else (lambda i: torch.zeros(8, device=dev))
-    batches = [(filler.synthetic_batch(900 + i, 8)[0].to(dev), labels(i)) for i in range(6)]
+    batches = [(H.zoo_prepare(name, m, filler.synthetic_batch(900 + i, 8)[0].to(dev)), labels(i)) for i in range(6)]
+    before = m.flat_params.clone()
     exp = VAEXperiment(m, {"LR": 0.0005, "weight_decay": 0.0, "scheduler_gamma": 0.95, "kld_weight": 0.00025, "hipgraph": True})
     exp.fit(lambda: iter(batches), lambda: iter(batches[:2]), max_epochs=1)
     torch.cuda.synchronize()
@@ -493,7 +529,7 @@ def test_lazy_zero_grad_gives_the_same_gradient_buffer(dev, name, cfg):
     from ctvae_amd.models import vae_models
     torch.manual_seed(3)
     m = vae_models[name](**{k: (list(v) if isinstance(v, list) else v) for k, v in cfg.items()}, name=name).to(dev).train()
-    x = filler.synthetic_batch(901, 8)[0].to(dev)
+    x = H.zoo_prepare(name, m, filler.synthetic_batch(901, 8)[0].to(dev))
     labels = H.cvae_labels(901, 8).to(dev) if name == "ConditionalVAE" else torch.zeros(8, device=dev)
 
     def grads(lazy):

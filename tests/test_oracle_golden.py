@@ -220,6 +220,31 @@ def test_mmd_models_forward_loss_grads(golden, tag):
             H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
 
 
+def test_mssim_vae_loss_grads(golden):
+    """MSSIMVAE (VanillaVAE's network, multi-scale SSIM reconstruction term): oracle against the reference's mssim_vae.py fixture,
+    and the loss module on its own against the recorded pair (value and full gradient)."""
+    g = golden("mssim_b4")
+    seed = int(g["seed"])
+    sd = O.leafify(filler.fill_state(H.vanilla_specs(), seed + 1))
+    x, eps = filler.synthetic_batch(seed, 4)
+    recons, inp, mu, log_var = O.vanilla_forward(sd, x, eps, True, {})
+    np.testing.assert_allclose(mu.detach().numpy(), g["mu"], atol=TOL, rtol=0)
+    l = O.mssimvae_loss(recons, inp, mu, log_var, float(g["M_N"]))
+    for k in ("loss", "Reconstruction_Loss", "KLD"):
+        want = float(g["loss." + k])
+        assert abs(l[k].item() - want) <= TOL * max(1.0, abs(want)), k
+    l["loss"].backward()
+    np.testing.assert_allclose(sd["fc_mu.bias"].grad.numpy(), g["grad.fc_mu.bias"], atol=1e-5, rtol=1e-3)
+    for k, v in sd.items():
+        if v.requires_grad:
+            H.assert_cks_close(H.cks(v.grad), g["gradcks." + k], rtol=1e-3, atol=1e-5, what=k)
+    a = torch.from_numpy(g["pair.a"]).requires_grad_(True)
+    val = O.mssim_loss(a, torch.from_numpy(g["pair.b"]))
+    assert abs(val.item() - float(g["pair.loss"])) <= 1e-6
+    val.backward()
+    np.testing.assert_allclose(a.grad.numpy(), g["pair.grad_a"], atol=1e-8, rtol=1e-4)
+
+
 def test_dip_vae_loss_grads(golden):
     """DIPVAE (VanillaVAE's network, sum-reduced objective + DIP-II regulariser): oracle against the reference's dip_vae.py fixture."""
     g = golden("dip_b4")
