@@ -148,8 +148,9 @@ int launch_dip_forward(const float* mu, long mu_rs, const float* lv, long lv_rs,
                        float* state, hipStream_t st);
 int launch_dip_backward(const float* state, const float* go, float* g_mu, float* g_lv, int B, int D, hipStream_t st);
 int launch_loss_forward(const float* r, const float* x, long n, const float* mu, long mu_rs, const float* lv, long lv_rs,
-                        int B, int L, float M_N, const float* extra, float* out3, float* ws, size_t ws_bytes, hipStream_t st,
-                        float logcosh_alpha);
+                        int B, int L, float M_N, const float* extra, float* out4, float* ws, size_t ws_bytes,
+                        hipStream_t st, float logcosh_alpha, float* g_r = nullptr, float* g_mu = nullptr, float* g_lv = nullptr,
+                        int ract = 0);
 int launch_mse_backward(const float* r, const float* x, const float* go, float* gr, long n, hipStream_t st, float logcosh_alpha,
                         int ract = 0);
 int launch_loss_backward(const float* r, const float* x, const float* go, float* gr, long n, float logcosh_alpha, const float* mu,
@@ -672,6 +673,14 @@ int ctvae_loss_forward(const float* recons, const float* x, long n, const float*
   if ((mu == nullptr) != (logvar == nullptr)) return kErrBadArg;
   return launch_loss_forward(recons, x, n, mu, mu_rs, logvar, lv_rs, B, L, M_N, extra, out4, ws, ws_bytes,
                              (hipStream_t)stream, 0.f);
+}
+
+int ctvae_loss_forward_grad(const float* recons, const float* x, long n, const float* mu, long mu_rs, const float* logvar,
+                            long lv_rs, int B, int L, float M_N, const float* extra, float* out4, float* g_recons, float* g_mu,
+                            float* g_logvar, int recons_act, float* ws, size_t ws_bytes, void* stream) {
+  if (!recons || !x || !out4 || !ws || n <= 0 || !mu || !logvar || !g_recons || !g_mu || !g_logvar) return kErrBadArg;
+  return launch_loss_forward(recons, x, n, mu, mu_rs, logvar, lv_rs, B, L, M_N, extra, out4, ws, ws_bytes,
+                             (hipStream_t)stream, 0.f, g_recons, g_mu, g_logvar, recons_act);
 }
 
 int ctvae_mse_backward(const float* recons, const float* x, const float* g_loss, float* g_recons, long n, int recons_act,

@@ -30,29 +30,58 @@ __device__ __forceinline__ float recon_term_grad(float d, float alpha) {
   }
 }
 
+// Optional: the gradients of loss = recon + M_N * kld for a unit upstream gradient, written by the SAME pass that forms the partial
+// sums (gr != null): the loss value is not needed for them, so the backward launch and its second read of both pictures
+// disappear whenever the loss is the root of the backward pass (kernels.VAELoss).  Same expressions as mse_bwd_body / kl_bwd_body
+// with go = 1: the same bits.
+struct LossGradOut {
+  float* gr;
+  float* gmu;
+  float* glv;
+  float scale;   // 1 / n
+  float M_N;
+  int ract;
+};
+
 template <int MODE>
 __global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ r, const float* __restrict__ x,
                                                           float* __restrict__ part, long n4, long n,
                                                           const float* __restrict__ mu, long mu_rs,
-                                                          const float* __restrict__ lv, long lv_rs, int B, int L, float alpha) {
+                                                          const float* __restrict__ lv, long lv_rs, int B, int L, float alpha,
+                                                          const LossGradOut go) {
   __shared__ float sm[4];
   float s = 0.f;
   const long stride = (long)gridDim.x * 256;
+  const float gsc = 1.f * go.scale;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     f32x4 a = reinterpret_cast<const f32x4*>(r)[i];
     f32x4 b = reinterpret_cast<const f32x4*>(x)[i];
 #pragma unroll
     for (int k = 0; k < 4; ++k) s += recon_term<MODE>(a[k] - b[k], alpha);
+    if (go.gr != nullptr) {
+      f32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = gsc * recon_term_grad<MODE>(a[k] - b[k], alpha) * act_bwd_from_out(a[k], go.ract);
+      reinterpret_cast<f32x4*>(go.gr)[i] = o;
+    }
   }
   if (blockIdx.x == 0) {  // tail (n % 4)
-    for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) s += recon_term<MODE>(r[i] - x[i], alpha);
+    for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) {
+      s += recon_term<MODE>(r[i] - x[i], alpha);
+      if (go.gr != nullptr) go.gr[i] = gsc * recon_term_grad<MODE>(r[i] - x[i], alpha) * act_bwd_from_out(r[i], go.ract);
+    }
   }
   float k = 0.f;          // KL terms 1 + lv - mu^2 - e^lv, spread over the same grid
   if (mu != nullptr) {
+    const float ksc = 1.f * go.M_N / (float)B;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)B * L; i += stride) {
       int b = (int)(i / L), d = (int)(i - (long)b * L);
       float m = mu[b * mu_rs + d], l = lv[b * lv_rs + d];
       k += 1.f + l - m * m - expf(l);
+      if (go.gmu != nullptr) {
+        go.gmu[i] = ksc * m;
+        go.glv[i] = ksc * 0.5f * (expf(l) - 1.f);
+      }
     }
   }
   s = block_sum_256(s, sm);
@@ -154,8 +183,9 @@ size_t loss_workspace_floats() { return 2 * kLossBlocks; }
 
 int launch_loss_forward(const float* r, const float* x, long n, const float* mu, long mu_rs, const float* lv, long lv_rs,
                         int B, int L, float M_N, const float* extra, float* out4, float* ws, size_t ws_bytes,
-                        hipStream_t st, float logcosh_alpha) {
+                        hipStream_t st, float logcosh_alpha, float* g_r, float* g_mu, float* g_lv, int ract) {
   if (ws_bytes / sizeof(float) < loss_workspace_floats() || n <= 0) return kErrWorkspace;
+  const LossGradOut go{g_r, g_mu, g_lv, (float)(1.0 / ((double)n * (logcosh_alpha > 0.f ? logcosh_alpha : 1.f))), M_N, ract};
   const long n4 = n / 4;
   long blocks = (n4 + 255) / 256;
   if (blocks > kLossBlocks) blocks = kLossBlocks;
@@ -163,11 +193,11 @@ int launch_loss_forward(const float* r, const float* x, long n, const float* mu,
   {
   ProfScope ps("mse_partial_kernel", st, 0.0, 8.0 * (double)n);
   if (logcosh_alpha > 0.f)
-    hipLaunchKernelGGL(mse_partial_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, r, x, ws, n4, n, mu, mu_rs, lv, lv_rs, B, L, logcosh_alpha);
+    hipLaunchKernelGGL(mse_partial_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, r, x, ws, n4, n, mu, mu_rs, lv, lv_rs, B, L, logcosh_alpha, go);
   else if (logcosh_alpha < 0.f)      // internal code for the squared + absolute error term (ctvae_l2l1_loss_forward)
-    hipLaunchKernelGGL(mse_partial_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, r, x, ws, n4, n, mu, mu_rs, lv, lv_rs, B, L, 0.f);
+    hipLaunchKernelGGL(mse_partial_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, r, x, ws, n4, n, mu, mu_rs, lv, lv_rs, B, L, 0.f, go);
   else
-    hipLaunchKernelGGL(mse_partial_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, r, x, ws, n4, n, mu, mu_rs, lv, lv_rs, B, L, 0.f);
+    hipLaunchKernelGGL(mse_partial_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, r, x, ws, n4, n, mu, mu_rs, lv, lv_rs, B, L, 0.f, go);
   }
   CTVAE_LAUNCH_CHECK();
   ProfScope ps2("loss_finish_kernel", st, 0.0, 8.0 * (double)B * L);

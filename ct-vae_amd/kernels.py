@@ -1028,6 +1028,7 @@ class VAELoss(Function):
             raise RuntimeError("mse_loss: shape mismatch")
         out = torch.empty(4, dtype=torch.float32, device=recons.device)
         ws = native.workspace(recons.device)
+        pre = None
         if mu is not None:
             mu_, mrs = _rows(mu)
             lv_, lrs = _rows(logvar)
@@ -1045,12 +1046,25 @@ class VAELoss(Function):
             native.call("ctvae_logcosh_loss_forward", recons.data_ptr(), x.data_ptr(), recons.numel(), float(logcosh_alpha),
                         native.ptr(mu_), mrs, native.ptr(lv_), lrs, B, L, float(M_N), out.data_ptr(), ws.data_ptr(), ws.numel() * 4)
         else:
-            native.call("ctvae_loss_forward", recons.data_ptr(), x.data_ptr(), recons.numel(), native.ptr(mu_), mrs, native.ptr(lv_),
-                        lrs, B, L, float(M_N), native.ptr(extra), out.data_ptr(), ws.data_ptr(), ws.numel() * 4)
+            if (_LOSS_GRAD_IN_FWD and mu is not None and ctx.needs_input_grad[0] and ctx.needs_input_grad[2] and ctx.needs_input_grad[3]):
+                # the gradients for a unit upstream gradient come out of the same pass (ctvae_loss_forward_grad); backward hands
+                # them over as they are when the loss is the root of the pass (kernels.backward), else it runs its own kernel
+                ctx.act_link = claim_out_act_link(recons)
+                ract = ctx.act_link.act if ctx.act_link is not None else ACT_NONE
+                pre = (torch.empty_like(recons), torch.empty((B, L), dtype=torch.float32, device=recons.device),
+                       torch.empty((B, L), dtype=torch.float32, device=recons.device))
+                native.call("ctvae_loss_forward_grad", recons.data_ptr(), x.data_ptr(), recons.numel(), mu_.data_ptr(), mrs, lv_.data_ptr(),
+                            lrs, B, L, float(M_N), native.ptr(extra), out.data_ptr(), pre[0].data_ptr(), pre[1].data_ptr(),
+                            pre[2].data_ptr(), ract, ws.data_ptr(), ws.numel() * 4)
+            else:
+                native.call("ctvae_loss_forward", recons.data_ptr(), x.data_ptr(), recons.numel(), native.ptr(mu_), mrs, native.ptr(lv_),
+                            lrs, B, L, float(M_N), native.ptr(extra), out.data_ptr(), ws.data_ptr(), ws.numel() * 4)
+        ctx.pre = pre
         ctx.save_for_backward(recons, x, mu_, lv_)
         ctx.meta = (mrs, lrs, B, L, float(M_N), tuple(extra.shape) if extra is not None else None)
         ctx.logcosh_alpha = float(logcosh_alpha)
-        ctx.act_link = claim_out_act_link(recons) if ctx.needs_input_grad[0] else None
+        if pre is None:
+            ctx.act_link = claim_out_act_link(recons) if ctx.needs_input_grad[0] else None
         return _scalar_outputs(ctx, out)
 
     @staticmethod
@@ -1059,6 +1073,13 @@ class VAELoss(Function):
         mrs, lrs, B, L, M_N, has_extra = ctx.meta
         if g_loss is None:
             return (None,) * 7
+        if ctx.pre is not None and _is_cached_root(g_loss):
+            # the loss is the root of this backward pass (kernels.backward): the forward pass has written these gradients
+            g_r, g_mu, g_lv = ctx.pre
+            if ctx.act_link is not None:
+                ctx.act_link.publish_done(g_r)
+            g_extra = g_loss.reshape(has_extra) if (has_extra is not None and ctx.needs_input_grad[4]) else None
+            return g_r, None, g_mu, g_lv, g_extra, None, None
         g_loss = _c(g_loss.reshape(1))               # d/d loss; mse and kld outputs are reported detached
         want_r = ctx.needs_input_grad[0]
         want_kl = mu_ is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
@@ -1476,6 +1497,13 @@ class DIPLoss(Function):
 
 
 _ones = {}
+_LOSS_GRAD_IN_FWD = os.environ.get("CTVAE_NO_LOSS_GRAD_IN_FWD", "0") != "1"   # diagnostic: the loss gradient always from its own launch
+
+
+def _is_cached_root(g):
+    """Is g the cached ones tensor kernels.backward() hands to autograd as the root gradient (value 1 by construction)?"""
+    one = _ones.get((g.device, g.dtype, tuple(g.shape)))
+    return one is not None and g.data_ptr() == one.data_ptr()
 
 
 class capture_graph:

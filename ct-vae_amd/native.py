@@ -63,6 +63,7 @@ SIGNATURES = {
     "ctvae_reparam_forward": [_fp, _l, _fp, _l, _fp, _fp, _i, _i, _vp],
     "ctvae_reparam_backward": [_fp, _fp, _l, _fp, _fp, _fp, _i, _i, _vp],
     "ctvae_loss_forward": [_fp, _fp, _l, _fp, _l, _fp, _l, _i, _i, _f, _fp, _fp, _fp, _sz, _vp],
+    "ctvae_loss_forward_grad": [_fp, _fp, _l, _fp, _l, _fp, _l, _i, _i, _f, _fp, _fp, _fp, _fp, _fp, _i, _fp, _sz, _vp],
     "ctvae_mse_backward": [_fp, _fp, _fp, _fp, _l, _i, _vp],
     "ctvae_logcosh_loss_forward": [_fp, _fp, _l, _f, _fp, _l, _fp, _l, _i, _i, _f, _fp, _fp, _sz, _vp],
     "ctvae_logcosh_backward": [_fp, _fp, _fp, _fp, _l, _f, _i, _vp],

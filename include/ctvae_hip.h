@@ -328,6 +328,13 @@ int ctvae_reparam_backward(const float* g_z, const float* logvar, long lv_row_st
 int ctvae_loss_forward(const float* recons, const float* x, long n, const float* mu, long mu_row_stride,
                        const float* logvar, long lv_row_stride, int B, int L, float M_N, const float* extra, float* out4,
                        float* ws, size_t ws_bytes, void* stream);
+/* The same, and in the same pass the gradients of `loss` for a unit upstream gradient: g_recons [n] (w.r.t. the input of
+ * recons_act when the reconstruction is that activation's output, as ctvae_loss_backward), g_mu / g_logvar [B][L] dense.
+ * The loss value is not an operand of its own gradient, so a caller whose backward pass starts at `loss` needs no
+ * ctvae_loss_backward launch (and no second read of both pictures). */
+int ctvae_loss_forward_grad(const float* recons, const float* x, long n, const float* mu, long mu_row_stride, const float* logvar,
+                            long lv_row_stride, int B, int L, float M_N, const float* extra, float* out4, float* g_recons,
+                            float* g_mu, float* g_logvar, int recons_act, float* ws, size_t ws_bytes, void* stream);
 /* recons_act (CTVAE_ACT_*; 0 = none) in the three reconstruction backward calls: recons is the OUTPUT of that activation
  * (the Tanh closing final_layer, vanilla_vae.py:74 / the decoder, mcq_vae.py:236) and g_recons is the gradient w.r.t. the
  * activation's input, g * act'(recons): the producer's activation-backward pass folded into this one. */
