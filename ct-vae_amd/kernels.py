@@ -1643,6 +1643,37 @@ def banked(params) -> bool:
     return all(p.is_contiguous() and p.shape == p0.shape and p.data_ptr() == p0.data_ptr() + k * n for k, p in enumerate(params))
 
 
+_flat_buffers = []     # [(weakref(flat parameter buffer), weakref(flat gradient buffer))] of the live FlatParamMixin models
+_alias_given = {}
+_GRAD_ALIAS = os.environ.get("CTVAE_NO_GRAD_ALIAS", "0") != "1"   # diagnostic: bank gradients in tensors of their own, copied by gather
+
+
+def register_flat_buffers(flat, gflat):
+    _flat_buffers[:] = [(f, g) for f, g in _flat_buffers if f() is not None and g() is not None]
+    _flat_buffers.append((weakref.ref(flat), weakref.ref(gflat)))
+
+
+def flat_grad_alias(t):
+    """For a contiguous tensor t that lies in a model's flat PARAMETER buffer (a bank of autograd-managed parameters): a fresh
+    view of the same range of the flat GRADIENT buffer, for the gradient kernel to write into -- autograd then attaches slices
+    of it as the parameters' .grad and gather_torch_grads() has nothing to copy (CT-MCQ-VAE: two multi-tensor copies of 21 and
+    18 us per step).  Handed out once per range and step: a second writer gets None and a tensor of its own, which autograd
+    adds to the first."""
+    if not _GRAD_ALIAS or t is None or not t.is_contiguous():
+        return None
+    for fr, gr in _flat_buffers:
+        f, g = fr(), gr()
+        if f is None or g is None or f.device != t.device:
+            continue
+        off = t.data_ptr() - f.data_ptr()
+        if off >= 0 and off % 4 == 0 and off + 4 * t.numel() <= 4 * f.numel():
+            if _alias_given.get(t.data_ptr()) == _param_epoch[0]:
+                return None
+            _alias_given[t.data_ptr()] = _param_epoch[0]
+            return g.as_strided(tuple(t.shape), tuple(t.stride()), off // 4)
+    return None
+
+
 class BankView(Function):
     """The G same-shaped parameters of a module bank (back to back in memory, see ``banked``) as ONE [G, *shape] tensor
     without a copy; backward hands every parameter its slice of the bank's gradient (views, no copies either)."""
@@ -1707,6 +1738,7 @@ class GroupLinear(Function):
                     nseg * N, B)
         ctx.save_for_backward(x, *[t for t in Ws], *[g for g in gs if g is not None])
         ctx.meta = (K, N, nseg, tuple(k for k, _ in spec), tuple(g is not None for g in gs), tuple(b is not None for b in bs))
+        ctx.bias_banks = bs
         return y
 
     @staticmethod
@@ -1743,11 +1775,19 @@ class GroupLinear(Function):
             whole = (ent is None and koffs[s] == 0 and W.shape[2] == K and (gs[s] is not None or G == 1)
                      and (has_b[s] or not any(has_b[t] for t in users)))
             if ent is None:
-                alloc = torch.empty_like if whole else torch.zeros_like
-                dW = alloc(W, memory_format=torch.contiguous_format)
+                dW = flat_grad_alias(W)              # the bank's own range of the flat gradient buffer, where there is one
+                if dW is None:
+                    dW = (torch.empty_like if whole else torch.zeros_like)(W, memory_format=torch.contiguous_format)
+                elif not whole:
+                    dW.zero_()
                 db = None
                 if any(has_b[t] for t in users):
-                    db = (torch.empty if whole else torch.zeros)((G, N), dtype=torch.float32, device=x.device)
+                    bt = next(ctx.bias_banks[t] for t in users if has_b[t])
+                    db = flat_grad_alias(bt) if tuple(bt.shape) == (G, N) else None
+                    if db is None:
+                        db = (torch.empty if whole else torch.zeros)((G, N), dtype=torch.float32, device=x.device)
+                    elif not whole:
+                        db.zero_()
                 ent = shared[key] = (dW, db)
                 grads[2 * s] = dW
                 if db is not None:           # the bias gradient goes to the first segment of this bank that has a bias input
@@ -1802,8 +1842,12 @@ class PairScores(Function):
                     dw2p[0].data_ptr(), db2p[0].data_ptr(), B, 64, H, PairMLP.SLOPE, 0, None)
         # per-sample partials -> rows of the scorer bank: discoverer 0 takes every sample, discoverer grp[b] sample b (in order,
         # no atomics; as torch ops this was one_hot^T @ parts plus the fills / casts / cats around it)
-        dw2 = torch.empty((G, H), dtype=torch.float32, device=uv.device)
-        db2 = torch.empty((G,), dtype=torch.float32, device=uv.device)
+        dw2 = flat_grad_alias(w2) if tuple(w2.shape) == (G, H) else None
+        db2 = flat_grad_alias(b2) if tuple(b2.shape) == (G,) else None
+        if dw2 is None:
+            dw2 = torch.empty((G, H), dtype=torch.float32, device=uv.device)
+        if db2 is None:
+            db2 = torch.empty((G,), dtype=torch.float32, device=uv.device)
         native.call("ctvae_group_rowsum", dw2p[0].data_ptr(), 0, 1, B, H, H, None, G, dw2.data_ptr(), 0)
         native.call("ctvae_group_rowsum", db2p[0].data_ptr(), 0, 1, B, 1, 1, None, G, db2.data_ptr(), 0)
         if nd == 2:

@@ -209,6 +209,8 @@ class FlatParamMixin:
                     self._grad_views.append((p, g))
                 off += n
         self._flat_params, self._flat_grads = flat, gflat
+        from .. import kernels as _K
+        _K.register_flat_buffers(flat, gflat)     # kernels.flat_grad_alias: bank gradients written in place
         self._torch_grad_views = [(p, g) for p, g in self._grad_views if id(p) in self._torch_param_ids]
         return flat, gflat
 
@@ -326,7 +328,9 @@ class FlatParamMixin:
         """Move autograd-produced gradients of torch-level parameters into their views of the flat gradient buffer and
         re-attach the views (call before the optimizer step / gradient exchange).  Completes a lazy zero_grad first."""
         self.settle_grads()
-        pairs = [(p, g) for p, g in getattr(self, "_torch_grad_views", ()) if p.grad is not None and p.grad is not g]
+        # (a gradient that a kernel wrote straight into the flat buffer -- kernels.flat_grad_alias -- is already in place)
+        pairs = [(p, g) for p, g in getattr(self, "_torch_grad_views", ())
+                 if p.grad is not None and p.grad is not g and p.grad.data_ptr() != g.data_ptr()]
         if pairs:
             with torch.no_grad():
                 torch._foreach_copy_([g for _, g in pairs], [p.grad for p, _ in pairs])
