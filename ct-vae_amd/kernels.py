@@ -1653,13 +1653,28 @@ def register_flat_buffers(flat, gflat):
     _flat_buffers.append((weakref.ref(flat), weakref.ref(gflat)))
 
 
+_alias_epoch = [-1, -1]   # parameter epoch of the last zero_grad; ... of the last zero_grad that also cleared the torch-level span
+
+
+def note_zero_grad(prezeroed):
+    """FlatParamMixin.zero_grad (after its epoch bump): gradient aliases may be handed out until the epoch moves again (an
+    optimizer step without a zero_grad behind it leaves .grad attached, and a kernel writing into the memory autograd is about to
+    add to would double the gradient); prezeroed: the whole autograd-managed span of the gradient buffer was cleared in one fill."""
+    _alias_epoch[0] = _param_epoch[0]
+    _alias_epoch[1] = _param_epoch[0] if prezeroed else -1
+
+
+def alias_prezeroed():
+    return _alias_epoch[1] == _param_epoch[0]
+
+
 def flat_grad_alias(t):
     """For a contiguous tensor t that lies in a model's flat PARAMETER buffer (a bank of autograd-managed parameters): a fresh
     view of the same range of the flat GRADIENT buffer, for the gradient kernel to write into -- autograd then attaches slices
     of it as the parameters' .grad and gather_torch_grads() has nothing to copy (CT-MCQ-VAE: two multi-tensor copies of 21 and
-    18 us per step).  Handed out once per range and step: a second writer gets None and a tensor of its own, which autograd
-    adds to the first."""
-    if not _GRAD_ALIAS or t is None or not t.is_contiguous():
+    18 us per step).  Only in the epoch a zero_grad opened, and once per range: a second writer gets None and a tensor of its
+    own, which autograd adds to the first."""
+    if not _GRAD_ALIAS or t is None or not t.is_contiguous() or _alias_epoch[0] != _param_epoch[0]:
         return None
     for fr, gr in _flat_buffers:
         f, g = fr(), gr()
@@ -1778,7 +1793,7 @@ class GroupLinear(Function):
                 dW = flat_grad_alias(W)              # the bank's own range of the flat gradient buffer, where there is one
                 if dW is None:
                     dW = (torch.empty_like if whole else torch.zeros_like)(W, memory_format=torch.contiguous_format)
-                elif not whole:
+                elif not whole and not alias_prezeroed():
                     dW.zero_()
                 db = None
                 if any(has_b[t] for t in users):
@@ -1786,7 +1801,7 @@ class GroupLinear(Function):
                     db = flat_grad_alias(bt) if tuple(bt.shape) == (G, N) else None
                     if db is None:
                         db = (torch.empty if whole else torch.zeros)((G, N), dtype=torch.float32, device=x.device)
-                    elif not whole:
+                    elif not whole and not alias_prezeroed():
                         db.zero_()
                 ent = shared[key] = (dW, db)
                 grads[2 * s] = dW

@@ -209,6 +209,7 @@ class FlatParamMixin:
                     self._grad_views.append((p, g))
                 off += n
         self._flat_params, self._flat_grads = flat, gflat
+        self._torch_span_cache = False
         from .. import kernels as _K
         _K.register_flat_buffers(flat, gflat)     # kernels.flat_grad_alias: bank gradients written in place
         self._torch_grad_views = [(p, g) for p, g in self._grad_views if id(p) in self._torch_param_ids]
@@ -282,19 +283,42 @@ class FlatParamMixin:
         from .. import kernels as _K
         _K.bump_param_epoch()          # a new step: transformed Winograd filters are remade once for all layers (kernels.wino_cache)
         if getattr(self, "_flat_grads", None) is not None:
+            prezeroed = False
             if lazy and _K.LAZY_ZERO_GRAD:
                 for blk in self._grad_blocks:
                     blk.fresh = True
                 self._lazy_zero = True
+                span = self._torch_span()
+                if span is not None:     # the autograd-managed tail of the buffer (CT layer): ONE fill instead of one per bank
+                    self._flat_grads[span[0]:span[1]].zero_()
+                    prezeroed = True
             else:
                 self._flat_grads.zero_()
                 for blk in self._grad_blocks:
                     blk.fresh = False
                 self._lazy_zero = False
+                prezeroed = True
+            self._torch_prezeroed = prezeroed
             for p, _ in getattr(self, "_torch_grad_views", ()):
                 p.grad = None
+            _K.note_zero_grad(prezeroed)
         else:
             super().zero_grad(set_to_none=set_to_none)
+
+    def _torch_span(self):
+        """[lo, hi) floats of the flat buffers that hold exactly the autograd-managed parameters (they are laid out behind every
+        kernel-managed block, _collect_blocks), or None when there are none / some kernel-managed block lies inside."""
+        sp = getattr(self, "_torch_span_cache", False)
+        if sp is False:
+            views = [g for _, g in getattr(self, "_torch_grad_views", ()) if g.is_contiguous()]
+            sp = None
+            if views and len(views) == len(self._torch_grad_views):
+                lo = min(g.storage_offset() for g in views)
+                hi = max(g.storage_offset() + g.numel() for g in views)
+                if all(b.hi <= lo or b.lo >= hi for b in self._grad_blocks):
+                    sp = (lo, hi)
+            self._torch_span_cache = sp
+        return sp
 
     def settle_grads(self):
         """Write the zeros that zero_grad(lazy=True) only declared, for every block no gradient kernel has written since
@@ -309,7 +333,7 @@ class FlatParamMixin:
                 ranges.append((blk.lo, blk.hi))
         with torch.no_grad():
             for p, g in getattr(self, "_torch_grad_views", ()):
-                if p.grad is None:
+                if p.grad is None and not getattr(self, "_torch_prezeroed", False):
                     if g.is_contiguous():
                         ranges.append((g.storage_offset(), g.storage_offset() + g.numel()))
                     else:
