@@ -146,6 +146,84 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
 }
 
+// Finalize + apply in ONE launch for layers with few partial rows (<= 128: the small deep layers, whose statistics come from
+// bn_stats_partial_kernel).  Workgroup (channel block of 32, row range): it merges the partial rows of ITS 32 channels itself
+// (24 KB from L2 at 64 rows -- every row range of a channel block repeats that merge, the first one also writes the statistics
+// and updates the running ones), then streams its rows: 128 contiguous bytes per row, eight threads per row.  One dependent
+// launch less per layer (~5 us in a replayed graph); the merge order is fixed (row lanes, then lanes): bit-reproducible.
+__global__ __launch_bounds__(256) void bn_finalize_apply_kernel(const float* __restrict__ y, const float* __restrict__ part, int nparts,
+                                                                int R, int C, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                                float* __restrict__ running_var, float momentum, float eps,
+                                                                float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                                float* __restrict__ scale, float* __restrict__ shift,
+                                                                long long* __restrict__ num_batches_tracked, float* __restrict__ out,
+                                                                int act) {
+  __shared__ float sm[256 * 3];
+  __shared__ __attribute__((aligned(16))) float sSc[32], sSh[32];
+  const int tid = threadIdx.x, cb = blockIdx.x, rs = blockIdx.y;
+  const int c0 = cb * 32, ch = tid & 31, rl = tid >> 5;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int b0 = rl; b0 < nparts; b0 += 8 * 4) {   // four rows per lane in flight
+    float pn[4], pm[4], pq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int b = b0 + 8 * u;
+      const float* p = part + ((long)(b < nparts ? b : b0) * C + c0 + ch) * 3;
+      pn[u] = b < nparts ? p[0] : 0.f;
+      pm[u] = p[1];
+      pq[u] = p[2];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) chan_merge(n, mean, m2, pn[u], pm[u], pq[u]);
+  }
+  sm[tid * 3] = n; sm[tid * 3 + 1] = mean; sm[tid * 3 + 2] = m2;
+  __syncthreads();
+  if (rl == 0) {
+    for (int l = 1; l < 8; ++l) {
+      const float* o = &sm[(l * 32 + ch) * 3];
+      chan_merge(n, mean, m2, o[0], o[1], o[2]);
+    }
+    const int c = c0 + ch;
+    const float var = m2 / n;
+    const float invstd = 1.0f / sqrtf(var + eps);
+    const float sc = gamma[c] * invstd, sh = beta[c] - mean * sc;
+    sSc[ch] = sc;
+    sSh[ch] = sh;
+    if (rs == 0) {
+      save_mean[c] = mean;
+      save_invstd[c] = invstd;
+      scale[c] = sc;
+      shift[c] = sh;
+      if (running_mean != nullptr) {
+        const float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+      }
+      if (c == 0 && num_batches_tracked != nullptr) num_batches_tracked[0] += 1;   // nn.BatchNorm2d bookkeeping
+    }
+  }
+  __syncthreads();
+  const int q = tid & 7;
+  const f32x4 sc4 = *reinterpret_cast<const f32x4*>(&sSc[4 * q]), sh4 = *reinterpret_cast<const f32x4*>(&sSh[4 * q]);
+  const int rows_per = (R + gridDim.y - 1) / gridDim.y;
+  const int r0 = rs * rows_per, r1 = r0 + rows_per < R ? r0 + rows_per : R;
+  for (int r = r0 + (tid >> 3); r < r1; r += 64) {
+    const long i0 = ((long)r * C + c0) / 4 + q, i1 = ((long)(r + 32) * C + c0) / 4 + q;
+    const bool two = r + 32 < r1;
+    const f32x4 v0 = reinterpret_cast<const f32x4*>(y)[i0];
+    const f32x4 v1 = two ? reinterpret_cast<const f32x4*>(y)[i1] : v0;
+    f32x4 o0, o1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      o0[k] = act_fwd(v0[k] * sc4[k] + sh4[k], act);
+      o1[k] = act_fwd(v1[k] * sc4[k] + sh4[k], act);
+    }
+    reinterpret_cast<f32x4*>(out)[i0] = o0;
+    if (two) reinterpret_cast<f32x4*>(out)[i1] = o1;
+  }
+}
+
 // eval-mode scale/shift from running statistics
 __global__ __launch_bounds__(256) void bn_eval_coeff_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ running_mean,
@@ -401,6 +479,19 @@ int launch_bn_finish_forward(const float* y, int R, int C, int nparts, const flo
   const size_t parts = nparts > kBnMaxBlocks ? (size_t)nparts : (size_t)kBnMaxBlocks;
   float* scale = coef_out != nullptr ? coef_out : ws + parts * C * 3;   // coef_out [2][C]: kept by the caller (lazy apply)
   float* shift = scale + C;
+  if (training && out != nullptr && nparts >= 1 && nparts <= 128 && C % 32 == 0) {
+    static const int on = [] { const char* e = getenv("CTVAE_BN_FIN_APPLY"); return e ? atoi(e) : 1; }();   // diagnostic: 0 = two launches
+    if (on) {
+      int rsn = 512 / (C / 32);
+      if (rsn > R / 32) rsn = R / 32;
+      if (rsn < 1) rsn = 1;
+      ProfScope ps("bn_finalize_apply_kernel", st, 0.0, 8.0 * (double)R * C + 12.0 * (double)nparts * C * rsn);
+      hipLaunchKernelGGL(bn_finalize_apply_kernel, dim3(C / 32, rsn), dim3(256), 0, st, y, ws, nparts, R, C, gamma, beta, running_mean,
+                         running_var, momentum, eps, save_mean, save_invstd, scale, shift, nbt, out, act);
+      CTVAE_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   if (training) {
     ProfScope ps("bn_finalize_kernel", st, 0.0, 12.0 * (double)nparts * C);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, ws, nparts, C, gamma, beta, running_mean,
