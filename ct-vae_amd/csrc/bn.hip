@@ -383,6 +383,62 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   }
 }
 
+// Backward finalize + apply in ONE launch where the per-tile sums are few rows (the deep layers): workgroup (channel block of
+// 32, row range) sums the rows of its channels itself (double, fixed order), forms k1, k2, k3 and the forward scale / shift,
+// the first row range commits d gamma / d beta, then every workgroup streams its rows of g_y.  The consumer's finishing launch
+// then carries no finalize, and its slab reduction can leave the backward chain (ctvae_defer_*).
+__global__ __launch_bounds__(256) void bn_bwd_finalize_apply_kernel(const float* __restrict__ ga, const float* __restrict__ y,
+                                                                    const float* __restrict__ part, int nblocks, int R, int C,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ save_mean,
+                                                                    const float* __restrict__ save_invstd, const float* __restrict__ beta,
+                                                                    int act, float* __restrict__ gy, float* __restrict__ dgamma,
+                                                                    float* __restrict__ dbeta, int accumulate) {
+  __shared__ double smd[256 * 2];
+  __shared__ __attribute__((aligned(16))) float sK[5][32];
+  const int tid = threadIdx.x, cb = blockIdx.x, rs = blockIdx.y;
+  const int c0 = cb * 32, ch = tid & 31, rl = tid >> 5;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = rl; b < nblocks; b += 8) {
+    s1 += (double)part[((long)b * C + c0 + ch) * 2 + 0];
+    s2 += (double)part[((long)b * C + c0 + ch) * 2 + 1];
+  }
+  smd[tid * 2] = s1; smd[tid * 2 + 1] = s2;
+  __syncthreads();
+  if (rl == 0) {
+    for (int l = 1; l < 8; ++l) {
+      s1 += smd[(l * 32 + ch) * 2];
+      s2 += smd[(l * 32 + ch) * 2 + 1];
+    }
+    const int c = c0 + ch;
+    const float db = (float)s1, dg = (float)s2;
+    const float invstd = save_invstd[c], mean = save_mean[c];
+    const float k1 = gamma[c] * invstd;
+    const float k2 = -k1 * dg / (float)R * invstd;
+    const float k3 = -k1 * db / (float)R - k2 * mean;
+    sK[0][ch] = k1; sK[1][ch] = k2; sK[2][ch] = k3; sK[3][ch] = k1; sK[4][ch] = beta[c] - mean * k1;
+    if (rs == 0) {
+      dgamma[c] = (accumulate ? dgamma[c] : 0.f) + dg;
+      dbeta[c] = (accumulate ? dbeta[c] : 0.f) + db;
+    }
+  }
+  __syncthreads();
+  const int q = tid & 7;
+  const f32x4 k1 = *reinterpret_cast<const f32x4*>(&sK[0][4 * q]), k2 = *reinterpret_cast<const f32x4*>(&sK[1][4 * q]);
+  const f32x4 k3 = *reinterpret_cast<const f32x4*>(&sK[2][4 * q]), sc = *reinterpret_cast<const f32x4*>(&sK[3][4 * q]);
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(&sK[4][4 * q]);
+  const int rows_per = (R + gridDim.y - 1) / gridDim.y;
+  const int r0 = rs * rows_per, r1 = r0 + rows_per < R ? r0 + rows_per : R;
+  for (int r = r0 + (tid >> 3); r < r1; r += 32) {
+    const long i = ((long)r * C + c0) / 4 + q;
+    const f32x4 g = reinterpret_cast<const f32x4*>(ga)[i], yv = reinterpret_cast<const f32x4*>(y)[i];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      o[k] = k1[k] * (g[k] * act_bwd_from_out(act_fwd(yv[k] * sc[k] + sh[k], act), act)) + k2[k] * yv[k] + k3[k];
+    reinterpret_cast<f32x4*>(gy)[i] = o;
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_finalize_job_kernel(BnFinJob j) {
   __shared__ double sm[8];
   bn_bwd_finalize_body(j, blockIdx.x, sm);
@@ -560,6 +616,19 @@ int launch_bn_backward(const float* ga, const float* beta, const float* y, int R
                        C, rpb, act);
   }
   CTVAE_LAUNCH_CHECK();
+  if (part_in != nullptr && gy != nullptr && coef_out == nullptr && nb <= 256 && C % 32 == 0) {
+    static const int on = [] { const char* e = getenv("CTVAE_BN_BWD_FIN_APPLY"); return e ? atoi(e) : 1; }();   // diagnostic
+    if (on) {
+      int rsn = 512 / (C / 32);
+      if (rsn > R / 32) rsn = R / 32;
+      if (rsn < 1) rsn = 1;
+      ProfScope ps("bn_bwd_finalize_apply_kernel", st, 0.0, 12.0 * (double)R * C + 8.0 * (double)nb * C * rsn);
+      hipLaunchKernelGGL(bn_bwd_finalize_apply_kernel, dim3(C / 32, rsn), dim3(256), 0, st, ga, y, part, nb, R, C, gamma, save_mean,
+                         save_invstd, beta, act, gy, dgamma, dbeta, accumulate);
+      CTVAE_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   {
     ProfScope ps("bn_bwd_finalize_kernel", st, 0.0, 8.0 * (double)nb * C);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, part, nb, C, (float)R, gamma,

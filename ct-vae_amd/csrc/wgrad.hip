@@ -718,24 +718,8 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
   const float* part = a.part;
   const float* pbias = a.pbias;
   const int ncls = g.ncls, N_ = a.N;
-  if (PairCtx* pc = pair_ctx()) {   // ctvae_conv_backward: behind the paired main launch, together with the split-K finish
-    pc->j1 = ReduceJob{part, dW, n, S, n, 0, 0};
-    pc->j2 = dbias ? ReduceJob{pbias, dbias, (long)N_, S * ncls, (long)N_, 0, 0} : ReduceJob{nullptr, nullptr, 0, 0, 0, 0, 0};
-    pc->nb1 = reduce_job_blocks(pc->j1);
-    pc->nb2 = reduce_job_blocks(pc->j2);
-    pc->accumulate = accumulate;
-    pc->bytesRed = 4.0 * (double)(S + 1) * n;
-    pc->haveRed = pc->nb1 + pc->nb2 > 0;
-    return 0;
-  }
-  char rname[96];
-  snprintf(rname, sizeof rname, "reduce_partials_kernel");
-  if (prof_detailed()) snprintf(rname, sizeof rname, "reduce_partials_kernel n=%ld S=%d", n, S);
-  ProfScope ps2(rname, st, 0.0, 4.0 * (double)(S + 1) * n);
-  if (dbias) launch_reduce2(part, dW, n, S, n, pbias, dbias, (long)N_, S * ncls, (long)N_, accumulate, st);
-  else launch_reduce(part, dW, n, S, n, accumulate, st);
-  CTVAE_LAUNCH_CHECK();
-  return 0;
+  // deferred (ctvae_defer_*), recorded for the call's finishing launch (ctvae_conv_backward), or issued now
+  return finish_reduce(part, dW, n, S, n, dbias ? pbias : nullptr, dbias, (long)N_, S * ncls, (long)N_, accumulate, st);
 }
 
 int launch_finish_recorded(const PairCtx& c, hipStream_t st) {

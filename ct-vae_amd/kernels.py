@@ -350,6 +350,10 @@ def conv_wgrad_raw(x, dy, w_param, b_param, spec: ConvSpec, in_coef=None, in_act
 _PAIR = os.environ.get("CTVAE_NO_PAIR", "0") != "1"     # diagnostic: separate wgrad / dgrad launches
 _BN_RIDER = os.environ.get("CTVAE_NO_BN_RIDER", "0") != "1"   # diagnostic: BatchNorm-backward finalize as its own launch
 _OUT_ACT_LINK = os.environ.get("CTVAE_NO_OUT_ACT_LINK", "0") != "1"   # diagnostic: final Tanh backward as its own launch
+# diagnostic, default off (0 = the finalize always rides in the consumer's finishing launch): with 128 the three deepest BatchNorm
+# layers finalize in their own apply launch and their consumers' slab reductions leave the chain -- 1.5992 / 1.5986 ms against
+# 1.5996 / 1.5988 ms (VanillaVAE bs = 256, same box): neutral, the one deferred launch grows by what the three removed ones took
+_BN_BWD_MERGE_ROWS = int(os.environ.get("CTVAE_BN_BWD_MERGE_ROWS", "0"))
 _ENC_BN_ON_LOAD = os.environ.get("CTVAE_NO_ENC_BN_ON_LOAD", "0") != "1"   # diagnostic: encoder.0's BatchNorm-backward apply as its own launch
 
 
@@ -381,7 +385,10 @@ def conv_backward_raw(x, dy, w_param, b_param, spec: ConvSpec, link=None, mask=N
         else:
             rows = 0
     bn = link if part is not None else None
-    coef = torch.empty(7 * spec.ci, dtype=torch.float32, device=dy.device) if (bn is not None and _BN_RIDER) else None
+    # few rows of sums (the deep layers): the BatchNorm's own launch finalizes AND applies (bn_bwd_finalize_apply_kernel), so this
+    # call's finishing launch carries no finalize and its slab reduction can leave the chain (kernels.backward's deferral)
+    rider = bn is not None and _BN_RIDER and not (0 < rows <= _BN_BWD_MERGE_ROWS and spec.ci % 32 == 0 and bn_commit is None)
+    coef = torch.empty(7 * spec.ci, dtype=torch.float32, device=dy.device) if rider else None
     sc = in_coef.data_ptr() if in_coef is not None else None
     sh = in_coef.data_ptr() + 4 * spec.ci if in_coef is not None else None
     by, bc, bact, bgy = (dy_bn[0].data_ptr(), dy_bn[1].data_ptr(), dy_bn[2], dy_bn[3].data_ptr()) if dy_bn is not None else (None, None, 0, None)
