@@ -112,3 +112,59 @@ def test_synthetic_batch_contract():
     d0 = SyntheticData({"train_batch_size": 4, "val_batch_size": 4}, {}, torch.device("cpu"), rank=0, world=2, steps_per_epoch=1)
     d1 = SyntheticData({"train_batch_size": 4, "val_batch_size": 4}, {}, torch.device("cpu"), rank=1, world=2, steps_per_epoch=1)
     assert not torch.equal(next(iter(d0.train()))[0], next(iter(d1.train()))[0])           # ranks see different rows
+
+
+def test_bank_gradients_written_in_place_reach_the_flat_buffer():
+    """kernels.flat_grad_alias (host logic, no kernel involved): a backward that writes a bank's gradient into the alias of the
+    flat gradient buffer leaves every parameter of the bank with the right gradient after gather_torch_grads(), whether or not
+    autograd kept the alias (it does when nobody else holds the tensor; a clone would only cost the copy back); the alias is
+    handed out once per zero_grad, and never after an optimizer-side epoch bump without a zero_grad."""
+    import torch
+    from ctvae_amd import kernels as K
+    from ctvae_amd.models.causal import _DiscoverBank
+    from ctvae_amd.models.packing import FlatParamMixin
+
+    class Root(FlatParamMixin, torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.bank = _DiscoverBank(3, 8, 4)
+            self.flatten_parameters()
+
+    class WritesInPlace(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, W):
+            ctx.save_for_backward(W)
+            return W.sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            (W,) = ctx.saved_tensors
+            dW = K.flat_grad_alias(W)
+            WritesInPlace.aliased.append(dW is not None)
+            if dW is None:
+                dW = torch.empty_like(W)
+            dW.copy_(torch.arange(W.numel(), dtype=torch.float32).view_as(W) * g)
+            return dW
+
+    r = Root()
+    plist = r.bank._lists()[0]
+    assert K.banked(plist)
+    want = torch.arange(plist[0].numel() * len(plist), dtype=torch.float32).view(len(plist), *plist[0].shape)
+    for lazy in (True, False):
+        WritesInPlace.aliased = []
+        r.zero_grad(lazy=lazy)
+        WritesInPlace.apply(K.BankView.apply(*plist)).backward()
+        assert WritesInPlace.aliased == [True]
+        r.gather_torch_grads()
+        for k, p in enumerate(plist):
+            assert torch.equal(p.grad, want[k])
+        base = r._flat_grads.data_ptr()
+        assert all(p.grad.data_ptr() == base + 4 * (plist[0].numel() * k + (plist[0].data_ptr() - r._flat_params.data_ptr()) // 4)
+                   for k, p in enumerate(plist))
+    # a second writer in the same step gets no alias (autograd adds its tensor), nor does anyone after an epoch bump
+    r.zero_grad(lazy=True)
+    W = K.BankView.apply(*plist)
+    assert K.flat_grad_alias(W) is not None and K.flat_grad_alias(W) is None
+    r.zero_grad(lazy=True)
+    K.bump_param_epoch()
+    assert K.flat_grad_alias(W) is None
