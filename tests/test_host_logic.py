@@ -168,3 +168,39 @@ def test_bank_gradients_written_in_place_reach_the_flat_buffer():
     r.zero_grad(lazy=True)
     K.bump_param_epoch()
     assert K.flat_grad_alias(W) is None
+
+
+def test_lazy_zero_grad_host_protocol():
+    """FlatParamMixin.zero_grad(lazy=True) / kernels.grad_target / settle_grads on the host (no kernel involved): a block is
+    declared zero without a fill, its first writer is told to overwrite (once), blocks nobody wrote are zero after the settle,
+    and the parameters of a PackedLinearGroup (one GEMM writes the whole block) share the flag."""
+    import torch
+    from ctvae_amd import kernels as K
+    from ctvae_amd.models.packing import FlatParamMixin, PackedConv, PackedLinear, PackedLinearGroup
+
+    class Root(FlatParamMixin, torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = PackedConv(4, 8, 3)
+            self.fc_a, self.fc_b = PackedLinear(16, 4), PackedLinear(16, 4)
+            grp = PackedLinearGroup([self.fc_a, self.fc_b])
+            self.fc_a._linear_group = self.fc_b._linear_group = grp
+            self.flatten_parameters()
+
+    r = Root()
+    r._flat_grads.fill_(7.0)                       # stale contents
+    r.zero_grad(lazy=True)
+    assert float(r._flat_grads.min()) == 7.0       # no fill happened
+    g, acc = K.grad_target(r.conv.weight)
+    assert acc == 0 and g is r.conv.weight.grad
+    g.fill_(1.0)                                   # "the kernel" overwrites
+    assert K.grad_target(r.conv.weight)[1] == 1    # a second writer accumulates
+    assert K.grad_target(r.fc_a.weight)[1] == 0 and K.grad_target(r.fc_b.weight)[1] == 1      # one flag for the group's block
+    r.fc_a.weight.grad.fill_(2.0)
+    r.fc_b.weight.grad.fill_(2.0)
+    r.settle_grads()
+    assert torch.all(r.conv.weight.grad == 1.0) and torch.all(r.fc_a.weight.grad == 2.0) and torch.all(r.fc_b.weight.grad == 2.0)
+    for p in (r.conv.bias, r.fc_a.bias, r.fc_b.bias):          # never written: zero after the settle
+        assert torch.all(p.grad == 0.0)
+    r.zero_grad()                                  # the eager form fills and clears every flag
+    assert float(r._flat_grads.abs().max()) == 0.0 and K.grad_target(r.conv.weight)[1] == 1
