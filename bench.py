@@ -6,8 +6,9 @@ all-reduce (N>1) + Adam) on synthetic 64x64x3 batches, one process per GPU.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): VanillaVAE, configs/vae.yaml shapes (in_channels 3, latent_dim 128),
-per-GPU batch 256, fp32 end to end (parity target 1e-4 forces exact-f32 MFMA).  Inputs are resident in HBM
+Workload = the configuration BASELINE.json's metric is quoted on: VanillaVAE, configs/vae.yaml shapes (in_channels 3,
+latent_dim 128), per-GPU batch 64, fp32 end to end (parity target 1e-4 forces exact-f32 MFMA); the bs=256, MCQ-VAE and
+CT-MCQ-VAE configurations of BASELINE.json ride in the line's `configs` array.  Inputs are resident in HBM
 before the timed region (4 rotating synthetic batches); forward/loss/backward (+Adam at N=1) replay as ONE
 hipGraph.  Prints one JSON line (rank 0) with the throughput, a `roofline` object for the dominant kernel
 (HIP-event timed per launch through the library's own profiler, algorithmic FLOPs from the launch geometry)
@@ -31,6 +32,7 @@ FLOP_PER_IMG = {"VanillaVAE": 312_606_720, "MCQVAE": 4_208_984_064,    # SURVEY.
                 "CTMCQVAE": 4_932_501_504}                             # action-mode pair, conv path only
 PEAK_F32_MFMA_TFLOPS = 157.3                                             # MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
+BASELINE_METRIC = "images/sec/GPU fwd+bwd, 64\u00d764\u00d73 bs=64; recon+KL vs CPU ref"   # BASELINE.json "metric", verbatim
 
 
 def parse():
@@ -38,7 +40,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 64 VanillaVAE = the metric's own "
+                                                             "configuration, 256 MCQVAE, 128 pairs CTMCQVAE)")
     ap.add_argument("--model", default="VanillaVAE", choices=["VanillaVAE", "MCQVAE", "CTMCQVAE"],
                     help="CTMCQVAE: ct_mcq_vae.yaml shapes, action-mode pairs (x, y, one-hot action), eager launches "
                          "(the causal-transition layer has data-dependent host control flow)")
@@ -57,12 +60,16 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--detail", action="store_true", help="per-shape kernel table on stderr (diagnostic)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.batch is None:
+        args.batch = {"VanillaVAE": 64, "MCQVAE": 256, "CTMCQVAE": 128}[args.model]
+    return args
 
 
-def pmc_traffic(kernel_name):
-    """HBM-side bytes per launch of `kernel_name` from the newest committed PMC summary that lists it (profiles/*_pmc_traffic.json,
-    written by tools/pmc_summary.py from two separate `rocprofv3 --pmc` passes of this same command) or None."""
+def pmc_traffic(kernel_name, workload):
+    """HBM-side bytes per launch of `kernel_name` from the newest committed PMC summary OF THIS WORKLOAD that lists it
+    (profiles/*_pmc_traffic.json, written by tools/pmc_summary.py from two separate `rocprofv3 --pmc` passes of this same
+    command; summaries written before round 3 carry no "workload" key and are VanillaVAE bs=256) or None."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     want = kernel_name.replace(" ", "")
@@ -71,6 +78,10 @@ def pmc_traffic(kernel_name):
             with open(path) as f:
                 d = json.load(f)
         except (OSError, ValueError):
+            continue
+        base = os.path.basename(path)
+        legacy = "CTMCQVAE bs=128 a12" if "ctmcqvae_a12" in base else "VanillaVAE bs=256"
+        if d.get("workload", legacy) != workload:
             continue
         for k, v in d.get("kernels", {}).items():
             if k.replace(" ", "") == want:
@@ -89,7 +100,7 @@ def build_model(name, dev, seed, action_dim=12):
         cfg["action_dim"] = action_dim          # 12 = TShapes3D (the YAML), 20 = TCelebA-shaped (BASELINE.json configs[4])
         torch.manual_seed(seed)
         m = vae_models[name](**cfg)
-        from tests import helpers as H
+        from ctvae_amd import specs as H
         conv = filler.fill_state(H.mcq_specs(H.CT_CONV_CFG), seed + 1)
         ctl = filler.fill_state(H.ct_layer_specs(action_dim), seed + 3)
         m.load_state_dict({**conv, **{"ct_layer." + k: v for k, v in ctl.items() if k != "pos_encoding.pe"}}, strict=False)
@@ -101,14 +112,29 @@ def build_model(name, dev, seed, action_dim=12):
     return m.to(dev).train()
 
 
+def _with_adam(sd, grads_of, lr):
+    """One CPU training step = grads_of(current state) followed by torch.optim.Adam on the float parameters (experiment.py:158)."""
+    cur = dict(sd)
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()
+              if v.is_floating_point() and not k.endswith(("running_mean", "running_var"))}
+    opt = torch.optim.Adam(list(leaves.values()), lr=lr)
+
+    def fn():
+        for k, g in grads_of(cur).items():
+            leaves[k].grad = g
+        opt.step()
+        cur.update({k: v.detach() for k, v in leaves.items()})
+    return fn
+
+
 def cpu_baseline(model_name, seconds, action_dim=12):
-    """Reference arithmetic (the oracle = pure-torch port, pinned by tests/golden/) forward + loss + backward on the host cores,
-    WITHOUT the optimizer step (the reference's CPU path would add torch.optim.Adam; it is < 2 % of a step).  VanillaVAE /
-    MCQVAE: BASELINE.json configs[0]'s batch (64).  CTMCQVAE: action-mode pairs incl. the causal-transition layer (its GATv2
-    part is the oracle's unpinned restatement), 8 pairs per step -- the pair tensors of the layer are 13 MB per sample."""
+    """Reference arithmetic (the oracle = pure-torch port, pinned by tests/golden/) forward + loss + backward + torch.optim.Adam
+    step on the host cores -- the same step contents as the GPU line (experiment.py:44-59,152-160).  VanillaVAE / MCQVAE: the
+    metric's own batch (64).  CTMCQVAE: action-mode pairs incl. the causal-transition layer (its GATv2 part is the oracle's
+    unpinned restatement), 8 pairs per step -- the pair tensors of the layer are 13 MB per sample -- without the optimizer."""
     from ctvae_amd import filler
     from oracle import vae_cpu as O
-    from tests import helpers as H
+    from ctvae_amd import specs as H
     # a one-GPU box grants ~16 host cores to the job; more torch threads than that only oversubscribes
     threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
     torch.set_num_threads(threads)
@@ -117,13 +143,13 @@ def cpu_baseline(model_name, seconds, action_dim=12):
         B = 64
         sd = filler.fill_state(H.vanilla_specs(), 1266)
         x, eps = filler.synthetic_batch(1265, B)
-        fn = lambda: O.vanilla_step(sd, x, eps, 0.00025)
+        fn = _with_adam(sd, lambda cur: O.vanilla_step(cur, x, eps, 0.00025)[1], 0.005)
         what = f"VanillaVAE bs={B}"
     elif model_name == "MCQVAE":
         B = 64
         sd = filler.fill_state(H.mcq_specs(H.MCQ_CFG), 1321)
         x, _ = filler.synthetic_batch(1320, B)
-        fn = lambda: O.mcq_step(sd, x, 4, 0.25)
+        fn = _with_adam(sd, lambda cur: O.mcq_step(cur, x, 4, 0.25)[1], 0.0005)
         what = f"MCQVAE (mcq_vae.yaml) bs={B}"
     else:
         import yaml
@@ -153,7 +179,8 @@ def cpu_baseline(model_name, seconds, action_dim=12):
         if el >= seconds or n >= 200:
             break
     return {"value": round(n * B / el, 2), "unit": unit, "cores": threads, "kind": "port",
-            "sample": f"{n} steps of {what} fwd+loss+bwd, no optimizer step (oracle/, torch CPU fp32, {threads} threads, {el:.1f} s)"}
+            "sample": f"{n} steps of {what} fwd+loss+bwd{'+Adam' if unit == 'images/s' else ', no optimizer step'} "
+                      f"(oracle/, torch CPU fp32, {threads} threads, {el:.1f} s)"}
 
 
 class Workload:
@@ -298,7 +325,8 @@ def run_workload(wl, args, ctx, want_kernels=False):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     res = {"ms_per_step": elapsed / args.steps * 1e3, "value": B * world * args.steps / elapsed, "elapsed": elapsed,
-           "hipgraph": graph is not None, "overlap": bool(split is not None and world > 1), "roofline": None, "kernels": None}
+           "hipgraph": graph is not None, "overlap": bool(split is not None and world > 1), "roofline": None, "kernels": None,
+           "hbm_kernels": None}
 
     if rank == 0 and not args.no_roofline:
         # per-kernel HIP-event timing on the launch stream (eager launches; the graph replays the same kernels)
@@ -354,11 +382,27 @@ def run_workload(wl, args, ctx, want_kernels=False):
                         "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
                         "avg_launch_us": round(top["ms"] / top["count"] * 1e3, 2),
                         "launches_per_step": top["count"] / nprof}
-        # the PMC passes were taken on VanillaVAE bs=256 and, for the Winograd kernels (names unique to it), on MCQVAE bs=256
-        if B == 256 and (wl.model == "VanillaVAE" or (wl.model == "MCQVAE" and name.startswith("wino_"))):
-            roofline["traffic"], src = pmc_traffic(name)
-            if src:
-                roofline["traffic_source"] = src + " (bytes per launch; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"
+        wl_key = f"{wl.model} bs={B}" + (f" a{wl.action_dim}" if wl.model == "CTMCQVAE" else "")
+        roofline["traffic"], src = pmc_traffic(name, "VanillaVAE bs=256" if (wl_key == "MCQVAE bs=256" and name.startswith("wino_")
+                                                                        and pmc_traffic(name, wl_key)[0] is None) else wl_key)
+        if src:
+            roofline["traffic_source"] = src + " (bytes per launch; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"
+        # GB/s against the 8 TB/s HBM peak for the HBM-bound kernels (loss reductions, reparameterisation, VQ lookup,
+        # BatchNorm, Adam, layout changes): algorithmic bytes of the launch geometry / HIP-event time; counter traffic beside it
+        hbm = []
+        for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"]):
+            if v["flops"] > 0 or v["bytes"] <= 0 or k == name:
+                continue
+            gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+            e = {"kernel": k, "launches_per_step": v["count"] / nprof, "avg_launch_us": round(v["ms"] / v["count"] * 1e3, 2),
+                 "algorithmic_bytes_per_launch": round(v["bytes"] / v["count"]), "achieved_gbs": round(gbs, 1),
+                 "frac_of_8tbs": round(gbs / PEAK_HBM_GBS, 4)}
+            t, _ = pmc_traffic(k, wl_key)
+            if t is not None:
+                e["traffic"] = t
+                e["traffic_gbs"] = round(t * v["count"] / (v["ms"] * 1e-3) / 1e9, 1)
+            hbm.append(e)
+        res["hbm_kernels"] = hbm[:12]
         roofline["event_pair_overhead_us"] = round(pair_ms * 1e3, 2)
         step_tflops = FLOP_PER_IMG[wl.model] * (B * args.steps / elapsed) / 1e12
         roofline["step_conv_tflops_per_gpu"] = round(step_tflops, 2)
@@ -416,8 +460,8 @@ def main():
     # line covers them: same step contents, same timing protocol, DDP exchange included at N>1 (the >= 6x scaling target
     # of BASELINE.json is quoted on CT-MCQ-VAE)
     extra = []
-    if not args.no_configs and (args.model, args.batch, args.action_dim) == ("VanillaVAE", 256, 12):
-        for wl in (Workload("VanillaVAE", 64), Workload("MCQVAE", 256), Workload("CTMCQVAE", 128, 12), Workload("CTMCQVAE", 128, 20)):
+    if not args.no_configs and (args.model, args.batch, args.action_dim) == ("VanillaVAE", 64, 12):
+        for wl in (Workload("VanillaVAE", 256), Workload("MCQVAE", 256), Workload("CTMCQVAE", 128, 12), Workload("CTMCQVAE", 128, 20)):
             e = run_workload(wl, args, ctx)
             entry = {"workload": wl.label(world), "per_gpu_batch": wl.batch, "global_batch": wl.batch * world,
                      "ms_per_step": round(e["ms_per_step"], 4), "value": round(e["value"], 1), "unit": wl.unit,
@@ -427,6 +471,8 @@ def main():
                 entry["step_frac_of_f32_mfma_peak"] = rf["step_frac_of_f32_mfma_peak"]
                 entry["roofline"] = {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_us",
                                                          "launches_per_step", "executed_frac", "conv_equivalent_frac") if k in rf}
+                if e["hbm_kernels"]:
+                    entry["hbm_kernels"] = e["hbm_kernels"][:5]
                 if wl.model == "CTMCQVAE":
                     entry["step_frac_note"] = "conv-path FLOP only (SURVEY 8d convention); the causal-transition layer's work is not counted"
             extra.append(entry)
@@ -439,12 +485,15 @@ def main():
         B = args.batch
         unit = head.unit
         line = {
-            "metric": f"{unit.split('/')[0]}/sec/GPU fwd+bwd, 64x64x3 bs={B}; recon+KL vs CPU ref",
+            # BASELINE.json's metric string verbatim for the configuration it is quoted on; other command lines say what they ran
+            "metric": (BASELINE_METRIC if (args.model, B) == ("VanillaVAE", 64)
+                       else f"{unit.split('/')[0]}/sec/GPU fwd+bwd, {args.model} 64x64x3 bs={B}; recon+KL vs CPU ref"),
             "value": round(r["value"], 1), "unit": unit, "per_gpu": round(r["value"] / world, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(r["ms_per_step"], 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": head.label(world) + (" (BASELINE.json configs[1]; the metric's bs=64 wording is configs[0]'s "
-                                                        "batch: see the bs=64 entry of `configs`)" if (args.model, B) == ("VanillaVAE", 256) else ""),
+            "config": {"workload": head.label(world) + (" (configs/vae.yaml shapes at the batch BASELINE.json's metric names, bs=64, on "
+                                                        "one MI355X; BASELINE.json configs[1..4] are the `configs` entries)"
+                                                        if (args.model, B) == ("VanillaVAE", 64) else ""),
                        "per_gpu_batch": B, "global_batch": B * world, "latent_dim": 128,
                        "parallelism": f"dp{world}" if world > 1 else "single", "hipgraph": r["hipgraph"],
                        "allreduce_overlap": r["overlap"]},
@@ -452,6 +501,8 @@ def main():
         }
         if extra:
             line["configs"] = extra
+        if r["hbm_kernels"]:
+            line["hbm_kernels"] = r["hbm_kernels"]
         if r["kernels"] is not None:
             line["kernels"] = r["kernels"]
         sys.stdout.flush()

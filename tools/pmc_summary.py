@@ -1,6 +1,7 @@
 """Per-kernel HBM-side traffic from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot share a pass on
 gfx950: TCC has 4 slots, they cost 3 + 2).  Usage:
-    python tools/pmc_summary.py <dir with FETCH pass> <dir with WRITE pass> <steps profiled> > profiles/rNN_pmc_traffic.json
+    python tools/pmc_summary.py <dir with FETCH pass> <dir with WRITE pass> <steps profiled> [workload label] > profiles/rNN_pmc_traffic.json
+(the label, e.g. "VanillaVAE bs=64", is what bench.py matches a summary to a configuration by)
 Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes: the counters are in KB; on gfx950
 FETCH_SIZE reports half of the bytes of coalesced streaming reads (128-B requests tallied at 64 B) -> doubled;
 WRITE_SIZE is taken as is."""
@@ -28,6 +29,7 @@ def load(d):
 
 
 fd, wd, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+workload = sys.argv[4] if len(sys.argv) > 4 else "VanillaVAE bs=256"
 F, W = load(fd), load(wd)
 out = {}
 for k in sorted(F, key=lambda k: -(2 * F[k][1] + W.get(k, [0, 0])[1])):
@@ -38,4 +40,4 @@ for k in sorted(F, key=lambda k: -(2 * F[k][1] + W.get(k, [0, 0])[1])):
               "fetch_bytes_corrected_per_launch": round(2 * fetch_raw), "write_bytes_per_launch": round(write),
               "hbm_bytes_per_launch": round(2 * fetch_raw + write)}
 json.dump({"note": "FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE as reported; separate --pmc passes, eager launches",
-           "steps": steps, "kernels": out}, sys.stdout, indent=1)
+           "workload": workload, "steps": steps, "kernels": out}, sys.stdout, indent=1)
