@@ -11,7 +11,7 @@ namespace ctvae {
 int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
                    const float* mask, int mask_act, float* S, int act, float* bn_part, float* ws, size_t ws_floats,
                    hipStream_t st, const BnBwdFuse* bnb = nullptr, const InXform* xf = nullptr,
-                   const WinoFilters* wf = nullptr);
+                   const WinoFilters* wf = nullptr, SplitKRaw* raw = nullptr);
 bool wino_supported(const ConvGeom& g, size_t ws_floats);
 bool wino_enabled();
 int wino_set_enabled(int on);
@@ -267,9 +267,19 @@ int ctvae_conv_bn_act_forward(int kind, const float* x, const float* w, const fl
   tapgemm_plan(g, wsf, plan);
   const int R = g.B * g.sH * g.sW;
   if (plan.splitk > 1 || !training) {
-    // small layer run split-K (or eval mode): conv first, then statistics from y with the stand-alone kernels
-    int rc = launch_tapgemm(g, x, w, bias, nullptr, nullptr, 0, y, ACT_NONE, nullptr, ws, wsf, (hipStream_t)stream);
+    // small layer run split-K (or eval mode).  Training, a few MB at most: the slices stay channel-major in the workspace and ONE
+    // channel-owner launch sums them, takes the statistics, finalizes and applies (bn.hip bn_fused_fwd_kernel).  Otherwise:
+    // conv (+ split-K finish) first, then statistics from y with the stand-alone kernels
+    SplitKRaw raw{ws, 0};
+    const bool fused = training && plan.splitk > 1 && bn_fused_ok(R, Co);
+    int rc = launch_tapgemm(g, x, w, bias, nullptr, nullptr, 0, y, ACT_NONE, nullptr, ws, wsf, (hipStream_t)stream, nullptr, nullptr,
+                            nullptr, fused ? &raw : nullptr);
     if (rc) return rc;
+    if (raw.splitk > 1) {
+      const BnFusedFwd p{ws, row_map_of(g), raw.splitk, R, Co, bias, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
+                         scale_shift_out, nbt, y, a_out, act};
+      return launch_bn_fused_forward(p, (hipStream_t)stream);
+    }
     return launch_bn_forward(y, R, Co, gamma, beta, running_mean, running_var, momentum, eps, training, act, a_out, save_mean,
                              save_invstd, ws, ws_bytes, nbt, (hipStream_t)stream, scale_shift_out);
   }
@@ -354,15 +364,17 @@ int ctvae_conv_backward_bn_rows(int kind, int B, int H, int W, int Ci, int Co, i
   return rows;
 }
 
-int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* w, float* dw, float* dbias, float* dx, int B,
+// dx_slices != nullptr: the data gradient must run split-K and leaves its raw slices there, channel-major (SplitKRaw); dx is
+// not written (ctvae_conv_backward_lazy)
+static int conv_backward_impl(int kind, const float* x, const float* dy, const float* w, float* dw, float* dbias, float* dx, int B,
                         int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int accumulate, const float* mask,
                         int mask_act, const float* wino_filters, const float* bn_y, const float* bn_mean,
                         const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int bn_act, float* bn_part,
                         int bn_part_rows, float* bn_coef_out, float* bn_dgamma, float* bn_dbeta, int bn_accumulate,
                         const float* in_scale, const float* in_shift, int in_act,
                         const float* dy_bn_y, const float* dy_bn_coef, int dy_bn_act, float* gy_out, float* ws, size_t ws_bytes,
-                        void* stream) {
-  if (!x || !dy || !w || !dw || !dx || !ws || !conv_kind_ok(kind)) return kErrBadArg;
+                        void* stream, float* dx_slices) {
+  if (!x || !dy || !w || !dw || (!dx && !dx_slices) || !ws || !conv_kind_ok(kind)) return kErrBadArg;
   const bool bn = bn_part != nullptr;
   if (bn_coef_out != nullptr && !bn) return kErrBadArg;
   if ((bn_dgamma != nullptr) != (bn_dbeta != nullptr) || (bn_dgamma != nullptr && bn_coef_out == nullptr)) return kErrBadArg;
@@ -419,8 +431,10 @@ int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* 
     const WinoFilters wf{wino_filters, nullptr};
     const BnBwdFuse f{bn_y, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_act, bn_part};
     // dy_bn_*: dy was g_a of the BatchNorm behind this layer; the weight-gradient kernel left g_y in gy_out for the data gradient
+      SplitKRaw raw{dx_slices, 0};
       rc = launch_tapgemm(gd, gy_out != nullptr ? gy_out : dy, w, nullptr, nullptr, mask, mask_act, dx, ACT_NONE, nullptr, ws_d,
-                          half_floats, st, bn ? &f : nullptr, nullptr, &wf);
+                          half_floats, st, bn ? &f : nullptr, nullptr, &wf, dx_slices != nullptr ? &raw : nullptr);
+      if (!rc && dx_slices != nullptr && raw.splitk <= 1) rc = kErrBadArg;   // the caller asked ctvae_conv_backward_lazy_slices first
     }
   }
   pair_ctx() = nullptr;
@@ -431,6 +445,58 @@ int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* 
                       bn_dgamma, bn_dbeta, bn_accumulate};
   }
   return pair_flush(ctx, st);
+}
+
+int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* w, float* dw, float* dbias, float* dx, int B,
+                        int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int accumulate, const float* mask,
+                        int mask_act, const float* wino_filters, const float* bn_y, const float* bn_mean,
+                        const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int bn_act, float* bn_part,
+                        int bn_part_rows, float* bn_coef_out, float* bn_dgamma, float* bn_dbeta, int bn_accumulate,
+                        const float* in_scale, const float* in_shift, int in_act,
+                        const float* dy_bn_y, const float* dy_bn_coef, int dy_bn_act, float* gy_out, float* ws, size_t ws_bytes,
+                        void* stream) {
+  return conv_backward_impl(kind, x, dy, w, dw, dbias, dx, B, H, W, Ci, Co, k, stride, pad, out_pad, accumulate, mask, mask_act,
+                            wino_filters, bn_y, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_act, bn_part, bn_part_rows, bn_coef_out,
+                            bn_dgamma, bn_dbeta, bn_accumulate, in_scale, in_shift, in_act, dy_bn_y, dy_bn_coef, dy_bn_act, gy_out, ws,
+                            ws_bytes, stream, nullptr);
+}
+
+int ctvae_conv_backward_lazy_slices(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
+                                    size_t ws_bytes) {
+  if (!conv_kind_ok(kind)) return 0;
+  ConvGeom g;
+  if (conv_geom(g, kind, 2, B, H, W, Ci, Co, k, stride, pad, out_pad)) return 0;
+  const size_t half_floats = ((ws_bytes / 2) & ~(size_t)255) / sizeof(float);
+  if (img_dgrad_supported(g) || (wino_enabled() && wino_supported(g, half_floats))) return 0;
+  PairCtx ctx;                      // plan as ctvae_conv_backward does
+  pair_ctx() = &ctx;
+  TapGemmPlan pl;
+  tapgemm_plan(g, half_floats, pl);
+  pair_ctx() = nullptr;
+  const long Mc = (long)g.B * g.Qh * g.Qw;
+  if (pl.thin || pl.splitk <= 1 || Mc % 4 != 0 || !bn_fused_ok(B * H * W, Ci)) return 0;
+  return pl.splitk;
+}
+
+int ctvae_conv_backward_lazy(int kind, const float* x, const float* dy, const float* w, float* dw, float* dbias, float* dx_slices,
+                             int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int accumulate, float* ws,
+                             size_t ws_bytes, void* stream) {
+  if (!dx_slices) return kErrBadArg;
+  return conv_backward_impl(kind, x, dy, w, dw, dbias, nullptr, B, H, W, Ci, Co, k, stride, pad, out_pad, accumulate, nullptr, 0,
+                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr,
+                            nullptr, 0, nullptr, nullptr, 0, nullptr, ws, ws_bytes, stream, dx_slices);
+}
+
+int ctvae_bn_backward_fused(const float* g_a_slices, int slices, int kind, int B, int H, int W, int Ci, int Co, int k, int stride,
+                            int pad, int out_pad, const float* y, const float* gamma, const float* beta, const float* save_mean,
+                            const float* save_invstd, int act, float* g_y, float* dgamma, float* dbeta, int accumulate, void* stream) {
+  if (!g_a_slices || slices < 1 || !y || !gamma || !beta || !save_mean || !save_invstd || !g_y || !dgamma || !dbeta) return kErrBadArg;
+  if (!conv_kind_ok(kind)) return kErrBadArg;
+  ConvGeom g;   // the data gradient that wrote the slices: its class-major row order -> pixels of y
+  if (conv_geom(g, kind, 2, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
+  const BnFusedBwd p{g_a_slices, row_map_of(g), slices, B * H * W, Ci, y, gamma, beta, save_mean, save_invstd, act, g_y, dgamma,
+                     dbeta, accumulate};
+  return launch_bn_fused_backward(p, (hipStream_t)stream);
 }
 
 int ctvae_conv_wgrad_bn_apply_supported(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad) {

@@ -505,6 +505,257 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// ---- small layers: the whole tail of a split-K convolution in ONE launch (channel owners) ------------------------------
+// At small batch the deep layers' GEMMs are split along K to fill the chip, and what followed was a chain of 5 us launches:
+// split-K sum -> statistics -> finalize(+apply) forward, split-K sum -> backward sums -> finalize -> apply backward.  Here the
+// tile kernel leaves its raw slices CHANNEL-MAJOR (SplitKRaw: part[S][C][R]), and a workgroup that owns 4 channels and ALL R
+// rows does the rest: it sums the slices of its channels (contiguous runs along r: coalesced 16-byte loads), holds the result
+// in registers (2 or 4 channels x 4 rows per thread), takes the exact two-pass statistics (forward) or the two backward sums
+// with block reductions in a fixed order, and writes the NHWC rows of its 4 channels as 16-byte stores.  No partial rows,
+// no second pass over memory, bit-reproducible.  The strided 16-byte row accesses touch a line per lane, which is why this
+// form is kept to tensors of a few MB (bn_fused_ok): measured on the 64 x 64 x 3, bs = 64 step.
+template <int TPB, int NV>
+__device__ __forceinline__ void block_sum_n(float (&v)[NV], float* sm /* [TPB/64][NV] */) {
+  constexpr int NW = TPB / 64;
+#pragma unroll
+  for (int c = 0; c < NV; ++c) v[c] = wave_sum(v[c]);
+  if constexpr (NW > 1) {
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int c = 0; c < NV; ++c) sm[w * NV + c] = v[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) t += sm[i * NV + c];
+      v[c] = t;
+    }
+  }
+}
+
+// v[c] = sum of the S slices of four consecutive rows of channel c (c < CPW): SU slices x CPW channels of loads go out together
+// (a slice index beyond S re-reads the last slice with weight 0: the loop body stays branch-free, the summation order fixed)
+template <int CPW, int SU>
+__device__ __forceinline__ void slice_sum4(f32x4 (&v)[CPW], const float* __restrict__ base, long chan_stride, long slice_stride, int S) {
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int z0 = 0; z0 < S; z0 += SU) {
+    f32x4 t[SU][CPW];
+#pragma unroll
+    for (int u = 0; u < SU; ++u)
+#pragma unroll
+      for (int c = 0; c < CPW; ++c)
+        t[u][c] = *reinterpret_cast<const f32x4*>(base + (long)(z0 + u < S ? z0 + u : S - 1) * slice_stride + c * chan_stride);
+#pragma unroll
+    for (int u = 0; u < SU; ++u)
+#pragma unroll
+      for (int c = 0; c < CPW; ++c) v[c] += z0 + u < S ? t[u][c] : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+// Channel group of a workgroup.  The groups of one 128-byte line of an NHWC row (32 channels) each write / read 8 or 16 bytes
+// of it: dealt to the XCDs in launch order (id % 8) they would leave pieces of every line in eight L2s -- partial-line
+// write-backs and eight fills per line.  Whole lines per XCD instead: id = (line % 8) + 8 * (slot + slots * (line / 8)).
+__device__ __forceinline__ int fused_group(int id, int C, int cpw) {
+  const int slots = 32 / cpw, lines = C / 32;
+  if (lines % 8 != 0) return id;
+  const int x = id & 7, t = id >> 3, slot = t % slots, jh = t / slots;
+  return (jh * 8 + x) * slots + slot;
+}
+
+// workgroup = CPW channels x all R rows (R <= 4 * TPB); thread = four consecutive rows of each of its CPW channels
+template <int TPB, int CPW, int SU>
+__global__ __launch_bounds__(TPB) void bn_fused_fwd_kernel(const BnFusedFwd p) {
+  typedef float rowv __attribute__((ext_vector_type(CPW)));
+  __shared__ float sm[(TPB / 64) * CPW];
+  const int tid = threadIdx.x, c0 = fused_group(blockIdx.x, p.C, CPW) * CPW, R = p.R, C = p.C;
+  const int r4 = 4 * tid;
+  const bool live = r4 < R;
+  // everything the tail needs is requested before the slices: nothing below waits for a second memory round trip
+  float gmv[CPW], btv[CPW], bsv[CPW], rmv[CPW], rvv[CPW];
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) {
+    gmv[c] = p.gamma[c0 + c];
+    btv[c] = p.beta[c0 + c];
+    bsv[c] = p.bias != nullptr ? p.bias[c0 + c] : 0.f;
+    rmv[c] = p.running_mean != nullptr ? p.running_mean[c0 + c] : 0.f;
+    rvv[c] = p.running_mean != nullptr ? p.running_var[c0 + c] : 0.f;
+  }
+  const long long nbt0 = (blockIdx.x == 0 && p.nbt != nullptr) ? p.nbt[0] : 0;
+  f32x4 v[CPW];
+  slice_sum4<CPW, SU>(v, p.part + (long)c0 * R + (live ? r4 : 0), R, (long)C * R, p.S);
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) v[c] = live ? v[c] + bsv[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+  float s[CPW];
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) s[c] = (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);   // rows beyond R hold zeros
+  block_sum_n<TPB, CPW>(s, sm);
+  float mean[CPW], q[CPW];
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) {
+    mean[c] = s[c] / (float)R;
+    float t = 0.f;
+    if (live) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[c][e] - mean[c];
+        t += d * d;
+      }
+    }
+    q[c] = t;
+  }
+  block_sum_n<TPB, CPW>(q, sm);
+  float sc[CPW], sh[CPW];
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) {
+    const float var = q[c] / (float)R;
+    const float invstd = 1.0f / sqrtf(var + p.eps);
+    sc[c] = gmv[c] * invstd;
+    sh[c] = btv[c] - mean[c] * sc[c];
+    if (tid == 0) {
+      p.save_mean[c0 + c] = mean[c];
+      p.save_invstd[c0 + c] = invstd;
+      if (p.scale_shift != nullptr) {
+        p.scale_shift[c0 + c] = sc[c];
+        p.scale_shift[C + c0 + c] = sh[c];
+      }
+      if (p.running_mean != nullptr) {
+        const float unbiased = R > 1 ? q[c] / (float)(R - 1) : var;
+        p.running_mean[c0 + c] = (1.f - p.momentum) * rmv[c] + p.momentum * mean[c];
+        p.running_var[c0 + c] = (1.f - p.momentum) * rvv[c] + p.momentum * unbiased;
+      }
+    }
+  }
+  if (tid == 0 && blockIdx.x == 0 && p.nbt != nullptr) p.nbt[0] = nbt0 + 1;   // nn.BatchNorm2d bookkeeping
+  if (live) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      rowv yr, ar;
+#pragma unroll
+      for (int c = 0; c < CPW; ++c) {
+        yr[c] = v[c][e];
+        ar[c] = act_fwd(yr[c] * sc[c] + sh[c], p.act);
+      }
+      const long o = (long)row_map_pixel(p.rows, r4 + e) * C + c0;
+      *reinterpret_cast<rowv*>(p.y + o) = yr;
+      if (p.a != nullptr) *reinterpret_cast<rowv*>(p.a + o) = ar;
+    }
+  }
+}
+
+template <int TPB, int CPW, int SU>
+__global__ __launch_bounds__(TPB) void bn_fused_bwd_kernel(const BnFusedBwd p) {
+  typedef float rowv __attribute__((ext_vector_type(CPW)));
+  __shared__ float sm[(TPB / 64) * 2 * CPW];
+  const int tid = threadIdx.x, c0 = fused_group(blockIdx.x, p.C, CPW) * CPW, R = p.R, C = p.C;
+  const int r4 = 4 * tid;
+  const bool live = r4 < R;
+  rowv yv[4];        // [row] along channels
+  f32x4 g[CPW];      // [channel] along rows: g_a, then g' = g_a * act'
+  long po[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) yv[e][c] = 0.f;
+    po[e] = live ? (long)row_map_pixel(p.rows, r4 + e) * C + c0 : 0;
+    if (live) yv[e] = *reinterpret_cast<const rowv*>(p.y + po[e]);
+  }
+  float mean[CPW], invstd[CPW], gm[CPW], bt[CPW], s12[2 * CPW], dg0[CPW], db0[CPW];
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) {
+    mean[c] = p.mean[c0 + c]; invstd[c] = p.invstd[c0 + c]; gm[c] = p.gamma[c0 + c]; bt[c] = p.beta[c0 + c];
+    dg0[c] = p.accumulate ? p.dgamma[c0 + c] : 0.f;   // requested with the rest: the commit below does not wait for memory
+    db0[c] = p.accumulate ? p.dbeta[c0 + c] : 0.f;
+  }
+  slice_sum4<CPW, SU>(g, p.part + (long)c0 * R + (live ? r4 : 0), R, (long)C * R, p.S);
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) {
+    if (!live) g[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (yv[e][c] - mean[c]) * invstd[c];
+      const float gp = g[c][e] * act_bwd_from_out(act_fwd(gm[c] * xh + bt[c], p.act), p.act);   // rows beyond R: g = 0
+      g[c][e] = gp;
+      s1 += gp;
+      s2 += gp * xh;
+    }
+    s12[c] = s1;
+    s12[CPW + c] = s2;
+  }
+  block_sum_n<TPB, 2 * CPW>(s12, sm);
+  float k1[CPW], k2[CPW], k3[CPW];
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) {
+    const float db = s12[c], dg = s12[CPW + c];
+    k1[c] = gm[c] * invstd[c];
+    k2[c] = -k1[c] * dg / (float)R * invstd[c];
+    k3[c] = -k1[c] * db / (float)R - k2[c] * mean[c];
+    if (tid == 0) {
+      p.dgamma[c0 + c] = dg0[c] + dg;
+      p.dbeta[c0 + c] = db0[c] + db;
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      rowv o;
+#pragma unroll
+      for (int c = 0; c < CPW; ++c) o[c] = k1[c] * g[c][e] + k2[c] * yv[e][c] + k3[c];
+      *reinterpret_cast<rowv*>(p.gy + po[e]) = o;
+    }
+  }
+}
+
+// rows / channels the channel-owner kernels take (and the tensor size up to which their strided row accesses pay)
+bool bn_fused_ok(int R, int C) {
+  static const long max_elems = [] { const char* e = getenv("CTVAE_BN_FUSED_MAX"); return e ? atol(e) : (1L << 20); }();   // 0 = off
+  return R > 0 && R % 4 == 0 && C % 4 == 0 && R <= 4096 && (long)R * C <= max_elems;
+}
+
+// threads = R / 4 rounded up to 64 / 256 / 1024; two channels per workgroup where four would leave most of the chip idle
+
+static int fused_two_below() {
+  static const int v = [] { const char* e = getenv("CTVAE_BN_FUSED_TWO"); return e ? atoi(e) : 256; }();   // diagnostic
+  return v;
+}
+
+#define CTVAE_BN_FUSED_LAUNCH(KERNEL, P, ST)                                                                      \
+  do {                                                                                                            \
+    const bool two = (P).C < fused_two_below();                                                                   \
+    const dim3 grid((P).C / (two ? 2 : 4));                                                                       \
+    if ((P).R <= 256) {                                                                                           \
+      if (two) hipLaunchKernelGGL((KERNEL<64, 2, 8>), grid, dim3(64), 0, ST, P);                                  \
+      else hipLaunchKernelGGL((KERNEL<64, 4, 8>), grid, dim3(64), 0, ST, P);                                      \
+    } else if ((P).R <= 1024) {                                                                                   \
+      if (two) hipLaunchKernelGGL((KERNEL<256, 2, 8>), grid, dim3(256), 0, ST, P);                                \
+      else hipLaunchKernelGGL((KERNEL<256, 4, 8>), grid, dim3(256), 0, ST, P);                                    \
+    } else {                                                                                                      \
+      if (two) hipLaunchKernelGGL((KERNEL<1024, 2, 4>), grid, dim3(1024), 0, ST, P);                              \
+      else hipLaunchKernelGGL((KERNEL<1024, 4, 4>), grid, dim3(1024), 0, ST, P);                                  \
+    }                                                                                                             \
+  } while (0)
+
+int launch_bn_fused_forward(const BnFusedFwd& p, hipStream_t st) {
+  if (!bn_fused_ok(p.R, p.C) || p.S < 1) return kErrBadArg;
+  ProfScope ps("bn_fused_fwd_kernel", st, 0.0, 4.0 * (double)p.R * p.C * (p.S + (p.a != nullptr ? 2 : 1)));
+  CTVAE_BN_FUSED_LAUNCH(bn_fused_fwd_kernel, p, st);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_bn_fused_backward(const BnFusedBwd& p, hipStream_t st) {
+  if (!bn_fused_ok(p.R, p.C) || p.S < 1) return kErrBadArg;
+  ProfScope ps("bn_fused_bwd_kernel", st, 0.0, 4.0 * (double)p.R * p.C * (p.S + 2));
+  CTVAE_BN_FUSED_LAUNCH(bn_fused_bwd_kernel, p, st);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
 static bool bn_shape_ok(int R, int C) {
   if (C % 4 != 0 || R <= 0) return false;
   const int Q = C / 4;

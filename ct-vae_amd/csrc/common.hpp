@@ -98,6 +98,36 @@ struct BnBwdFuse {
   float* part;   // [rows][C][2], rows = tapgemm_bnb_rows()
 };
 
+// Split-K launch whose consumer sums the slices itself (bn.hip bn_fused_fwd/bwd_kernel): the tile kernel leaves its raw
+// accumulators CHANNEL-MAJOR in part[S][N][R] (R = B*sH*sW scattered pixels; a lane's four consecutive rows are one 16-byte
+// store, and the channel owners of the consumer read their columns as contiguous runs) and no finishing launch is issued.
+// splitk is filled by the launcher: <= 1 means the plan did not split and the launch ran as usual (part untouched).
+// Rows are in class-major order r' = cls * (B*Qh*Qw) + m of the launch's geometry (RowMap: r' -> scattered pixel).
+struct SplitKRaw {
+  float* part;
+  int splitk;
+};
+
+// r' = cls * Mc + m (m = (b, qy, qx) of a ConvGeom's class grid) -> pixel index in the scattered tensor [B][sH][sW]
+struct RowMap {
+  int ncls, Mc, Qh, Qw, sH, sW, os;
+  int py[kMaxCls], px[kMaxCls];
+};
+
+inline RowMap row_map_of(const ConvGeom& g) {
+  RowMap m{};
+  m.ncls = g.ncls; m.Mc = g.B * g.Qh * g.Qw; m.Qh = g.Qh; m.Qw = g.Qw; m.sH = g.sH; m.sW = g.sW; m.os = g.os;
+  for (int c = 0; c < kMaxCls; ++c) { m.py[c] = g.py[c]; m.px[c] = g.px[c]; }
+  return m;
+}
+
+__device__ __forceinline__ int row_map_pixel(const RowMap& m, int r) {
+  if (m.ncls == 1) return r;
+  const int cls = r / m.Mc, mm = r - cls * m.Mc;
+  const int qhw = m.Qh * m.Qw, b = mm / qhw, rr = mm - b * qhw, qy = rr / m.Qw, qx = rr - qy * m.Qw;
+  return (b * m.sH + qy * m.os + m.py[cls]) * m.sW + qx * m.os + m.px[cls];
+}
+
 struct TapGemmPlan {
   int BM, BN, mtiles, ntiles, splitk;
   int thin;      // 1: VALU thin-layer kernels (thin.hip) instead of the MFMA tile kernel

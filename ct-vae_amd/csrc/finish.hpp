@@ -103,4 +103,37 @@ __device__ __forceinline__ void bn_bwd_finalize_body(const BnFinJob& j, int c, d
   }
 }
 
+// Channel-owner tails of a split-K convolution next to a train-mode BatchNorm (bn.hip bn_fused_fwd_kernel / bn_fused_bwd_kernel):
+// the slices arrive channel-major (SplitKRaw), everything behind the GEMM is one launch.
+struct BnFusedFwd {
+  const float* part;   // [S][C][R], rows in the producing launch's class-major order
+  RowMap rows;         // ... -> pixel of y / a
+  int S, R, C;
+  const float *bias, *gamma, *beta;
+  float *running_mean, *running_var;
+  float momentum, eps;
+  float *save_mean, *save_invstd, *scale_shift;   // scale_shift [2][C] may be null
+  long long* nbt;
+  float* y;            // [R][C] pre-BatchNorm output (the backward pass reads it)
+  float* a;            // [R][C] act(BN(y)); null when the consumer applies scale/shift on load
+  int act;
+};
+
+
+struct BnFusedBwd {
+  const float* part;   // [S][C][R] slices of g_a, the gradient w.r.t. act(BN(y)), rows in the data gradient's class-major order
+  RowMap rows;         // ... -> pixel of y / g_y
+  int S, R, C;
+  const float *y, *gamma, *beta, *mean, *invstd;
+  int act;
+  float* gy;           // [R][C]
+  float *dgamma, *dbeta;
+  int accumulate;
+};
+
+
+bool bn_fused_ok(int R, int C);
+int launch_bn_fused_forward(const BnFusedFwd& p, hipStream_t st);
+int launch_bn_fused_backward(const BnFusedBwd& p, hipStream_t st);
+
 }  // namespace ctvae

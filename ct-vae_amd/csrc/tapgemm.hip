@@ -598,7 +598,8 @@ void tapgemm_plan(const ConvGeom& g, size_t ws_floats, TapGemmPlan& p) {
   if (avec && bvec && (N % 4) == 0 && wgs < maxw && nch_min >= (paired ? 16 : 8)) {
     int sk = (int)((tgt + wgs - 1) / wgs);
     if (sk > nch_min / 4) sk = nch_min / 4;
-    if (sk > 16) sk = 16;
+    static const int sk_max = [] { const char* e = getenv("CTVAE_SK_MAX"); return e ? atoi(e) : 16; }();   // diagnostic
+    if (sk > sk_max) sk = sk_max;
     const size_t per = (size_t)g.B * g.sH * g.sW * N;
     while (sk > 1 && per * sk > ws_floats) --sk;
     if (sk > 1) p.splitk = sk;
@@ -628,7 +629,8 @@ bool wino_enabled();
 
 int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
                    const float* mask, int mask_act, float* S, int act, float* bn_part, float* ws, size_t ws_floats,
-                   hipStream_t st, const BnBwdFuse* bnb, const InXform* xf, const WinoFilters* wf) {
+                   hipStream_t st, const BnBwdFuse* bnb, const InXform* xf, const WinoFilters* wf, SplitKRaw* raw) {
+  if (raw != nullptr) raw->splitk = 0;
   // 3x3 / stride 1 / same-padding layers with plain epilogues: Winograd F(2x2,3x3), see wino.hip
   // (the skip operand `add` is taken by the Winograd epilogue; a mask is not)
   if (mask == nullptr && bn_part == nullptr && (bnb == nullptr || bnb->part == nullptr) &&
@@ -688,6 +690,14 @@ int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const floa
   if (plan.thin) return launch_thin_forward(g, G, W, bias, add, mask, mask_act, S, act, bn_part, st, xf);
   a.splitk = plan.splitk;
   a.part = ws;
+  // the consumer sums the slices itself: channel-major raw partials in its buffer, no finishing launch
+  // (bias / activation are then the consumer's job as well: they are NOT applied to the raw slices)
+  const bool raw_T = raw != nullptr && raw->part != nullptr && plan.splitk > 1 && avec && bvec && a.Mc % 4 == 0 &&
+                     add == nullptr && mask == nullptr;
+  if (raw_T) {
+    a.part = raw->part;
+    a.part_T = 1;
+  }
 
   if (plan.splitk > 1 && bn_part != nullptr) return kErrBadArg;  // caller must take BN statistics from S instead
   int rc;
@@ -705,6 +715,10 @@ int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const floa
     rc = launch_tapgemm_fast(a, plan, db ? 3 : 0, st);
   }
   if (rc || plan.splitk <= 1) return rc;
+  if (raw_T) {
+    raw->splitk = plan.splitk;
+    return 0;
+  }
   const long n = (long)g.B * g.sH * g.sW * a.N, n4 = n / 4;
   long blocks = (n4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;

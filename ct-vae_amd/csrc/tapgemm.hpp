@@ -26,6 +26,7 @@ struct TapGemmArgs {
   int bnb_act;
   float* part;     // split-K partial sums [splitk][B*sH*sW][N] (raw accumulators), used when splitk > 1
   int splitk;
+  int part_T;      // split-K partials channel-major [splitk][N][B*sH*sW] (SplitKRaw) instead of pixel-major [splitk][B*sH*sW][N]
   int lgQw, lgQhw; // log2(Qw), log2(Qh*Qw) when both are powers of two, else -1 (generic division)
   int act;
   int mask_act;

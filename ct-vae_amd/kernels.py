@@ -192,14 +192,34 @@ class BNLink:
     separate pass over (g_a, y).  The sums are only used when the gradient tensor that arrives is exactly the one the
     dgrad wrote (same storage pointer, same version counter): if autograd summed several contributions, or anything
     modified it in place, the BatchNorm falls back to its own pass."""
-    __slots__ = ("y", "mean", "invstd", "gamma", "beta", "act", "part", "rows", "coef", "g_ptr", "g_ver", "g_shape")
+    __slots__ = ("y", "mean", "invstd", "gamma", "beta", "act", "part", "rows", "coef", "g_ptr", "g_ver", "g_shape", "slices", "sole")
 
     def __init__(self, y, mean, invstd, gamma, beta, act):
         self.y, self.mean, self.invstd, self.gamma, self.beta, self.act = y, mean, invstd, gamma, beta, act
+        self.sole = False       # set by model code (mark_sole_consumer): the layer's output has exactly one consumer
         self.part = None
         self.rows = 0
         self.coef = None
+        self.slices = None
         self.g_ptr = self.g_ver = self.g_shape = None
+
+    def publish_lazy(self, g, slices, n, geom):
+        """Small layers (ctvae_conv_backward_lazy): the consumer's data gradient ran split-K and left its n raw slices
+        (channel-major, rows in that launch's own order: geom = its (kind, B, H, W, Ci, Co, k, stride, pad, out_pad)) in ``slices``; ``g`` is a placeholder that was never written -- the BatchNorm's backward sums the slices
+        itself (ctvae_bn_backward_fused).  Nothing else may consume g: take_lazy raises if another tensor arrives."""
+        self.slices = (slices, n, geom)
+        self.part, self.rows, self.coef = None, 0, None
+        self.g_ptr, self.g_ver, self.g_shape = g.data_ptr(), g._version, tuple(g.shape)
+
+    def take_lazy(self, g):
+        """(slices, n, geom) when the consumer left its data gradient as raw slices, else None.  One use only."""
+        sl, self.slices = self.slices, None
+        if sl is None:
+            return None
+        if g.data_ptr() != self.g_ptr or g._version != self.g_ver or tuple(g.shape) != self.g_shape:
+            raise RuntimeError("BNLink: the consumer left its data gradient as split-K slices for this BatchNorm's backward pass "
+                               "(sole consumer of the layer's output), but a different gradient tensor arrived")
+        return sl
 
     def publish(self, g, part, rows, coef=None):
         """coef [7][C]: the consumer's finishing launch already ran this BatchNorm's backward finalize on the sums
@@ -292,6 +312,17 @@ def pop_bn_link():
     return link
 
 
+def mark_sole_consumer(x):
+    """Model code promises that x -- the output of a train-mode ConvBNAct block -- is read by exactly ONE consumer (the next
+    block of a chain: blocks.Chain, or the one layer the model hands it to).  That consumer may then leave its data gradient as
+    split-K slices for the BatchNorm's backward launch to sum (BNLink.publish_lazy): the gradient tensor in between is never
+    written, so a second consumer would add garbage -- BNLink.take_lazy raises if anything but the placeholder arrives."""
+    link = getattr(x, "_ctvae_bn_link", None)
+    if link is not None:
+        link.sole = True
+    return x
+
+
 def link_of(x):
     """BNLink of a tensor that is the untouched, contiguous output of a train-mode ConvBNAct (else None)."""
     link = getattr(x, "_ctvae_bn_link", None)
@@ -354,6 +385,7 @@ _OUT_ACT_LINK = os.environ.get("CTVAE_NO_OUT_ACT_LINK", "0") != "1"   # diagnost
 # layers finalize in their own apply launch and their consumers' slab reductions leave the chain -- 1.5992 / 1.5986 ms against
 # 1.5996 / 1.5988 ms (VanillaVAE bs = 256, same box): neutral, the one deferred launch grows by what the three removed ones took
 _BN_BWD_MERGE_ROWS = int(os.environ.get("CTVAE_BN_BWD_MERGE_ROWS", "0"))
+_BN_LAZY = os.environ.get("CTVAE_NO_BN_LAZY", "0") != "1"     # diagnostic: small layers' data gradients summed by splitk_finish as before
 _ENC_BN_ON_LOAD = os.environ.get("CTVAE_NO_ENC_BN_ON_LOAD", "0") != "1"   # diagnostic: encoder.0's BatchNorm-backward apply as its own launch
 
 
@@ -375,6 +407,20 @@ def conv_backward_raw(x, dy, w_param, b_param, spec: ConvSpec, link=None, mask=N
             acc = 1
     dx = torch.empty((B, H, W, spec.ci), dtype=torch.float32, device=dy.device)
     part, rows = None, 0
+    if (link is not None and link.sole and _BN_LAZY and tuple(link.y.shape) == (B, H, W, spec.ci) and mask is None and wino_filters is None
+            and in_coef is None and dy_bn is None and bn_commit is None):
+        key = (spec.kind, B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, ws.numel(), "lazy")
+        n = _bn_rows_cache.get(key)
+        if n is None:
+            n = _bn_rows_cache[key] = native.load().ctvae_conv_backward_lazy_slices(*key[:-2], ws.numel() * 4)
+        if n > 1:
+            # small layer: the data gradient stays n raw split-K slices, summed by the BatchNorm's own backward launch
+            slices = torch.empty(n * B * H * W * spec.ci, dtype=torch.float32, device=dy.device)
+            native.call("ctvae_conv_backward_lazy", spec.kind, x.data_ptr(), dy.data_ptr(), w_param.data_ptr(), gw.data_ptr(),
+                        native.ptr(gb), slices.data_ptr(), B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad,
+                        acc, ws.data_ptr(), ws.numel() * 4)
+            link.publish_lazy(dx, slices, n, key[:10])
+            return dx
     if link is not None and tuple(link.y.shape) == (B, H, W, spec.ci):
         key = (spec.kind, B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, -ws.numel())
         rows = _bn_rows_cache.get(key)
@@ -743,6 +789,15 @@ class ConvBNAct(Function):
         if accg != accb:
             (gg if accg == 0 else gbt).zero_()
             accg = 1
+        lazy = ctx.link_out.take_lazy(g_a) if ctx.link_out is not None else None
+        if lazy is not None:
+            # g_a was never materialised: the consumer's split-K slices are summed here, with the sums, the finalize and the apply
+            g_y = torch.empty_like(y)
+            native.call("ctvae_bn_backward_fused", lazy[0].data_ptr(), lazy[1], *lazy[2], y.data_ptr(), gamma.data_ptr(),
+                        beta.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(), ctx.bn_act, g_y.data_ptr(), gg.data_ptr(),
+                        gbt.data_ptr(), accg)
+            g_x = wgrad_then_dgrad(x, g_y, w, b, spec, ctx.needs_input_grad[0], ctx.link_in)
+            return (g_x,) + (None,) * 10
         part, rows, coef = ctx.link_out.take(g_a) if ctx.link_out is not None else (None, 0, None)
         if coef is not None:
             part, rows = None, 0         # finalized by the consumer's finishing launch: apply + commit only

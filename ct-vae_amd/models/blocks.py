@@ -33,6 +33,20 @@ class ConvBNLeaky(nn.Module):
         return conv_bn_leaky(x, self._modules["0"], self._modules["1"], self.spec, self.training)
 
 
+class Chain(nn.Sequential):
+    """nn.Sequential (same children names, same state_dict) whose intermediate tensors provably have ONE consumer -- the next
+    child: each is marked for kernels.mark_sole_consumer, which lets a small layer's data gradient reach the BatchNorm below it
+    as split-K slices instead of a tensor.  The LAST child's output leaves the chain: its consumers are the caller's business."""
+
+    def forward(self, x):
+        last = len(self) - 1
+        for i, m in enumerate(self):
+            x = m(x)
+            if i != last:
+                K.mark_sole_consumer(x)
+        return x
+
+
 class ConvAct(nn.Module):
     """nn.Sequential(Conv2d|ConvTranspose2d, LeakyReLU|Tanh) (mcq_vae.py:168-173,176-180,187-191,203-209,221-237):
     one launch, bias + activation in the epilogue.  Child "0" holds the parameters."""

@@ -15,7 +15,7 @@ from torch import nn
 
 from .. import kernels as K
 from .base import BaseVAE
-from .blocks import ConvBNLeaky, conv_bn_leaky
+from .blocks import Chain, ConvBNLeaky, conv_bn_leaky
 from .packing import PackedBN, PackedConv, PackedLinear, PackedLinearGroup
 from .types_ import Tensor
 
@@ -62,7 +62,7 @@ class VanillaVAE(BaseVAE):
         for h in hidden_dims:
             enc.append(ConvBNLeaky(c, h, 3, 2, 1))
             c = h
-        self.encoder = nn.Sequential(*enc)
+        self.encoder = Chain(*enc)
         self.fc_mu = PackedLinear(hidden_dims[-1] * 4, latent_dim)
         self.fc_var = PackedLinear(hidden_dims[-1] * 4, latent_dim)
         grp = PackedLinearGroup([self.fc_mu, self.fc_var])
@@ -75,7 +75,7 @@ class VanillaVAE(BaseVAE):
         dec = []
         for i in range(len(hidden_dims) - 1):
             dec.append(ConvBNLeaky(hidden_dims[i], hidden_dims[i + 1], 3, 2, 1, out_pad=1, transposed=True))
-        self.decoder = nn.Sequential(*dec)
+        self.decoder = Chain(*dec)
         self.final_layer = _FinalLayer(hidden_dims[-1], 3)
         self._x_cache = None
         self.flatten_parameters()
@@ -96,7 +96,7 @@ class VanillaVAE(BaseVAE):
     def _encode_heads(self, input: Tensor) -> Tensor:
         """[B,C,64,64] -> [B, 2L]: fc_mu | fc_var of the flattened encoder output as one GEMM."""
         self.attach_grads()
-        h = self.encoder(self._input_nhwc(input))                       # [B,2,2,512] NHWC
+        h = K.mark_sole_consumer(self.encoder(self._input_nhwc(input)))   # [B,2,2,512] NHWC, read by the heads only
         if tuple(h.shape[1:3]) != (2, 2):
             raise RuntimeError("VanillaVAE: fc_mu / fc_var take hidden_dims[-1]*4 features, i.e. a 2x2 encoder output "
                                "(64x64 input through 5 stride-2 layers, vanilla_vae.py:36-37)")
@@ -113,7 +113,7 @@ class VanillaVAE(BaseVAE):
         B = z.shape[0]
         h = K.ConvAct.apply(z.reshape(B, 1, 1, -1), self.decoder_input.weight, self.decoder_input.bias, None, self._dec_in_spec)
         h = K._ToNHWC.apply(h.view(B, 512, 2, 2))                        # .view(-1,512,2,2) is NCHW
-        h = self.decoder(h)
+        h = K.mark_sole_consumer(self.decoder(h))                        # read by final_layer only
         return K.to_nchw_view(self.final_layer(h))
 
     def reparameterize(self, mu: Tensor, logvar: Tensor, eps: Tensor = None) -> Tensor:

@@ -25,6 +25,8 @@ SIGNATURES = {
     "ctvae_conv_wgrad": [_i, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _fp, _i, _fp, _sz, _vp],
     "ctvae_conv_backward": [_i, _fp, _fp, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _i,
                             _fp, _fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _sz, _vp],
+    "ctvae_conv_backward_lazy": [_i, _fp, _fp, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _sz, _vp],
+    "ctvae_bn_backward_fused": [_fp, _i] + [_i] * 10 + [_fp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _vp],
     "ctvae_bn_forward": [_fp, _i, _i, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _fp, _fp, _fp, _fp, _fp, _sz, _vp],
     "ctvae_bn_backward": [_fp, _fp, _fp, _i, _i, _fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _fp, _i, _fp, _fp, _fp, _sz, _vp],
     "ctvae_conv_dgrad_bn": [_i, _fp, _fp, _fp, _fp, _i, _fp] + [_i] * 9 + [_fp, _fp, _fp, _fp, _fp, _i, _fp, _i, _fp, _sz, _vp],
@@ -114,6 +116,7 @@ _RESTYPES = {
     "ctvae_prof_report": _c.c_size_t,
     "ctvae_conv_dgrad_bn_rows": _c.c_int,
     "ctvae_conv_backward_bn_rows": _c.c_int,
+    "ctvae_conv_backward_lazy_slices": _c.c_int,
     "ctvae_winograd_enable": _c.c_int,
     "ctvae_conv_wino_filter_floats": _c.c_size_t,
     "ctvae_dip_state_floats": _c.c_size_t,
@@ -157,6 +160,7 @@ def load():
                        "ctvae_prof_report": [_c.c_char_p, _c.c_size_t],
                        "ctvae_conv_dgrad_bn_rows": [_c.c_int] * 10 + [_c.c_size_t],
                        "ctvae_conv_backward_bn_rows": [_c.c_int] * 10 + [_c.c_size_t],
+                       "ctvae_conv_backward_lazy_slices": [_c.c_int] * 10 + [_c.c_size_t],
                        "ctvae_winograd_enable": [_c.c_int],
                        "ctvae_dip_state_floats": [_c.c_int, _c.c_int],
                        "ctvae_glinear_wgrad_ws_bytes": [_c.c_int, _c.c_int, _c.c_int],

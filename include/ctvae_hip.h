@@ -138,6 +138,27 @@ int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* 
                         const float* dy_bn_y, const float* dy_bn_coef, int dy_bn_act, float* gy_out, float* ws, size_t ws_bytes,
                         void* stream);
 
+/* Small layers behind a train-mode BatchNorm (the deep encoder / decoder blocks at small batch, vanilla_vae.py:25-35,47-62): the
+ * data gradient runs split-K and its consumer is that BatchNorm's backward pass, so the slices are never summed into a tensor of
+ * their own.  ctvae_conv_backward_lazy_slices: the number S (>= 2) of K slices such a call would produce for this geometry and
+ * workspace, or 0 when this form does not apply (unsplit / Winograd / picture-side data gradient, or a tensor beyond the few MB
+ * the channel-owner kernel pays for).  ctvae_conv_backward_lazy: weight (+ bias) gradient as ctvae_conv_backward, and the data
+ * gradient's raw slices, CHANNEL-MAJOR, in dx_slices [S][Ci][B*H*W] (no mask, no BatchNorm sums, dx itself is not written;
+ * the rows of a slice are in the data gradient's class-major order, not pixel order).
+ * ctvae_bn_backward_fused (kind ... out_pad: the geometry of the ctvae_conv_backward_lazy call that wrote the slices; the
+ * BatchNorm's tensor is that layer's input [B,H,W,Ci]): g_y, d gamma, d beta from those slices in ONE launch -- a workgroup
+ * owns 2 or 4 channels and all R = B*H*W rows: slice sum, g' = g_a * act'(gamma*xhat+beta), both reductions, the coefficients and g_y = k1*g' + k2*y + k3.
+ * Replaces split-K finish + ctvae_bn_backward's partial / finalize / apply launches (reference: autograd of
+ * nn.BatchNorm2d + nn.LeakyReLU). */
+int ctvae_conv_backward_lazy_slices(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
+                                    size_t ws_bytes);
+int ctvae_conv_backward_lazy(int kind, const float* x, const float* dy, const float* w, float* dw, float* dbias, float* dx_slices,
+                             int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int accumulate, float* ws,
+                             size_t ws_bytes, void* stream);
+int ctvae_bn_backward_fused(const float* g_a_slices, int slices, int kind, int B, int H, int W, int Ci, int Co, int k, int stride,
+                            int pad, int out_pad, const float* y, const float* gamma, const float* beta, const float* save_mean,
+                            const float* save_invstd, int act, float* g_y, float* dgamma, float* dbeta, int accumulate, void* stream);
+
 /* dy_bn_y / dy_bn_coef / gy_out (all or none): `dy` is then g_a, the gradient w.r.t. the output of the BatchNorm +
  * activation that follows this layer; the kernel forms g_y = k1*g_a*act'(y*scale+shift) + k2*y + k3 while loading
  * (coef = [5][Co]: k1,k2,k3,scale,shift as written by ctvae_bn_backward coef_out), uses it for dw/dbias and writes it to
