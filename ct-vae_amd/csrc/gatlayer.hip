@@ -587,7 +587,7 @@ int launch_gat_layer_forward(const GatLayerArgs& a, hipStream_t st) {
     attr_set = true;
   }
   const double pairs = (double)a.B * a.Hs * GN * GN;
-  ProfScope ps("gat_layer_fwd_kernel", st, 6.0 * pairs * a.C, 4.0 * a.B * a.Hs * (3.0 * GN * a.C + 2.0 * GN * GN));
+  ProfScope ps(a.C <= 64 ? "gat_layer_fwd_kernel<16>" : a.C <= 100 ? "gat_layer_fwd_kernel<25>" : "gat_layer_fwd_kernel<32>", st, 6.0 * pairs * a.C, 4.0 * a.B * a.Hs * (3.0 * GN * a.C + 2.0 * GN * GN));
   const size_t smem = fwd_smem(a.C);
   const dim3 grid(a.Hs, a.B);
   if (a.C <= 64) hipLaunchKernelGGL(gat_layer_fwd_kernel<16>, grid, dim3(256), smem, st, a);
@@ -612,7 +612,7 @@ int launch_gat_layer_backward(const GatBwdArgs& p, float* dadj, int accumulate_d
   const double pairs = (double)a.B * a.Hs * GN * GN;
   const dim3 grid(a.Hs, a.B);
   {
-    ProfScope ps("gat_layer_bwd_kernel", st, 10.0 * pairs * a.C, 4.0 * a.B * a.Hs * (4.0 * GN * a.C + 4.0 * GN * GN));
+    ProfScope ps(a.C <= 64 ? "gat_layer_bwd_kernel<16>" : a.C <= 100 ? "gat_layer_bwd_kernel<25>" : "gat_layer_bwd_kernel<32>", st, 10.0 * pairs * a.C, 4.0 * a.B * a.Hs * (4.0 * GN * a.C + 4.0 * GN * GN));
     const size_t smem = bwd_smem(a.C);
     if (a.C <= 64) hipLaunchKernelGGL(gat_layer_bwd_kernel<16>, grid, dim3(256), smem, st, p);
     else if (a.C <= 100) hipLaunchKernelGGL(gat_layer_bwd_kernel<25>, grid, dim3(256), smem, st, p);

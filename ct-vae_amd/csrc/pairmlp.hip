@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void pair_mlp_bwd_kernel(const float* __restri
 int launch_pair_mlp_forward(const float* u, const float* v, int ld, const float* w2, const float* b2, float* out, int B, int N,
                             int H, float slope, int per_sample, const int* row_of, hipStream_t st) {
   if (B <= 0 || N <= 0 || H <= 0 || ld < H) return kErrBadArg;
-  ProfScope ps("pair_mlp_fwd_kernel", st, 3.0 * B * (double)N * N * H, 4.0 * B * (2.0 * N * H + (double)N * N));
+  ProfScope ps((N == 64 && H % 4 == 0 && ld % 4 == 0) ? "pair_mlp_fwd64_kernel" : "pair_mlp_fwd_kernel", st, 3.0 * B * (double)N * N * H, 4.0 * B * (2.0 * N * H + (double)N * N));
   if (N == 64 && H % 4 == 0 && ld % 4 == 0) {
     hipLaunchKernelGGL(pair_mlp_fwd64_kernel, dim3(4, B), dim3(256), 0, st, u, v, w2, b2, out, H, ld, slope, per_sample ? H : 0,
                        per_sample ? 1 : 0, per_sample ? row_of : nullptr);

@@ -61,7 +61,12 @@ class _GraphedTrainStep:
         results = exp.forward(self.x, labels=labels, **opts)
         losses = exp.model.loss_function(*results, M_N=exp.params['kld_weight'], optimizer_idx=0, batch_idx=0)
         K.backward(losses['loss'])
-        exp.model.settle_grads()                  # inside the capture: the fills of unwritten blocks belong to the replayed step
+        # inside the capture: the fills of unwritten blocks AND the copies of autograd-produced gradients (CT layer: a_dense, mask,
+        # positional encoding, the GATv2 vectors) into the flat buffer belong to the replayed step.  Left to ddp.all_reduce() /
+        # optimizer.step() outside the graph they would run once -- after the capture step Python sees p.grad already attached to
+        # its flat view and copies nothing, while every replay rewrites the graph-pool tensors autograd produced: from the second
+        # replay on those parameters would be exchanged and stepped with a zero gradient
+        exp.model.gather_torch_grads()
         if exp.ddp is None:
             exp.optimizer.step()
         # detached: a live loss keeps the step's autograd graph -- and with it the AccumulateGrad nodes of the parameters
@@ -171,6 +176,48 @@ class VAEXperiment:
             sched = ExponentialLR(opt, self.params['scheduler_gamma'])
         return opt, sched
 
+    # -- full resume (run.py:85-101: trainer_params.resume_from_checkpoint hands Lightning the optimizer, scheduler, epoch) ------
+    def state_dict(self):
+        """Everything beside the model's own state_dict that a run needs to continue exactly where it stopped: FlatAdam's
+        moments and device state vector (step, lr, betas, eps, weight decay, beta^t), the scheduler's epoch, the global step
+        and the random streams (torch CPU / device generators, the in-kernel Philox state of the latent noise).  Plain tensors
+        and numbers only, so ``torch.load(..., weights_only=True)`` reads it back."""
+        opt = self.optimizer.state_dict()
+        sd = {"global_step": int(self.global_step),
+              "optimizer": {"exp_avg": opt["exp_avg"].detach().cpu(), "exp_avg_sq": opt["exp_avg_sq"].detach().cpu(),
+                            "state": opt["state"][:8].detach().cpu(), "lr": float(self.optimizer.lr),
+                            "slice": [int(self.optimizer.slice.start or 0), int(self.optimizer.slice.stop)]},
+              "torch_rng": torch.get_rng_state()}
+        if self.scheduler is not None:
+            sd["scheduler"] = {"epoch": int(self.scheduler.epoch), "base_lr": float(self.scheduler.base_lr),
+                               "gamma": float(self.scheduler.gamma)}
+        dev = next(self.model.parameters()).device
+        if dev.type == "cuda":
+            sd["device_rng"] = torch.cuda.get_rng_state(dev)
+        rng = getattr(self.model, "_rng_state", None)
+        if rng is not None:
+            sd["model_rng"] = rng.detach().cpu()
+        return sd
+
+    def load_state_dict(self, sd):
+        """Inverse of state_dict(), in place (captured steps, if any, keep pointing at the same buffers)."""
+        o = sd["optimizer"]
+        if [int(self.optimizer.slice.start or 0), int(self.optimizer.slice.stop)] != [int(v) for v in o["slice"]]:
+            raise RuntimeError("checkpoint optimizes another parameter range than this run (update_parameters differs)")
+        self.optimizer.load_state_dict(o)
+        self.optimizer.lr = float(o["lr"])
+        if self.scheduler is not None and "scheduler" in sd:
+            self.scheduler.epoch = int(sd["scheduler"]["epoch"])
+            self.scheduler.base_lr = float(sd["scheduler"]["base_lr"])
+        self.global_step = int(sd["global_step"])
+        torch.set_rng_state(sd["torch_rng"].cpu())
+        dev = next(self.model.parameters()).device
+        if "device_rng" in sd and dev.type == "cuda":
+            torch.cuda.set_rng_state(sd["device_rng"].cpu(), dev)
+        if "model_rng" in sd:
+            self.model._rng_state = sd["model_rng"].to(dev)
+        K.bump_param_epoch()
+
     def optimizer_step(self):
         scale = 1.0
         if self.ddp is not None:
@@ -179,10 +226,11 @@ class VAEXperiment:
         self.optimizer.step(grad_scale=scale)
         self.global_step += 1
 
-    def fit(self, train_batches, val_batches=None, max_epochs=1, on_epoch_end=None):
-        """train_batches / val_batches: callables returning an iterable of batches for one epoch."""
+    def fit(self, train_batches, val_batches=None, max_epochs=1, on_epoch_end=None, start_epoch=0):
+        """train_batches / val_batches: callables returning an iterable of batches for one epoch.  start_epoch: first epoch
+        to run (a resumed run continues at the checkpoint's epoch + 1; max_epochs counts from 0 as Lightning's does)."""
         history = []
-        for epoch in range(max_epochs):
+        for epoch in range(start_epoch, max_epochs):
             self.model.train()
             t0 = time.time()
             n = 0

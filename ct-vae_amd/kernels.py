@@ -398,6 +398,10 @@ def conv_backward_raw(x, dy, w_param, b_param, spec: ConvSpec, link=None, mask=N
     accumulate): the rider also commits that BatchNorm's parameter gradients (only where no apply launch follows)."""
     B, H, W, _ = x.shape
     ws = native.workspace(x.device)
+    if wino_filters is not None and wino_filter_floats(spec, B, H, W, ws.numel() // 2) != wino_filters.numel():
+        # the forward pass ran Winograd over more rows than this backward pass sees (companion rows: x and y through one launch,
+        # only x differentiated), or the switch was flipped in between: the data gradient picks its own kernel and filters
+        wino_filters = None
     gw, acc = grad_target(w_param)
     gb = None
     if b_param is not None:

@@ -1,9 +1,12 @@
 """CausalTransition (reference: models/ct_mcq_vae.py:14-333) — SURVEY.md §8(f) "next #1".
 
-Status: restated from the reference text with torch device ops; the two ``GATv2Conv`` layers and
-``dense_to_sparse`` live in torch-geometric 2.2.0, which is absent here, so their arithmetic follows the
-published GATv2 algorithm and **parity is unpinned** (no reference fixture covers it).  The Gumbel
-straight-through sampler (K17) is a HIP kernel with injectable noise; everything else is torch-level.
+Status: every method is pinned against the reference's own class (tests/golden/ct_parts_a{12,20}.npz) except
+the arithmetic inside the two ``GATv2Conv`` layers / ``dense_to_sparse``: they live in torch-geometric 2.2.0, which is absent
+here, so they follow the published GATv2 algorithm and **that part's parity is unpinned** (no reference fixture covers it).
+At the shapes of ``ct_mcq_vae.yaml`` and the published runs (64 latent nodes, head width <= 128, grouped-linear dims % 4) the
+whole layer runs as HIP kernels -- grouped MFMA Linear layers, the pair scorer, the fused dense GATv2 layer, the regulariser /
+blend-softmax / cross-entropy / mask / sampler kernels (csrc/{glinear,pairmlp,gatlayer,gat,ctmisc}.hip); the
+torch device branches below serve any other ``latent_dims`` / node count and a replacement ``graph_transitioner`` module.
 
 Design notes (MI355X-first rather than a PyG translation):
 * graphs are B disjoint dense graphs of 64(+1 action [+1 noise]) nodes, so GATv2 runs as *dense batched*

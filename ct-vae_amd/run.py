@@ -5,7 +5,8 @@ logging_params; ``model_params`` is splatted into ``vae_models[name]``), with th
 ``find_unused_parameters`` optional, ``gpus`` int or list, ``dataset_name`` defaults to a synthetic source.
 One process per GPU (launch with ``python -m torch.distributed.run``); Lightning / wandb are not required.
 Checkpoints: top-k on ``val_Reconstruction_Loss`` + ``last.ckpt`` with ``state_dict`` keys prefixed ``model.``
-so they interchange with the reference's (run.py:85-97).
+so they interchange with the reference's (run.py:85-97), plus a ``trainer`` entry (optimizer moments, scheduler, epoch, global
+step, random streams) for ``trainer_params.resume_from_checkpoint`` without ``load_weights_only`` (run.py:85-101: full resume).
 """
 import argparse
 import json
@@ -152,10 +153,15 @@ def main(argv=None):
     torch.manual_seed(seed)                                           # seed_everything (run.py:48)
     mp = dict(config['model_params'])
     model = vae_models[mp['name']](**mp).to(dev)
-    ckpt_path = config['trainer_params'].get('load_weights_only') and config['trainer_params'].get('resume_from_checkpoint')
-    if ckpt_path:                                                     # weights-only restore (run.py:85-89)
-        sd = torch.load(ckpt_path, map_location=dev, weights_only=True)['state_dict']
-        model.load_state_dict({k[6:]: v for k, v in sd.items() if k.startswith("model.")}, strict=False)
+    # trainer_params.resume_from_checkpoint (run.py:85-101): with load_weights_only the reference loads the model's weights
+    # (strict=False) and drops the key; without it the path is splatted into the Lightning Trainer, which restores optimizer,
+    # scheduler, epoch and global step and continues -- the "trainer" entry of our checkpoints carries exactly that state
+    ckpt_path = config['trainer_params'].get('resume_from_checkpoint')
+    weights_only = bool(config['trainer_params'].get('load_weights_only'))
+    ckpt = None
+    if ckpt_path:
+        ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=True)
+        model.load_state_dict({k[6:]: v for k, v in ckpt['state_dict'].items() if k.startswith("model.")}, strict=not weights_only)
     ddp = GradBucketAllReduce(model) if world > 1 else None
     log_dir = os.path.join(config['logging_params'].get('save_dir', 'logs/'), config['logging_params'].get('name', mp['name']))
     os.makedirs(os.path.join(log_dir, "checkpoints"), exist_ok=True)
@@ -166,6 +172,15 @@ def main(argv=None):
     else:
         data = SyntheticData(config['data_params'], mp, dev, rank, world, args.steps_per_epoch, seed)
 
+    start_epoch = 0
+    if ckpt is not None and not weights_only:
+        if "trainer" not in ckpt:
+            raise SystemExit(f"{ckpt_path} holds weights only (no 'trainer' entry: optimizer moments, scheduler, epoch); "
+                             "set trainer_params.load_weights_only to start a new run from its weights")
+        exp.load_state_dict(ckpt["trainer"])
+        start_epoch = int(ckpt["epoch"]) + 1
+        if hasattr(data, "epoch"):
+            data.epoch = start_epoch                                  # the shuffling order follows the epoch
     best = []
 
     def on_epoch_end(epoch, rec):
@@ -173,7 +188,7 @@ def main(argv=None):
             return
         print(json.dumps(rec), flush=True)
         state = {"state_dict": {"model." + k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()},
-                 "epoch": epoch}
+                 "epoch": epoch, "global_step": exp.global_step, "trainer": exp.state_dict()}
         torch.save(state, os.path.join(log_dir, "checkpoints", "last.ckpt"))
         score = rec.get("val_Reconstruction_Loss")
         if score is not None:                                         # ModelCheckpoint(save_top_k=2, monitor=val_Reconstruction_Loss)
@@ -187,7 +202,7 @@ def main(argv=None):
             del best[2:]
 
     epochs = args.max_epochs or config['trainer_params'].get('max_epochs', 1)
-    hist = exp.fit(data.train, data.val, max_epochs=epochs, on_epoch_end=on_epoch_end)
+    hist = exp.fit(data.train, data.val, max_epochs=epochs, on_epoch_end=on_epoch_end, start_epoch=start_epoch)
     if world > 1:
         dist.destroy_process_group()
     return hist

@@ -56,13 +56,27 @@ def test_vanilla_step_at_bench_batch_vs_oracle(dev, B):
     rep = native.prof_report()
     want = ["conv_bwd_pair_kernel", "img_fwd_kernel", "img_bwd_fused_kernel", "img_enc_fwd_kernel",
             "img_enc_wgrad_kernel", "up_fwd_kernel", "up_wgrad_kernel"]
+    if B == 64:
+        # the metric's own batch: the deep layers run split-K and everything behind the GEMM is one channel-owner launch per
+        # layer and direction (bn.hip bn_fused_fwd_kernel / bn_fused_bwd_kernel) instead of split-K finish + statistics +
+        # finalize + apply; the stand-alone statistics kernels must not run for those layers any more
+        want += ["bn_fused_fwd_kernel", "bn_fused_bwd_kernel"]
+        assert rep["bn_fused_fwd_kernel"]["count"] >= 5 and rep["bn_fused_bwd_kernel"]["count"] >= 3, rep
+        assert rep.get("bn_bwd_partial_kernel", {"count": 0})["count"] == 0, rep
     missing = [k for k in want if not any(r.startswith(k) for r in rep)]
     assert not missing, (missing, sorted(rep))
+    errs = {"recons": float((out[0].detach().cpu() - ref_out["recons"]).abs().max()),
+            "mu": float((out[2].detach().cpu() - ref_out["mu"]).abs().max()),
+            "log_var": float((out[3].detach().cpu() - ref_out["log_var"]).abs().max()),
+            **{k: abs(losses[k].item() - ref_losses[k].item()) for k in ("loss", "Reconstruction_Loss", "KLD")}}
+    print(f"VanillaVAE bs={B}: max abs errors vs the CPU oracle " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
     np.testing.assert_allclose(out[0].detach().cpu().numpy(), ref_out["recons"].numpy(), atol=TOL, rtol=0)
     np.testing.assert_allclose(out[2].detach().cpu().numpy(), ref_out["mu"].numpy(), atol=TOL, rtol=0)
     np.testing.assert_allclose(out[3].detach().cpu().numpy(), ref_out["log_var"].numpy(), atol=TOL, rtol=0)
-    for k in ("loss", "Reconstruction_Loss", "KLD"):
-        assert abs(losses[k].item() - ref_losses[k].item()) <= TOL * max(1.0, abs(ref_losses[k].item())), k
+    for k in ("loss", "Reconstruction_Loss"):
+        assert abs(losses[k].item() - ref_losses[k].item()) <= TOL, k          # ABSOLUTE 1e-4
+    # KLD is a sum over 128 latents of magnitude ~50: one fp32 ulp of it is 4e-6, the kernels' summation order differs from torch's
+    assert abs(losses["KLD"].item() - ref_losses["KLD"].item()) <= 2.5 * TOL, (losses["KLD"].item(), ref_losses["KLD"].item())
     _assert_grads(m, ref_grads)
     for k, b in m.named_buffers():
         if k in ref_nb:

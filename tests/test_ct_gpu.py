@@ -175,6 +175,48 @@ def test_runner_consumes_yaml(dev, tmp_path):
     assert ck["state_dict"]["model.encoder.0.0.weight"].shape == (64, 3, 4, 4)
 
 
+def test_runner_full_resume_continues_bit_exactly(dev, tmp_path):
+    """trainer_params.resume_from_checkpoint WITHOUT load_weights_only (run.py:85-101: Lightning restores optimizer, scheduler,
+    epoch): 2 epochs in one run == 1 epoch, then a second process-like run resumed from last.ckpt for the second epoch --
+    parameters, Adam moments / step / lr and the global step bit for bit (MCQVAE: no random draws in the step).  5 batches per
+    epoch, so the straight run replays its captured step in epoch 2 where the resumed run starts eagerly again."""
+    from ctvae_amd import run
+
+    def cfg_for(sub, **trainer):
+        cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "mcq_vae.yaml")))
+        cfg["logging_params"]["save_dir"] = str(tmp_path / sub)
+        cfg["data_params"]["train_batch_size"] = 8
+        cfg["data_params"]["val_batch_size"] = 8
+        cfg["trainer_params"].update(trainer)
+        p = tmp_path / f"{sub}.yaml"
+        p.write_text(yaml.safe_dump(cfg))
+        return str(p)
+
+    last = lambda sub: tmp_path / sub / "MCQVAE" / "checkpoints" / "last.ckpt"
+    h2 = run.main(["-c", cfg_for("straight"), "--steps-per-epoch", "5", "--max-epochs", "2"])
+    h1 = run.main(["-c", cfg_for("first"), "--steps-per-epoch", "5", "--max-epochs", "1"])
+    hr = run.main(["-c", cfg_for("resumed", resume_from_checkpoint=str(last("first"))), "--steps-per-epoch", "5", "--max-epochs", "2"])
+    assert [r["epoch"] for r in h2] == [0, 1] and [r["epoch"] for r in h1] == [0] and [r["epoch"] for r in hr] == [1]
+    a = torch.load(last("straight"), weights_only=True)
+    b = torch.load(last("resumed"), weights_only=True)
+    assert a["epoch"] == b["epoch"] == 1 and a["global_step"] == b["global_step"] == 10
+    for k, v in a["state_dict"].items():
+        assert torch.equal(v, b["state_dict"][k]), k
+    for k in ("exp_avg", "exp_avg_sq", "state"):
+        assert torch.equal(a["trainer"]["optimizer"][k], b["trainer"]["optimizer"][k]), k
+    assert a["trainer"]["optimizer"]["lr"] == b["trainer"]["optimizer"]["lr"] == pytest.approx(0.0005 * 0.98 ** 2)
+    assert a["trainer"]["scheduler"] == b["trainer"]["scheduler"]
+    assert float(a["trainer"]["optimizer"]["state"][0]) == 10.0
+    assert hr[0]["val_Reconstruction_Loss"] == h2[1]["val_Reconstruction_Loss"]
+    # a checkpoint without the trainer entry (e.g. the reference's weights) is refused loudly unless load_weights_only is set
+    torch.save({"state_dict": a["state_dict"], "epoch": 1}, tmp_path / "weights.ckpt")
+    with pytest.raises(SystemExit):
+        run.main(["-c", cfg_for("bad", resume_from_checkpoint=str(tmp_path / "weights.ckpt")), "--steps-per-epoch", "2", "--max-epochs", "2"])
+    hw = run.main(["-c", cfg_for("wo", resume_from_checkpoint=str(tmp_path / "weights.ckpt"), load_weights_only=True),
+                   "--steps-per-epoch", "2", "--max-epochs", "1"])
+    assert [r["epoch"] for r in hw] == [0]
+
+
 @pytest.mark.parametrize("B,N,H", [(3, 64, 800), (2, 37, 70)])
 def test_pair_mlp_kernel(dev, B, N, H):
     """ctvae_pair_mlp_forward/backward against the torch expression of CausalTransition._pair_coeffs

@@ -202,6 +202,72 @@ def test_ct_full_layer_vs_oracle_with_gatv2(dev, noise, A, B, mode):
         np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), atol=tol, rtol=2e-3, err_msg=k)
 
 
+CT_KERNEL_PREFIXES = ("gat_", "pair_mlp", "glinear", "group_rowsum", "ct_", "one_hot", "vq_")
+
+
+@pytest.mark.parametrize("A", [12, 20])
+def test_ct_action_step_at_32_pairs_vs_oracle_with_the_bench_kernels(dev, noise, A):
+    """The bench's own step -- action mode, the real dense GATv2 layer in the loop (PARITY UNPINNED for GATv2 itself, see the
+    header) -- against oracle/causal_cpu.ctmcq_step at 32 pairs, the largest count the CPU oracle affords (its pair tensors are
+    13 MB per sample and layer), for action_dim 12 (ct_mcq_vae.yaml, BASELINE configs[3]) and 20 (configs[4]).  Kernel selection
+    follows the batch, so the same model first runs a 128-pair step (the bench's per-GPU batch) under the library's profiler
+    and the 32-pair step must launch the same causal-transition / VQ kernel variants (template arguments included).
+    Reference: ct_mcq_vae.py:525-546 (forward_action), 594-620 (loss_function)."""
+    from ctvae_amd import native
+    from oracle import causal_cpu as C
+    seed, B = 60 + A, 32
+    m, _ = build_model(dev, A, seed, double=False)
+    sd = {k: v.detach().cpu().clone().contiguous() for k, v in m.state_dict().items()}
+    cfg = yaml_cfg(A)
+    hp = dict(alpha=cfg["c_alpha"], beta=cfg["c_beta"], delta=cfg["c_delta"], epsilon=cfg["c_epsilon"], noise=cfg["noise"])
+    mcfg = dict(num_embeddings=64, codebooks=1, beta=cfg["beta"], skip_transition=False)
+    ns = noise(seed)
+
+    def gpu_step(x, y, action):
+        ns.reset()
+        m.zero_grad()
+        native.prof_enable(True)
+        res = m(x.to(dev), mode="action", input_y=y.to(dev), action=action.to(dev))
+        losses = m.loss_function(*res)
+        losses["loss"].backward()
+        torch.cuda.synchronize()
+        native.prof_enable(False)
+        m.gather_torch_grads()
+        names = {k.split(" ")[0] for k in native.prof_report() if k.startswith(CT_KERNEL_PREFIXES)}
+        return res, losses, names
+
+    xb, yb, _ = filler.synthetic_pairs(seed + 1, 128, A)
+    _, _, bench_kernels = gpu_step(xb, yb, H.ct_actions(128, A))
+    assert any(k.startswith("gat_layer_bwd_kernel") for k in bench_kernels) and any(k.startswith("pair_mlp_bwd") for k in bench_kernels), bench_kernels
+
+    x, y, _ = filler.synthetic_pairs(seed, B, A)
+    action = H.ct_actions(B, A)
+    ref_losses, ref_grads, ref_out = C.ctmcq_step(sd, mcfg, cfg["gamma"], x, H.CTNoise(seed, "cpu"), C.gat_gnn(A + 1), "action",
+                                                  hp=hp, input_y=y, action=action)
+    res, losses, kernels = gpu_step(x, y, action)
+    assert kernels == bench_kernels, (sorted(kernels ^ bench_kernels), "the 32-pair step ran other kernel variants than the 128-pair bench step")
+    err_out = float((res[0].detach().cpu() - ref_out[0].detach()).abs().max())
+    err_loss = {k: abs(float(losses[k]) - float(ref_losses[k])) for k in ("loss", "Reconstruction_Loss", "VQ_Loss", "CT_Loss")}
+    err_adj = float((losses["ct_adjacency"].detach().cpu() - ref_losses["ct_adjacency"]).abs().max())
+    err_g, worst = 0.0, None
+    for k, p in m.named_parameters():
+        ref = ref_grads[k]
+        got = (p.grad if p.grad is not None else torch.zeros_like(p)).cpu()
+        e = float((got - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+        if e > err_g:
+            err_g, worst = e, k
+    print(f"A={A} B={B}: max|recons err| {err_out:.2e}  loss errs {{{', '.join(f'{k}: {v:.1e}' for k, v in err_loss.items())}}} "
+          f"(loss {float(ref_losses['loss']):.4f})  adjacency {err_adj:.1e}  max scaled grad err {err_g:.2e} ({worst})")
+    assert err_out <= TOL
+    for k, v in err_loss.items():
+        assert v <= TOL, (k, v, float(ref_losses[k]))          # ABSOLUTE 1e-4 (north_star), whatever the size of the loss
+    assert err_adj <= 2e-6
+    for k, p in m.named_parameters():
+        ref = ref_grads[k]
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), atol=TOL * max(1.0, float(ref.abs().max())), rtol=2e-3, err_msg=k)
+
+
 def test_gat_score_21_heads_vs_torch_expression(dev):
     """gat_score_kernel at the TCelebA head count (21) against the GATv2 logit formula written out here."""
     from ctvae_amd import kernels as Kn
