@@ -584,7 +584,10 @@ void tapgemm_plan(const ConvGeom& g, size_t ws_floats, TapGemmPlan& p) {
     if (nch < nch_min) nch_min = nch;
   }
   static const int sk_target = [] { const char* e = getenv("CTVAE_SK_TARGET"); return e ? atoi(e) : 768; }();   // diagnostic
-  static const int sk_maxwgs = [] { const char* e = getenv("CTVAE_SK_MAXWGS"); return e ? atoi(e) : 384; }();   // diagnostic
+  // a launch that already has a workgroup for every CU is not split (round 3: 384 -> 256; the bs = 64 step's encoder.1 -- 256
+  // tiles of 9 chunks -- keeps its BatchNorm statistics in the epilogue instead of three launches behind two slices: -1.4 %
+  // there, +-0.3 % on the other configurations)
+  static const int sk_maxwgs = [] { const char* e = getenv("CTVAE_SK_MAXWGS"); return e ? atoi(e) : 256; }();
   // a data gradient that shares its launch with the weight gradient (ctvae_conv_backward) does not have to fill the chip
   // on its own: the ~1000 weight-gradient workgroups do.  It is split only as far as its workgroups would otherwise be the
   // launch's long pole -- fewer partial sums to write and finish, and an unsplit launch keeps the fused BatchNorm-backward
@@ -592,7 +595,11 @@ void tapgemm_plan(const ConvGeom& g, size_t ws_floats, TapGemmPlan& p) {
   static const int pair_target = [] { const char* e = getenv("CTVAE_PAIR_SK_TARGET"); return e ? atoi(e) : 256; }();   // sweep, ms per step: 768 1.804, 512 1.798, 384 1.800, 256 1.796, 128 1.813, no split 1.847
   static const int pair_maxwgs = [] { const char* e = getenv("CTVAE_PAIR_SK_MAXWGS"); return e ? atoi(e) : 384; }();
   const bool paired = pair_ctx() != nullptr && g.wT != 0;
-  const int tgt = paired ? pair_target : sk_target, maxw = paired ? pair_maxwgs : sk_maxwgs;
+  // small problems (few scattered pixels in all): every slice is another copy of the output to write, flush at the kernel
+  // boundary and sum again -- a lower target (fewer, longer slices) wins there
+  static const int sk_small_m = [] { const char* e = getenv("CTVAE_SK_SMALL_M"); return e ? atoi(e) : 0; }();
+  static const int sk_small_target = [] { const char* e = getenv("CTVAE_SK_SMALL_TARGET"); return e ? atoi(e) : 256; }();
+  const int tgt = paired ? pair_target : ((long)Mc * g.ncls <= sk_small_m ? sk_small_target : sk_target), maxw = paired ? pair_maxwgs : sk_maxwgs;
   // paired with a reduction of fewer than 16 chunks (K < 512: the Linear heads' data gradient): splitting saves ~1 us of a
   // launch the weight gradient fills anyway and would cost the fused BatchNorm-backward sums of the layer below
   if (avec && bvec && (N % 4) == 0 && wgs < maxw && nch_min >= (paired ? 16 : 8)) {

@@ -554,6 +554,7 @@ def stage_batch(dst, src):
             and dst.permute(0, 2, 3, 1).is_contiguous() and not dst.is_contiguous()):
         B, C, H, W = src.shape
         native.call("ctvae_permute", src.data_ptr(), dst.data_ptr(), B, C, H * W, 1)
+        torch.autograd.graph.increment_version(dst)     # written through a raw pointer: caches keyed on (tensor, version) must see it
     else:
         dst.copy_(src, non_blocking=True)
     return dst
@@ -1585,6 +1586,8 @@ class capture_graph:
     def __enter__(self):
         import gc
         self._was = gc.isenabled()
+        if _DEFER_REDUCE and torch.cuda.is_available():
+            _defer_arena_for(torch.device("cuda", torch.cuda.current_device()))   # never from inside the capture (its private pool)
         r = self._cm.__enter__()      # synchronizes, collects, empties the cache, begins the capture
         gc.disable()
         return r
@@ -1603,6 +1606,15 @@ _DEFER_ARENA_BYTES = int(os.environ.get("CTVAE_DEFER_ARENA_MB", "2048")) << 20
 _defer_arena = {}
 
 
+def _defer_arena_for(device):
+    """The slab arena of deferred weight-gradient reductions on this device: 2 GB of the 288, allocated once, outside any graph
+    capture (capture_graph makes sure of that: an arena first requested inside a capture would live in that graph's pool)."""
+    arena = _defer_arena.get(device)
+    if arena is None:
+        arena = _defer_arena[device] = torch.empty(_DEFER_ARENA_BYTES // 4, dtype=torch.float32, device=device)
+    return arena
+
+
 def backward(loss):
     """``loss.backward()`` with the root gradient taken from a cached ones tensor: autograd otherwise fills a fresh
     ``ones_like(loss)`` on every call (one launch per step; the harness and bench.py call this).
@@ -1616,9 +1628,7 @@ def backward(loss):
     if not (_DEFER_REDUCE and loss.is_cuda):
         loss.backward(gradient=one)
         return
-    arena = _defer_arena.get(loss.device)
-    if arena is None:
-        arena = _defer_arena[loss.device] = torch.empty(_DEFER_ARENA_BYTES // 4, dtype=torch.float32, device=loss.device)
+    arena = _defer_arena_for(loss.device)
     lib = native.load()
     native.check(lib.ctvae_defer_begin(arena.data_ptr(), arena.numel() * 4), "ctvae_defer_begin")
     try:
