@@ -246,16 +246,40 @@ int ctvae_conv_input_transform_supported(int kind, int B, int H, int W, int Ci, 
   if (!conv_kind_ok(kind)) return 0;
   ConvGeom g;
   if (conv_geom(g, kind, 0, B, H, W, Ci, Co, k, stride, pad, out_pad)) return 0;
-  return (thin_forward_supported(g) && thin_wgrad_supported(g)) ? 1 : 0;
+  if (thin_forward_supported(g) && thin_wgrad_supported(g)) return 1;
+  // the general tile kernels: forward on the vector path (not one of the dedicated picture-side / transposed-conv kernels, not
+  // Winograd) and the weight gradient on the lean 64 x 64 kernel -- both form act(BN(.)) between the global load and the LDS store
+  if (upconv_wgrad_supported(g)) return 1;     // 32 -> 32 transposed conv: both kernels stage the input patch once per tile
+  if (img_enc_supported(g) || img_conv_supported(g)) return 0;
+  if (wino_enabled() && wino_supported(g, (size_t)1 << 26)) return 0;
+  TapGemmPlan pl;
+  tapgemm_plan(g, (size_t)1 << 26, pl);
+  if (pl.thin || pl.BM == 0) return 0;
+  return ((g.gC % KC) == 0 && (g.sC % 4) == 0 && g.wT == 0) ? 1 : 0;
+}
+
+int ctvae_conv_bn_act_apply_is_separate(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
+                                        size_t ws_bytes) {
+  if (!conv_kind_ok(kind)) return 0;
+  ConvGeom g;
+  if (conv_geom(g, kind, 0, B, H, W, Ci, Co, k, stride, pad, out_pad)) return 0;
+  TapGemmPlan plan;
+  tapgemm_plan(g, ws_bytes / sizeof(float), plan);
+  return (plan.splitk > 1 && bn_fused_ok(g.B * g.sH * g.sW, Co)) ? 0 : 1;   // 0: the channel-owner launch writes a anyway
 }
 
 int ctvae_conv_bn_act_forward(int kind, const float* x, const float* w, const float* bias, const float* gamma,
                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                               int training, int act, float* y, float* a_out, float* save_mean, float* save_invstd,
                               float* scale_shift_out, int64_t* num_batches_tracked, int B, int H, int W, int Ci, int Co, int k,
-                              int stride, int pad, int out_pad, float* ws, size_t ws_bytes, void* stream) {
+                              int stride, int pad, int out_pad, const float* in_scale, const float* in_shift, int in_act,
+                              float* ws, size_t ws_bytes, void* stream) {
   long long* nbt = (long long*)num_batches_tracked;
   if (!x || !w || !gamma || !beta || !y || !ws || !conv_kind_ok(kind)) return kErrBadArg;
+  if ((in_scale != nullptr) != (in_shift != nullptr)) return kErrBadArg;
+  if (in_scale != nullptr && !ctvae_conv_input_transform_supported(kind, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
+  const InXform xf{in_scale, in_shift, in_act};
+  const InXform* xfp = in_scale != nullptr ? &xf : nullptr;
   if (!a_out && !scale_shift_out) return kErrBadArg;   // either materialise a or hand out the coefficients
   if (training && (!save_mean || !save_invstd)) return kErrBadArg;
   if (!training && (!running_mean || !running_var)) return kErrBadArg;
@@ -272,7 +296,7 @@ int ctvae_conv_bn_act_forward(int kind, const float* x, const float* w, const fl
     // conv (+ split-K finish) first, then statistics from y with the stand-alone kernels
     SplitKRaw raw{ws, 0};
     const bool fused = training && plan.splitk > 1 && bn_fused_ok(R, Co);
-    int rc = launch_tapgemm(g, x, w, bias, nullptr, nullptr, 0, y, ACT_NONE, nullptr, ws, wsf, (hipStream_t)stream, nullptr, nullptr,
+    int rc = launch_tapgemm(g, x, w, bias, nullptr, nullptr, 0, y, ACT_NONE, nullptr, ws, wsf, (hipStream_t)stream, nullptr, xfp,
                             nullptr, fused ? &raw : nullptr);
     if (rc) return rc;
     if (raw.splitk > 1) {
@@ -285,7 +309,7 @@ int ctvae_conv_bn_act_forward(int kind, const float* x, const float* w, const fl
   }
   const int nparts = plan.bn_parts;
   if (wsf < bn_workspace_floats(Co, nparts)) return kErrWorkspace;
-  int rc = launch_tapgemm(g, x, w, bias, nullptr, nullptr, 0, y, ACT_NONE, ws, nullptr, 0, (hipStream_t)stream);
+  int rc = launch_tapgemm(g, x, w, bias, nullptr, nullptr, 0, y, ACT_NONE, ws, nullptr, 0, (hipStream_t)stream, nullptr, xfp);
   if (rc) return rc;
   return launch_bn_finish_forward(y, R, Co, nparts, gamma, beta, running_mean, running_var, momentum, eps, training, act,
                                   a_out, save_mean, save_invstd, ws, nbt, (hipStream_t)stream, scale_shift_out);
@@ -479,12 +503,12 @@ int ctvae_conv_backward_lazy_slices(int kind, int B, int H, int W, int Ci, int C
 }
 
 int ctvae_conv_backward_lazy(int kind, const float* x, const float* dy, const float* w, float* dw, float* dbias, float* dx_slices,
-                             int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int accumulate, float* ws,
-                             size_t ws_bytes, void* stream) {
+                             int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int accumulate,
+                             const float* in_scale, const float* in_shift, int in_act, float* ws, size_t ws_bytes, void* stream) {
   if (!dx_slices) return kErrBadArg;
   return conv_backward_impl(kind, x, dy, w, dw, dbias, nullptr, B, H, W, Ci, Co, k, stride, pad, out_pad, accumulate, nullptr, 0,
-                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr,
-                            nullptr, 0, nullptr, nullptr, 0, nullptr, ws, ws_bytes, stream, dx_slices);
+                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, in_scale,
+                            in_shift, in_act, nullptr, nullptr, 0, nullptr, ws, ws_bytes, stream, dx_slices);
 }
 
 int ctvae_bn_backward_fused(const float* g_a_slices, int slices, int kind, int B, int H, int W, int Ci, int Co, int k, int stride,

@@ -529,7 +529,7 @@ static int launch_masked(const TapGemmArgs& a, bool wt, bool avec, bool bvec, hi
 bool upconv_supported(const ConvGeom& g);
 int upconv_rows(const ConvGeom& g);
 int launch_upconv_forward(const ConvGeom& g, const float* X, const float* W, const float* bias, float* S, int act,
-                          float* bn_part, hipStream_t st);
+                          float* bn_part, hipStream_t st, const InXform* xf);
 bool img_enc_supported(const ConvGeom& g);
 int img_enc_rows(const ConvGeom& g);
 int launch_img_enc_forward(const ConvGeom& g, const float* X, const float* W, const float* bias, float* S, int act,
@@ -651,9 +651,8 @@ int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const floa
   if (img_enc_supported(g) && add == nullptr && mask == nullptr && (bnb == nullptr || bnb->part == nullptr) &&
       (xf == nullptr || xf->scale == nullptr))
     return launch_img_enc_forward(g, G, W, bias, S, act, bn_part, st);
-  if (upconv_supported(g) && add == nullptr && mask == nullptr && (bnb == nullptr || bnb->part == nullptr) &&
-      (xf == nullptr || xf->scale == nullptr))
-    return launch_upconv_forward(g, G, W, bias, S, act, bn_part, st);
+  if (upconv_supported(g) && add == nullptr && mask == nullptr && (bnb == nullptr || bnb->part == nullptr))
+    return launch_upconv_forward(g, G, W, bias, S, act, bn_part, st, xf);
   TapGemmArgs a{};
   a.bn_part = bn_part;
   if (bnb != nullptr && bnb->part != nullptr) {
@@ -693,7 +692,9 @@ int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const floa
   TapGemmPlan plan;
   tapgemm_plan(g, ws != nullptr ? ws_floats : 0, plan);
   if (a.bnb_part != nullptr && (plan.thin || plan.splitk > 1)) return kErrBadArg;   // see tapgemm_bnb_rows()
-  if (xf != nullptr && xf->scale != nullptr && !plan.thin) return kErrBadArg;   // only the thin kernels transform on load
+  // transform on load: the thin kernels and the vector tile kernel in forward orientation (tapgemm_fast_body.inc XF)
+  if (xf != nullptr && xf->scale != nullptr && !plan.thin && !(avec && bvec && !wt)) return kErrBadArg;
+  if (xf != nullptr && xf->scale != nullptr && !plan.thin) { a.xf_scale = xf->scale; a.xf_shift = xf->shift; a.xf_act = xf->act; }
   if (plan.thin) return launch_thin_forward(g, G, W, bias, add, mask, mask_act, S, act, bn_part, st, xf);
   a.splitk = plan.splitk;
   a.part = ws;

@@ -26,6 +26,11 @@ struct TapGemmArgs {
   int bnb_act;
   float* part;     // split-K partial sums [splitk][B*sH*sW][N] (raw accumulators), used when splitk > 1
   int splitk;
+  // lazy BatchNorm apply (InXform, fast kernel, forward orientation only): the gathered operand is act(G*scale[c] + shift[c])
+  // of the tensor bound as G, formed between the global load and the LDS store (padding and rows beyond Mc stay 0)
+  const float* xf_scale;
+  const float* xf_shift;
+  int xf_act;
   int part_T;      // split-K partials channel-major [splitk][N][B*sH*sW] (SplitKRaw) instead of pixel-major [splitk][B*sH*sW][N]
   int lgQw, lgQhw; // log2(Qw), log2(Qh*Qw) when both are powers of two, else -1 (generic division)
   int act;

@@ -50,7 +50,7 @@ extern "C" int ctvae_debug_phase_read(unsigned long long* out, int n) {
 #define PHASE(i) do {} while (0)
 #endif
 
-template <int WM, int WN, int TM, int TN, bool WT, int PF>
+template <int WM, int WN, int TM, int TN, bool WT, int PF, bool XF = false>
 __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) {
   __shared__ __attribute__((aligned(16))) float sAbuf[(PF == 3 ? 2 : 1) * (WM * TM * 32) * LDK];
   __shared__ __attribute__((aligned(16))) float sBbuf[(PF == 3 ? 2 : 1) * (WT ? (WN * TN * 32) * LDK : KC * (WN * TN * 32))];
@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) 
 // launches on their own are one lock-step round of workgroups that pays the kernel boundary (previous kernel's L2
 // write-back, launch gap, prologue, store burst: ~6.5 us) for ~20 us of MFMA work; sharing a launch
 // pays it once and lets the weight-gradient workgroups start while the data-gradient's stores drain.
+template <bool XFB>   // XFB: the weight-gradient role applies the previous block's BatchNorm + activation to its X operand on load
 __global__ __launch_bounds__(256) void conv_bwd_pair_kernel(const TapGemmArgs a, const WgradArgs w, int lgQw, int lgQhw, int lgC,
                                                             int nA, int gxA, int gyA, int gxB, int gyB) {
   // the data-gradient kernel's arrays; the weight-gradient workgroups use the first 8 KB of each for their X / dY chunks
@@ -77,12 +78,12 @@ __global__ __launch_bounds__(256) void conv_bwd_pair_kernel(const TapGemmArgs a,
   const int L = blockIdx.x;
   if (L < nA) {
     constexpr int WM = 2, WN = 2, TM = 1, TN = 1, PF = 3;
-    constexpr bool WT = true;
+    constexpr bool WT = true, XF = false;
     const int vbx = L % gxA, vr = L / gxA, vby = vr % gyA, vbz = vr / gyA, vgx = gxA;
 #include "tapgemm_fast_body.inc"
   } else {
     const int Lb = L - nA;
-    wgrad_fast_body<2, 2, 1, 1>(w, lgQw, lgQhw, lgC, sAbuf, sBbuf, sPix, sMsk, sOutB, Lb % gxB, Lb / gxB, gxB, gyB);
+    wgrad_fast_body<2, 2, 1, 1, XFB>(w, lgQw, lgQhw, lgC, sAbuf, sBbuf, sPix, sMsk, sOutB, Lb % gxB, Lb / gxB, gxB, gyB);
   }
 }
 
@@ -121,7 +122,8 @@ static int launch_fast_cfg(const TapGemmArgs& a, int pf, hipStream_t st) {
     }
   }
   char name[160];
-  snprintf(name, sizeof name, "tapgemm_fast_kernel<%d,%d,%d,%d,%s,%d>", WM, WN, TM, TN, wt ? "true" : "false", pf);
+  snprintf(name, sizeof name, "tapgemm_fast_kernel<%d,%d,%d,%d,%s,%d%s>", WM, WN, TM, TN, wt ? "true" : "false", pf,
+           (!wt && a.xf_scale != nullptr) ? ",true" : "");
   double macs = 0;
   for (int c = 0; c < a.g.ncls; ++c) macs += (double)a.Mc * a.N * a.g.ntaps[c] * a.g.gC;
   if constexpr (WM == 2 && WN == 2 && TM == 1 && TN == 1) {
@@ -142,7 +144,10 @@ static int launch_fast_cfg(const TapGemmArgs& a, int pf, hipStream_t st) {
   }
   const double bytes = 4.0 * ((double)a.g.B * a.g.gH * a.g.gW * a.g.gC + (double)a.g.B * a.g.sH * a.g.sW * a.g.sC);
   ProfScope ps(name, st, 2.0 * macs, bytes);
-  if (!wt) {
+  if (!wt && a.xf_scale != nullptr) {   // lazy BatchNorm apply on the gathered operand (forward launches only)
+    if (pf == 3) hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, false, 3, true>), grid, block, 0, st, args);
+    else hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, false, 0, true>), grid, block, 0, st, args);
+  } else if (!wt) {
     // PF 1 / 2 (plain double buffer, two-chunk register prefetch) were measured and lost to 3: not instantiated
     if (pf == 3) hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, false, 3>), grid, block, 0, st, args);
     else hipLaunchKernelGGL((tapgemm_fast_kernel<WM, WN, TM, TN, false, 0>), grid, block, 0, st, args);
@@ -163,8 +168,12 @@ int pair_flush(PairCtx& c, hipStream_t st) {
   if (c.haveA && c.haveB) {
     const unsigned nA = c.gxA * c.gyA * c.gzA, nB = c.gxB * c.gyB;
     ProfScope ps("conv_bwd_pair_kernel", st, c.flopsA + c.flopsB, c.bytesA + c.bytesB);
-    hipLaunchKernelGGL(conv_bwd_pair_kernel, dim3(nA + nB), dim3(256), 0, st, c.A, c.B, c.lgQw, c.lgQhw, c.lgC, (int)nA, (int)c.gxA,
-                       (int)c.gyA, (int)c.gxB, (int)c.gyB);
+    if (c.B.xf_scale != nullptr)
+      hipLaunchKernelGGL(conv_bwd_pair_kernel<true>, dim3(nA + nB), dim3(256), 0, st, c.A, c.B, c.lgQw, c.lgQhw, c.lgC, (int)nA,
+                         (int)c.gxA, (int)c.gyA, (int)c.gxB, (int)c.gyB);
+    else
+      hipLaunchKernelGGL(conv_bwd_pair_kernel<false>, dim3(nA + nB), dim3(256), 0, st, c.A, c.B, c.lgQw, c.lgQhw, c.lgC, (int)nA,
+                         (int)c.gxA, (int)c.gyA, (int)c.gxB, (int)c.gyB);
     CTVAE_LAUNCH_CHECK();
   } else if (c.haveA) {
     ProfScope ps("tapgemm_fast_kernel<2,2,1,1,true,3>", st, c.flopsA, c.bytesA);

@@ -38,6 +38,11 @@ struct UpArgs {
   const float* dy_coef;
   float* gy_out;
   int dy_act;
+  // lazy BatchNorm apply (InXform): X is the raw BatchNorm input of the previous block; the patch is staged as
+  // max(t, t*slope), t = X*scale[c] + shift[c] (LeakyReLU / ReLU / none), pixels beyond the image stay 0
+  const float* xf_scale;
+  const float* xf_shift;
+  int xf_act;
   int act;
   int B, H, W, tiles_y, tiles_x, ntiles;
   int ntaps[NCLS], cpy[NCLS], cpx[NCLS];
@@ -89,6 +94,24 @@ __device__ __forceinline__ void patch_store(const Patch& p, float* sA) {
     if (e < NP * 8) *reinterpret_cast<f32x4*>(&sA[(e >> 3) * LDA + 4 * (e & 7)]) = p.v[j];
   }
 }
+// the same with the lazy BatchNorm apply: a thread's channel quad (e & 7 = threadIdx.x & 7) is fixed, so are its coefficients
+__device__ __forceinline__ void patch_store_xf(const UpArgs& a, const TileXY& t, const Patch& p, float* sA, f32x4 sc, f32x4 sh,
+                                               float nslope) {
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const int e = threadIdx.x + 256 * j;
+    const int pp = e >> 3;
+    const int py = (pp * 1986) >> 16, px = pp - py * PW;
+    const float inside = (t.y0 + py < a.H && t.x0 + px < a.W) ? 1.f : 0.f;
+    f32x4 v = p.v[j];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float u = v[q] * sc[q] + sh[q] * inside;
+      v[q] = fmaxf(u, u * nslope);
+    }
+    if (e < NP * 8) *reinterpret_cast<f32x4*>(&sA[pp * LDA + 4 * (e & 7)]) = v;
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void up_fwd_kernel(const UpArgs a) {
@@ -106,12 +129,17 @@ __global__ __launch_bounds__(256, 2) void up_fwd_kernel(const UpArgs a) {
   const float bv = a.bias != nullptr ? a.bias[li] : 0.f;
   float sn = 0.f, smean = 0.f, sm2 = 0.f;
 
+  const bool xf = a.xf_scale != nullptr;
+  const f32x4 xsc = xf ? *reinterpret_cast<const f32x4*>(a.xf_scale + 4 * (tid & 7)) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 xsh = xf ? *reinterpret_cast<const f32x4*>(a.xf_shift + 4 * (tid & 7)) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const float xns = a.xf_act == ACT_LRELU ? kLeaky : (a.xf_act == ACT_RELU ? 0.f : 1.f);
   Patch pt;
   int tile = blockIdx.x;
   TileXY cur = tile_xy(a, tile < a.ntiles ? tile : 0);
   if (tile < a.ntiles) patch_load(a, rX, cur, pt);
   for (; tile < a.ntiles; tile += gridDim.x) {
-    patch_store(pt, sA);
+    if (xf) patch_store_xf(a, cur, pt, sA, xsc, xsh, xns);
+    else patch_store(pt, sA);
     __syncthreads();
     const int next = tile + gridDim.x;
     const TileXY nxt = tile_xy(a, next < a.ntiles ? next : 0);
@@ -255,6 +283,10 @@ __global__ __launch_bounds__(256, 2) void up_wgrad_kernel(const UpArgs a) {
   const float k1 = FUSED ? a.dy_coef[li] : 0.f, k2 = FUSED ? a.dy_coef[C + li] : 0.f, k3 = FUSED ? a.dy_coef[2 * C + li] : 0.f;
   const float ksc = FUSED ? a.dy_coef[3 * C + li] : 0.f, ksh = FUSED ? a.dy_coef[4 * C + li] : 0.f;
   const float nslope = a.dy_act == ACT_LRELU ? kLeaky : (a.dy_act == ACT_RELU ? 0.f : 1.f);   // host admits only these
+  const bool xf = a.xf_scale != nullptr;
+  const f32x4 xsc = xf ? *reinterpret_cast<const f32x4*>(a.xf_scale + 4 * (tid & 7)) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 xsh = xf ? *reinterpret_cast<const f32x4*>(a.xf_shift + 4 * (tid & 7)) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const float xns = a.xf_act == ACT_LRELU ? kLeaky : (a.xf_act == ACT_RELU ? 0.f : 1.f);
 
   f32x16 acc[NT];
 #pragma unroll
@@ -278,6 +310,20 @@ __global__ __launch_bounds__(256, 2) void up_wgrad_kernel(const UpArgs a) {
         const int iy = cur.y0 + py, ix = cur.x0 + px;
         const bool ok = e < NP * 8 && iy < a.H && ix < a.W;
         v[j] = ld4(rX, ok ? (unsigned)(((cur.b * a.H + iy) * a.W + ix) * C + 4 * c4) * 4u : kOOBu);
+      }
+      if (xf) {   // lazy BatchNorm apply of the previous block (channel quad e & 7 = tid & 7: per-thread coefficients)
+#pragma unroll
+        for (int j = 0; j < NLD / 2; ++j) {
+          const int e = tid + 256 * (j + h * (NLD / 2));
+          const int pp = e >> 3;
+          const int py = (pp * 1986) >> 16, px = pp - py * PW;
+          const float inside = (cur.y0 + py < a.H && cur.x0 + px < a.W) ? 1.f : 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float u = v[j][q] * xsc[q] + xsh[q] * inside;
+            v[j][q] = fmaxf(u, u * xns);
+          }
+        }
       }
 #pragma unroll
       for (int j = 0; j < NLD / 2; ++j) {
@@ -435,10 +481,14 @@ int upconv_rows(const ConvGeom& g) {
 }
 
 int launch_upconv_forward(const ConvGeom& g, const float* X, const float* W, const float* bias, float* S, int act,
-                          float* bn_part, hipStream_t st) {
+                          float* bn_part, hipStream_t st, const InXform* xf) {
   UpArgs a{};
   fill(a, g);
   a.X = X; a.Wt = W; a.bias = bias; a.out = S; a.act = act; a.bn_part = bn_part;
+  if (xf != nullptr && xf->scale != nullptr) {
+    if (xf->act != ACT_NONE && xf->act != ACT_RELU && xf->act != ACT_LRELU) return kErrBadArg;
+    a.xf_scale = xf->scale; a.xf_shift = xf->shift; a.xf_act = xf->act;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(up_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUpFwdSmem);
@@ -452,10 +502,14 @@ int launch_upconv_forward(const ConvGeom& g, const float* X, const float* W, con
 
 // partial slabs [parts][9][32][32] (+ bias partials [parts][32]) into ws; the caller reduces them
 int launch_upconv_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, float** part_out, float** pbias_out,
-                        int* nparts, bool want_bias, hipStream_t st, const DyXform* dyx) {
+                        int* nparts, bool want_bias, hipStream_t st, const DyXform* dyx, const InXform* xf) {
   UpArgs a{};
   fill(a, g);
   a.X = X; a.dY = dY;
+  if (xf != nullptr && xf->scale != nullptr) {
+    if (xf->act != ACT_NONE && xf->act != ACT_RELU && xf->act != ACT_LRELU) return kErrBadArg;
+    a.xf_scale = xf->scale; a.xf_shift = xf->shift; a.xf_act = xf->act;
+  }
   if (dyx != nullptr && dyx->y != nullptr && dyx->act != ACT_NONE && dyx->act != ACT_RELU && dyx->act != ACT_LRELU) return kErrBadArg;
   if (dyx != nullptr && dyx->y != nullptr) { a.dy_y = dyx->y; a.dy_coef = dyx->coef; a.gy_out = dyx->gy_out; a.dy_act = dyx->act; }
   const int nwg = upconv_rows(g);

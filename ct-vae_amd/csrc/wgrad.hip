@@ -98,6 +98,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     x_dx = tp.dx;
   }
 
+  const bool xf_on = XVEC && a.xf_scale != nullptr && x_kok;
+  const f32x4 xf_sc = xf_on ? *reinterpret_cast<const f32x4*>(a.xf_scale + x_c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 xf_sh = xf_on ? *reinterpret_cast<const f32x4*>(a.xf_shift + x_c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const float xf_ns = a.xf_act == ACT_LRELU ? kLeaky : (a.xf_act == ACT_RELU ? 0.f : 1.f);
   f32x4 rx[XVEC ? X_V : 1];
   float rxs[XVEC ? 1 : X_S];
   f32x4 rd[DVEC ? D_V : 1];
@@ -112,7 +116,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         int iy = (yx >> 16) + x_dy, ix = (yx & 0xffff) + x_dx;
         bool ok = x_kok && pix >= 0 && (unsigned)iy < (unsigned)g.gH && (unsigned)ix < (unsigned)g.gW;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) v = *reinterpret_cast<const f32x4*>(a.X + (long)(pix + x_dy * g.gW + x_dx) * gC + x_c);
+        if (ok) {
+          v = *reinterpret_cast<const f32x4*>(a.X + (long)(pix + x_dy * g.gW + x_dx) * gC + x_c);
+          if (xf_on) {   // lazy BatchNorm apply of the previous block (InXform); padding stays 0
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float t = v[e] * xf_sc[e] + xf_sh[e];
+              v[e] = fmaxf(t, t * xf_ns);
+            }
+          }
+        }
         rx[j] = v;
       }
     } else {
@@ -227,7 +240,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 }
 
 // ---- lean variant: body in wgrad_fast.hpp (shared with the paired backward launch of tapgemm_fast.hip) --------
-template <int WK, int WN, int TK, int TN>
+template <int WK, int WN, int TK, int TN, bool XF = false>
 __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradArgs a, int lgQw, int lgQhw, int lgC) {
   constexpr int KT = WK * TK * 32, NT = WN * TN * 32;
   __shared__ __attribute__((aligned(16))) float sX[MC * KT];
@@ -235,7 +248,7 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradArgs a, int 
   __shared__ unsigned sPix[2][MC];   // byte offset of the pixel base in X, or kOOBw
   __shared__ unsigned sMsk[2][MC];   // y/x validity bits (see tapgemm_fast.hip)
   __shared__ unsigned sOutB[2][MC];  // byte offset of the scatter pixel in dY, or kOOBw
-  wgrad_fast_body<WK, WN, TK, TN>(a, lgQw, lgQhw, lgC, sX, sD, sPix, sMsk, sOutB, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+  wgrad_fast_body<WK, WN, TK, TN, XF>(a, lgQw, lgQhw, lgC, sX, sD, sPix, sMsk, sOutB, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
 }
 
 // dst[i] = (accumulate ? dst[i] : 0) + sum_s part[s*stride + i], for up to two jobs (weights, bias) in ONE launch:
@@ -558,7 +571,7 @@ int launch_thin_wgrad(const ConvGeom& g, const float* X, const float* dY, float*
 
 bool upconv_wgrad_supported(const ConvGeom& g);
 int launch_upconv_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, float** part_out, float** pbias_out,
-                        int* nparts, bool want_bias, hipStream_t st, const DyXform* dyx);
+                        int* nparts, bool want_bias, hipStream_t st, const DyXform* dyx, const InXform* xf);
 bool img_enc_supported(const ConvGeom& g);
 int launch_img_enc_wgrad(const ConvGeom& g, const float* X, const float* dY, float* ws, float** part_out, float** pbias_out,
                          int* nparts, bool want_bias, hipStream_t st, const DyXform* dyx);
@@ -581,8 +594,7 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
     const long n = 9L * g.gC * g.sC;
     return finish_reduce(ws, dW, n, np, n, pb, dbias, (long)g.sC, np, (long)g.sC, accumulate, st);
   }
-  const bool up = upconv_wgrad_supported(g) && (xf == nullptr || xf->scale == nullptr) &&
-                  ws_bytes / sizeof(float) >= (size_t)512 * (9 * 32 * 32 + 32);
+  const bool up = upconv_wgrad_supported(g) && ws_bytes / sizeof(float) >= (size_t)512 * (9 * 32 * 32 + 32);
   const bool enc = img_enc_supported(g) && (xf == nullptr || xf->scale == nullptr) &&
                    ws_bytes / sizeof(float) >= (size_t)512 * (27 * 32 + 32);
   // BN-backward on load: the transposed-conv kernel (writes g_y for the data gradient) and encoder.0's (no data gradient, no g_y)
@@ -591,7 +603,7 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
   if (up) {
     float *part = nullptr, *pb = nullptr;
     int np = 0;
-    int rc = launch_upconv_wgrad(g, X, dY, ws, &part, &pb, &np, dbias != nullptr, st, dyx);
+    int rc = launch_upconv_wgrad(g, X, dY, ws, &part, &pb, &np, dbias != nullptr, st, dyx, xf);
     if (rc) return rc;
     const long n = 9L * 32 * 32;
     return finish_reduce(part, dW, n, np, n, pb, dbias, 32L, np, 32L, accumulate, st);
@@ -605,7 +617,10 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
     return finish_reduce(part, dW, n, np, n, pb, dbias, 32L, np, 32L, accumulate, st);
   }
   const bool thin = thin_wgrad_supported(g) && thin_wgrad_workspace_floats(g) <= ws_bytes / sizeof(float);
-  if (xf != nullptr && xf->scale != nullptr && !thin) return kErrBadArg;   // only the thin kernels transform on load
+  const bool has_xf = xf != nullptr && xf->scale != nullptr;
+  // transform on load: the thin kernels and the lean 64 x 64 kernel (wgrad_fast.hpp XF; also inside the paired launch)
+  // ... and the plain-load kernel of the narrow layers (N <= 32: per-thread coefficients as well)
+  if (has_xf && !thin && !((g.gC % 4) == 0 && (g.sC % 4) == 0 && g.wT == 0)) return kErrBadArg;
   if (thin) {
     float *part = nullptr, *pb = nullptr;
     int nw = 0, nb = 0;
@@ -629,7 +644,8 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
   const bool narrow = a.N <= 32;
   // 128x128 tiles for wide layers whose pixel range still leaves >= 8 chunks per workgroup at ~1024 workgroups
   static const int no_big = [] { const char* e = getenv("CTVAE_WGRAD_NO_BIG"); return e ? atoi(e) : 0; }();   // diagnostic
-  bool big = !no_big && xvec && dvec && (a.N % 128) == 0 && a.Mc >= 8192;
+  bool big = !no_big && !has_xf && xvec && dvec && (a.N % 128) == 0 && a.Mc >= 8192;
+  if (has_xf) { a.xf_scale = xf->scale; a.xf_shift = xf->shift; a.xf_act = xf->act; }
   for (int c = 0; c < g.ncls && big; ++c) big = (g.ntaps[c] * g.gC) % 128 == 0;
   if (big) {
     int tiles128 = 0;
@@ -708,6 +724,7 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
     const int lgQw = (lw >= 0 && lh2 >= 0) ? lw : -1, lgQhw = (lw >= 0 && lh2 >= 0) ? lw + lh2 : -1;
     const int lgC = lg2(g.gC);
     if (big) hipLaunchKernelGGL((wgrad_fast_kernel<2, 2, 2, 2>), grid, block, 0, st, a, lgQw, lgQhw, lgC);
+    else if (has_xf) hipLaunchKernelGGL((wgrad_fast_kernel<2, 2, 1, 1, true>), grid, block, 0, st, a, lgQw, lgQhw, lgC);
     else hipLaunchKernelGGL((wgrad_fast_kernel<2, 2, 1, 1>), grid, block, 0, st, a, lgQw, lgQhw, lgC);
   } else if (narrow) CTVAE_WG(4, 1);
   else CTVAE_WG(2, 2);
@@ -734,7 +751,10 @@ int launch_finish_recorded(const PairCtx& c, hipStream_t st) {
 
 int launch_wgrad_fast_recorded(const PairCtx& c, hipStream_t st) {
   ProfScope ps("wgrad_fast_kernel<2,2,1,1>", st, c.flopsB, c.bytesB);
-  hipLaunchKernelGGL((wgrad_fast_kernel<2, 2, 1, 1>), dim3(c.gxB, c.gyB), dim3(256), 0, st, c.B, c.lgQw, c.lgQhw, c.lgC);
+  if (c.B.xf_scale != nullptr)
+    hipLaunchKernelGGL((wgrad_fast_kernel<2, 2, 1, 1, true>), dim3(c.gxB, c.gyB), dim3(256), 0, st, c.B, c.lgQw, c.lgQhw, c.lgC);
+  else
+    hipLaunchKernelGGL((wgrad_fast_kernel<2, 2, 1, 1>), dim3(c.gxB, c.gyB), dim3(256), 0, st, c.B, c.lgQw, c.lgQhw, c.lgC);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }

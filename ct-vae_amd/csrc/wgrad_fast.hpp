@@ -15,6 +15,11 @@ struct WgradArgs {
   int rows_total;          // taps_total * gC
   int ktile_start[kMaxCls + 1];
   int ntiles;
+  // lazy BatchNorm apply (InXform, lean kernel): the X operand is act(X*scale[c] + shift[c]) of the tensor bound as X (the raw
+  // BatchNorm input of the previous block), formed between the global load and the LDS store; padding stays 0
+  const float* xf_scale;
+  const float* xf_shift;
+  int xf_act;
 };
 
 constexpr int MC = 32;
@@ -34,7 +39,7 @@ constexpr unsigned kOOBw = 0x80000000u;
 // sX[MC*KT], sD[MC*NT], sPix / sMsk / sOutB [2][MC]: the workgroup's LDS, five DISTINCT arrays of the calling kernel (carving them
 // from one buffer costs the tile kernels their no-alias information: 83 -> 116 VGPRs, measured on the tap-GEMM body).
 // vbx, vby / vgx, vgy: the workgroup's position in / the size of the kernel's own (tile, slice) grid.
-template <int WK, int WN, int TK, int TN>
+template <int WK, int WN, int TK, int TN, bool XF = false>
 __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, int lgQw, int lgQhw, int lgC, float* sX, float* sD,
                                                 unsigned (*sPix)[MC], unsigned (*sMsk)[MC], unsigned (*sOutB)[MC], int vbx,
                                                 int vby, int vgx, int vgy) {
@@ -108,6 +113,7 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, int lgQw, in
   unsigned x_const = 0;
   int x_sy = 0, x_sx = 0;
   bool x_kok;
+  [[maybe_unused]] f32x4 xsc = {0.f, 0.f, 0.f, 0.f}, xsh = {0.f, 0.f, 0.f, 0.f};   // XF: this thread's four channels, fixed for the launch
   {
     const int k = kt0 + 4 * (tid % XQ);
     x_kok = k < Ktot;
@@ -115,6 +121,12 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, int lgQw, in
     if (x_kok) {
       t = lgC >= 0 ? (k >> lgC) : (k / gC);
       c = k - t * gC;
+    }
+    if constexpr (XF) {
+      if (x_kok) {
+        xsc = *reinterpret_cast<const f32x4*>(a.xf_scale + c);
+        xsh = *reinterpret_cast<const f32x4*>(a.xf_shift + c);
+      }
     }
     const Tap tp = g.taps[cls][t];
     x_const = (unsigned)(((tp.dy * g.gW + tp.dx) * gC + c) * 4);
@@ -124,6 +136,7 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, int lgQw, in
   const unsigned d_const = (n0 + 4 * (tid % DQ) < N) ? (unsigned)(n0 + 4 * (tid % DQ)) * 4u : kOOBw;
 
   f32x4 rx[X_V], rd[D_V];
+  [[maybe_unused]] float rx_in[X_V];   // XF: 1 where the loaded pixel lies inside the image (the shift applies), else 0
   auto load_chunk = [&](int buf) {
 #pragma unroll
     for (int j = 0; j < X_V; ++j) {
@@ -131,6 +144,7 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, int lgQw, in
       const unsigned msk = sMsk[buf][r];
       const bool ok = x_kok && ((msk >> x_sy) & (msk >> x_sx) & 1u) != 0;
       rx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, (int)(ok ? sPix[buf][r] + x_const : kOOBw), 0, 0));
+      if constexpr (XF) rx_in[j] = (ok && sPix[buf][r] != kOOBw) ? 1.f : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < D_V; ++j) {
@@ -140,6 +154,16 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, int lgQw, in
     }
   };
   auto store_chunk = [&]() {
+    if constexpr (XF) {
+      const float nslope = a.xf_act == ACT_LRELU ? kLeaky : (a.xf_act == ACT_RELU ? 0.f : 1.f);   // act(t) = max(t, t * nslope)
+#pragma unroll
+      for (int j = 0; j < X_V; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = rx[j][e] * xsc[e] + xsh[e] * rx_in[j];
+          rx[j][e] = fmaxf(t, t * nslope);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < X_V; ++j) *reinterpret_cast<f32x4*>(&sX[(tid / XQ + (256 / XQ) * j) * KT + 4 * (tid % XQ)]) = rx[j];
 #pragma unroll

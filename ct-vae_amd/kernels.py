@@ -304,6 +304,34 @@ def pop_act_link():
 
 
 _last_link = None     # set by ConvBNAct.forward, picked up by the caller of .apply (models/blocks.py) right after
+_last_lazy = None     # set by ConvBNAct.forward(lazy_out=True): (scale | shift [2][C], activation) of the tensor it returned
+
+
+def pop_lazy_bn():
+    global _last_lazy
+    lz, _last_lazy = _last_lazy, None
+    return lz
+
+
+_apply_sep_cache = {}
+
+
+def bn_apply_is_separate(spec, B, H, W) -> bool:
+    """Does a training ConvBNAct of this geometry run its BatchNorm apply as a launch of its own (ctvae_conv_bn_act_apply_is_separate)?
+    Only then is it worth handing the consumer the raw tensor: applying on load costs the consumer's tile kernels ~4 vector
+    instructions per element next to their f32 MFMAs (+10-16 % per launch, measured)."""
+    ws = native.workspace(torch.device("cuda", torch.cuda.current_device()))
+    key = (spec.kind, B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, ws.numel())
+    v = _apply_sep_cache.get(key)
+    if v is None:
+        v = _apply_sep_cache[key] = bool(native.load().ctvae_conv_bn_act_apply_is_separate(*key[:10], ws.numel() * 4))
+    return v
+
+
+def lazy_bn_input_supported(spec, B, H, W) -> bool:
+    """Can a train-mode ConvBNAct layer of this geometry read its input through the previous block's BatchNorm + activation
+    (forward tile kernel and weight-gradient kernel both transform on load: ctvae_conv_input_transform_supported)?"""
+    return _LAZY_BN and input_transform_supported(spec, B, H, W)      # (the tile kernels form max(t, slope*t): LeakyReLU / ReLU / none)
 
 
 def pop_bn_link():
@@ -385,6 +413,7 @@ _OUT_ACT_LINK = os.environ.get("CTVAE_NO_OUT_ACT_LINK", "0") != "1"   # diagnost
 # layers finalize in their own apply launch and their consumers' slab reductions leave the chain -- 1.5992 / 1.5986 ms against
 # 1.5996 / 1.5988 ms (VanillaVAE bs = 256, same box): neutral, the one deferred launch grows by what the three removed ones took
 _BN_BWD_MERGE_ROWS = int(os.environ.get("CTVAE_BN_BWD_MERGE_ROWS", "0"))
+_LAZY_BN = os.environ.get("CTVAE_NO_LAZY_BN_APPLY", "0") != "1"   # diagnostic: every BatchNorm + activation output is materialised
 _BN_LAZY = os.environ.get("CTVAE_NO_BN_LAZY", "0") != "1"     # diagnostic: small layers' data gradients summed by splitk_finish as before
 _ENC_BN_ON_LOAD = os.environ.get("CTVAE_NO_ENC_BN_ON_LOAD", "0") != "1"   # diagnostic: encoder.0's BatchNorm-backward apply as its own launch
 
@@ -412,7 +441,7 @@ def conv_backward_raw(x, dy, w_param, b_param, spec: ConvSpec, link=None, mask=N
     dx = torch.empty((B, H, W, spec.ci), dtype=torch.float32, device=dy.device)
     part, rows = None, 0
     if (link is not None and link.sole and _BN_LAZY and tuple(link.y.shape) == (B, H, W, spec.ci) and mask is None and wino_filters is None
-            and in_coef is None and dy_bn is None and bn_commit is None):
+            and dy_bn is None and bn_commit is None):
         key = (spec.kind, B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, ws.numel(), "lazy")
         n = _bn_rows_cache.get(key)
         if n is None:
@@ -422,7 +451,8 @@ def conv_backward_raw(x, dy, w_param, b_param, spec: ConvSpec, link=None, mask=N
             slices = torch.empty(n * B * H * W * spec.ci, dtype=torch.float32, device=dy.device)
             native.call("ctvae_conv_backward_lazy", spec.kind, x.data_ptr(), dy.data_ptr(), w_param.data_ptr(), gw.data_ptr(),
                         native.ptr(gb), slices.data_ptr(), B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad,
-                        acc, ws.data_ptr(), ws.numel() * 4)
+                        acc, in_coef.data_ptr() if in_coef is not None else None,
+                        in_coef.data_ptr() + 4 * spec.ci if in_coef is not None else None, in_act, ws.data_ptr(), ws.numel() * 4)
             link.publish_lazy(dx, slices, n, key[:10])
             return dx
     if link is not None and tuple(link.y.shape) == (B, H, W, spec.ci):
@@ -456,15 +486,15 @@ def conv_backward_raw(x, dy, w_param, b_param, spec: ConvSpec, link=None, mask=N
     return dx
 
 
-def wgrad_then_dgrad(x, g, w_param, b_param, spec, need_dgrad, link=None, wino_filters=None):
+def wgrad_then_dgrad(x, g, w_param, b_param, spec, need_dgrad, link=None, wino_filters=None, in_coef=None, in_act=ACT_NONE):
     """Weight gradient (accumulated straight into ``.grad``) and data gradient of one layer, on the launch stream.
     Measured on MI355X: putting the wgrad kernels on a second HIP stream (joined right after dgrad, or once at the
     end of backward) is SLOWER than back-to-back launches (2.43 vs 2.32 ms/step) -- each GEMM launch already covers
     every CU, and the fork/join edges cost more than the overlap of prologue/epilogue phases returns.  What does pay is
     ONE launch for both GEMMs (ctvae_conv_backward / conv_bwd_pair_kernel)."""
     if need_dgrad and _PAIR:
-        return conv_backward_raw(x, g, w_param, b_param, spec, link=link, wino_filters=wino_filters)
-    conv_wgrad_raw(x, g, w_param, b_param, spec)
+        return conv_backward_raw(x, g, w_param, b_param, spec, link=link, wino_filters=wino_filters, in_coef=in_coef, in_act=in_act)
+    conv_wgrad_raw(x, g, w_param, b_param, spec, in_coef=in_coef, in_act=in_act)
     if not need_dgrad:
         return None
     if link is not None:
@@ -756,27 +786,42 @@ class ConvBNAct(Function):
     """a = act(BatchNorm2d(conv(x, w) + b)) with train-mode batch statistics (vanilla_vae.py:25-35,47-75)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, training, spec, bn_act, num_batches_tracked=None):
+    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, training, spec, bn_act, num_batches_tracked=None,
+                lazy_out=False):
+        """lazy_out (model code, blocks.Chain: the ONE consumer of the output applies BatchNorm + activation while it loads):
+        the returned tensor holds the raw conv output y and carries ``_ctvae_lazy_bn = (coef [2][C], act)``; the stand-alone
+        apply launch and the activated tensor do not exist.  An input tagged that way is read through its own coefficients."""
         global _last_link
         _req_cuda(x, w, gamma)
         ctx.link_in = link_of(x)
+        lazy_in = getattr(x, "_ctvae_lazy_bn", None) if x.is_contiguous() else None
         x = _c(x)
         B, H, W, _ = x.shape
         ho, wo = spec.out_hw(H, W)
         C = spec.co
         y = torch.empty((B, ho, wo, C), dtype=torch.float32, device=x.device)
-        a = torch.empty_like(y)
+        a = None if lazy_out else torch.empty_like(y)
+        coef = torch.empty(2 * C, dtype=torch.float32, device=x.device) if lazy_out else None
         ws = native.workspace(x.device)
         save_mean = torch.empty(C, dtype=torch.float32, device=x.device)
         save_invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        isc = lazy_in[0].data_ptr() if lazy_in is not None else None
+        ish = lazy_in[0].data_ptr() + 4 * spec.ci if lazy_in is not None else None
         native.call("ctvae_conv_bn_act_forward", spec.kind, x.data_ptr(), w.data_ptr(), native.ptr(b), gamma.data_ptr(),
                     beta.data_ptr(), native.ptr(running_mean), native.ptr(running_var), BN_MOMENTUM, BN_EPS,
-                    1 if training else 0, bn_act, y.data_ptr(), a.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(),
-                    None, native.ptr(num_batches_tracked) if training else None, B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, ws.data_ptr(), ws.numel() * 4)
+                    1 if training else 0, bn_act, y.data_ptr(), native.ptr(a), save_mean.data_ptr(), save_invstd.data_ptr(),
+                    native.ptr(coef), native.ptr(num_batches_tracked) if training else None, B, H, W, spec.ci, spec.co, spec.k,
+                    spec.stride, spec.pad, spec.out_pad, isc, ish, lazy_in[1] if lazy_in is not None else ACT_NONE,
+                    ws.data_ptr(), ws.numel() * 4)
         ctx.spec, ctx.bn_act, ctx.training = spec, bn_act, training
         ctx.params = (w, b, gamma, beta)
-        ctx.save_for_backward(x, y, a, save_mean, save_invstd)
+        ctx.lazy_in = lazy_in
+        ctx.save_for_backward(x, y, save_mean, save_invstd)
         ctx.link_out = _last_link = BNLink(y, save_mean, save_invstd, gamma, beta, bn_act) if training else None
+        if lazy_out:
+            global _last_lazy
+            _last_lazy = (coef, bn_act)        # picked up by the caller of .apply (pop_lazy_bn), which tags the returned tensor
+            return y                           # the output IS the raw conv output (also saved above for backward)
         return a
 
     @staticmethod
@@ -785,9 +830,10 @@ class ConvBNAct(Function):
             raise RuntimeError("backward through eval-mode BatchNorm is not supported on the HIP path")
         spec = ctx.spec
         w, b, gamma, beta = ctx.params
-        x, y, a, save_mean, save_invstd = ctx.saved_tensors
+        x, y, save_mean, save_invstd = ctx.saved_tensors
         g_a = _c(g_a)
         B, H, W, C = y.shape
+        in_coef, in_act = (ctx.lazy_in[0], ctx.lazy_in[1]) if ctx.lazy_in is not None else (None, ACT_NONE)
         ws = native.workspace(x.device)
         gg, accg = grad_target(gamma)
         gbt, accb = grad_target(beta)
@@ -801,8 +847,8 @@ class ConvBNAct(Function):
             native.call("ctvae_bn_backward_fused", lazy[0].data_ptr(), lazy[1], *lazy[2], y.data_ptr(), gamma.data_ptr(),
                         beta.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(), ctx.bn_act, g_y.data_ptr(), gg.data_ptr(),
                         gbt.data_ptr(), accg)
-            g_x = wgrad_then_dgrad(x, g_y, w, b, spec, ctx.needs_input_grad[0], ctx.link_in)
-            return (g_x,) + (None,) * 10
+            g_x = wgrad_then_dgrad(x, g_y, w, b, spec, ctx.needs_input_grad[0], ctx.link_in, in_coef=in_coef, in_act=in_act)
+            return (g_x,) + (None,) * 11
         part, rows, coef = ctx.link_out.take(g_a) if ctx.link_out is not None else (None, 0, None)
         if coef is not None:
             part, rows = None, 0         # finalized by the consumer's finishing launch: apply + commit only
@@ -810,13 +856,13 @@ class ConvBNAct(Function):
                 # the first layer of the encoder: no data gradient follows, so g_y is only the weight gradient's operand -- formed
                 # on load from (g_a, y, coef); the apply launch and its 33 MB output are not needed
                 conv_wgrad_raw(x, g_a, w, b, spec, dy_bn=(y, coef, ctx.bn_act, None), bn_commit=(gg, gbt, accg))
-                return (None,) * 11
+                return (None,) * 12
         g_y = torch.empty_like(y)
         native.call("ctvae_bn_backward", g_a.data_ptr(), beta.data_ptr(), y.data_ptr(), B * H * W, C, gamma.data_ptr(),
                     save_mean.data_ptr(), save_invstd.data_ptr(), ctx.bn_act, g_y.data_ptr(), gg.data_ptr(), gbt.data_ptr(),
                     accg, native.ptr(part), rows, None, native.ptr(coef), ws.data_ptr(), ws.numel() * 4)
-        g_x = wgrad_then_dgrad(x, g_y, w, b, spec, ctx.needs_input_grad[0], ctx.link_in)
-        return (g_x,) + (None,) * 10
+        g_x = wgrad_then_dgrad(x, g_y, w, b, spec, ctx.needs_input_grad[0], ctx.link_in, in_coef=in_coef, in_act=in_act)
+        return (g_x,) + (None,) * 11
 
 
 _xform_ok_cache = {}
@@ -861,6 +907,7 @@ class ConvBNActConvAct(Function):
     def forward(ctx, x, w1, b1, gamma, beta, running_mean, running_var, num_batches_tracked, w2, b2, training, spec1, spec2, bn_act):
         _req_cuda(x, w1, w2, gamma)
         ctx.link_in = link_of(x)
+        lazy_in = ctx.lazy_in = getattr(x, "_ctvae_lazy_bn", None) if x.is_contiguous() else None
         x = _c(x)
         B, H, W, _ = x.shape
         ho, wo = spec1.out_hw(H, W)
@@ -874,7 +921,10 @@ class ConvBNActConvAct(Function):
                     beta.data_ptr(), native.ptr(running_mean), native.ptr(running_var), BN_MOMENTUM, BN_EPS,
                     1 if training else 0, bn_act, y1.data_ptr(), None, save_mean.data_ptr(), save_invstd.data_ptr(),
                     coef.data_ptr(), native.ptr(num_batches_tracked) if training else None, B, H, W, spec1.ci, spec1.co,
-                    spec1.k, spec1.stride, spec1.pad, spec1.out_pad, ws.data_ptr(), ws.numel() * 4)
+                    spec1.k, spec1.stride, spec1.pad, spec1.out_pad,
+                    lazy_in[0].data_ptr() if lazy_in is not None else None,
+                    lazy_in[0].data_ptr() + 4 * spec1.ci if lazy_in is not None else None,
+                    lazy_in[1] if lazy_in is not None else ACT_NONE, ws.data_ptr(), ws.numel() * 4)
         r = conv_forward_raw(y1, w2, b2, spec2, in_coef=coef, in_act=bn_act)
         ctx.act_out = offer_out_act_link(r, spec2.act) if (training and spec2.act != ACT_NONE and _OUT_ACT_LINK) else None
         ctx.specs, ctx.bn_act, ctx.training = (spec1, spec2), bn_act, training
@@ -930,19 +980,21 @@ class ConvBNActConvAct(Function):
             native.call("ctvae_bn_backward", g_a.data_ptr(), beta.data_ptr(), y1.data_ptr(), B * H * W, C, gamma.data_ptr(),
                         save_mean.data_ptr(), save_invstd.data_ptr(), ctx.bn_act, g_y.data_ptr(), gg.data_ptr(), gbt.data_ptr(),
                         accg, None, 0, None, c7.data_ptr(), ws.data_ptr(), ws.numel() * 4)
+        in_coef, in_act = (ctx.lazy_in[0], ctx.lazy_in[1]) if ctx.lazy_in is not None else (None, ACT_NONE)
         if lazy:
             # the weight-gradient kernel turns g_a into g_y on load and leaves g_y behind for the data gradient
             if ctx.needs_input_grad[0] and _PAIR:
-                g_x = conv_backward_raw(x, g_a, w1, b1, spec1, link=ctx.link_in, dy_bn=(y1, bcoef, ctx.bn_act, g_y))
+                g_x = conv_backward_raw(x, g_a, w1, b1, spec1, link=ctx.link_in, dy_bn=(y1, bcoef, ctx.bn_act, g_y),
+                                        in_coef=in_coef, in_act=in_act)
             else:
-                conv_wgrad_raw(x, g_a, w1, b1, spec1, dy_bn=(y1, bcoef, ctx.bn_act, g_y))
+                conv_wgrad_raw(x, g_a, w1, b1, spec1, dy_bn=(y1, bcoef, ctx.bn_act, g_y), in_coef=in_coef, in_act=in_act)
                 g_x = None
                 if ctx.needs_input_grad[0]:
                     g_x = None if ctx.link_in is None else conv_dgrad_bn_raw(g_y, w1, spec1, (x.shape[1], x.shape[2]), ctx.link_in)
                     if g_x is None:
                         g_x = conv_dgrad_raw(g_y, w1, spec1, (x.shape[1], x.shape[2]))
         else:
-            g_x = wgrad_then_dgrad(x, g_y, w1, b1, spec1, ctx.needs_input_grad[0], ctx.link_in)
+            g_x = wgrad_then_dgrad(x, g_y, w1, b1, spec1, ctx.needs_input_grad[0], ctx.link_in, in_coef=in_coef, in_act=in_act)
         return (g_x,) + (None,) * 13
 
 

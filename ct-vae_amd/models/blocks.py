@@ -8,14 +8,18 @@ from .. import kernels as K
 from .packing import PackedBN, PackedConv
 
 
-def conv_bn_leaky(x, conv, bn, spec, training):
-    """Conv (+bias) -> train/eval BatchNorm2d -> LeakyReLU on the holders `conv` / `bn`."""
+def conv_bn_leaky(x, conv, bn, spec, training, lazy_out=False):
+    """Conv (+bias) -> train/eval BatchNorm2d -> LeakyReLU on the holders `conv` / `bn`.  lazy_out: see kernels.ConvBNAct --
+    only for a tensor whose one consumer is a ConvBNLeaky block that reads it through the coefficients (blocks.Chain)."""
     # num_batches_tracked is advanced by the finalize kernel (no separate launch)
     a = K.ConvBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                          training, spec, K.ACT_LRELU, bn.num_batches_tracked)
+                          training, spec, K.ACT_LRELU, bn.num_batches_tracked, lazy_out)
     link = K.pop_bn_link()
     if link is not None:
         a._ctvae_bn_link = link     # lets the consumer's dgrad emit this BatchNorm's backward sums (kernels.BNLink)
+    lazy = K.pop_lazy_bn()
+    if lazy is not None:
+        a._ctvae_lazy_bn = lazy     # the tensor holds the raw conv output: the consumer applies BatchNorm + LeakyReLU on load
     return a
 
 
@@ -29,8 +33,13 @@ class ConvBNLeaky(nn.Module):
         self.add_module("1", PackedBN(co))
         self.spec = K.ConvSpec(K.CONVT if transposed else K.CONV, ci, co, k, stride, pad, out_pad, K.ACT_NONE)
 
-    def forward(self, x):
-        return conv_bn_leaky(x, self._modules["0"], self._modules["1"], self.spec, self.training)
+    def forward(self, x, lazy_out=False):
+        return conv_bn_leaky(x, self._modules["0"], self._modules["1"], self.spec, self.training, lazy_out)
+
+    def reads_lazy_input(self, x_shape):
+        """Can this block read an NHWC input of this shape through the previous block's BatchNorm coefficients?"""
+        B, H, W, _ = x_shape
+        return K.lazy_bn_input_supported(self.spec, B, H, W)
 
 
 class Chain(nn.Sequential):
@@ -38,11 +47,22 @@ class Chain(nn.Sequential):
     child: each is marked for kernels.mark_sole_consumer, which lets a small layer's data gradient reach the BatchNorm below it
     as split-K slices instead of a tensor.  The LAST child's output leaves the chain: its consumers are the caller's business."""
 
-    def forward(self, x):
-        last = len(self) - 1
-        for i, m in enumerate(self):
-            x = m(x)
-            if i != last:
+    def forward(self, x, last_reader=None):
+        """last_reader: the module that is the ONE consumer of the chain's output (the caller hands it nothing else); if it has
+        ``reads_lazy_input`` the last block may leave its BatchNorm + activation to it as well."""
+        mods = list(self)
+        last = len(mods) - 1
+        for i, m in enumerate(mods):
+            lazy = False
+            reader = mods[i + 1] if i != last else last_reader
+            if isinstance(m, ConvBNLeaky) and hasattr(reader, "reads_lazy_input") and x.dim() == 4:
+                # the reader is the tensor's one consumer: if it can apply this block's BatchNorm + LeakyReLU while it loads,
+                # the activated tensor and its apply launch are skipped (kernels.ConvBNAct lazy_out)
+                ho, wo = m.spec.out_hw(x.shape[1], x.shape[2])
+                lazy = (x.is_cuda and K.bn_apply_is_separate(m.spec, x.shape[0], x.shape[1], x.shape[2])
+                        and reader.reads_lazy_input((x.shape[0], ho, wo, m.spec.co)))
+            x = m(x, lazy_out=True) if lazy else m(x)
+            if i != last or last_reader is not None:
                 K.mark_sole_consumer(x)
         return x
 

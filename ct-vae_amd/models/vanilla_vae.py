@@ -32,6 +32,13 @@ class _FinalLayer(nn.Module):
         self.spec_up = K.ConvSpec(K.CONVT, c, c, 3, 2, 1, 1, K.ACT_NONE)
         self.spec_out = K.ConvSpec(K.CONV, c, out_channels, 3, 1, 1, 0, K.ACT_TANH)
 
+    def reads_lazy_input(self, x_shape):
+        """blocks.Chain: can the final block read its input through the previous block's BatchNorm coefficients?  (Only its
+        one-node form does: the transposed conv's forward / weight-gradient kernels apply them while staging their patches.)"""
+        B, H, W, _ = x_shape
+        ho, wo = self.spec_up.out_hw(H, W)
+        return K.input_transform_supported(self.spec_out, B, ho, wo) and K.lazy_bn_input_supported(self.spec_up, B, H, W)
+
     def forward(self, x):
         up, bn, conv = self._modules["0"], self._modules["1"], self._modules["3"]
         B, H, W, _ = x.shape
@@ -113,7 +120,7 @@ class VanillaVAE(BaseVAE):
         B = z.shape[0]
         h = K.ConvAct.apply(z.reshape(B, 1, 1, -1), self.decoder_input.weight, self.decoder_input.bias, None, self._dec_in_spec)
         h = K._ToNHWC.apply(h.view(B, 512, 2, 2))                        # .view(-1,512,2,2) is NCHW
-        h = K.mark_sole_consumer(self.decoder(h))                        # read by final_layer only
+        h = self.decoder(h, last_reader=self.final_layer)                # read by final_layer only (marked by the chain)
         return K.to_nchw_view(self.final_layer(h))
 
     def reparameterize(self, mu: Tensor, logvar: Tensor, eps: Tensor = None) -> Tensor:

@@ -20,12 +20,12 @@ SIGNATURES = {
     "ctvae_conv_forward": [_i, _fp, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _fp, _i, _fp, _fp, _fp, _sz, _vp],
     "ctvae_wino_filters_batch": [_i, _vp, _vp, _vp, _vp, _vp, _vp],
     "ctvae_conv_bn_act_forward": [_i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp] + [_i] * 9
-                                 + [_fp, _sz, _vp],
+                                 + [_fp, _fp, _i, _fp, _sz, _vp],
     "ctvae_conv_dgrad": [_i, _fp, _fp, _fp, _fp, _i, _fp] + [_i] * 9 + [_fp, _fp, _sz, _vp],
     "ctvae_conv_wgrad": [_i, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _fp, _i, _fp, _sz, _vp],
     "ctvae_conv_backward": [_i, _fp, _fp, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _i,
                             _fp, _fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _sz, _vp],
-    "ctvae_conv_backward_lazy": [_i, _fp, _fp, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _sz, _vp],
+    "ctvae_conv_backward_lazy": [_i, _fp, _fp, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _fp, _i, _fp, _sz, _vp],
     "ctvae_bn_backward_fused": [_fp, _i] + [_i] * 10 + [_fp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _vp],
     "ctvae_bn_forward": [_fp, _i, _i, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _fp, _fp, _fp, _fp, _fp, _sz, _vp],
     "ctvae_bn_backward": [_fp, _fp, _fp, _i, _i, _fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _fp, _i, _fp, _fp, _fp, _sz, _vp],
@@ -117,6 +117,7 @@ _RESTYPES = {
     "ctvae_conv_dgrad_bn_rows": _c.c_int,
     "ctvae_conv_backward_bn_rows": _c.c_int,
     "ctvae_conv_backward_lazy_slices": _c.c_int,
+    "ctvae_conv_bn_act_apply_is_separate": _c.c_int,
     "ctvae_winograd_enable": _c.c_int,
     "ctvae_conv_wino_filter_floats": _c.c_size_t,
     "ctvae_dip_state_floats": _c.c_size_t,
@@ -161,6 +162,7 @@ def load():
                        "ctvae_conv_dgrad_bn_rows": [_c.c_int] * 10 + [_c.c_size_t],
                        "ctvae_conv_backward_bn_rows": [_c.c_int] * 10 + [_c.c_size_t],
                        "ctvae_conv_backward_lazy_slices": [_c.c_int] * 10 + [_c.c_size_t],
+                       "ctvae_conv_bn_act_apply_is_separate": [_c.c_int] * 10 + [_c.c_size_t],
                        "ctvae_winograd_enable": [_c.c_int],
                        "ctvae_dip_state_floats": [_c.c_int, _c.c_int],
                        "ctvae_glinear_wgrad_ws_bytes": [_c.c_int, _c.c_int, _c.c_int],

@@ -74,12 +74,21 @@ int ctvae_conv_input_transform_supported(int kind, int B, int H, int W, int Ci, 
  * y = conv(x)+bias (kept for backward); the conv epilogue emits per-tile (count, mean, M2) so the batch
  * statistics cost no extra pass over y; a_out = act(BN(y)).  Arguments as ctvae_conv_forward / ctvae_bn_forward.
  * scale_shift_out [2][Co] (may be NULL): receives the per-channel affine a = act(y*scale + shift); with a_out == NULL
- * the apply pass is skipped altogether and the consumer applies it on load (ctvae_conv_forward in_scale/in_shift). */
+ * the apply pass is skipped altogether and the consumer applies it on load (ctvae_conv_forward in_scale/in_shift).
+ * in_scale / in_shift [Ci] / in_act (both NULL normally): x is itself the raw BatchNorm input of the PREVIOUS block, handed over
+ * that way, and this layer reads act(x*in_scale + in_shift) -- where ctvae_conv_input_transform_supported() says 1; the chain
+ * Conv -> BN -> LeakyReLU -> Conv -> BN ... (vanilla_vae.py:25-35,47-62) then runs without a stand-alone apply launch. */
+/* 1 when a training call of ctvae_conv_bn_act_forward with this geometry runs BatchNorm's apply as a launch of its own (which
+ * a_out == NULL + scale_shift_out saves), 0 when the activated tensor comes out of the channel-owner launch that follows a
+ * split-K convolution anyway (then handing the consumer the raw tensor only costs it arithmetic). */
+int ctvae_conv_bn_act_apply_is_separate(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
+                                        size_t ws_bytes);
 int ctvae_conv_bn_act_forward(int kind, const float* x, const float* w, const float* bias, const float* gamma,
                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                               int training, int act, float* y, float* a_out, float* save_mean, float* save_invstd,
                               float* scale_shift_out, int64_t* num_batches_tracked, int B, int H, int W, int Ci, int Co, int k,
-                              int stride, int pad, int out_pad, float* ws, size_t ws_bytes, void* stream);
+                              int stride, int pad, int out_pad, const float* in_scale, const float* in_shift, int in_act,
+                              float* ws, size_t ws_bytes, void* stream);
 
 /* dx = (dgrad(dy, w) + add) * act'(mask)      (autograd of the ops above)
  * add / mask (saved post-activation output of the PREVIOUS layer, layout of dx) may be NULL.
@@ -142,7 +151,8 @@ int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* 
  * data gradient runs split-K and its consumer is that BatchNorm's backward pass, so the slices are never summed into a tensor of
  * their own.  ctvae_conv_backward_lazy_slices: the number S (>= 2) of K slices such a call would produce for this geometry and
  * workspace, or 0 when this form does not apply (unsplit / Winograd / picture-side data gradient, or a tensor beyond the few MB
- * the channel-owner kernel pays for).  ctvae_conv_backward_lazy: weight (+ bias) gradient as ctvae_conv_backward, and the data
+ * the channel-owner kernel pays for).  ctvae_conv_backward_lazy: weight (+ bias) gradient as ctvae_conv_backward (in_scale /
+ * in_shift / in_act: its x operand read through the previous block's BatchNorm + activation, as there), and the data
  * gradient's raw slices, CHANNEL-MAJOR, in dx_slices [S][Ci][B*H*W] (no mask, no BatchNorm sums, dx itself is not written;
  * the rows of a slice are in the data gradient's class-major order, not pixel order).
  * ctvae_bn_backward_fused (kind ... out_pad: the geometry of the ctvae_conv_backward_lazy call that wrote the slices; the
@@ -153,8 +163,8 @@ int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* 
 int ctvae_conv_backward_lazy_slices(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
                                     size_t ws_bytes);
 int ctvae_conv_backward_lazy(int kind, const float* x, const float* dy, const float* w, float* dw, float* dbias, float* dx_slices,
-                             int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int accumulate, float* ws,
-                             size_t ws_bytes, void* stream);
+                             int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int accumulate,
+                             const float* in_scale, const float* in_shift, int in_act, float* ws, size_t ws_bytes, void* stream);
 int ctvae_bn_backward_fused(const float* g_a_slices, int slices, int kind, int B, int H, int W, int Ci, int Co, int k, int stride,
                             int pad, int out_pad, const float* y, const float* gamma, const float* beta, const float* save_mean,
                             const float* save_invstd, int act, float* g_y, float* dgamma, float* dbeta, int accumulate, void* stream);
