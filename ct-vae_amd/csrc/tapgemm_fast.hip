@@ -50,7 +50,7 @@ extern "C" int ctvae_debug_phase_read(unsigned long long* out, int n) {
 #define PHASE(i) do {} while (0)
 #endif
 
-template <int WM, int WN, int TM, int TN, bool WT, int PF, bool XF = false>
+template <int WM, int WN, int TM, int TN, bool WT, int PF, bool XF = false, int PD = 1>
 __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) {
   __shared__ __attribute__((aligned(16))) float sAbuf[(PF == 3 ? 2 : 1) * (WM * TM * 32) * LDK];
   __shared__ __attribute__((aligned(16))) float sBbuf[(PF == 3 ? 2 : 1) * (WT ? (WN * TN * 32) * LDK : KC * (WN * TN * 32))];
@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) 
 // launches on their own are one lock-step round of workgroups that pays the kernel boundary (previous kernel's L2
 // write-back, launch gap, prologue, store burst: ~6.5 us) for ~20 us of MFMA work; sharing a launch
 // pays it once and lets the weight-gradient workgroups start while the data-gradient's stores drain.
-template <bool XFB>   // XFB: the weight-gradient role applies the previous block's BatchNorm + activation to its X operand on load
+// XFB: the weight-gradient role applies the previous block's BatchNorm + activation to its X operand on load
+// PDA: prefetch depth (chunks) of the data-gradient role's global loads (4 for launches of at most two workgroups per CU)
+template <bool XFB, int PDA = 1>
 __global__ __launch_bounds__(256) void conv_bwd_pair_kernel(const TapGemmArgs a, const WgradArgs w, int lgQw, int lgQhw, int lgC,
                                                             int nA, int gxA, int gyA, int gxB, int gyB) {
   // the data-gradient kernel's arrays; the weight-gradient workgroups use the first 8 KB of each for their X / dY chunks
@@ -79,6 +81,7 @@ __global__ __launch_bounds__(256) void conv_bwd_pair_kernel(const TapGemmArgs a,
   if (L < nA) {
     constexpr int WM = 2, WN = 2, TM = 1, TN = 1, PF = 3;
     constexpr bool WT = true, XF = false;
+    constexpr int PD = PDA;
     const int vbx = L % gxA, vr = L / gxA, vby = vr % gyA, vbz = vr / gyA, vgx = gxA;
 #include "tapgemm_fast_body.inc"
   } else {
@@ -121,9 +124,12 @@ static int launch_fast_cfg(const TapGemmArgs& a, int pf, hipStream_t st) {
       if (big == 2 && grid.x % 8 == 0 && grid.z == 1) args.cls_rot = 2;
     }
   }
+  // (deep prefetch -- four register sets of loads in flight, template parameter PD = 4 of the tile kernel -- was measured for
+  // launches of at most two workgroups per CU and LOST: bs = 64 step 0.825 -> 0.857 ms; tools/negative/README.md.  Not instantiated.)
+  constexpr bool deep = false;
   char name[160];
   snprintf(name, sizeof name, "tapgemm_fast_kernel<%d,%d,%d,%d,%s,%d%s>", WM, WN, TM, TN, wt ? "true" : "false", pf,
-           (!wt && a.xf_scale != nullptr) ? ",true" : "");
+           (!wt && a.xf_scale != nullptr) ? ",true" : (deep ? ",false,4" : ""));
   double macs = 0;
   for (int c = 0; c < a.g.ncls; ++c) macs += (double)a.Mc * a.N * a.g.ntaps[c] * a.g.gC;
   if constexpr (WM == 2 && WN == 2 && TM == 1 && TN == 1) {
@@ -168,12 +174,12 @@ int pair_flush(PairCtx& c, hipStream_t st) {
   if (c.haveA && c.haveB) {
     const unsigned nA = c.gxA * c.gyA * c.gzA, nB = c.gxB * c.gyB;
     ProfScope ps("conv_bwd_pair_kernel", st, c.flopsA + c.flopsB, c.bytesA + c.bytesB);
-    if (c.B.xf_scale != nullptr)
-      hipLaunchKernelGGL(conv_bwd_pair_kernel<true>, dim3(nA + nB), dim3(256), 0, st, c.A, c.B, c.lgQw, c.lgQhw, c.lgC, (int)nA,
-                         (int)c.gxA, (int)c.gyA, (int)c.gxB, (int)c.gyB);
-    else
-      hipLaunchKernelGGL(conv_bwd_pair_kernel<false>, dim3(nA + nB), dim3(256), 0, st, c.A, c.B, c.lgQw, c.lgQhw, c.lgC, (int)nA,
-                         (int)c.gxA, (int)c.gyA, (int)c.gxB, (int)c.gyB);
+#define CTVAE_PAIR(XFB_, PD_)                                                                                                  \
+  hipLaunchKernelGGL((conv_bwd_pair_kernel<XFB_, PD_>), dim3(nA + nB), dim3(256), 0, st, c.A, c.B, c.lgQw, c.lgQhw, c.lgC, (int)nA, \
+                     (int)c.gxA, (int)c.gyA, (int)c.gxB, (int)c.gyB)
+    if (c.B.xf_scale != nullptr) CTVAE_PAIR(true, 1);
+    else CTVAE_PAIR(false, 1);
+#undef CTVAE_PAIR
     CTVAE_LAUNCH_CHECK();
   } else if (c.haveA) {
     ProfScope ps("tapgemm_fast_kernel<2,2,1,1,true,3>", st, c.flopsA, c.bytesA);
