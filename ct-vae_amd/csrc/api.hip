@@ -53,10 +53,11 @@ int launch_gat_score(int mode, const float* xl, const float* xr, const float* at
 int launch_gat_score_backward(const float* xl, const float* xr, const float* attr, const float* we, const float* att,
                               const float* g, float* dxl, float* dxr, float* datt_part, float* dwe_part, int B, int N, int H,
                               int C, float slope, hipStream_t st);
-int launch_gauss_latent_fwd(const float* heads, const float* eps_in, const unsigned long long* rng, float* eps_out, float* z, int B,
-                            int L, hipStream_t st);
+int launch_gauss_latent_fwd(float* heads, const float* eps_in, const unsigned long long* rng, float* eps_out, float* z, int B,
+                            int L, hipStream_t st, const float* slices, int S, const float* bias);
+int launch_splitk_permute(const float* slices, int S, float* out, int B, int C, int P, hipStream_t st);
 int launch_gauss_latent_bwd(const float* g_mu, const float* g_lv, const float* g_z, const float* heads, const float* eps,
-                            float* g_heads, unsigned long long* rng_bump, int B, int L, hipStream_t st);
+                            float* g_heads, unsigned long long* rng_bump, int B, int L, hipStream_t st, int gz_slices);
 int launch_ct_reg_forward(const float* adj, const float* graph, const float* uni, float* part, float ckl, float cgs, float cpt,
                           int B, int N, hipStream_t st);
 int launch_ct_reg_backward(const float* adj, const float* graph, const float* uni, const float* part, const float* g_loss,
@@ -388,6 +389,8 @@ int ctvae_conv_backward_bn_rows(int kind, int B, int H, int W, int Ci, int Co, i
   return rows;
 }
 
+static thread_local int g_lazy_pixel_major = 0;   // layout of the slices the next conv_backward_impl(dx_slices) leaves (set by its caller)
+
 // dx_slices != nullptr: the data gradient must run split-K and leaves its raw slices there, channel-major (SplitKRaw); dx is
 // not written (ctvae_conv_backward_lazy)
 static int conv_backward_impl(int kind, const float* x, const float* dy, const float* w, float* dw, float* dbias, float* dx, int B,
@@ -455,7 +458,8 @@ static int conv_backward_impl(int kind, const float* x, const float* dy, const f
     const WinoFilters wf{wino_filters, nullptr};
     const BnBwdFuse f{bn_y, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_act, bn_part};
     // dy_bn_*: dy was g_a of the BatchNorm behind this layer; the weight-gradient kernel left g_y in gy_out for the data gradient
-      SplitKRaw raw{dx_slices, 0};
+      SplitKRaw raw{dx_slices, 0, g_lazy_pixel_major};
+      g_lazy_pixel_major = 0;
       rc = launch_tapgemm(gd, gy_out != nullptr ? gy_out : dy, w, nullptr, nullptr, mask, mask_act, dx, ACT_NONE, nullptr, ws_d,
                           half_floats, st, bn ? &f : nullptr, nullptr, &wf, dx_slices != nullptr ? &raw : nullptr);
       if (!rc && dx_slices != nullptr && raw.splitk <= 1) rc = kErrBadArg;   // the caller asked ctvae_conv_backward_lazy_slices first
@@ -486,7 +490,7 @@ int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* 
 }
 
 int ctvae_conv_backward_lazy_slices(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
-                                    size_t ws_bytes) {
+                                    int for_bn, size_t ws_bytes) {
   if (!conv_kind_ok(kind)) return 0;
   ConvGeom g;
   if (conv_geom(g, kind, 2, B, H, W, Ci, Co, k, stride, pad, out_pad)) return 0;
@@ -498,14 +502,17 @@ int ctvae_conv_backward_lazy_slices(int kind, int B, int H, int W, int Ci, int C
   tapgemm_plan(g, half_floats, pl);
   pair_ctx() = nullptr;
   const long Mc = (long)g.B * g.Qh * g.Qw;
-  if (pl.thin || pl.splitk <= 1 || Mc % 4 != 0 || !bn_fused_ok(B * H * W, Ci)) return 0;
+  if (pl.thin || pl.splitk <= 1) return 0;
+  if (for_bn && (Mc % 4 != 0 || !bn_fused_ok(B * H * W, Ci))) return 0;   // channel-major slices for the BatchNorm's channel owners
   return pl.splitk;
 }
 
 int ctvae_conv_backward_lazy(int kind, const float* x, const float* dy, const float* w, float* dw, float* dbias, float* dx_slices,
                              int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int accumulate,
-                             const float* in_scale, const float* in_shift, int in_act, float* ws, size_t ws_bytes, void* stream) {
+                             const float* in_scale, const float* in_shift, int in_act, int pixel_major, float* ws, size_t ws_bytes,
+                             void* stream) {
   if (!dx_slices) return kErrBadArg;
+  g_lazy_pixel_major = pixel_major;
   return conv_backward_impl(kind, x, dy, w, dw, dbias, nullptr, B, H, W, Ci, Co, k, stride, pad, out_pad, accumulate, nullptr, 0,
                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, in_scale,
                             in_shift, in_act, nullptr, nullptr, 0, nullptr, ws, ws_bytes, stream, dx_slices);
@@ -588,14 +595,44 @@ int ctvae_gat_layer_backward(const float* xl, const float* xr, int ld, const flo
   return launch_gat_layer_backward(p, d_adj, accumulate_dadj, (hipStream_t)stream);
 }
 
-int ctvae_gauss_latent_forward(const float* heads, const float* eps_in, const uint64_t* rng, float* eps_out, float* z, int B, int L,
-                               void* stream) {
-  return launch_gauss_latent_fwd(heads, eps_in, (const unsigned long long*)rng, eps_out, z, B, L, (hipStream_t)stream);
+int ctvae_gauss_latent_forward(float* heads, const float* eps_in, const uint64_t* rng, float* eps_out, float* z, int B, int L,
+                               const float* head_slices, int slices, const float* head_bias, void* stream) {
+  return launch_gauss_latent_fwd(heads, eps_in, (const unsigned long long*)rng, eps_out, z, B, L, (hipStream_t)stream, head_slices,
+                                 slices, head_bias);
 }
 
 int ctvae_gauss_latent_backward(const float* g_mu, const float* g_logvar, const float* g_z, const float* heads, const float* eps,
-                                float* g_heads, uint64_t* rng_bump, int B, int L, void* stream) {
-  return launch_gauss_latent_bwd(g_mu, g_logvar, g_z, heads, eps, g_heads, (unsigned long long*)rng_bump, B, L, (hipStream_t)stream);
+                                float* g_heads, uint64_t* rng_bump, int B, int L, int g_z_slices, void* stream) {
+  return launch_gauss_latent_bwd(g_mu, g_logvar, g_z, heads, eps, g_heads, (unsigned long long*)rng_bump, B, L, (hipStream_t)stream,
+                                 g_z_slices);
+}
+
+int ctvae_splitk_permute(const float* slices, int n_slices, float* out, int B, int C, int P, void* stream) {
+  return launch_splitk_permute(slices, n_slices, out, B, C, P, (hipStream_t)stream);
+}
+
+int ctvae_conv_forward_lazy_slices(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
+                                   size_t ws_bytes) {
+  if (!conv_kind_ok(kind)) return 0;
+  ConvGeom g;
+  if (conv_geom(g, kind, 0, B, H, W, Ci, Co, k, stride, pad, out_pad)) return 0;
+  const size_t wsf = ws_bytes / sizeof(float);
+  if (img_enc_supported(g) || img_conv_supported(g) || upconv_wgrad_supported(g) || (wino_enabled() && wino_supported(g, wsf))) return 0;
+  TapGemmPlan pl;
+  tapgemm_plan(g, wsf, pl);
+  return (pl.thin || pl.splitk <= 1) ? 0 : pl.splitk;
+}
+
+int ctvae_conv_forward_lazy(int kind, const float* x, const float* w, float* y_slices, int B, int H, int W, int Ci, int Co, int k,
+                            int stride, int pad, int out_pad, float* ws, size_t ws_bytes, void* stream) {
+  if (!x || !w || !y_slices || !ws || !conv_kind_ok(kind)) return kErrBadArg;
+  ConvGeom g;
+  if (conv_geom(g, kind, 0, B, H, W, Ci, Co, k, stride, pad, out_pad)) return kErrBadArg;
+  SplitKRaw raw{y_slices, 0, 1};
+  const int rc = launch_tapgemm(g, x, w, nullptr, nullptr, nullptr, 0, nullptr, ACT_NONE, nullptr, ws, ws_bytes / sizeof(float),
+                                (hipStream_t)stream, nullptr, nullptr, nullptr, &raw);
+  if (rc) return rc;
+  return raw.splitk > 1 ? 0 : kErrBadArg;   // the caller asked ctvae_conv_forward_lazy_slices first
 }
 
 int ctvae_ct_reg_forward(const float* adj, const float* graph, const float* uniform, float* part4, float ckl, float cgs, float cpt,

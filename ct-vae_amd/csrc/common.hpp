@@ -106,6 +106,8 @@ struct BnBwdFuse {
 struct SplitKRaw {
   float* part;
   int splitk;
+  int pixel_major = 0;   // 1: the ordinary layout part[S][R][N] (pixel rows as in the output tensor) -- for element-wise consumers
+                         // that sum the slices while they read their operand (gauss_latent_*, splitk_permute_kernel)
 };
 
 // r' = cls * Mc + m (m = (b, qy, qx) of a ConvGeom's class grid) -> pixel index in the scattered tensor [B][sH][sW]

@@ -106,9 +106,13 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
   o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
 
-__global__ __launch_bounds__(256) void gauss_latent_fwd_kernel(const float* __restrict__ heads, const float* __restrict__ eps_in,
+// slices != nullptr: the heads are still S raw split-K slices [S][B][2L] of the fc_mu | fc_var GEMM (SplitKRaw, pixel-major):
+// this kernel sums them (+ bias), writes `heads` for the loss / the backward pass and goes on -- the split-K finish launch between
+// the GEMM and the latent disappears
+__global__ __launch_bounds__(256) void gauss_latent_fwd_kernel(float* __restrict__ heads, const float* __restrict__ eps_in,
                                                               const unsigned long long* __restrict__ rng, float* __restrict__ eps_out,
-                                                              float* __restrict__ z, int B, int L) {
+                                                              float* __restrict__ z, int B, int L, const float* __restrict__ slices,
+                                                              int S, const float* __restrict__ bias) {
   const int q = blockIdx.x * 256 + threadIdx.x;          // one thread = four consecutive elements (L % 4 == 0)
   const int i = 4 * q;
   if (i >= B * L) return;
@@ -129,8 +133,34 @@ __global__ __launch_bounds__(256) void gauss_latent_fwd_kernel(const float* __re
     __sincosf(6.28318530718f * u3, &s1, &c1);
     e = f32x4{r0 * c0, r0 * s0, r1 * c1, r1 * s1};
   }
-  const f32x4 mu = *reinterpret_cast<const f32x4*>(heads + (long)b * 2 * L + d);
-  const f32x4 lv = *reinterpret_cast<const f32x4*>(heads + (long)b * 2 * L + L + d);
+  f32x4 mu, lv;
+  if (slices != nullptr) {
+    const long o = (long)b * 2 * L + d, st = (long)B * 2 * L;
+    mu = f32x4{0.f, 0.f, 0.f, 0.f};
+    lv = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < S; s0 += 8) {   // eight slices of loads in flight (a slice index beyond S re-reads the last one, weight 0)
+      f32x4 tm[8], tl[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long so = (long)(s0 + u < S ? s0 + u : S - 1) * st + o;
+        tm[u] = *reinterpret_cast<const f32x4*>(slices + so);
+        tl[u] = *reinterpret_cast<const f32x4*>(slices + so + L);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (s0 + u < S) { mu += tm[u]; lv += tl[u]; }
+      }
+    }
+    if (bias != nullptr) {
+      mu += *reinterpret_cast<const f32x4*>(bias + d);
+      lv += *reinterpret_cast<const f32x4*>(bias + L + d);
+    }
+    *reinterpret_cast<f32x4*>(heads + o) = mu;
+    *reinterpret_cast<f32x4*>(heads + o + L) = lv;
+  } else {
+    mu = *reinterpret_cast<const f32x4*>(heads + (long)b * 2 * L + d);
+    lv = *reinterpret_cast<const f32x4*>(heads + (long)b * 2 * L + L + d);
+  }
   f32x4 zz;
 #pragma unroll
   for (int k = 0; k < 4; ++k) zz[k] = e[k] * expf(0.5f * lv[k]) + mu[k];
@@ -141,13 +171,26 @@ __global__ __launch_bounds__(256) void gauss_latent_fwd_kernel(const float* __re
 __global__ __launch_bounds__(256) void gauss_latent_bwd_kernel(const float* __restrict__ g_mu, const float* __restrict__ g_lv,
                                                               const float* __restrict__ g_z, const float* __restrict__ heads,
                                                               const float* __restrict__ eps, float* __restrict__ g_heads,
-                                                              unsigned long long* __restrict__ rng_bump, int B, int L) {
+                                                              unsigned long long* __restrict__ rng_bump, int B, int L, int gz_slices) {
+  // gz_slices > 0: g_z is gz_slices raw split-K slices [S][B][L] of decoder_input's data gradient, summed here
   const int i = 4 * (blockIdx.x * 256 + threadIdx.x);
   if (i == 0 && rng_bump != nullptr) rng_bump[1] += 1ull;
   if (i >= B * L) return;
   const int b = i / L, d = i - b * L;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  const f32x4 gz = g_z ? *reinterpret_cast<const f32x4*>(g_z + i) : zero;
+  f32x4 gz = zero;
+  if (g_z) {
+    const int S = gz_slices > 0 ? gz_slices : 1;
+    for (int s0 = 0; s0 < S; s0 += 8) {   // eight slices of loads in flight
+      f32x4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4*>(g_z + (long)(s0 + u < S ? s0 + u : S - 1) * B * L + i);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (s0 + u < S) gz += t[u];
+      }
+    }
+  }
   const f32x4 gm = g_mu ? *reinterpret_cast<const f32x4*>(g_mu + i) : zero;
   const f32x4 gl = g_lv ? *reinterpret_cast<const f32x4*>(g_lv + i) : zero;
   const f32x4 lv = *reinterpret_cast<const f32x4*>(heads + (long)b * 2 * L + L + d);
@@ -337,21 +380,45 @@ int launch_adam(float* p, const float* g, float* m, float* v, float* state, long
   return 0;
 }
 
-int launch_gauss_latent_fwd(const float* heads, const float* eps_in, const unsigned long long* rng, float* eps_out, float* z, int B,
-                            int L, hipStream_t st) {
-  if (!heads || !eps_out || !z || (!eps_in && !rng) || B <= 0 || L <= 0 || L % 4) return kErrBadArg;
-  ProfScope ps("gauss_latent_fwd_kernel", st, 0.0, 4.0 * 5.0 * B * L);
-  hipLaunchKernelGGL(gauss_latent_fwd_kernel, dim3((B * L / 4 + 255) / 256), dim3(256), 0, st, heads, eps_in, rng, eps_out, z, B, L);
+int launch_gauss_latent_fwd(float* heads, const float* eps_in, const unsigned long long* rng, float* eps_out, float* z, int B,
+                            int L, hipStream_t st, const float* slices, int S, const float* bias) {
+  if (!heads || !eps_out || !z || (!eps_in && !rng) || B <= 0 || L <= 0 || L % 4 || (slices != nullptr && S < 1)) return kErrBadArg;
+  ProfScope ps("gauss_latent_fwd_kernel", st, 0.0, 4.0 * (5.0 + (slices ? 2.0 * S : 0.0)) * B * L);
+  hipLaunchKernelGGL(gauss_latent_fwd_kernel, dim3((B * L / 4 + 255) / 256), dim3(256), 0, st, heads, eps_in, rng, eps_out, z, B, L,
+                     slices, S, bias);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_gauss_latent_bwd(const float* g_mu, const float* g_lv, const float* g_z, const float* heads, const float* eps,
-                            float* g_heads, unsigned long long* rng_bump, int B, int L, hipStream_t st) {
-  if (!heads || !eps || !g_heads || B <= 0 || L <= 0 || L % 4) return kErrBadArg;
-  ProfScope ps("gauss_latent_bwd_kernel", st, 0.0, 4.0 * 7.0 * B * L);
+                            float* g_heads, unsigned long long* rng_bump, int B, int L, hipStream_t st, int gz_slices) {
+  if (!heads || !eps || !g_heads || B <= 0 || L <= 0 || L % 4 || (gz_slices > 0 && !g_z)) return kErrBadArg;
+  ProfScope ps("gauss_latent_bwd_kernel", st, 0.0, 4.0 * (7.0 + (gz_slices > 1 ? gz_slices - 1.0 : 0.0)) * B * L);
   hipLaunchKernelGGL(gauss_latent_bwd_kernel, dim3((B * L / 4 + 255) / 256), dim3(256), 0, st, g_mu, g_lv, g_z, heads, eps, g_heads,
-                     rng_bump, B, L);
+                     rng_bump, B, L, gz_slices);
+  CTVAE_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[b][c][p] (NCHW) = sum_s slices[s][(b*P + p)*C + c]: the split-K finish of a data gradient written NHWC and the
+// NHWC -> NCHW layout change behind it (decoder.0's data gradient in front of decoder_input, vanilla_vae.py:102) as one launch.
+// Tiny tensors ([B,512,2,2]): thread = one output element, reads along c are strided by design.
+__global__ __launch_bounds__(256) void splitk_permute_kernel(const float* __restrict__ slices, int S, float* __restrict__ out, int B,
+                                                            int C, int P) {
+  const long n = (long)B * C * P, i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int p = (int)(i % P), c = (int)((i / P) % C), b = (int)(i / ((long)P * C));
+  const long src = ((long)b * P + p) * C + c;
+  float v = slices[src];
+  for (int s = 1; s < S; ++s) v += slices[(long)s * n + src];
+  out[i] = v;
+}
+
+int launch_splitk_permute(const float* slices, int S, float* out, int B, int C, int P, hipStream_t st) {
+  if (!slices || !out || S < 1 || B <= 0 || C <= 0 || P <= 0) return kErrBadArg;
+  const long n = (long)B * C * P;
+  ProfScope ps("splitk_permute_kernel", st, 0.0, 4.0 * (S + 1.0) * n);
+  hipLaunchKernelGGL(splitk_permute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slices, S, out, B, C, P);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }

@@ -700,11 +700,11 @@ int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const floa
   a.part = ws;
   // the consumer sums the slices itself: channel-major raw partials in its buffer, no finishing launch
   // (bias / activation are then the consumer's job as well: they are NOT applied to the raw slices)
-  const bool raw_T = raw != nullptr && raw->part != nullptr && plan.splitk > 1 && avec && bvec && a.Mc % 4 == 0 &&
+  const bool raw_T = raw != nullptr && raw->part != nullptr && plan.splitk > 1 && avec && bvec && (raw->pixel_major || a.Mc % 4 == 0) &&
                      add == nullptr && mask == nullptr;
   if (raw_T) {
     a.part = raw->part;
-    a.part_T = 1;
+    a.part_T = raw->pixel_major ? 0 : 1;
   }
 
   if (plan.splitk > 1 && bn_part != nullptr) return kErrBadArg;  // caller must take BN statistics from S instead

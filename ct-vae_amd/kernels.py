@@ -294,6 +294,33 @@ def claim_out_act_link(t):
     return link
 
 
+# Gradients handed on as raw split-K slices (pixel-major) to an element-wise consumer that sums them while it reads: the producer
+# (conv_backward_raw, asked by a layer whose input tensor carries ``_ctvae_grad_slices_ok``) registers the placeholder it returns,
+# the consumer's backward (GaussianLatent, _ToNHWC) claims it.  The tag is a promise of model code that the tensor's gradient goes
+# to that consumer and nowhere else: the placeholder is never written.
+_lazy_grads = {}
+
+
+def offer_lazy_grad(g, slices, n):
+    if len(_lazy_grads) > 16:
+        _lazy_grads.clear()
+    _lazy_grads[g.data_ptr()] = (slices, n, g._version, g.numel())
+
+
+def claim_lazy_grad(g):
+    """(slices, n) if ``g`` is a registered, untouched placeholder, else None."""
+    e = _lazy_grads.pop(g.data_ptr(), None)
+    if e is None or e[2] != g._version or e[3] != g.numel():
+        return None
+    return e[0], e[1]
+
+
+def grad_slices_ok(t):
+    """Model code: the gradient w.r.t. ``t`` is consumed by ONE backward that can sum split-K slices (see _lazy_grads)."""
+    t._ctvae_grad_slices_ok = True
+    return t
+
+
 _last_act_link = None  # set by ConvAct.forward (fused activation), picked up by the caller of .apply right after
 
 
@@ -304,6 +331,15 @@ def pop_act_link():
 
 
 _last_link = None     # set by ConvBNAct.forward, picked up by the caller of .apply (models/blocks.py) right after
+_last_fwd_slices = None   # set by ConvAct.forward(lazy_slices=True): (slices, n, bias) of the placeholder it returned
+
+
+def pop_fwd_slices():
+    global _last_fwd_slices
+    fs, _last_fwd_slices = _last_fwd_slices, None
+    return fs
+
+
 _last_lazy = None     # set by ConvBNAct.forward(lazy_out=True): (scale | shift [2][C], activation) of the tensor it returned
 
 
@@ -413,13 +449,14 @@ _OUT_ACT_LINK = os.environ.get("CTVAE_NO_OUT_ACT_LINK", "0") != "1"   # diagnost
 # layers finalize in their own apply launch and their consumers' slab reductions leave the chain -- 1.5992 / 1.5986 ms against
 # 1.5996 / 1.5988 ms (VanillaVAE bs = 256, same box): neutral, the one deferred launch grows by what the three removed ones took
 _BN_BWD_MERGE_ROWS = int(os.environ.get("CTVAE_BN_BWD_MERGE_ROWS", "0"))
+_GRAD_SLICES = os.environ.get("CTVAE_NO_GRAD_SLICES", "0") != "1"   # diagnostic: every split-K result is summed by its own finish launch
 _LAZY_BN = os.environ.get("CTVAE_NO_LAZY_BN_APPLY", "0") != "1"   # diagnostic: every BatchNorm + activation output is materialised
 _BN_LAZY = os.environ.get("CTVAE_NO_BN_LAZY", "0") != "1"     # diagnostic: small layers' data gradients summed by splitk_finish as before
 _ENC_BN_ON_LOAD = os.environ.get("CTVAE_NO_ENC_BN_ON_LOAD", "0") != "1"   # diagnostic: encoder.0's BatchNorm-backward apply as its own launch
 
 
 def conv_backward_raw(x, dy, w_param, b_param, spec: ConvSpec, link=None, mask=None, mask_act=ACT_NONE, wino_filters=None,
-                      in_coef=None, in_act=ACT_NONE, dy_bn=None, bn_commit=None):
+                      in_coef=None, in_act=ACT_NONE, dy_bn=None, bn_commit=None, grad_slices=False):
     """ctvae_conv_backward: weight (+bias) gradient into ``.grad`` and the data gradient of one layer in one call (the
     two GEMMs share a launch when both run their 64x64 tile kernels).  ``link``: BNLink of the layer that produced x --
     its BatchNorm-backward sums come out of the data gradient's epilogues and its finalize rides in this call's finishing
@@ -445,15 +482,30 @@ def conv_backward_raw(x, dy, w_param, b_param, spec: ConvSpec, link=None, mask=N
         key = (spec.kind, B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, ws.numel(), "lazy")
         n = _bn_rows_cache.get(key)
         if n is None:
-            n = _bn_rows_cache[key] = native.load().ctvae_conv_backward_lazy_slices(*key[:-2], ws.numel() * 4)
+            n = _bn_rows_cache[key] = native.load().ctvae_conv_backward_lazy_slices(*key[:-2], 1, ws.numel() * 4)
         if n > 1:
             # small layer: the data gradient stays n raw split-K slices, summed by the BatchNorm's own backward launch
             slices = torch.empty(n * B * H * W * spec.ci, dtype=torch.float32, device=dy.device)
             native.call("ctvae_conv_backward_lazy", spec.kind, x.data_ptr(), dy.data_ptr(), w_param.data_ptr(), gw.data_ptr(),
                         native.ptr(gb), slices.data_ptr(), B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad,
                         acc, in_coef.data_ptr() if in_coef is not None else None,
-                        in_coef.data_ptr() + 4 * spec.ci if in_coef is not None else None, in_act, ws.data_ptr(), ws.numel() * 4)
+                        in_coef.data_ptr() + 4 * spec.ci if in_coef is not None else None, in_act, 0, ws.data_ptr(), ws.numel() * 4)
             link.publish_lazy(dx, slices, n, key[:10])
+            return dx
+    if (grad_slices and _GRAD_SLICES and link is None and mask is None and wino_filters is None and dy_bn is None
+            and bn_commit is None):
+        key = (spec.kind, B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, ws.numel(), "slices")
+        n = _bn_rows_cache.get(key)
+        if n is None:
+            n = _bn_rows_cache[key] = native.load().ctvae_conv_backward_lazy_slices(*key[:-2], 0, ws.numel() * 4)
+        if n > 1:
+            # the consumer of this gradient sums split-K slices itself (offer_lazy_grad): no finish launch, dx is a placeholder
+            slices = torch.empty(n * B * H * W * spec.ci, dtype=torch.float32, device=dy.device)
+            native.call("ctvae_conv_backward_lazy", spec.kind, x.data_ptr(), dy.data_ptr(), w_param.data_ptr(), gw.data_ptr(),
+                        native.ptr(gb), slices.data_ptr(), B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad,
+                        acc, in_coef.data_ptr() if in_coef is not None else None,
+                        in_coef.data_ptr() + 4 * spec.ci if in_coef is not None else None, in_act, 1, ws.data_ptr(), ws.numel() * 4)
+            offer_lazy_grad(dx, slices, n)
             return dx
     if link is not None and tuple(link.y.shape) == (B, H, W, spec.ci):
         key = (spec.kind, B, H, W, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, -ws.numel())
@@ -486,14 +538,16 @@ def conv_backward_raw(x, dy, w_param, b_param, spec: ConvSpec, link=None, mask=N
     return dx
 
 
-def wgrad_then_dgrad(x, g, w_param, b_param, spec, need_dgrad, link=None, wino_filters=None, in_coef=None, in_act=ACT_NONE):
+def wgrad_then_dgrad(x, g, w_param, b_param, spec, need_dgrad, link=None, wino_filters=None, in_coef=None, in_act=ACT_NONE,
+                     grad_slices=False):
     """Weight gradient (accumulated straight into ``.grad``) and data gradient of one layer, on the launch stream.
     Measured on MI355X: putting the wgrad kernels on a second HIP stream (joined right after dgrad, or once at the
     end of backward) is SLOWER than back-to-back launches (2.43 vs 2.32 ms/step) -- each GEMM launch already covers
     every CU, and the fork/join edges cost more than the overlap of prologue/epilogue phases returns.  What does pay is
     ONE launch for both GEMMs (ctvae_conv_backward / conv_bwd_pair_kernel)."""
     if need_dgrad and _PAIR:
-        return conv_backward_raw(x, g, w_param, b_param, spec, link=link, wino_filters=wino_filters, in_coef=in_coef, in_act=in_act)
+        return conv_backward_raw(x, g, w_param, b_param, spec, link=link, wino_filters=wino_filters, in_coef=in_coef, in_act=in_act,
+                                 grad_slices=grad_slices)
     conv_wgrad_raw(x, g, w_param, b_param, spec, in_coef=in_coef, in_act=in_act)
     if not need_dgrad:
         return None
@@ -533,6 +587,12 @@ class _ToNHWC(Function):
     @staticmethod
     def backward(ctx, g):
         B, C, H, W = ctx.dims
+        lazy = claim_lazy_grad(g) if g.is_contiguous() else None
+        if lazy is not None:
+            # the gradient arrives as split-K slices of the consumer's data gradient: summed while the layout changes
+            out = torch.empty((B, C, H, W), dtype=torch.float32, device=g.device)
+            native.call("ctvae_splitk_permute", lazy[0].data_ptr(), lazy[1], out.data_ptr(), B, C, H * W)
+            return out
         return permute_raw(_c(g), B, C, H * W, False).view(B, C, H, W)
 
 
@@ -640,7 +700,7 @@ def _with_aux(x, aux, fn):
 _flat_specs = {}
 
 
-def flatten_linear(h, w, b, out_features):
+def flatten_linear(h, w, b, out_features, lazy_slices=False):
     """nn.Linear(C*k*k, out_features) applied to torch.flatten(h_nchw, start_dim=1), for the NHWC tensor h [B,k,k,C] -> [B, out]
     (vanilla_vae.py:87-91 and every model built on that encoder).  k = 2 with 32-aligned widths: a 2x2 stride-2 convolution
     straight on the NHWC tensor over the Linear layer's own [in][out] block (CONV_FLAT) -- no layout copies, and the data
@@ -656,6 +716,14 @@ def flatten_linear(h, w, b, out_features):
             spec = ConvSpec(CONV, C * k * k2, out_features, 1)
         _flat_specs[key] = spec
     if spec.kind == CONV_FLAT:
+        if lazy_slices:
+            # the caller hands the result to GaussianLatent only, which sums the GEMM's split-K slices itself
+            y = ConvAct.apply(h, w, b, None, spec, None, True)
+            fs = pop_fwd_slices()
+            out = y.view(B, -1)
+            if fs is not None:
+                out._ctvae_fwd_slices = fs
+            return out
         return ConvAct.apply(h, w, b, None, spec).view(B, -1)
     flat = _ToNCHW.apply(h).view(B, 1, 1, -1)
     return ConvAct.apply(flat, w, b, None, spec).view(B, -1)
@@ -665,11 +733,34 @@ class ConvAct(Function):
     """y = act(conv(x, w) + b + add).  Conv2d/ConvTranspose2d/Linear forward, dgrad and wgrad on HIP."""
 
     @staticmethod
-    def forward(ctx, x, w, b, add, spec, aux=None):
-        """aux: companion rows (see above); returns (y, y_aux) then."""
-        global _last_act_link
+    def forward(ctx, x, w, b, add, spec, aux=None, lazy_slices=False):
+        """aux: companion rows (see above); returns (y, y_aux) then.  lazy_slices (model code: the ONE consumer of y sums split-K
+        slices itself, e.g. GaussianLatent): where the launch splits K, y is an unwritten placeholder and the raw slices (no bias)
+        wait in kernels.pop_fwd_slices() for the caller to hang on it."""
+        global _last_act_link, _last_fwd_slices
         _req_cuda(x, w)
         ctx.link_in = link_of(x)
+        ctx.x_slices_ok = bool(getattr(x, "_ctvae_grad_slices_ok", False))
+        if lazy_slices and _GRAD_SLICES and aux is None and add is None and spec.act == ACT_NONE and x.is_contiguous():
+            B, H, W_, _ = x.shape
+            ws = native.workspace(x.device)
+            key = (spec.kind, B, H, W_, spec.ci, spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, ws.numel(), "fwd-slices")
+            n = _bn_rows_cache.get(key)
+            if n is None:
+                n = _bn_rows_cache[key] = native.load().ctvae_conv_forward_lazy_slices(*key[:10], ws.numel() * 4)
+            if n > 1:
+                ho, wo = spec.out_hw(H, W_)
+                y = torch.empty((B, ho, wo, spec.co), dtype=torch.float32, device=x.device)
+                slices = torch.empty(n * y.numel(), dtype=torch.float32, device=x.device)
+                native.call("ctvae_conv_forward_lazy", spec.kind, x.data_ptr(), w.data_ptr(), slices.data_ptr(), B, H, W_, spec.ci,
+                            spec.co, spec.k, spec.stride, spec.pad, spec.out_pad, ws.data_ptr(), ws.numel() * 4)
+                ctx.act_in = getattr(x, "_ctvae_act_link", None)
+                ctx.act_out = None
+                ctx.wino_u = None
+                ctx.spec, ctx.w, ctx.b, ctx.has_add = spec, w, b, False
+                ctx.save_for_backward(x, None)
+                _last_fwd_slices = (slices, n, b)
+                return y
         ctx.act_in = getattr(x, "_ctvae_act_link", None) if x.is_contiguous() else None
         ctx.act_out = _last_act_link = ActLink(spec.act) if spec.act != ACT_NONE else None
         x = _c(x)
@@ -704,7 +795,7 @@ class ConvAct(Function):
     @staticmethod
     def backward(ctx, g_y, *_g_aux):
         if g_y is None:
-            return (None,) * 6
+            return (None,) * 7
         spec = ctx.spec
         x, y = ctx.saved_tensors
         g_y = _c(g_y)
@@ -721,9 +812,10 @@ class ConvAct(Function):
                 g_x = conv_dgrad_raw(g_pre, ctx.w, spec, (x.shape[1], x.shape[2]), mask=x, mask_act=ctx.act_in.act)
             ctx.act_in.publish_done(g_x)
         else:
-            g_x = wgrad_then_dgrad(x, g_pre, ctx.w, ctx.b, spec, ctx.needs_input_grad[0], ctx.link_in, ctx.wino_u)
+            g_x = wgrad_then_dgrad(x, g_pre, ctx.w, ctx.b, spec, ctx.needs_input_grad[0], ctx.link_in, ctx.wino_u,
+                                   grad_slices=ctx.x_slices_ok)
         g_add = g_pre if (ctx.has_add and ctx.needs_input_grad[3]) else None
-        return g_x, None, None, g_add, None, None
+        return g_x, None, None, g_add, None, None, None
 
 
 class ResBlock(Function):
@@ -794,6 +886,7 @@ class ConvBNAct(Function):
         global _last_link
         _req_cuda(x, w, gamma)
         ctx.link_in = link_of(x)
+        ctx.x_slices_ok = bool(getattr(x, "_ctvae_grad_slices_ok", False))
         lazy_in = getattr(x, "_ctvae_lazy_bn", None) if x.is_contiguous() else None
         x = _c(x)
         B, H, W, _ = x.shape
@@ -847,7 +940,8 @@ class ConvBNAct(Function):
             native.call("ctvae_bn_backward_fused", lazy[0].data_ptr(), lazy[1], *lazy[2], y.data_ptr(), gamma.data_ptr(),
                         beta.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(), ctx.bn_act, g_y.data_ptr(), gg.data_ptr(),
                         gbt.data_ptr(), accg)
-            g_x = wgrad_then_dgrad(x, g_y, w, b, spec, ctx.needs_input_grad[0], ctx.link_in, in_coef=in_coef, in_act=in_act)
+            g_x = wgrad_then_dgrad(x, g_y, w, b, spec, ctx.needs_input_grad[0], ctx.link_in, in_coef=in_coef, in_act=in_act,
+                                   grad_slices=ctx.x_slices_ok)
             return (g_x,) + (None,) * 11
         part, rows, coef = ctx.link_out.take(g_a) if ctx.link_out is not None else (None, 0, None)
         if coef is not None:
@@ -861,7 +955,8 @@ class ConvBNAct(Function):
         native.call("ctvae_bn_backward", g_a.data_ptr(), beta.data_ptr(), y.data_ptr(), B * H * W, C, gamma.data_ptr(),
                     save_mean.data_ptr(), save_invstd.data_ptr(), ctx.bn_act, g_y.data_ptr(), gg.data_ptr(), gbt.data_ptr(),
                     accg, native.ptr(part), rows, None, native.ptr(coef), ws.data_ptr(), ws.numel() * 4)
-        g_x = wgrad_then_dgrad(x, g_y, w, b, spec, ctx.needs_input_grad[0], ctx.link_in, in_coef=in_coef, in_act=in_act)
+        g_x = wgrad_then_dgrad(x, g_y, w, b, spec, ctx.needs_input_grad[0], ctx.link_in, in_coef=in_coef, in_act=in_act,
+                               grad_slices=ctx.x_slices_ok)
         return (g_x,) + (None,) * 11
 
 
@@ -1095,6 +1190,7 @@ class GaussianLatent(Function):
     @staticmethod
     def forward(ctx, heads, eps, rng):
         _req_cuda(heads)
+        fs = getattr(heads, "_ctvae_fwd_slices", None) if heads.is_contiguous() else None   # (slices, n, bias): heads not written yet
         heads = _c(heads)
         B, L2 = heads.shape
         L = L2 // 2
@@ -1104,7 +1200,8 @@ class GaussianLatent(Function):
         eps_out = torch.empty((B, L), dtype=torch.float32, device=heads.device)
         z = torch.empty((B, L), dtype=torch.float32, device=heads.device)
         native.call("ctvae_gauss_latent_forward", heads.data_ptr(), native.ptr(eps_in), native.ptr(rng) if eps_in is None else None,
-                    eps_out.data_ptr(), z.data_ptr(), B, L)
+                    eps_out.data_ptr(), z.data_ptr(), B, L, fs[0].data_ptr() if fs else None, fs[1] if fs else 0,
+                    native.ptr(fs[2]) if fs else None)
         ctx.save_for_backward(heads, eps_out)
         ctx.rng = rng if eps_in is None else None
         ctx.set_materialize_grads(False)
@@ -1116,10 +1213,11 @@ class GaussianLatent(Function):
         B, L2 = heads.shape
         g_mu = _c(g_mu) if g_mu is not None else None
         g_lv = _c(g_lv) if g_lv is not None else None
+        lazy = claim_lazy_grad(g_z) if (g_z is not None and g_z.is_contiguous()) else None
         g_z = _c(g_z) if g_z is not None else None
         g_heads = torch.empty_like(heads)
-        native.call("ctvae_gauss_latent_backward", native.ptr(g_mu), native.ptr(g_lv), native.ptr(g_z), heads.data_ptr(), eps.data_ptr(),
-                    g_heads.data_ptr(), native.ptr(ctx.rng), B, L2 // 2)
+        native.call("ctvae_gauss_latent_backward", native.ptr(g_mu), native.ptr(g_lv), lazy[0].data_ptr() if lazy else native.ptr(g_z),
+                    heads.data_ptr(), eps.data_ptr(), g_heads.data_ptr(), native.ptr(ctx.rng), B, L2 // 2, lazy[1] if lazy else 0)
         return g_heads, None, None
 
 

@@ -100,14 +100,15 @@ class VanillaVAE(BaseVAE):
         return K.to_nhwc(input)
 
     # -- reference API ----------------------------------------------------------------------------
-    def _encode_heads(self, input: Tensor) -> Tensor:
-        """[B,C,64,64] -> [B, 2L]: fc_mu | fc_var of the flattened encoder output as one GEMM."""
+    def _encode_heads(self, input: Tensor, for_latent_node: bool = False) -> Tensor:
+        """[B,C,64,64] -> [B, 2L]: fc_mu | fc_var of the flattened encoder output as one GEMM.  for_latent_node: the result goes to
+        kernels.GaussianLatent and nowhere else, which may then receive the GEMM's split-K slices instead of the summed tensor."""
         self.attach_grads()
         h = K.mark_sole_consumer(self.encoder(self._input_nhwc(input)))   # [B,2,2,512] NHWC, read by the heads only
         if tuple(h.shape[1:3]) != (2, 2):
             raise RuntimeError("VanillaVAE: fc_mu / fc_var take hidden_dims[-1]*4 features, i.e. a 2x2 encoder output "
                                "(64x64 input through 5 stride-2 layers, vanilla_vae.py:36-37)")
-        return K.flatten_linear(h, self.fc_mu.weight, self.fc_mu.bias, 2 * self.latent_dim)
+        return K.flatten_linear(h, self.fc_mu.weight, self.fc_mu.bias, 2 * self.latent_dim, lazy_slices=for_latent_node)
 
     def encode(self, input: Tensor) -> List[Tensor]:
         """[B,C,64,64] -> [mu [B,L], log_var [B,L]] (vanilla_vae.py:77-92)."""
@@ -118,8 +119,11 @@ class VanillaVAE(BaseVAE):
         """[B,L] -> [B,3,64,64] (vanilla_vae.py:94-105)."""
         self.attach_grads()
         B = z.shape[0]
-        h = K.ConvAct.apply(z.reshape(B, 1, 1, -1), self.decoder_input.weight, self.decoder_input.bias, None, self._dec_in_spec)
-        h = K._ToNHWC.apply(h.view(B, 512, 2, 2))                        # .view(-1,512,2,2) is NCHW
+        zr = z.reshape(B, 1, 1, -1)
+        if getattr(z, "_ctvae_grad_slices_ok", False):
+            K.grad_slices_ok(zr)
+        h = K.ConvAct.apply(zr, self.decoder_input.weight, self.decoder_input.bias, None, self._dec_in_spec)
+        h = K.grad_slices_ok(K._ToNHWC.apply(h.view(B, 512, 2, 2)))      # .view(-1,512,2,2) is NCHW; read by decoder.0 only
         h = self.decoder(h, last_reader=self.final_layer)                # read by final_layer only (marked by the chain)
         return K.to_nchw_view(self.final_layer(h))
 
@@ -140,12 +144,14 @@ class VanillaVAE(BaseVAE):
     def forward(self, input: Tensor, eps: Tensor = None, **kwargs) -> List[Tensor]:
         """encode -> reparameterize -> decode (vanilla_vae.py:119-122).  The latent section runs as one node
         (kernels.GaussianLatent): with eps None and gradients on, the N(0,1) noise is drawn inside its kernel."""
-        heads = self._encode_heads(input)
-        if self.latent_dim % 4 == 0 and type(self).reparameterize is VanillaVAE.reparameterize:
+        one_node = self.latent_dim % 4 == 0 and type(self).reparameterize is VanillaVAE.reparameterize
+        heads = self._encode_heads(input, for_latent_node=one_node)
+        if one_node:
             if eps is None and not (torch.is_grad_enabled() and heads.requires_grad):
                 eps = torch.randn((heads.shape[0], self.latent_dim), dtype=heads.dtype, device=heads.device)   # no backward: no state bump
             rng = self._latent_rng(heads.device) if eps is None else None
             mu, log_var, z = K.GaussianLatent.apply(heads, eps.to(heads.device) if eps is not None else None, rng)
+            K.grad_slices_ok(z)          # z's gradient comes back to that node only (decode below is its one consumer)
         else:
             mu, log_var = K.SplitHeads.apply(heads, self.latent_dim)
             z = self.reparameterize(mu, log_var, eps)

@@ -25,7 +25,7 @@ SIGNATURES = {
     "ctvae_conv_wgrad": [_i, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _fp, _i, _fp, _sz, _vp],
     "ctvae_conv_backward": [_i, _fp, _fp, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _i,
                             _fp, _fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _sz, _vp],
-    "ctvae_conv_backward_lazy": [_i, _fp, _fp, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _fp, _i, _fp, _sz, _vp],
+    "ctvae_conv_backward_lazy": [_i, _fp, _fp, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _fp, _i, _i, _fp, _sz, _vp],
     "ctvae_bn_backward_fused": [_fp, _i] + [_i] * 10 + [_fp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _vp],
     "ctvae_bn_forward": [_fp, _i, _i, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _fp, _fp, _fp, _fp, _fp, _sz, _vp],
     "ctvae_bn_backward": [_fp, _fp, _fp, _i, _i, _fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _fp, _i, _fp, _fp, _fp, _sz, _vp],
@@ -60,8 +60,10 @@ SIGNATURES = {
     "ctvae_pair_mlp_backward": [_fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _f, _i, _fp, _vp],
     "ctvae_act_forward": [_fp, _fp, _l, _i, _vp],
     "ctvae_act_backward": [_fp, _fp, _fp, _l, _i, _vp],
-    "ctvae_gauss_latent_forward": [_fp, _fp, _fp, _fp, _fp, _i, _i, _vp],
-    "ctvae_gauss_latent_backward": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _vp],
+    "ctvae_gauss_latent_forward": [_fp, _fp, _fp, _fp, _fp, _i, _i, _fp, _i, _fp, _vp],
+    "ctvae_gauss_latent_backward": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _vp],
+    "ctvae_conv_forward_lazy": [_i, _fp, _fp, _fp] + [_i] * 9 + [_fp, _sz, _vp],
+    "ctvae_splitk_permute": [_fp, _i, _fp, _i, _i, _i, _vp],
     "ctvae_reparam_forward": [_fp, _l, _fp, _l, _fp, _fp, _i, _i, _vp],
     "ctvae_reparam_backward": [_fp, _fp, _l, _fp, _fp, _fp, _i, _i, _vp],
     "ctvae_loss_forward": [_fp, _fp, _l, _fp, _l, _fp, _l, _i, _i, _f, _fp, _fp, _fp, _sz, _vp],
@@ -117,6 +119,7 @@ _RESTYPES = {
     "ctvae_conv_dgrad_bn_rows": _c.c_int,
     "ctvae_conv_backward_bn_rows": _c.c_int,
     "ctvae_conv_backward_lazy_slices": _c.c_int,
+    "ctvae_conv_forward_lazy_slices": _c.c_int,
     "ctvae_conv_bn_act_apply_is_separate": _c.c_int,
     "ctvae_winograd_enable": _c.c_int,
     "ctvae_conv_wino_filter_floats": _c.c_size_t,
@@ -161,7 +164,8 @@ def load():
                        "ctvae_prof_report": [_c.c_char_p, _c.c_size_t],
                        "ctvae_conv_dgrad_bn_rows": [_c.c_int] * 10 + [_c.c_size_t],
                        "ctvae_conv_backward_bn_rows": [_c.c_int] * 10 + [_c.c_size_t],
-                       "ctvae_conv_backward_lazy_slices": [_c.c_int] * 10 + [_c.c_size_t],
+                       "ctvae_conv_backward_lazy_slices": [_c.c_int] * 11 + [_c.c_size_t],
+                       "ctvae_conv_forward_lazy_slices": [_c.c_int] * 10 + [_c.c_size_t],
                        "ctvae_conv_bn_act_apply_is_separate": [_c.c_int] * 10 + [_c.c_size_t],
                        "ctvae_winograd_enable": [_c.c_int],
                        "ctvae_dip_state_floats": [_c.c_int, _c.c_int],

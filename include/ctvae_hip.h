@@ -151,7 +151,9 @@ int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* 
  * data gradient runs split-K and its consumer is that BatchNorm's backward pass, so the slices are never summed into a tensor of
  * their own.  ctvae_conv_backward_lazy_slices: the number S (>= 2) of K slices such a call would produce for this geometry and
  * workspace, or 0 when this form does not apply (unsplit / Winograd / picture-side data gradient, or a tensor beyond the few MB
- * the channel-owner kernel pays for).  ctvae_conv_backward_lazy: weight (+ bias) gradient as ctvae_conv_backward (in_scale /
+ * the channel-owner kernel pays for; for_bn = 0 drops that size condition -- any split data gradient -- for consumers that take
+ * the slices pixel-major, see ctvae_gauss_latent_backward / ctvae_splitk_permute).  ctvae_conv_backward_lazy (pixel_major = 0
+ * for the BatchNorm consumer): weight (+ bias) gradient as ctvae_conv_backward (in_scale /
  * in_shift / in_act: its x operand read through the previous block's BatchNorm + activation, as there), and the data
  * gradient's raw slices, CHANNEL-MAJOR, in dx_slices [S][Ci][B*H*W] (no mask, no BatchNorm sums, dx itself is not written;
  * the rows of a slice are in the data gradient's class-major order, not pixel order).
@@ -161,10 +163,11 @@ int ctvae_conv_backward(int kind, const float* x, const float* dy, const float* 
  * Replaces split-K finish + ctvae_bn_backward's partial / finalize / apply launches (reference: autograd of
  * nn.BatchNorm2d + nn.LeakyReLU). */
 int ctvae_conv_backward_lazy_slices(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
-                                    size_t ws_bytes);
+                                    int for_bn, size_t ws_bytes);
 int ctvae_conv_backward_lazy(int kind, const float* x, const float* dy, const float* w, float* dw, float* dbias, float* dx_slices,
                              int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int accumulate,
-                             const float* in_scale, const float* in_shift, int in_act, float* ws, size_t ws_bytes, void* stream);
+                             const float* in_scale, const float* in_shift, int in_act, int pixel_major, float* ws, size_t ws_bytes,
+                             void* stream);
 int ctvae_bn_backward_fused(const float* g_a_slices, int slices, int kind, int B, int H, int W, int Ci, int Co, int k, int stride,
                             int pad, int out_pad, const float* y, const float* gamma, const float* beta, const float* save_mean,
                             const float* save_invstd, int act, float* g_y, float* dgamma, float* dbeta, int accumulate, void* stream);
@@ -344,10 +347,23 @@ int ctvae_act_backward(const float* g_out, const float* out, float* g_in, long n
  * the kernel (Philox4x32-10 keyed by rng[0], stream position rng[1]; rng: two uint64 on the device) -- eps_out [B,L] keeps it
  * for backward.  backward: g_heads [B][2L] = (g_mu + g_z | g_logvar + g_z*eps*0.5*exp(0.5*logvar)) in one launch (any of the
  * three incoming gradients may be NULL = 0); rng_bump != NULL advances rng[1] by one (pass it when eps was drawn in forward). */
-int ctvae_gauss_latent_forward(const float* heads, const float* eps_in, const uint64_t* rng, float* eps_out, float* z, int B, int L,
-                               void* stream);
+int ctvae_gauss_latent_forward(float* heads, const float* eps_in, const uint64_t* rng, float* eps_out, float* z, int B, int L,
+                               const float* head_slices, int slices, const float* head_bias, void* stream);
 int ctvae_gauss_latent_backward(const float* g_mu, const float* g_logvar, const float* g_z, const float* heads, const float* eps,
-                                float* g_heads, uint64_t* rng_bump, int B, int L, void* stream);
+                                float* g_heads, uint64_t* rng_bump, int B, int L, int g_z_slices, void* stream);
+/* Split-K results handed to an element-wise consumer as raw slices (the small-batch step: one launch less per hand-over).
+ * head_slices [slices][B][2L] + head_bias [2L] (NULL normally): the fused heads are still the slices of their GEMM
+ * (ctvae_conv_forward_lazy); ctvae_gauss_latent_forward sums them, writes `heads` (then an output) and goes on.
+ * g_z_slices > 0: g_z is that many slices [S][B][L] of decoder_input's data gradient (ctvae_conv_backward_lazy, pixel_major).
+ * ctvae_conv_forward_lazy_slices / ctvae_conv_forward_lazy: the number of K slices a forward conv of this geometry would run
+ * (0: not split / not the general tile kernel) and the launch that leaves them, without bias or activation, in
+ * y_slices [S][B*Ho*Wo][Co].  ctvae_splitk_permute: out[b][c][p] = sum_s slices[s][(b*P+p)*C+c] -- the slice sum of an NHWC
+ * data gradient and the NHWC -> NCHW change behind it (the .view(-1,512,2,2) of vanilla_vae.py:102, backward) in one launch. */
+int ctvae_conv_forward_lazy_slices(int kind, int B, int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad,
+                                   size_t ws_bytes);
+int ctvae_conv_forward_lazy(int kind, const float* x, const float* w, float* y_slices, int B, int H, int W, int Ci, int Co, int k,
+                            int stride, int pad, int out_pad, float* ws, size_t ws_bytes, void* stream);
+int ctvae_splitk_permute(const float* slices, int n_slices, float* out, int B, int C, int P, void* stream);
 /* z = eps*exp(0.5*logvar)+mu (vanilla_vae.py:115-117); mu/logvar rows may be strided (slices of one head GEMM) */
 int ctvae_reparam_forward(const float* mu, long mu_row_stride, const float* logvar, long lv_row_stride, const float* eps,
                           float* z, int B, int L, void* stream);
