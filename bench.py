@@ -84,9 +84,16 @@ def pmc_traffic(kernel_name, workload):
         legacy = "CTMCQVAE bs=128 a12" if "ctmcqvae_a12" in base else "VanillaVAE bs=256"
         if d.get("workload", legacy) != workload:
             continue
-        for k, v in d.get("kernels", {}).items():
+        kern = d.get("kernels", {})
+        for k, v in kern.items():
             if k.replace(" ", "") == want:
                 return v["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+        # the library's profiler names a kernel without the template arguments its variants carry in the trace
+        # (conv_bwd_pair_kernel<false, 1> / <true, 1>): launch-weighted mean over the variants
+        var = [v for k, v in kern.items() if "<" not in want and k.split("<")[0] == want]
+        if var:
+            w = sum(v["launches_per_step"] for v in var)
+            return round(sum(v["hbm_bytes_per_launch"] * v["launches_per_step"] for v in var) / max(w, 1e-9)), os.path.relpath(path, ROOT)
     return None, None
 
 
