@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) 
 // PDA: prefetch depth (chunks) of the data-gradient role's global loads (4 for launches of at most two workgroups per CU)
 template <bool XFB, int PDA = 1>
 __global__ __launch_bounds__(256) void conv_bwd_pair_kernel(const TapGemmArgs a, const WgradArgs w, int lgQw, int lgQhw, int lgC,
-                                                            int nA, int gxA, int gyA, int gxB, int gyB) {
+                                                            int nA, int gxA, int gyA, int gxB, int gyB, int role_xcd_on) {
   // the data-gradient kernel's arrays; the weight-gradient workgroups use the first 8 KB of each for their X / dY chunks
   __shared__ __attribute__((aligned(16))) float sAbuf[2 * 64 * LDK];
   __shared__ __attribute__((aligned(16))) float sBbuf[2 * 64 * LDK];
@@ -86,7 +86,20 @@ __global__ __launch_bounds__(256) void conv_bwd_pair_kernel(const TapGemmArgs a,
 #include "tapgemm_fast_body.inc"
   } else {
     const int Lb = L - nA;
-    wgrad_fast_body<2, 2, 1, 1, XFB>(w, lgQw, lgQhw, lgC, sAbuf, sBbuf, sPix, sMsk, sOutB, Lb % gxB, Lb / gxB, gxB, gyB);
+    // Role-aware XCD placement (round 3).  Workgroups go to the 8 XCDs round-robin by their launch index L.  The data-gradient
+    // role gives XCD X a contiguous eighth of its tiles, i.e. of the dY pixel range it gathers; the weight-gradient role used to
+    // deal its pixel slices to the XCDs by (slice & 7), so every L2 fetched dY once for each role.  With S % 8 == 0 slices the
+    // weight-gradient workgroups of XCD X now take the slices [X*S/8, (X+1)*S/8) -- the same eighth of the pixels -- and all
+    // output tiles of a slice stay on one XCD as before.  Measured (VanillaVAE bs = 256, two --pmc passes each): fetch traffic of
+    // the BatchNorm layers' paired launches 51.2 -> 39.7 MB per launch, 3.35 -> 3.28 GB per step -- and 1.599 -> 1.612 ms per
+    // step (three alternating runs), the slice count rounded to a multiple of 8 costing more than the L2 hits return to an
+    // MFMA-bound launch.  Hence OFF by default (CTVAE_PAIR_ROLE_XCD=1 turns it on, e.g. where the fabric is shared with RCCL).
+    if (gyB % 8 == 0 && role_xcd_on) {
+      const int X = L & 7, j = Lb >> 3, T = gxB;
+      wgrad_fast_body<2, 2, 1, 1, XFB, true>(w, lgQw, lgQhw, lgC, sAbuf, sBbuf, sPix, sMsk, sOutB, j % T, X * (gyB >> 3) + j / T, gxB, gyB);
+    } else {
+      wgrad_fast_body<2, 2, 1, 1, XFB>(w, lgQw, lgQhw, lgC, sAbuf, sBbuf, sPix, sMsk, sOutB, Lb % gxB, Lb / gxB, gxB, gyB);
+    }
   }
 }
 
@@ -174,9 +187,10 @@ int pair_flush(PairCtx& c, hipStream_t st) {
   if (c.haveA && c.haveB) {
     const unsigned nA = c.gxA * c.gyA * c.gzA, nB = c.gxB * c.gyB;
     ProfScope ps("conv_bwd_pair_kernel", st, c.flopsA + c.flopsB, c.bytesA + c.bytesB);
+    static const int role_xcd = [] { const char* e = getenv("CTVAE_PAIR_ROLE_XCD"); return e ? atoi(e) : 0; }();   // 1 = role-aware placement (see the kernel)
 #define CTVAE_PAIR(XFB_, PD_)                                                                                                  \
   hipLaunchKernelGGL((conv_bwd_pair_kernel<XFB_, PD_>), dim3(nA + nB), dim3(256), 0, st, c.A, c.B, c.lgQw, c.lgQhw, c.lgC, (int)nA, \
-                     (int)c.gxA, (int)c.gyA, (int)c.gxB, (int)c.gyB)
+                     (int)c.gxA, (int)c.gyA, (int)c.gxB, (int)c.gyB, role_xcd)
     if (c.B.xf_scale != nullptr) CTVAE_PAIR(true, 1);
     else CTVAE_PAIR(false, 1);
 #undef CTVAE_PAIR

@@ -668,7 +668,11 @@ int launch_wgrad(const ConvGeom& g, const float* X, const float* dY, float* dW, 
   const bool will_pair = pcw != nullptr && !pcw->haveB && xvec && dvec && !narrow && !big;
   const bool coarse = will_pair && pcw->dgrad_wgs > 0 && pcw->dgrad_wgs < 1024 && pcw->dgrad_chunks >= 12;
   const int tgt_small = tgt_env ? tgt_env : (coarse ? 768 : 1024);
-  const int S = choose_splits(g, KT, NT, ws_floats, big ? 512 : tgt_small);
+  int S = choose_splits(g, KT, NT, ws_floats, big ? 512 : tgt_small);
+  // paired launch: a multiple of 8 slices lets the pair kernel give each XCD one contiguous eighth of the pixels in BOTH roles
+  // (conv_bwd_pair_kernel, role-aware placement); rounded down, never below 8 nor above what the workspace / chunk count allow
+  static const int role_xcd = [] { const char* e = getenv("CTVAE_PAIR_ROLE_XCD"); return e ? atoi(e) : 0; }();
+  if (will_pair && role_xcd && S >= 8) S &= ~7;
   if (wgrad_workspace_floats(g, S) > ws_floats) return kErrWorkspace;
   a.S = S;
   const int nchunks = ceil_div(a.Mc, MC);

@@ -39,7 +39,8 @@ constexpr unsigned kOOBw = 0x80000000u;
 // sX[MC*KT], sD[MC*NT], sPix / sMsk / sOutB [2][MC]: the workgroup's LDS, five DISTINCT arrays of the calling kernel (carving them
 // from one buffer costs the tile kernels their no-alias information: 83 -> 116 VGPRs, measured on the tap-GEMM body).
 // vbx, vby / vgx, vgy: the workgroup's position in / the size of the kernel's own (tile, slice) grid.
-template <int WK, int WN, int TK, int TN, bool XF = false>
+// PLACED: (vbx, vby) = (output tile, pixel slice) as they are -- the caller has done the XCD placement (conv_bwd_pair_kernel)
+template <int WK, int WN, int TK, int TN, bool XF = false, bool PLACED = false>
 __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, int lgQw, int lgQhw, int lgC, float* sX, float* sD,
                                                 unsigned (*sPix)[MC], unsigned (*sMsk)[MC], unsigned (*sOutB)[MC], int vbx,
                                                 int vby, int vgx, int vgy) {
@@ -54,7 +55,7 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, int lgQw, in
   // round-robin to the 8 XCDs (one L2 each) in linear order -> give each group of 8 slices one XCD per slice, so a
   // slice's rows are filled into ONE L2 instead of eight.  The last (gridDim.y % 8) slices keep the plain order.
   int split = vby, xtile = vbx;
-  {
+  if constexpr (!PLACED) {
     const int T = vgx, L = vby * T + vbx, full = (vgy >> 3) * 8 * T;
     if (L < full) {
       const int grp = L / (8 * T), r = L - grp * 8 * T;
