@@ -42,6 +42,11 @@ struct TapGemmArgs {
   // fast kernel only: parity class of workgroup row blockIdx.y (+ blockIdx.z when cls_rot) -- see launch_fast_cfg
   int cls_order[kMaxCls];
   int cls_rot;
+  // the tap table and tap counts once more, in LAUNCH order (row i = class cls_order[i]): a workgroup indexes them with what it
+  // knows from blockIdx alone, so the lane-indexed table load goes out together with the first kernel-argument loads instead of
+  // behind the cls_order lookup -- one dependent round trip less in front of the first operand tile (round 3)
+  int ntaps_l[kMaxCls];
+  Tap taps_l[kMaxCls][kMaxTaps];
 };
 
 constexpr int KC = 32;

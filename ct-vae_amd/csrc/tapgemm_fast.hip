@@ -137,6 +137,11 @@ static int launch_fast_cfg(const TapGemmArgs& a, int pf, hipStream_t st) {
       if (big == 2 && grid.x % 8 == 0 && grid.z == 1) args.cls_rot = 2;
     }
   }
+  for (int i = 0; i < kMaxCls; ++i) {   // launch-order copies of the tap table (TapGemmArgs::taps_l)
+    const int c = args.cls_order[i];
+    args.ntaps_l[i] = a.g.ntaps[c];
+    for (int t = 0; t < kMaxTaps; ++t) args.taps_l[i][t] = a.g.taps[c][t];
+  }
   // (deep prefetch -- four register sets of loads in flight, template parameter PD = 4 of the tile kernel -- was measured for
   // launches of at most two workgroups per CU and LOST: bs = 64 step 0.825 -> 0.857 ms; tools/negative/README.md.  Not instantiated.)
   constexpr bool deep = false;
