@@ -442,6 +442,87 @@ def test_bn_backward_sums_fused_into_dgrad(K, transposed, B, H):
     # (conv biases in front of train-mode BN have an analytically zero gradient -- pure summation noise, not compared)
 
 
+CHAIN_CASES = [
+    # transposed, B, H, channel widths, kernels that must have run            what the round-3 paths must cover
+    (False, 8, 8, (128, 256, 512), ("bn_fused_fwd_kernel", "bn_fused_bwd_kernel")),    # deep stride-2 encoder blocks: dense forward slices, class-major backward slices
+    (True, 8, 2, (256, 128, 64, 32), ("bn_fused_fwd_kernel", "bn_fused_bwd_kernel")),  # transposed decoder blocks: class-major forward slices, dense backward slices, 2-channel owners
+    (False, 8, 32, (32, 64, 128, 256), ("bn_fused_fwd_kernel",)),                      # 2048 -> 512 -> 128 pixels; short paired data gradients stay unsplit
+    (False, 64, 32, (32, 64, 128), ("lazy-apply",)),                                   # bs = 64 shapes of encoder.1 / encoder.2: the unsplit producer hands its raw output on
+    (False, 3, 16, (32, 64, 128), ("bn_fused_fwd_kernel",)),                           # odd batch: 192 / 48 / 12 pixels, lanes beyond R
+]
+
+
+@pytest.mark.parametrize("case", CHAIN_CASES)
+def test_chain_of_bn_blocks_small_batch_paths(K, case):
+    """blocks.Chain of Conv|ConvTranspose -> BatchNorm -> LeakyReLU blocks (vanilla_vae.py:25-35,47-62) at small batch against torch
+    autograd on the CPU: outputs, running statistics, every gradient.  The shapes are chosen so that the round-3 paths run --
+    split-K slices kept channel-major and finished by bn_fused_fwd_kernel / bn_fused_bwd_kernel, the data gradient in front of a
+    BatchNorm handed over as slices (placeholder tensor), and a block whose apply would be a launch of its own handing its
+    consumer the raw tensor (tile kernel / weight-gradient kernel with the lazy apply) -- and the test asserts that they did."""
+    from ctvae_amd import native
+    from ctvae_amd.models import blocks
+    transposed, B, H, widths, expect = case
+    g = torch.Generator().manual_seed(77 + B + H)
+    dev = torch.device("cuda")
+    x = torch.randn(B, widths[0], H, H, generator=g).requires_grad_(True)
+    ws_, bs_, gms, bts = [], [], [], []
+    for ci, co in zip(widths[:-1], widths[1:]):
+        ws_.append((torch.randn((ci, co, 3, 3) if transposed else (co, ci, 3, 3), generator=g) / (ci * 9) ** 0.5).requires_grad_(True))
+        bs_.append(torch.randn(co, generator=g).requires_grad_(True))
+        gms.append((torch.rand(co, generator=g) + 0.5).requires_grad_(True))
+        bts.append((torch.rand(co, generator=g) - 0.5).requires_grad_(True))
+    # torch reference
+    t = x
+    rstats = []
+    for w, b, gm, bt in zip(ws_, bs_, gms, bts):
+        t = F.conv_transpose2d(t, w, b, stride=2, padding=1, output_padding=1) if transposed else F.conv2d(t, w, b, stride=2, padding=1)
+        rm, rv = torch.zeros(t.shape[1]), torch.ones(t.shape[1])
+        t = F.leaky_relu(F.batch_norm(t, rm, rv, gm, bt, True, 0.1, 1e-5), 0.01)
+        rstats.append((rm, rv))
+    go = torch.randn(t.shape, generator=g)
+    t.backward(go)
+    # product
+    mods = []
+    for (ci, co), w, b, gm, bt in zip(zip(widths[:-1], widths[1:]), ws_, bs_, gms, bts):
+        m = blocks.ConvBNLeaky(ci, co, 3, 2, 1, out_pad=1 if transposed else 0, transposed=transposed)
+        with torch.no_grad():
+            m._modules["0"].weight.copy_(w)
+            m._modules["0"].bias.copy_(b)
+            m._modules["1"].weight.copy_(gm)
+            m._modules["1"].bias.copy_(bt)
+        mods.append(m)
+    chain = blocks.Chain(*mods).to(dev).train()
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+    native.prof_enable(True)
+    out = chain(xd)
+    out.backward(go.permute(0, 2, 3, 1).contiguous().to(dev))
+    torch.cuda.synchronize()
+    native.prof_enable(False)
+    rep = native.prof_report()
+    names = " ".join(rep)
+    for want in expect:
+        if want == "lazy-apply":
+            assert "false,3,true>" in names or "false,0,true>" in names, sorted(rep)     # the tile kernel with the lazy apply
+            assert rep.get("bn_apply_act_kernel", {"count": 0})["count"] < len(mods), sorted(rep)
+        else:
+            assert want in rep, (want, sorted(rep))
+    sc = max(1.0, float(t.detach().abs().max()))
+    bad = np.abs(out.detach().cpu().permute(0, 3, 1, 2).numpy() - t.detach().numpy()) > 2 * TOL * sc
+    assert bad.mean() < 5e-4, f"{bad.sum()} of {bad.size} outputs differ"       # (a pre-activation within rounding of 0 may flip its slope)
+    for m, (rm, rv) in zip(mods, rstats):
+        np.testing.assert_allclose(m._modules["1"].running_mean.cpu().numpy(), rm.numpy(), atol=1e-5, rtol=1e-4)
+        np.testing.assert_allclose(m._modules["1"].running_var.cpu().numpy(), rv.numpy(), atol=1e-5, rtol=1e-4)
+        assert int(m._modules["1"].num_batches_tracked) == 1
+    ref = x.grad.permute(0, 2, 3, 1).numpy()
+    gsc = max(1.0, float(np.abs(ref).max()))
+    badg = np.abs(xd.grad.cpu().numpy() - ref) > 2 * TOL * gsc + 2e-3 * np.abs(ref)
+    assert badg.mean() < 2e-3, f"{badg.sum()} of {badg.size} input-gradient elements differ"
+    for m, w, gm, bt in zip(mods, ws_, gms, bts):
+        for got, want in ((m._modules["0"].weight.grad, w.grad), (m._modules["1"].weight.grad, gm.grad), (m._modules["1"].bias.grad, bt.grad)):
+            err = float((got.cpu() - want).norm() / want.norm())
+            assert err < 2e-3, err
+
+
 WINO_CASES = [
     # B, H, Ci, Co     (fewer than 200 workgroups of 64 tiles x 64 channels -> the frequency-split kernel, 64 x 32)
     (256, 8, 256, 256),    # the MCQ-VAE residual 3x3 at its bench batch: 256 workgroups, wino_conv_kernel
