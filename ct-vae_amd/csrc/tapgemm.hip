@@ -602,7 +602,8 @@ void tapgemm_plan(const ConvGeom& g, size_t ws_floats, TapGemmPlan& p) {
   const int tgt = paired ? pair_target : ((long)Mc * g.ncls <= sk_small_m ? sk_small_target : sk_target), maxw = paired ? pair_maxwgs : sk_maxwgs;
   // paired with a reduction of fewer than 16 chunks (K < 512: the Linear heads' data gradient): splitting saves ~1 us of a
   // launch the weight gradient fills anyway and would cost the fused BatchNorm-backward sums of the layer below
-  if (avec && bvec && (N % 4) == 0 && wgs < maxw && nch_min >= (paired ? 16 : 8)) {
+  static const int pair_minch = [] { const char* e = getenv("CTVAE_PAIR_SK_MINCH"); return e ? atoi(e) : 8; }();   // round 3: 16 -> 8 (the slices go to the BatchNorm's channel-owner launch: bs = 64 -0.9 %, bs = 256 -0.3 %)
+  if (avec && bvec && (N % 4) == 0 && wgs < maxw && nch_min >= (paired ? pair_minch : 8)) {
     int sk = (int)((tgt + wgs - 1) / wgs);
     if (sk > nch_min / 4) sk = nch_min / 4;
     static const int sk_max = [] { const char* e = getenv("CTVAE_SK_MAX"); return e ? atoi(e) : 16; }();   // diagnostic
