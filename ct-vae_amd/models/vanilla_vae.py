@@ -8,6 +8,7 @@ Same constructor kwargs, method signatures, return lists, loss-dict keys and ``s
 * ``reparameterize`` takes an optional ``eps`` so that noise can be injected (SURVEY N1);
 * parameters are views of one packed buffer (``packing.py``); ``fc_mu``/``fc_var`` run as one GEMM.
 """
+import os
 from typing import List
 
 import torch
@@ -37,6 +38,8 @@ class _FinalLayer(nn.Module):
         one-node form does: the transposed conv's forward / weight-gradient kernels apply them while staging their patches.)"""
         B, H, W, _ = x_shape
         ho, wo = self.spec_up.out_hw(H, W)
+        if os.environ.get("CTVAE_NO_LAZY_FINAL", "0") == "1":      # diagnostic
+            return False
         return K.input_transform_supported(self.spec_out, B, ho, wo) and K.lazy_bn_input_supported(self.spec_up, B, H, W)
 
     def forward(self, x):
