@@ -204,3 +204,66 @@ def test_lazy_zero_grad_host_protocol():
         assert torch.all(p.grad == 0.0)
     r.zero_grad()                                  # the eager form fills and clears every flag
     assert float(r._flat_grads.abs().max()) == 0.0 and K.grad_target(r.conv.weight)[1] == 1
+
+
+def test_placeholder_gradient_protocols():
+    """Host side of the round-3 hand-overs (no kernel runs): a consumer may leave its data gradient as split-K slices plus an
+    unwritten placeholder only for a tensor model code declared single-consumer, the BatchNorm that takes the slices insists on
+    exactly that placeholder (anything else would be garbage: it raises), and the element-wise consumers' registry hands a
+    placeholder out once, and only while it is untouched."""
+    from ctvae_amd import kernels as K
+    y = torch.zeros(2, 4, 4, 8)
+    link = K.BNLink(y, torch.zeros(8), torch.ones(8), torch.ones(8), torch.zeros(8), K.ACT_LRELU)
+    assert link.sole is False
+    a = torch.zeros(2, 4, 4, 8)
+    a._ctvae_bn_link = link
+    assert K.mark_sole_consumer(a) is a and link.sole is True
+    assert K.mark_sole_consumer(torch.zeros(3)) is not None            # a tensor without a link: nothing to mark, no error
+    g, slices = torch.empty(2, 4, 4, 8), torch.empty(3 * 256)
+    geom = (K.CONV, 2, 4, 4, 8, 16, 3, 2, 1, 0)
+    link.publish_lazy(g, slices, 3, geom)
+    assert link.take(g) == (None, 0, None)                              # the ordinary sums are not published in that mode
+    link.publish_lazy(g, slices, 3, geom)
+    got = link.take_lazy(g)
+    assert got[0] is slices and got[1] == 3 and got[2] == geom
+    assert link.take_lazy(g) is None                                    # one use only
+    link.publish_lazy(g, slices, 3, geom)
+    with pytest.raises(RuntimeError):
+        link.take_lazy(g + 1.0)                                         # autograd summed something onto it / another tensor arrived
+    link.publish_lazy(g, slices, 3, geom)
+    g.add_(0.0)                                                         # touched in place: version changed
+    with pytest.raises(RuntimeError):
+        link.take_lazy(g)
+    # the registry of element-wise consumers
+    h = torch.empty(2, 128)
+    K.offer_lazy_grad(h, slices, 4)
+    assert K.claim_lazy_grad(h.view(2, 1, 1, 128))[1] == 4              # a view (reshape's backward) is the same placeholder
+    assert K.claim_lazy_grad(h) is None                                 # handed out once
+    K.offer_lazy_grad(h, slices, 4)
+    h.mul_(1.0)
+    assert K.claim_lazy_grad(h) is None                                 # modified since: not the placeholder any more
+    t = K.grad_slices_ok(torch.zeros(2, 3))
+    assert t._ctvae_grad_slices_ok is True
+
+
+def test_chain_marks_intermediates_and_keeps_reference_keys():
+    """blocks.Chain is nn.Sequential for state_dict purposes (same child names) and declares the single consumer of every
+    intermediate tensor; VanillaVAE's encoder / decoder are Chains, the zoo models that build their own Sequential are not."""
+    from ctvae_amd.models import blocks
+    m = vae_models["VanillaVAE"](in_channels=3, latent_dim=128)
+    assert isinstance(m.encoder, blocks.Chain) and isinstance(m.decoder, blocks.Chain)
+    assert isinstance(m.encoder, torch.nn.Sequential)
+    assert list(m.encoder._modules) == ["0", "1", "2", "3", "4"] and list(m.decoder._modules) == ["0", "1", "2", "3"]
+    assert hasattr(m.final_layer, "reads_lazy_input") and all(hasattr(b, "reads_lazy_input") for b in m.encoder)
+    seen = []
+
+    class Probe(torch.nn.Module):
+        def forward(self, x):
+            seen.append(x)
+            return x + 1
+
+    c = blocks.Chain(Probe(), Probe(), Probe())
+    out = c(torch.zeros(2))
+    assert float(out[0]) == 3.0 and len(seen) == 3
+    lv = vae_models["LVAE"](**H.LVAE_CFG)
+    assert not isinstance(lv.decoder, blocks.Chain)
