@@ -192,11 +192,12 @@ class BNLink:
     separate pass over (g_a, y).  The sums are only used when the gradient tensor that arrives is exactly the one the
     dgrad wrote (same storage pointer, same version counter): if autograd summed several contributions, or anything
     modified it in place, the BatchNorm falls back to its own pass."""
-    __slots__ = ("y", "mean", "invstd", "gamma", "beta", "act", "part", "rows", "coef", "g_ptr", "g_ver", "g_shape", "slices", "sole")
+    __slots__ = ("y", "mean", "invstd", "gamma", "beta", "act", "part", "rows", "coef", "g_ptr", "g_ver", "g_shape", "slices", "sole", "g_hold")
 
     def __init__(self, y, mean, invstd, gamma, beta, act):
         self.y, self.mean, self.invstd, self.gamma, self.beta, self.act = y, mean, invstd, gamma, beta, act
         self.sole = False       # set by model code (mark_sole_consumer): the layer's output has exactly one consumer
+        self.g_hold = None      # the placeholder of publish_lazy, kept alive until take_lazy (its address is not recycled meanwhile)
         self.part = None
         self.rows = 0
         self.coef = None
@@ -208,12 +209,14 @@ class BNLink:
         (channel-major, rows in that launch's own order: geom = its (kind, B, H, W, Ci, Co, k, stride, pad, out_pad)) in ``slices``; ``g`` is a placeholder that was never written -- the BatchNorm's backward sums the slices
         itself (ctvae_bn_backward_fused).  Nothing else may consume g: take_lazy raises if another tensor arrives."""
         self.slices = (slices, n, geom)
+        self.g_hold = g
         self.part, self.rows, self.coef = None, 0, None
         self.g_ptr, self.g_ver, self.g_shape = g.data_ptr(), g._version, tuple(g.shape)
 
     def take_lazy(self, g):
         """(slices, n, geom) when the consumer left its data gradient as raw slices, else None.  One use only."""
         sl, self.slices = self.slices, None
+        self.g_hold = None
         if sl is None:
             return None
         if g.data_ptr() != self.g_ptr or g._version != self.g_ver or tuple(g.shape) != self.g_shape:
@@ -304,7 +307,9 @@ _lazy_grads = {}
 def offer_lazy_grad(g, slices, n):
     if len(_lazy_grads) > 16:
         _lazy_grads.clear()
-    _lazy_grads[g.data_ptr()] = (slices, n, g._version, g.numel())
+    # the entry keeps the placeholder alive: its address cannot be handed to another tensor while the entry exists, so a match
+    # on (address, version, size) below IS the placeholder (or a view of it), never a newcomer at a recycled address
+    _lazy_grads[g.data_ptr()] = (slices, n, g._version, g.numel(), g)
 
 
 def claim_lazy_grad(g):
@@ -1778,6 +1783,7 @@ def backward(loss):
     if not (_DEFER_REDUCE and loss.is_cuda):
         loss.backward(gradient=one)
         return
+    _lazy_grads.clear()            # placeholders of an earlier pass that nobody claimed (a pass cut short) are not valid in this one
     arena = _defer_arena_for(loss.device)
     lib = native.load()
     native.check(lib.ctvae_defer_begin(arena.data_ptr(), arena.numel() * 4), "ctvae_defer_begin")
