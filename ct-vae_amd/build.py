@@ -18,6 +18,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libctvae_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("CTVAE_EXTRA_HIPCC_FLAGS", "").split()      # diagnostics only (e.g. -DCTVAE_PHASES, csrc/phase.hpp)
 
 
 def _hipcc():

@@ -27,7 +27,10 @@
 //   gat_adj_reduce_kernel  d a = edge * (sum_slots d a' + (sum_slots d a'[c,c]) / deg[c])
 #include "common.hpp"
 #include "gatlayer.hpp"
+#include "phase.hpp"
 #include "prof.hpp"
+
+CTVAE_PHASE_DECL(gat)
 
 namespace ctvae {
 
@@ -119,8 +122,10 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fwd_kernel(GatLayerArgs a) {
   const int tid = threadIdx.x, hs = blockIdx.x, b = blockIdx.y;
   const int head = a.head_map ? a.head_map[b * a.Hs + hs] : hs;
   const int tr = tid >> 4, tc = tid & 15;
+  CTVAE_PH(gat, 0, 0);
   stage_T(a.xl, (long)b * GN, a.ld, hs * C, C, XL);
   stage_T(a.xr, (long)b * GN, a.ld, hs * C, C, XR);
+  CTVAE_PH(gat, 0, 1);
   for (int k = tid; k < C; k += 256) {
     sWe[k] = a.we[head * C + k];
     sAt[k] = a.att[head * C + k] * (1.f - a.slope);
@@ -128,6 +133,7 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fwd_kernel(GatLayerArgs a) {
   float av[4][4];
   unsigned keep;
   load_adj_block(a.adj, b, tr, tc, av, keep, Ss, sLoop, sDeg);      // two barriers inside: the staging above is visible
+  CTVAE_PH(gat, 0, 2);
   // lrelu(m) = slope*m + (1-slope)*relu(m): the first term is linear in xl, xr, a' and is summed per node, not per pair
   if (tid < 2 * GN) {
     const float* T = tid < GN ? XL : XR;
@@ -140,6 +146,7 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fwd_kernel(GatLayerArgs a) {
     for (int k = 0; k < C; ++k) s += a.att[head * C + k] * a.we[head * C + k];
     sAW[0] = s;
   }
+  CTVAE_PH(gat, 0, 3);
   f32x2 acc[4][2], a2[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -163,7 +170,9 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fwd_kernel(GatLayerArgs a) {
       acc[i][1] += ak2 * f32x2{relu(m1[0]), relu(m1[1])};
     }
   }
+  CTVAE_PH(gat, 0, 4);
   __syncthreads();
+  CTVAE_PH(gat, 0, 5);
   {
     const float aw = sAW[0];
 #pragma unroll
@@ -177,6 +186,7 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fwd_kernel(GatLayerArgs a) {
     }
   }
   __syncthreads();
+  CTVAE_PH(gat, 0, 6);
   // softmax over the sources r of every target column c: thread = (c, quarter of the rows)
   {
     const int c = tid & (GN - 1), q = tid >> 6;
@@ -205,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fwd_kernel(GatLayerArgs a) {
     }
   }
   __syncthreads();
+  CTVAE_PH(gat, 0, 7);
   // out[c][k] = sum_r alpha[r][c] * xl[r][k]: thread = (c, quarter of the channels)
   {
     const int c = tid & (GN - 1), k0 = (tid >> 6) * KQ;
@@ -228,7 +239,9 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fwd_kernel(GatLayerArgs a) {
     for (int kk = 0; kk < KQ; ++kk)
       if (k0 + kk < C) O[c * os + k0 + kk] = o[kk];
   }
+  CTVAE_PH(gat, 0, 8);
   __syncthreads();
+  CTVAE_PH(gat, 0, 9);
   {
     const float* O = XR;
     const int os = C | 1;
@@ -241,6 +254,7 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fwd_kernel(GatLayerArgs a) {
       }
     }
   }
+  CTVAE_PH(gat, 0, 10);
 }
 
 template <int KQ>
@@ -261,6 +275,7 @@ __global__ __launch_bounds__(256, 2) void gat_layer_bwd_kernel(GatBwdArgs p) {
   const int tid = threadIdx.x, hs = blockIdx.x, b = blockIdx.y;
   const int head = a.head_map ? a.head_map[b * a.Hs + hs] : hs;
   const int tr = tid >> 4, tc = tid & 15;
+  CTVAE_PH(gat, 1, 0);
   stage_T(a.xl, (long)b * GN, a.ld, hs * C, C, XL);
   {                                                     // G[k][c] = g_out[c][k] * act'(out[c][k])
     const int c4 = C >> 2, n4 = GN * c4;
@@ -300,7 +315,9 @@ __global__ __launch_bounds__(256, 2) void gat_layer_bwd_kernel(GatBwdArgs p) {
   }
   float av[4][4];
   unsigned keep;
+  CTVAE_PH(gat, 1, 1);
   load_adj_block(a.adj, b, tr, tc, av, keep, sRed, sLoop, sDeg);
+  CTVAE_PH(gat, 1, 2);
   if (tid < C) {                                        // bias gradient: sum over the targets
     float s = 0.f;
     for (int c = 0; c < GN; ++c) s += R2[tid * LS + c];
@@ -310,6 +327,7 @@ __global__ __launch_bounds__(256, 2) void gat_layer_bwd_kernel(GatBwdArgs p) {
     for (int k = 0; k < C; ++k) s += a.att[head * C + k] * a.we[head * C + k];
     sAW[0] = s;
   }
+  CTVAE_PH(gat, 1, 3);
   // d alpha[r][c] = sum_k xl[r][k] * G[k][c]
   f32x2 da[4][2];
 #pragma unroll
@@ -325,6 +343,7 @@ __global__ __launch_bounds__(256, 2) void gat_layer_bwd_kernel(GatBwdArgs p) {
       da[i][1] += li * g23;
     }
   }
+  CTVAE_PH(gat, 1, 4);
   // softmax backward per target column: dS = alpha * (d alpha - sum_r alpha * d alpha)
   float al[4][4];
   {
@@ -348,6 +367,7 @@ __global__ __launch_bounds__(256, 2) void gat_layer_bwd_kernel(GatBwdArgs p) {
     }
     __syncthreads();
   }
+  CTVAE_PH(gat, 1, 5);
   float ds[4][4];
   {
     float* dS = p.dS + (((long)b * a.Hs + hs) * GN + 4 * tr) * GN + 4 * tc;
@@ -362,6 +382,7 @@ __global__ __launch_bounds__(256, 2) void gat_layer_bwd_kernel(GatBwdArgs p) {
       *reinterpret_cast<f32x4*>(dS + i * GN) = v;
     }
   }
+  CTVAE_PH(gat, 1, 6);
   // the aggregation's share of d xl[r][k] = sum_c alpha[r][c] * G[k][c]: thread = (r, quarter of the channels)
   float o[KQ];
   {
@@ -380,6 +401,7 @@ __global__ __launch_bounds__(256, 2) void gat_layer_bwd_kernel(GatBwdArgs p) {
       }
     }
   }
+  CTVAE_PH(gat, 1, 7);
   __syncthreads();                                     // G is dead
   {
     const int r = tid & (GN - 1), k0 = (tid >> 6) * KQ, os = C | 1;
@@ -396,8 +418,10 @@ __global__ __launch_bounds__(256, 2) void gat_layer_bwd_kernel(GatBwdArgs p) {
     }
   }
   __syncthreads();
+  CTVAE_PH(gat, 1, 8);
   stage_T(a.xr, (long)b * GN, a.ld, hs * C, C, R2);
   __syncthreads();
+  CTVAE_PH(gat, 1, 9);
   // d a'[r][c] = dS * sum_k att we lrelu'(m) = dS * (slope * sum_k att we + (1-slope) * sum_k att we [m > 0])
   f32x2 t[4][2], a2[4][2];
 #pragma unroll
@@ -423,6 +447,7 @@ __global__ __launch_bounds__(256, 2) void gat_layer_bwd_kernel(GatBwdArgs p) {
       t[i][1] += aw2 * f32x2{__builtin_amdgcn_fmed3f(m1[0], 0.f, 1.f), __builtin_amdgcn_fmed3f(m1[1], 0.f, 1.f)};
     }
   }
+  CTVAE_PH(gat, 1, 10);
   {
     const float aw = sAW[0] * a.slope;
     float* dA = p.dattr + (((long)b * a.Hs + hs) * GN + 4 * tr) * GN + 4 * tc;
@@ -434,6 +459,7 @@ __global__ __launch_bounds__(256, 2) void gat_layer_bwd_kernel(GatBwdArgs p) {
       *reinterpret_cast<f32x4*>(dA + i * GN) = v;
     }
   }
+  CTVAE_PH(gat, 1, 11);
 }
 
 // d xl (added to what gat_layer_bwd_kernel left), d xr, d att, d we from dS.  grid (Hs, B); blockDim = 4 * CP, CP = C rounded
