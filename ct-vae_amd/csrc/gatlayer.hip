@@ -29,6 +29,7 @@
 #include "gatlayer.hpp"
 #include "phase.hpp"
 #include "prof.hpp"
+#include "satmath.hpp"
 
 CTVAE_PHASE_DECL(gat)
 
@@ -83,7 +84,7 @@ __device__ __forceinline__ void load_adj_block(const float* __restrict__ adj, in
 
 // xl / xr of one head slot, transposed into LDS: T[k][n].  16-byte global loads, all of a thread's loads issued before the
 // first LDS store (<= 8 per thread for C <= 128), so their latencies overlap; C % 4 == 0.
-__device__ __forceinline__ void stage_T(const float* __restrict__ src, long row0, int ld, int col0, int C, float* T) {
+__device__ __forceinline__ void stage_T(const float* __restrict__ src, long row0, int ld, int col0, int C, float* T, float scale = 1.f) {
   const int c4 = C >> 2, n4 = GN * c4;
   f32x4 v[8];
   int nn[8], kk[8];
@@ -99,13 +100,13 @@ __device__ __forceinline__ void stage_T(const float* __restrict__ src, long row0
   for (int it = 0; it < 8; ++it) {
     if (threadIdx.x + 256 * it < n4) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) T[(kk[it] + j) * LS + nn[it]] = v[it][j];
+      for (int j = 0; j < 4; ++j) T[(kk[it] + j) * LS + nn[it]] = v[it][j] * scale;
     }
   }
 }
 
 template <int KQ>   // channels per thread in the aggregation: ceil(C / 4) <= KQ
-__global__ __launch_bounds__(256, 2) void gat_layer_fwd_kernel(GatLayerArgs a) {
+__global__ __launch_bounds__(256, 2) void gat_layer_fwd_old_kernel(GatLayerArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int C = a.C;
   float* XL = smem;                 // [C][LS]
@@ -255,6 +256,179 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fwd_kernel(GatLayerArgs a) {
     }
   }
   CTVAE_PH(gat, 0, 10);
+}
+
+// MFMA helper of the fused layer kernels: D[m][n] (+)= sum_{r < 64} A[r][m] * B[n][r] for one 32 x 32 tile, A rows of stride sa
+// (element [r][m] at A[r * sa + m]), B rows of stride LS holding 64 consecutive r.  v_mfma_f32_32x32x2_f32 takes two values of
+// the reduction index per step (lane >> 5 picks which); the r order is permuted so that a lane's B operands of four steps are ONE
+// 16-byte LDS read (r = 8 q + 4 (lane >> 5) + j, conflict-free for row stride 68).  Result: lane holds n = lane & 31, register i
+// holds m = 8 (i >> 2) + 4 (lane >> 5) + (i & 3).
+__device__ __forceinline__ f32x16 mfma_tile_64(const float* A, int sa, const float* B, int lane) {
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int lh = lane >> 5, ln = lane & 31;
+  const float* ap = A + (4 * lh) * sa + ln;
+  const float* bp = B + ln * LS + 4 * lh;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + 8 * q);
+    const float a0 = ap[(8 * q) * sa], a1 = ap[(8 * q + 1) * sa], a2 = ap[(8 * q + 2) * sa], a3 = ap[(8 * q + 3) * sa];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b4[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b4[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b4[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b4[3], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// Forward.  The per-pair part of the score is relu: lrelu(m) = slope m + (1 - slope) relu(m), the linear part sums per node.  xl, xr
+// and we are staged scaled by 2^-64 so that relu is the clamp of the packed fma that forms m (satmath.hpp): 1.5 instructions per
+// (pair, channel).  The alpha-weighted aggregation out = alpha^T xl is four to eight 32 x 32 MFMA tiles straight from the LDS
+// operands, written to global memory from the accumulators.
+__global__ __launch_bounds__(256, 2) void gat_layer_fwd_kernel(GatLayerArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int C = a.C;
+  float* XL = smem;                 // [C][LS]  xl * 2^-64
+  float* XR = XL + C * LS;          // [C][LS]  xr * 2^-64
+  float* Ss = XR + C * LS;          // [GN][SS]
+  float* sWA = Ss + GN * SS;        // [C + 1][2]  {we * 2^-64, att * (1 - slope)}   (8-byte aligned: every array before it has an even length)
+  float* sAtt = sWA + 2 * (C + 1);  // [C]
+  float* sP = sAtt + C;             // [2][GN][4] partial sums of att . xl / att . xr (quarter of the channels each)
+  sP += (4 - ((sP - smem) & 3)) & 3;
+  float* sCol = sP + 2 * GN * 4;    // [4][GN]
+  float* sLoop = sCol + 4 * GN;     // [GN]
+  float* sDeg = sLoop + GN;         // [GN]
+  const int tid = threadIdx.x, hs = blockIdx.x, b = blockIdx.y, lane = tid & 63, wave = tid >> 6;
+  const int head = a.head_map ? a.head_map[b * a.Hs + hs] : hs;
+  const int tr = tid >> 4, tc = tid & 15;
+  CTVAE_PH(gat, 0, 0);
+  stage_T(a.xl, (long)b * GN, a.ld, hs * C, C, XL, kSatDown);
+  stage_T(a.xr, (long)b * GN, a.ld, hs * C, C, XR, kSatDown);
+  for (int k = tid; k < C; k += 256) {
+    const float w = a.we[head * C + k], t = a.att[head * C + k];
+    sWA[2 * k] = w * kSatDown;
+    sWA[2 * k + 1] = t * (1.f - a.slope);
+    sAtt[k] = t;
+  }
+  if (tid < 2) sWA[2 * C + tid] = 0.f;                                   // the score loop reads one channel ahead
+  CTVAE_PH(gat, 0, 1);
+  float av[4][4];
+  unsigned keep;
+  load_adj_block(a.adj, b, tr, tc, av, keep, Ss, sLoop, sDeg);      // two barriers inside: the staging above is visible
+  CTVAE_PH(gat, 0, 2);
+  // lrelu(m) = slope*m + (1-slope)*relu(m): the first term is linear in xl, xr, a' and is summed per node, not per pair
+  float aw;                                                            // sum_k att we * 2^-64
+  {
+    const int n = tid & (GN - 1), q = tid >> 6, cq = C >> 2;
+    float pl = 0.f, pr = 0.f;
+#pragma unroll 5
+    for (int k = q * cq; k < (q + 1) * cq; ++k) {
+      const float t = sAtt[k];
+      pl += t * XL[k * LS + n];
+      pr += t * XR[k * LS + n];
+    }
+    sP[n * 4 + q] = pl;
+    sP[(GN + n) * 4 + q] = pr;
+    float s = 0.f;
+    for (int k = lane; k < C; k += 64) s += sAtt[k] * sWA[2 * k];
+    aw = wave_sum(s);
+  }
+  CTVAE_PH(gat, 0, 3);
+  f32x2 acc[4][2], a2[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      acc[i][jp] = f32x2{0.f, 0.f};
+      a2[i][jp] = f32x2{av[i][2 * jp], av[i][2 * jp + 1]};
+    }
+  {
+    const float* pl = XL + 4 * tr;
+    const float* pr = XR + 4 * tc;
+    f32x4 l4 = *reinterpret_cast<const f32x4*>(pl), r4 = *reinterpret_cast<const f32x4*>(pr);
+    f32x2 wa = *reinterpret_cast<const f32x2*>(sWA);
+#pragma unroll 2
+    for (int k = 0; k < C; ++k) {
+      pl += LS;
+      pr += LS;
+      const f32x4 l4n = *reinterpret_cast<const f32x4*>(pl), r4n = *reinterpret_cast<const f32x4*>(pr);   // row C: the next array (in bounds)
+      const f32x2 wan = *reinterpret_cast<const f32x2*>(sWA + 2 * (k + 1));
+      const f32x2 r01 = {r4[0], r4[1]}, r23 = {r4[2], r4[3]};
+      score_2x4(acc[0][0], acc[0][1], acc[1][0], acc[1][1], f32x2{l4[0], l4[1]}, r01, r23, wa, a2[0][0], a2[0][1], a2[1][0], a2[1][1]);
+      score_2x4(acc[2][0], acc[2][1], acc[3][0], acc[3][1], f32x2{l4[2], l4[3]}, r01, r23, wa, a2[2][0], a2[2][1], a2[3][0], a2[3][1]);
+      l4 = l4n; r4 = r4n; wa = wan;
+    }
+  }
+  CTVAE_PH(gat, 0, 4);
+  __syncthreads();
+  CTVAE_PH(gat, 0, 5);
+  {
+    float al[4], ar[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 u = *reinterpret_cast<const f32x4*>(sP + (4 * tr + i) * 4), v = *reinterpret_cast<const f32x4*>(sP + (GN + 4 * tc + i) * 4);
+      al[i] = (u[0] + u[1]) + (u[2] + u[3]);
+      ar[i] = (v[0] + v[1]) + (v[2] + v[3]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float s = (a.slope * (al[i] + ar[j] + av[i][j] * aw) + acc[i][j >> 1][j & 1]) * kSatUp;
+        Ss[(4 * tr + i) * SS + 4 * tc + j] = ((keep >> (4 * i + j)) & 1u) ? s : -INFINITY;
+      }
+  }
+  __syncthreads();
+  CTVAE_PH(gat, 0, 6);
+  // softmax over the sources r of every target column c: thread = (c, quarter of the rows)
+  {
+    const int c = tid & (GN - 1), q = tid >> 6;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, Ss[(16 * q + i) * SS + c]);
+    sCol[q * GN + c] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sCol[c], sCol[GN + c]), fmaxf(sCol[2 * GN + c], sCol[3 * GN + c]));   // finite: the self loop is kept
+    __syncthreads();
+    float e[16], sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      e[i] = __expf(Ss[(16 * q + i) * SS + c] - mx);
+      sum += e[i];
+    }
+    sCol[q * GN + c] = sum;
+    __syncthreads();
+    const float inv = 1.f / (sCol[c] + sCol[GN + c] + sCol[2 * GN + c] + sCol[3 * GN + c]);
+    float* al = a.alpha + (((long)b * a.Hs + hs) * GN + 16 * q) * GN + c;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float p = e[i] * inv;
+      Ss[(16 * q + i) * SS + c] = p;
+      al[i * GN] = p;
+    }
+  }
+  __syncthreads();
+  CTVAE_PH(gat, 0, 7);
+  // out[c][k] = 2^64 sum_r alpha[r][c] * xl'[r][k]: tile = (32 targets, 32 channels); tiles past C read the next array (discarded)
+  {
+    const int nt2 = 2 * ((C + 31) >> 5), lh = lane >> 5, ln = lane & 31;
+    for (int t = wave; t < nt2; t += 4) {
+      const int mt = t & 1, k = 32 * (t >> 1) + ln;
+      const f32x16 o = mfma_tile_64(Ss + 32 * mt, SS, XL + 32 * (t >> 1) * LS, lane);
+      if (k < C) {
+        const float bias = a.bias[head * C + k];
+        float* op = a.out + ((long)b * GN + 32 * mt + 4 * lh) * a.ldo + hs * C + k;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float v = o[i] * kSatUp + bias;
+          if (a.act == ACT_LRELU) v = v > 0.f ? v : v * kLeaky;
+          op[(long)(8 * (i >> 2) + (i & 3)) * a.ldo] = v;
+        }
+      }
+    }
+  }
+  CTVAE_PH(gat, 0, 8);
 }
 
 template <int KQ>
@@ -466,7 +640,7 @@ __global__ __launch_bounds__(256, 2) void gat_layer_bwd_kernel(GatBwdArgs p) {
 // up to 16: thread = (channel k, quarter of the sources).  xl[r,k] and its gradient stay in registers (16 sources per
 // thread), dS and a' of the head are read from LDS as broadcasts, the four partial sums over the sources meet in two
 // shuffles.
-__global__ __launch_bounds__(512) void gat_proj_bwd_kernel(GatBwdArgs p) {
+__global__ __launch_bounds__(512) void gat_proj_bwd_old_kernel(GatBwdArgs p) {
   __shared__ __attribute__((aligned(16))) float sG[GN][GN + 4];   // [c][r]
   __shared__ __attribute__((aligned(16))) float sA[GN][GN + 4];
   __shared__ float sLoop[GN];
@@ -550,6 +724,159 @@ __global__ __launch_bounds__(512) void gat_proj_bwd_kernel(GatBwdArgs p) {
   }
 }
 
+// d xl (added to what gat_layer_bwd_kernel left), d xr, d att, d we from dS.  With lrelu'(m) = slope + (1 - slope) [m > 0] and
+// P[r,c,k] = dS[r,c] [m[r,c,k] > 0] everything is three sums of P plus terms linear in dS that never enter the pair loop:
+//     Ql[r,k] = sum_c P        Qr[c,k] = sum_r P        Qa[k] = sum_rc P a'[r,c]          RS / CS = row / column sums of dS, DA = sum dS a'
+//     d xl[r,k] += att_k (slope RS[r] + (1-slope) Ql)      d xr[c,k] = att_k (slope CS[c] + (1-slope) Qr)      d we[k] = att_k (slope DA + (1-slope) Qa)
+//     d att[k]   = sum_r xl[r,k] (slope RS[r] + (1-slope) Ql[r,k]) + sum_c xr[c,k] (slope CS[c] + (1-slope) Qr[c,k]) + we_k (slope DA + (1-slope) Qa[k])
+// (dS relu(m) = P m and m = xl + xr + a' we).  grid (Hs, B), 256 threads: thread = (4 channels kq -- two packed pairs --, 8 sources
+// q8); xl and Ql of its (source, channel)s stay in registers, dS and a' of the head sit transposed in LDS (16-byte reads shared by
+// the lanes of a channel group), the step function is the clamp of a packed add on operands scaled by 2^60 (satmath.hpp): five
+// packed instructions per two (pair, channel)s.  Qr meets in the 8 lanes through DPP adds: one producer per output element,
+// fixed order, no atomics.
+__global__ __launch_bounds__(256, 4) void gat_proj_bwd_kernel(GatBwdArgs p) {
+  constexpr int TS = GN + 4;
+  __shared__ __attribute__((aligned(16))) float sG[GN * TS];   // [c][r] dS
+  __shared__ __attribute__((aligned(16))) float sA[GN * TS];   // [c][r] a' (self-loop mean on the diagonal)
+  __shared__ float sRS[GN], sCS[GN], sDAc[GN], sLoop[GN];
+  const GatLayerArgs& a = p.f;
+  const int C = a.C;
+  const int tid = threadIdx.x, hs = blockIdx.x, b = blockIdx.y;
+  const int head = a.head_map ? a.head_map[b * a.Hs + hs] : hs;
+  CTVAE_PH(gat, 2, 0);
+  {
+    const float* dS = p.dS + ((long)b * a.Hs + hs) * GN * GN;
+    const float* adj = a.adj + (long)b * GN * GN;
+    float gv[16], av[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      gv[t] = dS[tid + 256 * t];
+      av[t] = adj[tid + 256 * t];
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int e = tid + 256 * t, r = e >> 6, c = e & 63;
+      sG[c * TS + r] = gv[t];
+      sA[c * TS + r] = (r == c) ? 0.f : av[t];
+    }
+  }
+  __syncthreads();
+  if (tid < GN) {                    // self-loop attribute: mean of the incoming edges of target c = tid; CS[c]
+    float s = 0.f, d = 0.f, cs = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < GN; ++r) {
+      const float v = sA[tid * TS + r];
+      s += v;
+      d += v != 0.f ? 1.f : 0.f;
+      cs += sG[tid * TS + r];
+    }
+    sLoop[tid] = s / fmaxf(d, 1.f);
+    sCS[tid] = cs;
+  } else if (tid < 2 * GN) {         // RS[r]
+    const int r = tid - GN;
+    float s = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < GN; ++c) s += sG[c * TS + r];
+    sRS[r] = s;
+  }
+  __syncthreads();
+  if (tid < GN) sA[tid * TS + tid] = sLoop[tid];
+  __syncthreads();
+  if (tid < GN) {                    // DA = sum dS a'
+    float s = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < GN; ++r) s += sG[tid * TS + r] * sA[tid * TS + r];
+    s = wave_sum(s);
+    if (tid == 0) sDAc[0] = s;
+  }
+  __syncthreads();
+  CTVAE_PH(gat, 2, 1);
+  const int kq = tid >> 3, q8 = tid & 7, k0 = 4 * kq, r0 = 8 * q8;
+  if (k0 >= C) return;               // C % 4 == 0: a channel group is inside or outside
+  const float slope = a.slope, oms = 1.f - a.slope;
+  const f32x2 up = {kStepUp, kStepUp};
+  f32x2 xl2[2][8], ql[2][8];
+  {
+    const float* xp = a.xl + ((long)b * GN + r0) * a.ld + hs * C + k0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(xp + (long)r * a.ld);
+      xl2[0][r] = f32x2{x[0], x[1]} * up;
+      xl2[1][r] = f32x2{x[2], x[3]} * up;
+      ql[0][r] = ql[1][r] = f32x2{0.f, 0.f};
+    }
+  }
+  const float* wep = a.we + head * C + k0;
+  const float* atp = a.att + head * C + k0;
+  const f32x2 at2[2] = {{atp[0], atp[1]}, {atp[2], atp[3]}};
+  const f32x2 ws2[2] = {f32x2{wep[0], wep[1]} * up, f32x2{wep[2], wep[3]} * up};
+  const float* xrp = a.xr + (long)b * GN * a.ld + hs * C + k0;
+  float* dxrp = p.dxr + (long)b * GN * p.ldd + hs * C + k0;
+  f32x4 xr_next = *reinterpret_cast<const f32x4*>(xrp);
+  f32x2 qa[2] = {{0.f, 0.f}, {0.f, 0.f}}, dc[2] = {{0.f, 0.f}, {0.f, 0.f}};
+  for (int c = 0; c < GN; ++c) {
+    const f32x4 xr4 = xr_next;
+    xrp += a.ld;
+    if (c + 1 < GN) xr_next = *reinterpret_cast<const f32x4*>(xrp);     // one target ahead
+    const f32x2 xr2[2] = {f32x2{xr4[0], xr4[1]} * up, f32x2{xr4[2], xr4[3]} * up};
+    const f32x4 g4a = *reinterpret_cast<const f32x4*>(&sG[c * TS + r0]), g4b = *reinterpret_cast<const f32x4*>(&sG[c * TS + r0 + 4]);
+    const f32x4 a4a = *reinterpret_cast<const f32x4*>(&sA[c * TS + r0]), a4b = *reinterpret_cast<const f32x4*>(&sA[c * TS + r0 + 4]);
+    f32x2 qr[2] = {{0.f, 0.f}, {0.f, 0.f}};
+#define CTVAE_PROJ(R, A2, G2)                                                                                              \
+    proj_step2x2(ql[0][R], ql[0][R + 1], ql[1][R], ql[1][R + 1], qr[0], qr[1], qa[0], qa[1], A2, G2, ws2[0], ws2[1], xl2[0][R], \
+                 xl2[0][R + 1], xl2[1][R], xl2[1][R + 1], xr2[0], xr2[1])
+    CTVAE_PROJ(0, (f32x2{a4a[0], a4a[1]}), (f32x2{g4a[0], g4a[1]}));
+    CTVAE_PROJ(2, (f32x2{a4a[2], a4a[3]}), (f32x2{g4a[2], g4a[3]}));
+    CTVAE_PROJ(4, (f32x2{a4b[0], a4b[1]}), (f32x2{g4b[0], g4b[1]}));
+    CTVAE_PROJ(6, (f32x2{a4b[2], a4b[3]}), (f32x2{g4b[2], g4b[3]}));
+#undef CTVAE_PROJ
+    const float cs = slope * sCS[c];
+    f32x4 o;
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+      const f32x2 q = {oct_sum(qr[pp][0]), oct_sum(qr[pp][1])};
+      const f32x2 d = f32x2{cs, cs} + f32x2{oms, oms} * q;
+      dc[pp] += xr2[pp] * d;
+      o[2 * pp] = at2[pp][0] * d[0];
+      o[2 * pp + 1] = at2[pp][1] * d[1];
+    }
+    if (q8 == 0) *reinterpret_cast<f32x4*>(dxrp) = o;
+    dxrp += p.ldd;
+  }
+  CTVAE_PH(gat, 2, 2);
+  f32x2 dr[2] = {{0.f, 0.f}, {0.f, 0.f}};
+  {
+    float* dp = p.dxl + ((long)b * GN + r0) * p.ldd + hs * C + k0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float rs = slope * sRS[r0 + r];
+      const f32x2 d0 = f32x2{rs, rs} + f32x2{oms, oms} * ql[0][r], d1 = f32x2{rs, rs} + f32x2{oms, oms} * ql[1][r];
+      dr[0] += xl2[0][r] * d0;
+      dr[1] += xl2[1][r] * d1;
+      f32x4 v = *reinterpret_cast<const f32x4*>(dp);
+      v += f32x4{at2[0][0] * d0[0], at2[0][1] * d0[1], at2[1][0] * d1[0], at2[1][1] * d1[1]};
+      *reinterpret_cast<f32x4*>(dp) = v;
+      dp += p.ldd;
+    }
+  }
+  const float da = slope * sDAc[0];
+  f32x4 datt, dwe;
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float lin = da + oms * oct_sum(qa[pp][h]);                   // slope DA + (1 - slope) Qa[k]
+      datt[2 * pp + h] = (oct_sum(dr[pp][h]) + dc[pp][h]) * kStepDown + wep[2 * pp + h] * lin;
+      dwe[2 * pp + h] = at2[pp][h] * lin;
+    }
+  if (q8 == 0) {
+    const long o = ((long)b * a.Hs + hs) * C + k0;
+    *reinterpret_cast<f32x4*>(p.datt_part + o) = datt;
+    *reinterpret_cast<f32x4*>(p.dwe_part + o) = dwe;
+  }
+  CTVAE_PH(gat, 2, 3);
+}
+
 // d adj[b][r][c] = edge[r][c] * (sum_slots d a'[r][c] + (sum_slots d a'[c][c]) / deg[c]); grid B, 256 threads
 __global__ __launch_bounds__(256) void gat_adj_reduce_kernel(const float* __restrict__ dattr, const float* __restrict__ adj,
                                                             float* __restrict__ dadj, int Hs, int accumulate) {
@@ -593,7 +920,8 @@ __global__ __launch_bounds__(256) void gat_adj_reduce_kernel(const float* __rest
   }
 }
 
-size_t fwd_smem(int C) { return ((size_t)2 * C * LS + GN * SS + 2 * C + 4 * GN + 4 * GN + 4) * sizeof(float); }
+size_t fwd_smem(int C) { return ((size_t)2 * C * LS + GN * SS + 2 * C + 4 * GN + 4 * GN + 4) * sizeof(float); }      // the first version's layout
+size_t fwd2_smem(int C) { return ((size_t)2 * C * LS + GN * SS + 1 + 2 * (C + 1) + C + 4 + 2 * GN * 4 + 4 * GN + 2 * GN) * sizeof(float); }
 size_t bwd_smem(int C) { return ((size_t)2 * C * LS + GN * SS + 2 * C + 2 * 16 * GN + 3 * GN + 4) * sizeof(float); }
 
 bool args_ok(const GatLayerArgs& a) {
@@ -607,18 +935,21 @@ int launch_gat_layer_forward(const GatLayerArgs& a, hipStream_t st) {
   if (!args_ok(a)) return kErrBadArg;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_fwd_kernel<25>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_fwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_fwd_old_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_fwd_old_kernel<25>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_fwd_old_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const double pairs = (double)a.B * a.Hs * GN * GN;
   ProfScope ps(a.C <= 64 ? "gat_layer_fwd_kernel<16>" : a.C <= 100 ? "gat_layer_fwd_kernel<25>" : "gat_layer_fwd_kernel<32>", st, 6.0 * pairs * a.C, 4.0 * a.B * a.Hs * (3.0 * GN * a.C + 2.0 * GN * GN));
   const size_t smem = fwd_smem(a.C);
   const dim3 grid(a.Hs, a.B);
-  if (a.C <= 64) hipLaunchKernelGGL(gat_layer_fwd_kernel<16>, grid, dim3(256), smem, st, a);
-  else if (a.C <= 100) hipLaunchKernelGGL(gat_layer_fwd_kernel<25>, grid, dim3(256), smem, st, a);
-  else hipLaunchKernelGGL(gat_layer_fwd_kernel<32>, grid, dim3(256), smem, st, a);
+  static const bool old_fwd = getenv("CTVAE_GAT_FWD_OLD") != nullptr;       // diagnostic
+  if (!old_fwd) hipLaunchKernelGGL(gat_layer_fwd_kernel, grid, dim3(256), fwd2_smem(a.C), st, a);
+  else if (a.C <= 64) hipLaunchKernelGGL(gat_layer_fwd_old_kernel<16>, grid, dim3(256), smem, st, a);
+  else if (a.C <= 100) hipLaunchKernelGGL(gat_layer_fwd_old_kernel<25>, grid, dim3(256), smem, st, a);
+  else hipLaunchKernelGGL(gat_layer_fwd_old_kernel<32>, grid, dim3(256), smem, st, a);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }
@@ -647,8 +978,9 @@ int launch_gat_layer_backward(const GatBwdArgs& p, float* dadj, int accumulate_d
   }
   {
     ProfScope ps("gat_proj_bwd_kernel", st, 9.0 * pairs * a.C, 4.0 * a.B * a.Hs * (4.0 * GN * a.C + 2.0 * GN * GN));
-    const int threads = 4 * ((a.C + 15) / 16 * 16);
-    hipLaunchKernelGGL(gat_proj_bwd_kernel, grid, dim3(threads), 0, st, p);
+    static const bool old_proj = getenv("CTVAE_GAT_PROJ_OLD") != nullptr;       // diagnostic
+    if (old_proj) hipLaunchKernelGGL(gat_proj_bwd_old_kernel, grid, dim3(4 * ((a.C + 15) / 16 * 16)), 0, st, p);
+    else hipLaunchKernelGGL(gat_proj_bwd_kernel, grid, dim3(256), 0, st, p);
     CTVAE_LAUNCH_CHECK();
   }
   if (dadj != nullptr) {

@@ -94,6 +94,68 @@ __device__ __forceinline__ void relu_fma_4x4(f32x2 (&acc)[4][2], f32x2 u01, f32x
 #undef CTVAE_ROWS2
 }
 
+// Two sources (r, r + 1) x four channels (two packed pairs A, B) of the GATv2 projection gradients (gatlayer.hip gat_proj_bwd_kernel):
+//   ind_r = sat(a_r * w + xl_r + xr)      ql_r += g_r * ind_r      qr += g_r * ind_r      qa += (g_r a_r) * ind_r
+// a = {a_r, a_r+1} and g likewise (natural pairs out of 16-byte LDS reads, broadcast per half through op_sel); w, xl_r, xr = two
+// channels each.  21 instructions for 8 (pair, channel)s; the temporaries never leave the block.
+__device__ __forceinline__ void proj_step2x2(f32x2& qlA0, f32x2& qlA1, f32x2& qlB0, f32x2& qlB1, f32x2& qrA, f32x2& qrB, f32x2& qaA,
+                                             f32x2& qaB, f32x2 a, f32x2 g, f32x2 wA, f32x2 wB, f32x2 xlA0, f32x2 xlA1, f32x2 xlB0,
+                                             f32x2 xlB1, f32x2 xrA, f32x2 xrB) {
+  f32x2 t0, t1, t2, t3, ga;
+  asm("v_pk_mul_f32 %[ga], %[g], %[a]\n\t"
+      "v_pk_fma_f32 %[t0], %[a], %[wA], %[xA0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %[t1], %[a], %[wA], %[xA1] op_sel:[1,0,0]\n\t"
+      "v_pk_fma_f32 %[t2], %[a], %[wB], %[xB0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %[t3], %[a], %[wB], %[xB1] op_sel:[1,0,0]\n\t"
+      "v_pk_add_f32 %[t0], %[t0], %[xrA] clamp\n\t"
+      "v_pk_add_f32 %[t1], %[t1], %[xrA] clamp\n\t"
+      "v_pk_add_f32 %[t2], %[t2], %[xrB] clamp\n\t"
+      "v_pk_add_f32 %[t3], %[t3], %[xrB] clamp\n\t"
+      "v_pk_fma_f32 %[qA0], %[g], %[t0], %[qA0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %[qB0], %[g], %[t2], %[qB0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %[qrA], %[g], %[t0], %[qrA] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %[qrB], %[g], %[t2], %[qrB] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %[qaA], %[ga], %[t0], %[qaA] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %[qaB], %[ga], %[t2], %[qaB] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %[qA1], %[g], %[t1], %[qA1] op_sel:[1,0,0]\n\t"
+      "v_pk_fma_f32 %[qB1], %[g], %[t3], %[qB1] op_sel:[1,0,0]\n\t"
+      "v_pk_fma_f32 %[qrA], %[g], %[t1], %[qrA] op_sel:[1,0,0]\n\t"
+      "v_pk_fma_f32 %[qrB], %[g], %[t3], %[qrB] op_sel:[1,0,0]\n\t"
+      "v_pk_fma_f32 %[qaA], %[ga], %[t1], %[qaA] op_sel:[1,0,0]\n\t"
+      "v_pk_fma_f32 %[qaB], %[ga], %[t3], %[qaB] op_sel:[1,0,0]"
+      : [qA0] "+v"(qlA0), [qA1] "+v"(qlA1), [qB0] "+v"(qlB0), [qB1] "+v"(qlB1), [qrA] "+v"(qrA), [qrB] "+v"(qrB), [qaA] "+v"(qaA),
+        [qaB] "+v"(qaB), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [ga] "=&v"(ga)
+      : [a] "v"(a), [g] "v"(g), [wA] "v"(wA), [wB] "v"(wB), [xA0] "v"(xlA0), [xA1] "v"(xlA1), [xB0] "v"(xlB0), [xB1] "v"(xlB1),
+        [xrA] "v"(xrA), [xrB] "v"(xrB));
+}
+
+// One channel of the GATv2 score on two source rows x four target columns (gatlayer.hip):
+//   acc[r][c] += at * sat(l_r + r_c + a[r][c] * w)           l = {l_r, l_r+1}, wa = {w, at}, columns in two packed pairs
+// 12 instructions for 8 (pair, channel)s.
+__device__ __forceinline__ void score_2x4(f32x2& acc00, f32x2& acc01, f32x2& acc10, f32x2& acc11, f32x2 l, f32x2 r01, f32x2 r23, f32x2 wa,
+                                          f32x2 a00, f32x2 a01, f32x2 a10, f32x2 a11) {
+  f32x2 t0, t1, t2, t3;
+  asm("v_pk_add_f32 %[t0], %[l], %[r01] op_sel_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[t1], %[l], %[r23] op_sel_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[t2], %[l], %[r01] op_sel:[1,0]\n\t"
+      "v_pk_add_f32 %[t3], %[l], %[r23] op_sel:[1,0]\n\t"
+      "v_pk_fma_f32 %[t0], %[a00], %[wa], %[t0] op_sel_hi:[1,0,1] clamp\n\t"
+      "v_pk_fma_f32 %[t1], %[a01], %[wa], %[t1] op_sel_hi:[1,0,1] clamp\n\t"
+      "v_pk_fma_f32 %[t2], %[a10], %[wa], %[t2] op_sel_hi:[1,0,1] clamp\n\t"
+      "v_pk_fma_f32 %[t3], %[a11], %[wa], %[t3] op_sel_hi:[1,0,1] clamp\n\t"
+      "v_pk_fma_f32 %[c00], %[wa], %[t0], %[c00] op_sel:[1,0,0]\n\t"
+      "v_pk_fma_f32 %[c01], %[wa], %[t1], %[c01] op_sel:[1,0,0]\n\t"
+      "v_pk_fma_f32 %[c10], %[wa], %[t2], %[c10] op_sel:[1,0,0]\n\t"
+      "v_pk_fma_f32 %[c11], %[wa], %[t3], %[c11] op_sel:[1,0,0]"
+      : [c00] "+v"(acc00), [c01] "+v"(acc01), [c10] "+v"(acc10), [c11] "+v"(acc11), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+        [t3] "=&v"(t3)
+      : [l] "v"(l), [r01] "v"(r01), [r23] "v"(r23), [wa] "v"(wa), [a00] "v"(a00), [a01] "v"(a01), [a10] "v"(a10), [a11] "v"(a11));
+}
+
+// Same block for the backward's step function: acc[r][c] += c_k * [l_r + r_c + a[r][c] * w > 0], operands pre-scaled by 2^60,
+// wa = {w * 2^60, att_k we_k (1 - slope)}.  (The instruction sequence is the forward's: sat() of the scaled sum IS the step.)
+#define step_2x4 score_2x4
+
 // sum over the 4 / 8 lanes of an aligned lane group, result in every lane of the group (DPP adds, no LDS)
 __device__ __forceinline__ float quad_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
