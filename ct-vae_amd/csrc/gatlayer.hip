@@ -258,22 +258,22 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fwd_old_kernel(GatLayerArgs 
   CTVAE_PH(gat, 0, 10);
 }
 
-// MFMA helper of the fused layer kernels: D[m][n] (+)= sum_{r < 64} A[r][m] * B[n][r] for one 32 x 32 tile, A rows of stride sa
-// (element [r][m] at A[r * sa + m]), B rows of stride LS holding 64 consecutive r.  v_mfma_f32_32x32x2_f32 takes two values of
-// the reduction index per step (lane >> 5 picks which); the r order is permuted so that a lane's B operands of four steps are ONE
-// 16-byte LDS read (r = 8 q + 4 (lane >> 5) + j, conflict-free for row stride 68).  Result: lane holds n = lane & 31, register i
-// holds m = 8 (i >> 2) + 4 (lane >> 5) + (i & 3).
-__device__ __forceinline__ f32x16 mfma_tile_64(const float* A, int sa, const float* B, int lane) {
+// MFMA helper of the fused layer kernels: D[m][n] = sum_{r < 64} A(r, m) * B[n][r] for one 32 x 32 tile; A(r, m) sits at
+// A[r * ars + m * ams], B rows have stride LS and hold 64 consecutive r.  v_mfma_f32_32x32x2_f32 takes two values of the reduction
+// index per step (lane >> 5 picks which); the r order is permuted so that a lane's B operands of four steps are ONE 16-byte LDS
+// read (r = 8 q + 4 (lane >> 5) + j, conflict-free for row stride 68).  Result: lane holds n = lane & 31, register i holds
+// m = 8 (i >> 2) + 4 (lane >> 5) + (i & 3).
+__device__ __forceinline__ f32x16 mfma_tile_64(const float* A, int ars, int ams, const float* B, int lane) {
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   const int lh = lane >> 5, ln = lane & 31;
-  const float* ap = A + (4 * lh) * sa + ln;
+  const float* ap = A + (4 * lh) * ars + ln * ams;
   const float* bp = B + ln * LS + 4 * lh;
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + 8 * q);
-    const float a0 = ap[(8 * q) * sa], a1 = ap[(8 * q + 1) * sa], a2 = ap[(8 * q + 2) * sa], a3 = ap[(8 * q + 3) * sa];
+    const float a0 = ap[(8 * q) * ars], a1 = ap[(8 * q + 1) * ars], a2 = ap[(8 * q + 2) * ars], a3 = ap[(8 * q + 3) * ars];
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b4[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b4[1], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b4[2], acc, 0, 0, 0);
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fwd_kernel(GatLayerArgs a) {
     const int nt2 = 2 * ((C + 31) >> 5), lh = lane >> 5, ln = lane & 31;
     for (int t = wave; t < nt2; t += 4) {
       const int mt = t & 1, k = 32 * (t >> 1) + ln;
-      const f32x16 o = mfma_tile_64(Ss + 32 * mt, SS, XL + 32 * (t >> 1) * LS, lane);
+      const f32x16 o = mfma_tile_64(Ss + 32 * mt, SS, 1, XL + 32 * (t >> 1) * LS, lane);
       if (k < C) {
         const float bias = a.bias[head * C + k];
         float* op = a.out + ((long)b * GN + 32 * mt + 4 * lh) * a.ldo + hs * C + k;
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fwd_kernel(GatLayerArgs a) {
 }
 
 template <int KQ>
-__global__ __launch_bounds__(256, 2) void gat_layer_bwd_kernel(GatBwdArgs p) {
+__global__ __launch_bounds__(256, 2) void gat_layer_bwd_old_kernel(GatBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const GatLayerArgs& a = p.f;
   const int C = a.C;
@@ -634,6 +634,185 @@ __global__ __launch_bounds__(256, 2) void gat_layer_bwd_kernel(GatBwdArgs p) {
     }
   }
   CTVAE_PH(gat, 1, 11);
+}
+
+// Backward of the layer up to dS (gat_proj_bwd_kernel takes it from there): d alpha = xl G^T and the aggregation's share of d xl,
+// alpha G, as MFMA tiles from the LDS operands; softmax backward on the accumulators; the edge-attribute gradient
+// d a'[r][c] = dS (slope sum_k att we + (1 - slope) sum_k att we [m > 0]) with the step function as the clamp of the packed fma that
+// forms m (operands scaled by 2^60, satmath.hpp): 1.5 instructions per (pair, channel).
+__global__ __launch_bounds__(256, 2) void gat_layer_bwd_kernel(GatBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const GatLayerArgs& a = p.f;
+  const int C = a.C;
+  float* XL = smem;                 // [C][LS]  xl * 2^60
+  float* R2 = XL + C * LS;          // [C][LS]: G[k][c], then xr[k][c] * 2^60
+  float* Ss = R2 + C * LS;          // [GN][SS] scratch of load_adj_block, then alpha, then dS
+  float* sWA = Ss + GN * SS;        // [C + 1][2]  {we * 2^60, att we (1 - slope)}
+  float* sT = sWA + 2 * (C + 1);    // [2][GN]
+  float* sLoop = sT + 2 * GN;
+  float* sDeg = sLoop + GN;
+  const int tid = threadIdx.x, hs = blockIdx.x, b = blockIdx.y, lane = tid & 63, wave = tid >> 6, lh = lane >> 5, ln = lane & 31;
+  const int head = a.head_map ? a.head_map[b * a.Hs + hs] : hs;
+  const int tr = tid >> 4, tc = tid & 15;
+  CTVAE_PH(gat, 1, 0);
+  float alv[16];                                         // alpha of the head: in flight while the operands are staged
+  {
+    const float* al = a.alpha + ((long)b * a.Hs + hs) * GN * GN;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) alv[t] = al[tid + 256 * t];
+  }
+  stage_T(a.xl, (long)b * GN, a.ld, hs * C, C, XL, kStepUp);
+  {                                                     // G[k][c] = g_out[c][k] * act'(out[c][k])
+    const int c4 = C >> 2, n4 = GN * c4;
+    f32x4 gv[8], ov[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int e = tid + 256 * it;
+      const int n = e / c4;
+      const long o = ((long)b * GN + n) * a.ldo + hs * C + (e - n * c4) * 4;
+      if (e < n4) {
+        gv[it] = *reinterpret_cast<const f32x4*>(p.g_out + o);
+        if (a.act == ACT_LRELU) ov[it] = *reinterpret_cast<const f32x4*>(a.out + o);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int e = tid + 256 * it;
+      if (e < n4) {
+        const int n = e / c4, k = (e - n * c4) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float g = gv[it][j];
+          if (a.act == ACT_LRELU) g *= ov[it][j] > 0.f ? 1.f : kLeaky;
+          R2[(k + j) * LS + n] = g;
+        }
+      }
+    }
+  }
+  for (int k = tid; k < C; k += 256) {
+    const float w = a.we[head * C + k];
+    sWA[2 * k] = w * kStepUp;
+    sWA[2 * k + 1] = a.att[head * C + k] * w * (1.f - a.slope);
+  }
+  if (tid < 2) sWA[2 * C + tid] = 0.f;
+  CTVAE_PH(gat, 1, 1);
+  float av[4][4];
+  unsigned keep;
+  load_adj_block(a.adj, b, tr, tc, av, keep, Ss, sLoop, sDeg);     // two barriers inside: the staging above is visible
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int e = tid + 256 * t;
+    Ss[(e >> 6) * SS + (e & 63)] = alv[t];
+  }
+  CTVAE_PH(gat, 1, 2);
+  if (tid < C) {                                        // bias gradient: sum over the targets
+    float s = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < GN; ++c) s += R2[tid * LS + c];
+    p.dbias_part[((long)b * a.Hs + hs) * C + tid] = s;
+  }
+  float aw;                                             // slope * sum_k att we
+  {
+    float s = 0.f;
+    for (int k = lane; k < C; k += 64) s += a.att[head * C + k] * a.we[head * C + k];
+    aw = wave_sum(s) * a.slope;
+  }
+  CTVAE_PH(gat, 1, 3);
+  // d alpha[r][c] = sum_k xl[r][k] * G[k][c]: one 32 x 32 tile per wave, two channels per MFMA step
+  const int mt = wave >> 1, nt = wave & 1;
+  f32x16 da;
+  {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) da[i] = 0.f;
+    const float* ap = XL + lh * LS + 32 * mt + ln;
+    const float* bp = R2 + lh * LS + 32 * nt + ln;
+#pragma unroll 4
+    for (int k = 0; k < C; k += 2) da = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k * LS], bp[k * LS], da, 0, 0, 0);
+  }
+  __syncthreads();                                      // alpha is in Ss
+  CTVAE_PH(gat, 1, 4);
+  // softmax backward per target column: dS = alpha * (d alpha - sum_r alpha * d alpha).  The lane holds column c = 32 nt + ln and
+  // the rows r = 32 mt + 8 (i >> 2) + 4 lh + (i & 3).
+  float alr[16];
+  {
+    const float* sp = Ss + (32 * mt + 4 * lh) * SS + 32 * nt + ln;
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      da[i] *= kStepDown;
+      alr[i] = sp[(8 * (i >> 2) + (i & 3)) * SS];
+      part += alr[i] * da[i];
+    }
+    part += __shfl_xor(part, 32, 64);
+    if (lh == 0) sT[mt * GN + 32 * nt + ln] = part;
+  }
+  // the aggregation's share of d xl[r][k] = sum_c alpha[r][c] * G[k][c]: tile = (32 sources, 32 channels), straight to global memory
+  {
+    const int nt2 = 2 * ((C + 31) >> 5);
+    for (int t = wave; t < nt2; t += 4) {
+      const int m2 = t & 1, k = 32 * (t >> 1) + ln;
+      const f32x16 o = mfma_tile_64(Ss + 32 * m2 * SS, 1, SS, R2 + 32 * (t >> 1) * LS, lane);
+      if (k < C) {
+        float* op = p.dxl + ((long)b * GN + 32 * m2 + 4 * lh) * p.ldd + hs * C + k;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) op[(long)(8 * (i >> 2) + (i & 3)) * p.ldd] = o[i];
+      }
+    }
+  }
+  __syncthreads();                                      // alpha and G are dead, sT is complete
+  CTVAE_PH(gat, 1, 5);
+  {
+    const float tcol = sT[32 * nt + ln] + sT[GN + 32 * nt + ln];
+    float* sp = Ss + (32 * mt + 4 * lh) * SS + 32 * nt + ln;
+    float* gp = p.dS + (((long)b * a.Hs + hs) * GN + 32 * mt + 4 * lh) * GN + 32 * nt + ln;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float d = alr[i] * (da[i] - tcol);
+      sp[(8 * (i >> 2) + (i & 3)) * SS] = d;
+      gp[(8 * (i >> 2) + (i & 3)) * GN] = d;
+    }
+  }
+  stage_T(a.xr, (long)b * GN, a.ld, hs * C, C, R2, kStepUp);
+  __syncthreads();
+  CTVAE_PH(gat, 1, 6);
+  // d a'[r][c] = dS * (slope * sum_k att we + (1 - slope) * sum_k att we [m > 0]): thread = 4 x 4 block of pairs
+  f32x2 t[4][2], a2[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      t[i][jp] = f32x2{0.f, 0.f};
+      a2[i][jp] = f32x2{av[i][2 * jp], av[i][2 * jp + 1]};
+    }
+  {
+    const float* pl = XL + 4 * tr;
+    const float* pr = R2 + 4 * tc;
+    f32x4 l4 = *reinterpret_cast<const f32x4*>(pl), r4 = *reinterpret_cast<const f32x4*>(pr);
+    f32x2 wa = *reinterpret_cast<const f32x2*>(sWA);
+#pragma unroll 2
+    for (int k = 0; k < C; ++k) {
+      pl += LS;
+      pr += LS;
+      const f32x4 l4n = *reinterpret_cast<const f32x4*>(pl), r4n = *reinterpret_cast<const f32x4*>(pr);   // row C: the next array (in bounds)
+      const f32x2 wan = *reinterpret_cast<const f32x2*>(sWA + 2 * (k + 1));
+      const f32x2 r01 = {r4[0], r4[1]}, r23 = {r4[2], r4[3]};
+      step_2x4(t[0][0], t[0][1], t[1][0], t[1][1], f32x2{l4[0], l4[1]}, r01, r23, wa, a2[0][0], a2[0][1], a2[1][0], a2[1][1]);
+      step_2x4(t[2][0], t[2][1], t[3][0], t[3][1], f32x2{l4[2], l4[3]}, r01, r23, wa, a2[2][0], a2[2][1], a2[3][0], a2[3][1]);
+      l4 = l4n; r4 = r4n; wa = wan;
+    }
+  }
+  CTVAE_PH(gat, 1, 7);
+  {
+    float* dA = p.dattr + (((long)b * a.Hs + hs) * GN + 4 * tr) * GN + 4 * tc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = Ss[(4 * tr + i) * SS + 4 * tc + j] * (aw + t[i][j >> 1][j & 1]);
+      *reinterpret_cast<f32x4*>(dA + i * GN) = v;
+    }
+  }
+  CTVAE_PH(gat, 1, 8);
 }
 
 // d xl (added to what gat_layer_bwd_kernel left), d xr, d att, d we from dS.  grid (Hs, B); blockDim = 4 * CP, CP = C rounded
@@ -922,7 +1101,8 @@ __global__ __launch_bounds__(256) void gat_adj_reduce_kernel(const float* __rest
 
 size_t fwd_smem(int C) { return ((size_t)2 * C * LS + GN * SS + 2 * C + 4 * GN + 4 * GN + 4) * sizeof(float); }      // the first version's layout
 size_t fwd2_smem(int C) { return ((size_t)2 * C * LS + GN * SS + 1 + 2 * (C + 1) + C + 4 + 2 * GN * 4 + 4 * GN + 2 * GN) * sizeof(float); }
-size_t bwd_smem(int C) { return ((size_t)2 * C * LS + GN * SS + 2 * C + 2 * 16 * GN + 3 * GN + 4) * sizeof(float); }
+size_t bwd_smem(int C) { return ((size_t)2 * C * LS + GN * SS + 2 * C + 2 * 16 * GN + 3 * GN + 4) * sizeof(float); }     // the first version's layout
+size_t bwd2_smem(int C) { return ((size_t)2 * C * LS + GN * SS + 2 * (C + 1) + 2 * GN + 2 * GN) * sizeof(float); }
 
 bool args_ok(const GatLayerArgs& a) {
   return a.xl && a.xr && a.adj && a.we && a.att && a.bias && a.out && a.alpha && a.B > 0 && a.Hs > 0 && a.C >= 16 && a.C <= 128 &&
@@ -961,9 +1141,10 @@ int launch_gat_layer_backward(const GatBwdArgs& p, float* dadj, int accumulate_d
     return kErrBadArg;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_bwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_bwd_kernel<25>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_bwd_old_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_bwd_old_kernel<25>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_bwd_old_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const double pairs = (double)a.B * a.Hs * GN * GN;
@@ -971,9 +1152,11 @@ int launch_gat_layer_backward(const GatBwdArgs& p, float* dadj, int accumulate_d
   {
     ProfScope ps(a.C <= 64 ? "gat_layer_bwd_kernel<16>" : a.C <= 100 ? "gat_layer_bwd_kernel<25>" : "gat_layer_bwd_kernel<32>", st, 10.0 * pairs * a.C, 4.0 * a.B * a.Hs * (4.0 * GN * a.C + 4.0 * GN * GN));
     const size_t smem = bwd_smem(a.C);
-    if (a.C <= 64) hipLaunchKernelGGL(gat_layer_bwd_kernel<16>, grid, dim3(256), smem, st, p);
-    else if (a.C <= 100) hipLaunchKernelGGL(gat_layer_bwd_kernel<25>, grid, dim3(256), smem, st, p);
-    else hipLaunchKernelGGL(gat_layer_bwd_kernel<32>, grid, dim3(256), smem, st, p);
+    static const bool old_bwd = getenv("CTVAE_GAT_BWD_OLD") != nullptr;       // diagnostic
+    if (!old_bwd) hipLaunchKernelGGL(gat_layer_bwd_kernel, grid, dim3(256), bwd2_smem(a.C), st, p);
+    else if (a.C <= 64) hipLaunchKernelGGL(gat_layer_bwd_old_kernel<16>, grid, dim3(256), smem, st, p);
+    else if (a.C <= 100) hipLaunchKernelGGL(gat_layer_bwd_old_kernel<25>, grid, dim3(256), smem, st, p);
+    else hipLaunchKernelGGL(gat_layer_bwd_old_kernel<32>, grid, dim3(256), smem, st, p);
     CTVAE_LAUNCH_CHECK();
   }
   {
