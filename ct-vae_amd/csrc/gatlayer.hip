@@ -105,157 +105,45 @@ __device__ __forceinline__ void stage_T(const float* __restrict__ src, long row0
   }
 }
 
-template <int KQ>   // channels per thread in the aggregation: ceil(C / 4) <= KQ
-__global__ __launch_bounds__(256, 2) void gat_layer_fwd_old_kernel(GatLayerArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int C = a.C;
-  float* XL = smem;                 // [C][LS]
-  float* XR = XL + C * LS;          // [C][LS]; later O[c][C|1]
-  float* Ss = XR + C * LS;          // [GN][SS]
-  float* sWe = Ss + GN * SS;        // [C]
-  float* sAt = sWe + C;             // [C]  att * (1 - slope)
-  float* sCol = sAt + C;            // [4][GN]
-  float* sLoop = sCol + 4 * GN;     // [GN]
-  float* sDeg = sLoop + GN;         // [GN]
-  float* sAL = sDeg + GN;           // [GN] sum_k att xl[r,k]
-  float* sAR = sAL + GN;            // [GN]
-  float* sAW = sAR + GN;            // [1]
-  const int tid = threadIdx.x, hs = blockIdx.x, b = blockIdx.y;
-  const int head = a.head_map ? a.head_map[b * a.Hs + hs] : hs;
-  const int tr = tid >> 4, tc = tid & 15;
-  CTVAE_PH(gat, 0, 0);
-  stage_T(a.xl, (long)b * GN, a.ld, hs * C, C, XL);
-  stage_T(a.xr, (long)b * GN, a.ld, hs * C, C, XR);
-  CTVAE_PH(gat, 0, 1);
-  for (int k = tid; k < C; k += 256) {
-    sWe[k] = a.we[head * C + k];
-    sAt[k] = a.att[head * C + k] * (1.f - a.slope);
-  }
-  float av[4][4];
-  unsigned keep;
-  load_adj_block(a.adj, b, tr, tc, av, keep, Ss, sLoop, sDeg);      // two barriers inside: the staging above is visible
-  CTVAE_PH(gat, 0, 2);
-  // lrelu(m) = slope*m + (1-slope)*relu(m): the first term is linear in xl, xr, a' and is summed per node, not per pair
-  if (tid < 2 * GN) {
-    const float* T = tid < GN ? XL : XR;
-    const int n = tid & (GN - 1);
-    float s = 0.f;
-    for (int k = 0; k < C; ++k) s += a.att[head * C + k] * T[k * LS + n];
-    (tid < GN ? sAL : sAR)[n] = s;
-  } else if (tid == 2 * GN) {
-    float s = 0.f;
-    for (int k = 0; k < C; ++k) s += a.att[head * C + k] * a.we[head * C + k];
-    sAW[0] = s;
-  }
-  CTVAE_PH(gat, 0, 3);
-  f32x2 acc[4][2], a2[4][2];
+// The pair loop of the forward score and of the backward's edge-attribute gradient: thread = 4 x 4 block of (source, target) pairs,
+// acc[r][c] += wa.y * sat(l[k][r] + r[k][c] + a[r][c] * wa.x) over the C channels (score_2x4, satmath.hpp).  Operands of four
+// channels are read from LDS as one group while the previous group is evaluated (a 16-byte read takes longer than the 24
+// instructions of one channel, and only two waves share a SIMD); the last group's read-ahead lands in the arrays that follow
+// (in bounds, unused).  C % 4 == 0.
+__device__ __forceinline__ void pair_loop(f32x2 (&acc)[4][2], const f32x2 (&a2)[4][2], const float* pl, const float* pr, const float* pw, int C) {
+  f32x4 l[4], r[4];
+  f32x2 w[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int j = 0; j < 4; ++j) {
+    l[j] = *reinterpret_cast<const f32x4*>(pl + j * LS);
+    r[j] = *reinterpret_cast<const f32x4*>(pr + j * LS);
+    w[j] = *reinterpret_cast<const f32x2*>(pw + 2 * j);
+  }
+  for (int k = 0; k < C; k += 4) {
+    pl += 4 * LS;
+    pr += 4 * LS;
+    pw += 8;
+    f32x4 ln[4], rn[4];
+    f32x2 wn[4];
 #pragma unroll
-    for (int jp = 0; jp < 2; ++jp) {
-      acc[i][jp] = f32x2{0.f, 0.f};
-      a2[i][jp] = f32x2{av[i][2 * jp], av[i][2 * jp + 1]};
+    for (int j = 0; j < 4; ++j) {
+      ln[j] = *reinterpret_cast<const f32x4*>(pl + j * LS);
+      rn[j] = *reinterpret_cast<const f32x4*>(pr + j * LS);
+      wn[j] = *reinterpret_cast<const f32x2*>(pw + 2 * j);
     }
-  for (int k = 0; k < C; ++k) {
-    const f32x4 l4 = *reinterpret_cast<const f32x4*>(XL + k * LS + 4 * tr);
-    const f32x4 r4 = *reinterpret_cast<const f32x4*>(XR + k * LS + 4 * tc);
-    const float wk = sWe[k], ak = sAt[k];
-    const f32x2 wk2 = {wk, wk}, ak2 = {ak, ak};
-    const f32x2 r01 = {r4[0], r4[1]}, r23 = {r4[2], r4[3]};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const f32x2 li = {l4[i], l4[i]};
-      const f32x2 m0 = (li + r01) + a2[i][0] * wk2;
-      const f32x2 m1 = (li + r23) + a2[i][1] * wk2;
-      acc[i][0] += ak2 * f32x2{relu(m0[0]), relu(m0[1])};
-      acc[i][1] += ak2 * f32x2{relu(m1[0]), relu(m1[1])};
+    for (int j = 0; j < 4; ++j) {
+      const f32x2 r01 = {r[j][0], r[j][1]}, r23 = {r[j][2], r[j][3]};
+      score_2x4(acc[0][0], acc[0][1], acc[1][0], acc[1][1], f32x2{l[j][0], l[j][1]}, r01, r23, w[j], a2[0][0], a2[0][1], a2[1][0], a2[1][1]);
+      score_2x4(acc[2][0], acc[2][1], acc[3][0], acc[3][1], f32x2{l[j][2], l[j][3]}, r01, r23, w[j], a2[2][0], a2[2][1], a2[3][0], a2[3][1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      l[j] = ln[j];
+      r[j] = rn[j];
+      w[j] = wn[j];
     }
   }
-  CTVAE_PH(gat, 0, 4);
-  __syncthreads();
-  CTVAE_PH(gat, 0, 5);
-  {
-    const float aw = sAW[0];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float al = sAL[4 * tr + i];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float s = a.slope * (al + sAR[4 * tc + j] + av[i][j] * aw) + acc[i][j >> 1][j & 1];
-        Ss[(4 * tr + i) * SS + 4 * tc + j] = ((keep >> (4 * i + j)) & 1u) ? s : -INFINITY;
-      }
-    }
-  }
-  __syncthreads();
-  CTVAE_PH(gat, 0, 6);
-  // softmax over the sources r of every target column c: thread = (c, quarter of the rows)
-  {
-    const int c = tid & (GN - 1), q = tid >> 6;
-    float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, Ss[(16 * q + i) * SS + c]);
-    sCol[q * GN + c] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(sCol[c], sCol[GN + c]), fmaxf(sCol[2 * GN + c], sCol[3 * GN + c]));   // finite: the self loop is kept
-    __syncthreads();
-    float e[16], sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      e[i] = __expf(Ss[(16 * q + i) * SS + c] - mx);
-      sum += e[i];
-    }
-    sCol[q * GN + c] = sum;
-    __syncthreads();
-    const float inv = 1.f / (sCol[c] + sCol[GN + c] + sCol[2 * GN + c] + sCol[3 * GN + c]);
-    float* al = a.alpha + (((long)b * a.Hs + hs) * GN + 16 * q) * GN + c;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float p = e[i] * inv;
-      Ss[(16 * q + i) * SS + c] = p;
-      al[i * GN] = p;
-    }
-  }
-  __syncthreads();
-  CTVAE_PH(gat, 0, 7);
-  // out[c][k] = sum_r alpha[r][c] * xl[r][k]: thread = (c, quarter of the channels)
-  {
-    const int c = tid & (GN - 1), k0 = (tid >> 6) * KQ;
-    float o[KQ];
-#pragma unroll
-    for (int kk = 0; kk < KQ; ++kk) o[kk] = 0.f;
-    for (int r4 = 0; r4 < 16; ++r4) {
-      const float p0 = Ss[(4 * r4) * SS + c], p1 = Ss[(4 * r4 + 1) * SS + c], p2 = Ss[(4 * r4 + 2) * SS + c],
-                  p3 = Ss[(4 * r4 + 3) * SS + c];
-#pragma unroll
-      for (int kk = 0; kk < KQ; ++kk) {
-        if (k0 + kk < C) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(XL + (k0 + kk) * LS + 4 * r4);     // same address in the whole wave
-          o[kk] += p0 * v[0] + p1 * v[1] + p2 * v[2] + p3 * v[3];
-        }
-      }
-    }
-    float* O = XR;                     // XR is dead: every wave passed the barriers behind the score loop
-    const int os = C | 1;
-#pragma unroll
-    for (int kk = 0; kk < KQ; ++kk)
-      if (k0 + kk < C) O[c * os + k0 + kk] = o[kk];
-  }
-  CTVAE_PH(gat, 0, 8);
-  __syncthreads();
-  CTVAE_PH(gat, 0, 9);
-  {
-    const float* O = XR;
-    const int os = C | 1;
-    for (int n = tid >> 6; n < GN; n += 4) {
-      float* row = a.out + ((long)b * GN + n) * a.ldo + hs * C;
-      for (int k = tid & 63; k < C; k += 64) {
-        float v = O[n * os + k] + a.bias[head * C + k];
-        if (a.act == ACT_LRELU) v = v > 0.f ? v : v * kLeaky;
-        row[k] = v;
-      }
-    }
-  }
-  CTVAE_PH(gat, 0, 10);
 }
 
 // MFMA helper of the fused layer kernels: D[m][n] = sum_{r < 64} A(r, m) * B[n][r] for one 32 x 32 tile; A(r, m) sits at
@@ -292,8 +180,8 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fwd_kernel(GatLayerArgs a) {
   float* XL = smem;                 // [C][LS]  xl * 2^-64
   float* XR = XL + C * LS;          // [C][LS]  xr * 2^-64
   float* Ss = XR + C * LS;          // [GN][SS]
-  float* sWA = Ss + GN * SS;        // [C + 1][2]  {we * 2^-64, att * (1 - slope)}   (8-byte aligned: every array before it has an even length)
-  float* sAtt = sWA + 2 * (C + 1);  // [C]
+  float* sWA = Ss + GN * SS;        // [C + 4][2]  {we * 2^-64, att * (1 - slope)}   (8-byte aligned: every array before it has an even length)
+  float* sAtt = sWA + 2 * (C + 4);  // [C]
   float* sP = sAtt + C;             // [2][GN][4] partial sums of att . xl / att . xr (quarter of the channels each)
   sP += (4 - ((sP - smem) & 3)) & 3;
   float* sCol = sP + 2 * GN * 4;    // [4][GN]
@@ -311,7 +199,6 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fwd_kernel(GatLayerArgs a) {
     sWA[2 * k + 1] = t * (1.f - a.slope);
     sAtt[k] = t;
   }
-  if (tid < 2) sWA[2 * C + tid] = 0.f;                                   // the score loop reads one channel ahead
   CTVAE_PH(gat, 0, 1);
   float av[4][4];
   unsigned keep;
@@ -343,23 +230,7 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fwd_kernel(GatLayerArgs a) {
       acc[i][jp] = f32x2{0.f, 0.f};
       a2[i][jp] = f32x2{av[i][2 * jp], av[i][2 * jp + 1]};
     }
-  {
-    const float* pl = XL + 4 * tr;
-    const float* pr = XR + 4 * tc;
-    f32x4 l4 = *reinterpret_cast<const f32x4*>(pl), r4 = *reinterpret_cast<const f32x4*>(pr);
-    f32x2 wa = *reinterpret_cast<const f32x2*>(sWA);
-#pragma unroll 2
-    for (int k = 0; k < C; ++k) {
-      pl += LS;
-      pr += LS;
-      const f32x4 l4n = *reinterpret_cast<const f32x4*>(pl), r4n = *reinterpret_cast<const f32x4*>(pr);   // row C: the next array (in bounds)
-      const f32x2 wan = *reinterpret_cast<const f32x2*>(sWA + 2 * (k + 1));
-      const f32x2 r01 = {r4[0], r4[1]}, r23 = {r4[2], r4[3]};
-      score_2x4(acc[0][0], acc[0][1], acc[1][0], acc[1][1], f32x2{l4[0], l4[1]}, r01, r23, wa, a2[0][0], a2[0][1], a2[1][0], a2[1][1]);
-      score_2x4(acc[2][0], acc[2][1], acc[3][0], acc[3][1], f32x2{l4[2], l4[3]}, r01, r23, wa, a2[2][0], a2[2][1], a2[3][0], a2[3][1]);
-      l4 = l4n; r4 = r4n; wa = wan;
-    }
-  }
+  pair_loop(acc, a2, XL + 4 * tr, XR + 4 * tc, sWA, C);
   CTVAE_PH(gat, 0, 4);
   __syncthreads();
   CTVAE_PH(gat, 0, 5);
@@ -431,211 +302,6 @@ __global__ __launch_bounds__(256, 2) void gat_layer_fwd_kernel(GatLayerArgs a) {
   CTVAE_PH(gat, 0, 8);
 }
 
-template <int KQ>
-__global__ __launch_bounds__(256, 2) void gat_layer_bwd_old_kernel(GatBwdArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const GatLayerArgs& a = p.f;
-  const int C = a.C;
-  float* XL = smem;                 // [C][LS]
-  float* R2 = XL + C * LS;          // [C][LS]: G[k][c], then O[r][C|1], then XR[k][c]
-  float* Ss = R2 + C * LS;          // [GN][SS] alpha
-  float* sWe = Ss + GN * SS;        // [C]
-  float* sAw = sWe + C;             // [C]  att*we*(1-slope)
-  float* sRed = sAw + C;            // [16][GN] scratch (also load_adj_block's 2*16*GN)
-  float* sT = sRed + 2 * 16 * GN;   // [GN]
-  float* sLoop = sT + GN;
-  float* sDeg = sLoop + GN;
-  float* sAW = sDeg + GN;           // [1]
-  const int tid = threadIdx.x, hs = blockIdx.x, b = blockIdx.y;
-  const int head = a.head_map ? a.head_map[b * a.Hs + hs] : hs;
-  const int tr = tid >> 4, tc = tid & 15;
-  CTVAE_PH(gat, 1, 0);
-  stage_T(a.xl, (long)b * GN, a.ld, hs * C, C, XL);
-  {                                                     // G[k][c] = g_out[c][k] * act'(out[c][k])
-    const int c4 = C >> 2, n4 = GN * c4;
-    f32x4 gv[8], ov[8];
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int e = tid + 256 * it;
-      const int n = e / c4;
-      const long o = ((long)b * GN + n) * a.ldo + hs * C + (e - n * c4) * 4;
-      if (e < n4) {
-        gv[it] = *reinterpret_cast<const f32x4*>(p.g_out + o);
-        if (a.act == ACT_LRELU) ov[it] = *reinterpret_cast<const f32x4*>(a.out + o);
-      }
-    }
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int e = tid + 256 * it;
-      if (e < n4) {
-        const int n = e / c4, k = (e - n * c4) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float g = gv[it][j];
-          if (a.act == ACT_LRELU) g *= ov[it][j] > 0.f ? 1.f : kLeaky;
-          R2[(k + j) * LS + n] = g;
-        }
-      }
-    }
-  }
-  for (int k = tid; k < C; k += 256) {
-    const float w = a.we[head * C + k];
-    sWe[k] = w;
-    sAw[k] = a.att[head * C + k] * w * (1.f - a.slope);
-  }
-  {
-    const float* al = a.alpha + ((long)b * a.Hs + hs) * GN * GN;
-    for (int e = tid; e < GN * GN; e += 256) Ss[(e >> 6) * SS + (e & 63)] = al[e];
-  }
-  float av[4][4];
-  unsigned keep;
-  CTVAE_PH(gat, 1, 1);
-  load_adj_block(a.adj, b, tr, tc, av, keep, sRed, sLoop, sDeg);
-  CTVAE_PH(gat, 1, 2);
-  if (tid < C) {                                        // bias gradient: sum over the targets
-    float s = 0.f;
-    for (int c = 0; c < GN; ++c) s += R2[tid * LS + c];
-    p.dbias_part[((long)b * a.Hs + hs) * C + tid] = s;
-  } else if (tid == 255) {
-    float s = 0.f;
-    for (int k = 0; k < C; ++k) s += a.att[head * C + k] * a.we[head * C + k];
-    sAW[0] = s;
-  }
-  CTVAE_PH(gat, 1, 3);
-  // d alpha[r][c] = sum_k xl[r][k] * G[k][c]
-  f32x2 da[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) da[i][0] = da[i][1] = f32x2{0.f, 0.f};
-  for (int k = 0; k < C; ++k) {
-    const f32x4 l4 = *reinterpret_cast<const f32x4*>(XL + k * LS + 4 * tr);
-    const f32x4 g4 = *reinterpret_cast<const f32x4*>(R2 + k * LS + 4 * tc);
-    const f32x2 g01 = {g4[0], g4[1]}, g23 = {g4[2], g4[3]};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const f32x2 li = {l4[i], l4[i]};
-      da[i][0] += li * g01;
-      da[i][1] += li * g23;
-    }
-  }
-  CTVAE_PH(gat, 1, 4);
-  // softmax backward per target column: dS = alpha * (d alpha - sum_r alpha * d alpha)
-  float al[4][4];
-  {
-    float part[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        al[i][j] = Ss[(4 * tr + i) * SS + 4 * tc + j];
-        part[j] += al[i][j] * da[i][j >> 1][j & 1];
-      }
-    __syncthreads();                                   // sRed was load_adj_block's scratch
-#pragma unroll
-    for (int j = 0; j < 4; ++j) sRed[tr * GN + 4 * tc + j] = part[j];
-    __syncthreads();
-    if (tid < GN) {
-      float s = 0.f;
-#pragma unroll
-      for (int t = 0; t < 16; ++t) s += sRed[t * GN + tid];
-      sT[tid] = s;
-    }
-    __syncthreads();
-  }
-  CTVAE_PH(gat, 1, 5);
-  float ds[4][4];
-  {
-    float* dS = p.dS + (((long)b * a.Hs + hs) * GN + 4 * tr) * GN + 4 * tc;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      f32x4 v;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        ds[i][j] = al[i][j] * (da[i][j >> 1][j & 1] - sT[4 * tc + j]);
-        v[j] = ds[i][j];
-      }
-      *reinterpret_cast<f32x4*>(dS + i * GN) = v;
-    }
-  }
-  CTVAE_PH(gat, 1, 6);
-  // the aggregation's share of d xl[r][k] = sum_c alpha[r][c] * G[k][c]: thread = (r, quarter of the channels)
-  float o[KQ];
-  {
-    const int r = tid & (GN - 1), k0 = (tid >> 6) * KQ;
-#pragma unroll
-    for (int kk = 0; kk < KQ; ++kk) o[kk] = 0.f;
-    for (int c4 = 0; c4 < 16; ++c4) {
-      const float p0 = Ss[r * SS + 4 * c4], p1 = Ss[r * SS + 4 * c4 + 1], p2 = Ss[r * SS + 4 * c4 + 2],
-                  p3 = Ss[r * SS + 4 * c4 + 3];
-#pragma unroll
-      for (int kk = 0; kk < KQ; ++kk) {
-        if (k0 + kk < C) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(R2 + (k0 + kk) * LS + 4 * c4);
-          o[kk] += p0 * v[0] + p1 * v[1] + p2 * v[2] + p3 * v[3];
-        }
-      }
-    }
-  }
-  CTVAE_PH(gat, 1, 7);
-  __syncthreads();                                     // G is dead
-  {
-    const int r = tid & (GN - 1), k0 = (tid >> 6) * KQ, os = C | 1;
-#pragma unroll
-    for (int kk = 0; kk < KQ; ++kk)
-      if (k0 + kk < C) R2[r * os + k0 + kk] = o[kk];
-  }
-  __syncthreads();
-  {
-    const int os = C | 1;
-    for (int n = tid >> 6; n < GN; n += 4) {
-      float* row = p.dxl + ((long)b * GN + n) * p.ldd + hs * C;
-      for (int k = tid & 63; k < C; k += 64) row[k] = R2[n * os + k];
-    }
-  }
-  __syncthreads();
-  CTVAE_PH(gat, 1, 8);
-  stage_T(a.xr, (long)b * GN, a.ld, hs * C, C, R2);
-  __syncthreads();
-  CTVAE_PH(gat, 1, 9);
-  // d a'[r][c] = dS * sum_k att we lrelu'(m) = dS * (slope * sum_k att we + (1-slope) * sum_k att we [m > 0])
-  f32x2 t[4][2], a2[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int jp = 0; jp < 2; ++jp) {
-      t[i][jp] = f32x2{0.f, 0.f};
-      a2[i][jp] = f32x2{av[i][2 * jp], av[i][2 * jp + 1]};
-    }
-  const f32x2 big = {1e30f, 1e30f};
-  for (int k = 0; k < C; ++k) {
-    const f32x4 l4 = *reinterpret_cast<const f32x4*>(XL + k * LS + 4 * tr);
-    const f32x4 r4 = *reinterpret_cast<const f32x4*>(R2 + k * LS + 4 * tc);
-    const float wk = sWe[k], awk = sAw[k];
-    const f32x2 wk2 = {wk, wk}, aw2 = {awk, awk};
-    const f32x2 r01 = {r4[0], r4[1]}, r23 = {r4[2], r4[3]};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const f32x2 li = {l4[i], l4[i]};
-      const f32x2 m0 = ((li + r01) + a2[i][0] * wk2) * big;       // [m > 0] = med3(m * 1e30, 0, 1) (m == 0 -> 0, like m > 0)
-      const f32x2 m1 = ((li + r23) + a2[i][1] * wk2) * big;
-      t[i][0] += aw2 * f32x2{__builtin_amdgcn_fmed3f(m0[0], 0.f, 1.f), __builtin_amdgcn_fmed3f(m0[1], 0.f, 1.f)};
-      t[i][1] += aw2 * f32x2{__builtin_amdgcn_fmed3f(m1[0], 0.f, 1.f), __builtin_amdgcn_fmed3f(m1[1], 0.f, 1.f)};
-    }
-  }
-  CTVAE_PH(gat, 1, 10);
-  {
-    const float aw = sAW[0] * a.slope;
-    float* dA = p.dattr + (((long)b * a.Hs + hs) * GN + 4 * tr) * GN + 4 * tc;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      f32x4 v;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = ds[i][j] * (aw + t[i][j >> 1][j & 1]);
-      *reinterpret_cast<f32x4*>(dA + i * GN) = v;
-    }
-  }
-  CTVAE_PH(gat, 1, 11);
-}
-
 // Backward of the layer up to dS (gat_proj_bwd_kernel takes it from there): d alpha = xl G^T and the aggregation's share of d xl,
 // alpha G, as MFMA tiles from the LDS operands; softmax backward on the accumulators; the edge-attribute gradient
 // d a'[r][c] = dS (slope sum_k att we + (1 - slope) sum_k att we [m > 0]) with the step function as the clamp of the packed fma that
@@ -647,8 +313,8 @@ __global__ __launch_bounds__(256, 2) void gat_layer_bwd_kernel(GatBwdArgs p) {
   float* XL = smem;                 // [C][LS]  xl * 2^60
   float* R2 = XL + C * LS;          // [C][LS]: G[k][c], then xr[k][c] * 2^60
   float* Ss = R2 + C * LS;          // [GN][SS] scratch of load_adj_block, then alpha, then dS
-  float* sWA = Ss + GN * SS;        // [C + 1][2]  {we * 2^60, att we (1 - slope)}
-  float* sT = sWA + 2 * (C + 1);    // [2][GN]
+  float* sWA = Ss + GN * SS;        // [C + 4][2]  {we * 2^60, att we (1 - slope)}
+  float* sT = sWA + 2 * (C + 4);    // [2][GN]
   float* sLoop = sT + 2 * GN;
   float* sDeg = sLoop + GN;
   const int tid = threadIdx.x, hs = blockIdx.x, b = blockIdx.y, lane = tid & 63, wave = tid >> 6, lh = lane >> 5, ln = lane & 31;
@@ -694,7 +360,6 @@ __global__ __launch_bounds__(256, 2) void gat_layer_bwd_kernel(GatBwdArgs p) {
     sWA[2 * k] = w * kStepUp;
     sWA[2 * k + 1] = a.att[head * C + k] * w * (1.f - a.slope);
   }
-  if (tid < 2) sWA[2 * C + tid] = 0.f;
   CTVAE_PH(gat, 1, 1);
   float av[4][4];
   unsigned keep;
@@ -784,23 +449,7 @@ __global__ __launch_bounds__(256, 2) void gat_layer_bwd_kernel(GatBwdArgs p) {
       t[i][jp] = f32x2{0.f, 0.f};
       a2[i][jp] = f32x2{av[i][2 * jp], av[i][2 * jp + 1]};
     }
-  {
-    const float* pl = XL + 4 * tr;
-    const float* pr = R2 + 4 * tc;
-    f32x4 l4 = *reinterpret_cast<const f32x4*>(pl), r4 = *reinterpret_cast<const f32x4*>(pr);
-    f32x2 wa = *reinterpret_cast<const f32x2*>(sWA);
-#pragma unroll 2
-    for (int k = 0; k < C; ++k) {
-      pl += LS;
-      pr += LS;
-      const f32x4 l4n = *reinterpret_cast<const f32x4*>(pl), r4n = *reinterpret_cast<const f32x4*>(pr);   // row C: the next array (in bounds)
-      const f32x2 wan = *reinterpret_cast<const f32x2*>(sWA + 2 * (k + 1));
-      const f32x2 r01 = {r4[0], r4[1]}, r23 = {r4[2], r4[3]};
-      step_2x4(t[0][0], t[0][1], t[1][0], t[1][1], f32x2{l4[0], l4[1]}, r01, r23, wa, a2[0][0], a2[0][1], a2[1][0], a2[1][1]);
-      step_2x4(t[2][0], t[2][1], t[3][0], t[3][1], f32x2{l4[2], l4[3]}, r01, r23, wa, a2[2][0], a2[2][1], a2[3][0], a2[3][1]);
-      l4 = l4n; r4 = r4n; wa = wan;
-    }
-  }
+  pair_loop(t, a2, XL + 4 * tr, R2 + 4 * tc, sWA, C);
   CTVAE_PH(gat, 1, 7);
   {
     float* dA = p.dattr + (((long)b * a.Hs + hs) * GN + 4 * tr) * GN + 4 * tc;
@@ -813,94 +462,6 @@ __global__ __launch_bounds__(256, 2) void gat_layer_bwd_kernel(GatBwdArgs p) {
     }
   }
   CTVAE_PH(gat, 1, 8);
-}
-
-// d xl (added to what gat_layer_bwd_kernel left), d xr, d att, d we from dS.  grid (Hs, B); blockDim = 4 * CP, CP = C rounded
-// up to 16: thread = (channel k, quarter of the sources).  xl[r,k] and its gradient stay in registers (16 sources per
-// thread), dS and a' of the head are read from LDS as broadcasts, the four partial sums over the sources meet in two
-// shuffles.
-__global__ __launch_bounds__(512) void gat_proj_bwd_old_kernel(GatBwdArgs p) {
-  __shared__ __attribute__((aligned(16))) float sG[GN][GN + 4];   // [c][r]
-  __shared__ __attribute__((aligned(16))) float sA[GN][GN + 4];
-  __shared__ float sLoop[GN];
-  const GatLayerArgs& a = p.f;
-  const int C = a.C;
-  const int tid = threadIdx.x, hs = blockIdx.x, b = blockIdx.y, k = tid >> 2, qt = tid & 3;
-  const int head = a.head_map ? a.head_map[b * a.Hs + hs] : hs;
-  const bool kok = k < C;
-  const int r0 = 16 * qt;
-  {
-    const float* dS = p.dS + ((long)b * a.Hs + hs) * GN * GN;
-    const float* adj = a.adj + (long)b * GN * GN;
-    for (int e = tid; e < GN * GN; e += blockDim.x) {
-      const int r = e >> 6, c = e & 63;
-      const float v = adj[e];
-      sG[c][r] = dS[e];
-      sA[c][r] = (r == c) ? 0.f : v;
-    }
-  }
-  __syncthreads();
-  if (tid < GN) {                    // self-loop attribute: mean of the incoming edges of target c = tid
-    float s = 0.f, d = 0.f;
-    for (int r = 0; r < GN; ++r) {
-      const float v = sA[tid][r];
-      s += v;
-      d += v != 0.f ? 1.f : 0.f;
-    }
-    sLoop[tid] = s / fmaxf(d, 1.f);
-  }
-  __syncthreads();
-  if (tid < GN) sA[tid][tid] = sLoop[tid];
-  f32x2 xlr[8], dl[8];
-  const long rowl = ((long)b * GN + r0) * a.ld + hs * C + k;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    xlr[i >> 1][i & 1] = kok ? a.xl[rowl + (long)i * a.ld] : 0.f;
-    dl[i >> 1][i & 1] = 0.f;
-  }
-  const float wk = kok ? a.we[head * C + k] : 0.f, ak = kok ? a.att[head * C + k] : 0.f;
-  const f32x2 wk2 = {wk, wk};
-  const float slope = a.slope;
-  f32x2 datt2 = {0.f, 0.f}, dwe2 = {0.f, 0.f};
-  __syncthreads();
-  const long rowr = ((long)b * GN) * a.ld + hs * C + k;
-  float xr_next = kok ? a.xr[rowr] : 0.f;                        // one target ahead: the load is off the dependency chain
-  for (int c = 0; c < GN; ++c) {
-    const float xrc = xr_next;
-    if (c + 1 < GN) xr_next = kok ? a.xr[rowr + (long)(c + 1) * a.ld] : 0.f;
-    const f32x2 xrc2 = {xrc, xrc};
-    f32x2 dr2 = {0.f, 0.f};
-#pragma unroll
-    for (int i2 = 0; i2 < 8; ++i2) {
-      const f32x2 g2 = *reinterpret_cast<const f32x2*>(&sG[c][r0 + 2 * i2]);
-      const f32x2 a2 = *reinterpret_cast<const f32x2*>(&sA[c][r0 + 2 * i2]);
-      const f32x2 m = (xlr[i2] + xrc2) + a2 * wk2;
-      const f32x2 sl = {m[0] > 0.f ? 1.f : slope, m[1] > 0.f ? 1.f : slope};
-      const f32x2 gs = g2 * sl;            // dS * lrelu'(m); the factor att[k] is applied once at the end
-      datt2 += gs * m;                     // dS * lrelu(m)
-      dl[i2] += gs;
-      dr2 += gs;
-      dwe2 += gs * a2;
-    }
-    float dr = dr2[0] + dr2[1];
-    dr += __shfl_xor(dr, 1, 64);
-    dr += __shfl_xor(dr, 2, 64);
-    if (kok && qt == 0) p.dxr[((long)b * GN + c) * p.ldd + hs * C + k] = dr * ak;
-  }
-  float datt = datt2[0] + datt2[1], dwe = dwe2[0] + dwe2[1];
-  datt += __shfl_xor(datt, 1, 64);
-  datt += __shfl_xor(datt, 2, 64);
-  dwe += __shfl_xor(dwe, 1, 64);
-  dwe += __shfl_xor(dwe, 2, 64);
-  if (kok) {
-    const long rowd = ((long)b * GN + r0) * p.ldd + hs * C + k;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) p.dxl[rowd + (long)i * p.ldd] += dl[i >> 1][i & 1] * ak;
-    if (qt == 0) {
-      p.datt_part[((long)b * a.Hs + hs) * C + k] = datt;
-      p.dwe_part[((long)b * a.Hs + hs) * C + k] = dwe * ak;
-    }
-  }
 }
 
 // d xl (added to what gat_layer_bwd_kernel left), d xr, d att, d we from dS.  With lrelu'(m) = slope + (1 - slope) [m > 0] and
@@ -1099,10 +660,8 @@ __global__ __launch_bounds__(256) void gat_adj_reduce_kernel(const float* __rest
   }
 }
 
-size_t fwd_smem(int C) { return ((size_t)2 * C * LS + GN * SS + 2 * C + 4 * GN + 4 * GN + 4) * sizeof(float); }      // the first version's layout
-size_t fwd2_smem(int C) { return ((size_t)2 * C * LS + GN * SS + 1 + 2 * (C + 1) + C + 4 + 2 * GN * 4 + 4 * GN + 2 * GN) * sizeof(float); }
-size_t bwd_smem(int C) { return ((size_t)2 * C * LS + GN * SS + 2 * C + 2 * 16 * GN + 3 * GN + 4) * sizeof(float); }     // the first version's layout
-size_t bwd2_smem(int C) { return ((size_t)2 * C * LS + GN * SS + 2 * (C + 1) + 2 * GN + 2 * GN) * sizeof(float); }
+size_t fwd_smem(int C) { return ((size_t)2 * C * LS + GN * SS + 2 * (C + 4) + C + 4 + 2 * GN * 4 + 4 * GN + 2 * GN) * sizeof(float); }
+size_t bwd_smem(int C) { return ((size_t)2 * C * LS + GN * SS + 2 * (C + 4) + 2 * GN + 2 * GN) * sizeof(float); }
 
 bool args_ok(const GatLayerArgs& a) {
   return a.xl && a.xr && a.adj && a.we && a.att && a.bias && a.out && a.alpha && a.B > 0 && a.Hs > 0 && a.C >= 16 && a.C <= 128 &&
@@ -1116,20 +675,13 @@ int launch_gat_layer_forward(const GatLayerArgs& a, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_fwd_old_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_fwd_old_kernel<25>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_fwd_old_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const double pairs = (double)a.B * a.Hs * GN * GN;
-  ProfScope ps(a.C <= 64 ? "gat_layer_fwd_kernel<16>" : a.C <= 100 ? "gat_layer_fwd_kernel<25>" : "gat_layer_fwd_kernel<32>", st, 6.0 * pairs * a.C, 4.0 * a.B * a.Hs * (3.0 * GN * a.C + 2.0 * GN * GN));
-  const size_t smem = fwd_smem(a.C);
+  // per (pair, channel): add + clamped fma + fma in the pair loop (5 FLOP), the aggregation's multiply-add on MFMA (2)
+  ProfScope ps(a.C <= 64 ? "gat_layer_fwd_kernel[C<=64]" : "gat_layer_fwd_kernel[C>64]", st, 7.0 * pairs * a.C, 4.0 * a.B * a.Hs * (3.0 * GN * a.C + 2.0 * GN * GN));
   const dim3 grid(a.Hs, a.B);
-  static const bool old_fwd = getenv("CTVAE_GAT_FWD_OLD") != nullptr;       // diagnostic
-  if (!old_fwd) hipLaunchKernelGGL(gat_layer_fwd_kernel, grid, dim3(256), fwd2_smem(a.C), st, a);
-  else if (a.C <= 64) hipLaunchKernelGGL(gat_layer_fwd_old_kernel<16>, grid, dim3(256), smem, st, a);
-  else if (a.C <= 100) hipLaunchKernelGGL(gat_layer_fwd_old_kernel<25>, grid, dim3(256), smem, st, a);
-  else hipLaunchKernelGGL(gat_layer_fwd_old_kernel<32>, grid, dim3(256), smem, st, a);
+  hipLaunchKernelGGL(gat_layer_fwd_kernel, grid, dim3(256), fwd_smem(a.C), st, a);
   CTVAE_LAUNCH_CHECK();
   return 0;
 }
@@ -1142,28 +694,19 @@ int launch_gat_layer_backward(const GatBwdArgs& p, float* dadj, int accumulate_d
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_bwd_old_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_bwd_old_kernel<25>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_layer_bwd_old_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const double pairs = (double)a.B * a.Hs * GN * GN;
   const dim3 grid(a.Hs, a.B);
   {
-    ProfScope ps(a.C <= 64 ? "gat_layer_bwd_kernel<16>" : a.C <= 100 ? "gat_layer_bwd_kernel<25>" : "gat_layer_bwd_kernel<32>", st, 10.0 * pairs * a.C, 4.0 * a.B * a.Hs * (4.0 * GN * a.C + 4.0 * GN * GN));
-    const size_t smem = bwd_smem(a.C);
-    static const bool old_bwd = getenv("CTVAE_GAT_BWD_OLD") != nullptr;       // diagnostic
-    if (!old_bwd) hipLaunchKernelGGL(gat_layer_bwd_kernel, grid, dim3(256), bwd2_smem(a.C), st, p);
-    else if (a.C <= 64) hipLaunchKernelGGL(gat_layer_bwd_old_kernel<16>, grid, dim3(256), smem, st, p);
-    else if (a.C <= 100) hipLaunchKernelGGL(gat_layer_bwd_old_kernel<25>, grid, dim3(256), smem, st, p);
-    else hipLaunchKernelGGL(gat_layer_bwd_old_kernel<32>, grid, dim3(256), smem, st, p);
+    // pair loop 5 FLOP per (pair, channel), d alpha and the aggregation's d xl on MFMA 2 each
+    ProfScope ps(a.C <= 64 ? "gat_layer_bwd_kernel[C<=64]" : "gat_layer_bwd_kernel[C>64]", st, 9.0 * pairs * a.C, 4.0 * a.B * a.Hs * (4.0 * GN * a.C + 4.0 * GN * GN));
+    hipLaunchKernelGGL(gat_layer_bwd_kernel, grid, dim3(256), bwd_smem(a.C), st, p);
     CTVAE_LAUNCH_CHECK();
   }
   {
     ProfScope ps("gat_proj_bwd_kernel", st, 9.0 * pairs * a.C, 4.0 * a.B * a.Hs * (4.0 * GN * a.C + 2.0 * GN * GN));
-    static const bool old_proj = getenv("CTVAE_GAT_PROJ_OLD") != nullptr;       // diagnostic
-    if (old_proj) hipLaunchKernelGGL(gat_proj_bwd_old_kernel, grid, dim3(4 * ((a.C + 15) / 16 * 16)), 0, st, p);
-    else hipLaunchKernelGGL(gat_proj_bwd_kernel, grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL(gat_proj_bwd_kernel, grid, dim3(256), 0, st, p);
     CTVAE_LAUNCH_CHECK();
   }
   if (dadj != nullptr) {

@@ -490,7 +490,8 @@ int launch_pair_mlp_backward(const float* u, const float* v, int ld, const float
   if (B <= 0 || N <= 0 || H <= 0 || N > NMAX || ld < H || ldd < H) return kErrBadArg;
   static const bool old_bwd = getenv("CTVAE_PAIR_BWD_OLD") != nullptr;      // diagnostic: the any-N kernel at N == 64 too
   if (N == 64 && !old_bwd) {
-    ProfScope ps("pair_mlp_bwd64_kernel", st, 3.0 * B * (double)N * N * H, 4.0 * B * (4.0 * N * H + 2.0 * N * N));
+    ProfScope ps("pair_mlp_bwd64_kernel", st, 5.0 * B * (double)N * N * H,      // clamped add + two fmas per (pair, h)
+                 4.0 * B * (4.0 * N * H + 2.0 * N * N));
     // 4-wave workgroups: ceil(nw / 4) per sample.  (5-wave workgroups tile H = 800 exactly but only two of them fit a CU's wave
     // slots, 4 + 4 + ... per SIMD: 640 workgroups then take two rounds -- 69 us against 56 us.)
     const int nw = (H + 31) / 32;
