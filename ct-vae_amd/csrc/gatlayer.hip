@@ -572,9 +572,12 @@ __global__ __launch_bounds__(256, 4) void gat_proj_bwd_kernel(GatBwdArgs p) {
 #undef CTVAE_PROJ
     const float cs = slope * sCS[c];
     f32x4 o;
+    float q0 = qr[0][0], q1 = qr[0][1], q2 = qr[1][0], q3 = qr[1][1];
+    oct_sum4(q0, q1, q2, q3);
+    const f32x2 qs[2] = {{q0, q1}, {q2, q3}};
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) {
-      const f32x2 q = {oct_sum(qr[pp][0]), oct_sum(qr[pp][1])};
+      const f32x2 q = qs[pp];
       const f32x2 d = f32x2{cs, cs} + f32x2{oms, oms} * q;
       dc[pp] += xr2[pp] * d;
       o[2 * pp] = at2[pp][0] * d[0];
