@@ -620,47 +620,51 @@ __global__ __launch_bounds__(256, 4) void gat_proj_bwd_kernel(GatBwdArgs p) {
   CTVAE_PH(gat, 2, 3);
 }
 
-// d adj[b][r][c] = edge[r][c] * (sum_slots d a'[r][c] + (sum_slots d a'[c][c]) / deg[c]); grid B, 256 threads
+// d adj[b][r][c] = edge[r][c] * (sum_slots d a'[r][c] + (sum_slots d a'[c][c]) / deg[c]); grid (4, B), 256 threads: a workgroup owns
+// 16 rows of the sample (thread = (row, 4 columns)); the in-degrees come from the whole adjacency (16 KB, every workgroup counts
+// them itself), the diagonal of the summed slots from Hs scattered loads per column.  All loads of a thread are issued before the
+// first use: with one workgroup per sample and a loop over the slots this was a 29 us launch for 27 MB.
 __global__ __launch_bounds__(256) void gat_adj_reduce_kernel(const float* __restrict__ dattr, const float* __restrict__ adj,
                                                             float* __restrict__ dadj, int Hs, int accumulate) {
   __shared__ float sD[16][GN];
   __shared__ float sDiag[GN], sDeg[GN];
-  const int tid = threadIdx.x, b = blockIdx.x, tr = tid >> 4, tc = tid & 15;
-  float v[4][4], d[4][4], cd[4] = {0.f, 0.f, 0.f, 0.f};
+  const int tid = threadIdx.x, b = blockIdx.y, tr = tid >> 4, tc = tid & 15, r = 16 * blockIdx.x + tr;
+  const float* ab = adj + (long)b * GN * GN;
+  f32x4 cnt4[4];                                       // rows tr, tr + 16, tr + 32, tr + 48 of the whole adjacency: column counts
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const long o = ((long)b * GN + 4 * tr + i) * GN + 4 * tc;
-    const f32x4 av = *reinterpret_cast<const f32x4*>(adj + o);
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int h = 0; h < Hs; ++h) s += *reinterpret_cast<const f32x4*>(dattr + (((long)b * Hs + h) * GN + 4 * tr + i) * GN + 4 * tc);
+  for (int i = 0; i < 4; ++i) cnt4[i] = *reinterpret_cast<const f32x4*>(ab + (tr + 16 * i) * GN + 4 * tc);
+  const f32x4 av = *reinterpret_cast<const f32x4*>(ab + r * GN + 4 * tc);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int h = 0; h < Hs; ++h) s += *reinterpret_cast<const f32x4*>(dattr + (((long)b * Hs + h) * GN + r) * GN + 4 * tc);
+  float dg = 0.f;
+  if (tid < GN)
+    for (int h = 0; h < Hs; ++h) dg += dattr[(((long)b * Hs + h) * GN + tid) * GN + tid];
+  const f32x4 prev = accumulate ? *reinterpret_cast<const f32x4*>(dadj + ((long)b * GN + r) * GN + 4 * tc) : f32x4{0.f, 0.f, 0.f, 0.f};
+  float cd[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bool diag = (tr == tc) && (i == j);
-      const bool e = av[j] != 0.f && !diag;
-      v[i][j] = e ? 1.f : 0.f;
-      d[i][j] = s[j];
-      if (e) cd[j] += 1.f;
-      if (diag) sDiag[4 * tc + j] = s[j];
-    }
-  }
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (cnt4[i][j] != 0.f && tr + 16 * i != 4 * tc + j) cd[j] += 1.f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) sD[tr][4 * tc + j] = cd[j];
+  if (tid < GN) sDiag[tid] = dg;
   __syncthreads();
   if (tid < GN) {
-    float s = 0.f;
+    float t = 0.f;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) s += sD[t][tid];
-    sDeg[tid] = fmaxf(s, 1.f);
+    for (int q = 0; q < 16; ++q) t += sD[q][tid];
+    sDeg[tid] = fmaxf(t, 1.f);
   }
   __syncthreads();
+  f32x4 o = prev;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const long o = ((long)b * GN + 4 * tr + i) * GN + 4 * tc;
-    f32x4 r = accumulate ? *reinterpret_cast<const f32x4*>(dadj + o) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] += v[i][j] * (d[i][j] + sDiag[4 * tc + j] / sDeg[4 * tc + j]);
-    *reinterpret_cast<f32x4*>(dadj + o) = r;
+  for (int j = 0; j < 4; ++j) {
+    const int c = 4 * tc + j;
+    const bool e = av[j] != 0.f && r != c;
+    o[j] += e ? s[j] + sDiag[c] / sDeg[c] : 0.f;
   }
+  *reinterpret_cast<f32x4*>(dadj + ((long)b * GN + r) * GN + 4 * tc) = o;
 }
 
 size_t fwd_smem(int C) { return ((size_t)2 * C * LS + GN * SS + 2 * (C + 4) + C + 4 + 2 * GN * 4 + 4 * GN + 2 * GN) * sizeof(float); }
@@ -714,7 +718,7 @@ int launch_gat_layer_backward(const GatBwdArgs& p, float* dadj, int accumulate_d
   }
   if (dadj != nullptr) {
     ProfScope ps("gat_adj_reduce_kernel", st, 0.0, 4.0 * a.B * (a.Hs + 2.0) * GN * GN);
-    hipLaunchKernelGGL(gat_adj_reduce_kernel, dim3(a.B), dim3(256), 0, st, p.dattr, a.adj, dadj, a.Hs, accumulate_dadj);
+    hipLaunchKernelGGL(gat_adj_reduce_kernel, dim3(4, a.B), dim3(256), 0, st, p.dattr, a.adj, dadj, a.Hs, accumulate_dadj);
     CTVAE_LAUNCH_CHECK();
   }
   return 0;
