@@ -241,6 +241,60 @@ def test_pair_mlp_kernel(dev, B, N, H):
         np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=1e-5 * max(1.0, float(want.abs().max())), rtol=1e-4)
 
 
+@pytest.mark.parametrize("scale", [1e-4, 1.0, 3e3])
+def test_clamp_kernels_hold_over_input_magnitudes(dev, scale):
+    """relu / step of the N = 64 pair kernels and of the fused GATv2 layer are the VOP3P clamp of packed adds / fmas on operands
+    scaled by 2^-64 / 2^60 (csrc/satmath.hpp): exact while |t| < 2^64 and, for the step, t > 2^-60.  Values and every gradient
+    must keep matching the torch expressions when the pre-activations are 1e-4 .. 3e3 times their usual size (relative
+    tolerances: the references are float32 torch ops themselves)."""
+    import torch.nn.functional as F
+    from ctvae_amd import kernels as K
+    from ctvae_amd.models.causal import DenseGATv2
+    g = torch.Generator().manual_seed(777)
+    B, N, H = 2, 64, 96
+    u = (scale * torch.randn(B, N, H, generator=g)).requires_grad_(True)
+    v = (scale * torch.randn(B, N, H, generator=g)).requires_grad_(True)
+    w2 = (torch.randn(H, generator=g) / (scale * H ** 0.5)).requires_grad_(True)
+    b2 = torch.randn(1, generator=g).requires_grad_(True)
+    ref = torch.sigmoid(F.linear(F.leaky_relu(u.unsqueeze(2) + v.unsqueeze(1)), w2.view(1, -1), b2)).squeeze(-1)
+    go = torch.randn(B, N, N, generator=g)
+    ref.backward(go)
+    ud, vd, wd, bd = (t.detach().to(dev).requires_grad_(True) for t in (u, v, w2, b2))
+    out = K.PairMLP.apply(ud, vd, wd, bd)
+    out.backward(go.to(dev))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=3e-6, rtol=1e-5)
+    for name, got, want in (("dU", ud.grad, u.grad), ("dV", vd.grad, v.grad), ("dw2", wd.grad, w2.grad), ("db2", bd.grad, b2.grad)):
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=2e-5 * float(want.abs().max()), rtol=2e-4, err_msg=name)
+    # the fused layer on the 64 latent nodes against the head-by-head torch expression of the same module
+    torch.manual_seed(778)
+    layer = DenseGATv2(24, 32, 3)
+    with torch.no_grad():
+        layer.bias.uniform_(-0.1, 0.1)
+        layer.lin_l.weight.mul_(scale)
+        layer.lin_r.weight.mul_(scale)
+        layer.lin_edge.weight.mul_(scale)
+        layer.att.div_(scale)
+    x = torch.randn(B, 64, 24, requires_grad=True)
+    adj = (torch.rand(B, 64, 64) * (torch.rand(B, 64, 64) > 0.4)).requires_grad_(True)
+    ref = layer(x, adj)
+    go = torch.randn_like(ref)
+    ref.backward(go)
+    want = {k: p.grad.clone() for k, p in layer.named_parameters()}
+    layer_d = DenseGATv2(24, 32, 3).to(dev)
+    layer_d.load_state_dict(layer.state_dict())
+    xd, ad = x.detach().to(dev).requires_grad_(True), adj.detach().to(dev).requires_grad_(True)
+    assert layer_d.fused_ok(xd)
+    out = layer_d.forward_fused(xd, ad)
+    out.backward(go.to(dev))
+    torch.cuda.synchronize()
+    tol = lambda t: 3e-4 * max(1e-30, float(t.detach().abs().max()))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=tol(ref), rtol=1e-3)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), x.grad.numpy(), atol=tol(x.grad), rtol=2e-3)
+    np.testing.assert_allclose(ad.grad.cpu().numpy(), adj.grad.numpy(), atol=tol(adj.grad), rtol=2e-3)
+    for k, p in layer_d.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), want[k].numpy(), atol=tol(want[k]), rtol=2e-3, err_msg=k)
+
+
 @pytest.mark.parametrize("B,N,Hh,C", [(2, 65, 13, 100), (3, 65, 13, 64), (2, 9, 3, 20)])
 def test_gat_score_kernel_and_layer(dev, B, N, Hh, C):
     """ctvae_gat_score(+backward) against the head-by-head torch expression of DenseGATv2 (GATv2Conv attention logits,

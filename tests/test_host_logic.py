@@ -267,3 +267,19 @@ def test_chain_marks_intermediates_and_keeps_reference_keys():
     assert float(out[0]) == 3.0 and len(seen) == 3
     lv = vae_models["LVAE"](**H.LVAE_CFG)
     assert not isinstance(lv.decoder, blocks.Chain)
+
+
+def test_clamp_scaling_constants_are_exact_powers_of_two():
+    """csrc/satmath.hpp: relu(t) = 2^64 sat(t 2^-64), [t > 0] = sat(t 2^60).  The scalings are exact in binary floating point only
+    if the constants are the powers of two they claim to be (and float32 holds them exactly)."""
+    import os
+    import re
+    import numpy as np
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ct-vae_amd", "csrc", "satmath.hpp")).read()
+    vals = {m.group(1): float(m.group(2)) for m in re.finditer(r"constexpr float (k\w+) = ([0-9.e+-]+)f;", src)}
+    assert set(vals) >= {"kSatDown", "kSatUp", "kStepUp", "kStepDown"}
+    want = {"kSatDown": 2.0 ** -64, "kSatUp": 2.0 ** 64, "kStepUp": 2.0 ** 60, "kStepDown": 2.0 ** -60}
+    for k, w in want.items():
+        assert float(np.float32(vals[k])) == w, (k, vals[k], w)
+    assert float(np.float32(vals["kSatDown"]) * np.float32(vals["kSatUp"])) == 1.0
+    assert float(np.float32(vals["kStepDown"]) * np.float32(vals["kStepUp"])) == 1.0
