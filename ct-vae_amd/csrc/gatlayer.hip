@@ -111,37 +111,32 @@ __device__ __forceinline__ void stage_T(const float* __restrict__ src, long row0
 // instructions of one channel, and only two waves share a SIMD); the last group's read-ahead lands in the arrays that follow
 // (in bounds, unused).  C % 4 == 0.
 __device__ __forceinline__ void pair_loop(f32x2 (&acc)[4][2], const f32x2 (&a2)[4][2], const float* pl, const float* pr, const float* pw, int C) {
-  f32x4 l[4], r[4];
-  f32x2 w[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    l[j] = *reinterpret_cast<const f32x4*>(pl + j * LS);
-    r[j] = *reinterpret_cast<const f32x4*>(pr + j * LS);
-    w[j] = *reinterpret_cast<const f32x2*>(pw + 2 * j);
-  }
-  for (int k = 0; k < C; k += 4) {
-    pl += 4 * LS;
-    pr += 4 * LS;
-    pw += 8;
-    f32x4 ln[4], rn[4];
-    f32x2 wn[4];
+  struct Group { f32x4 l[4], r[4]; f32x2 w[4]; };
+  auto load = [&](Group& g, int k) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      ln[j] = *reinterpret_cast<const f32x4*>(pl + j * LS);
-      rn[j] = *reinterpret_cast<const f32x4*>(pr + j * LS);
-      wn[j] = *reinterpret_cast<const f32x2*>(pw + 2 * j);
+      g.l[j] = *reinterpret_cast<const f32x4*>(pl + (k + j) * LS);
+      g.r[j] = *reinterpret_cast<const f32x4*>(pr + (k + j) * LS);
+      g.w[j] = *reinterpret_cast<const f32x2*>(pw + 2 * (k + j));
     }
+  };
+  auto eval = [&](const Group& g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const f32x2 r01 = {r[j][0], r[j][1]}, r23 = {r[j][2], r[j][3]};
-      score_2x4(acc[0][0], acc[0][1], acc[1][0], acc[1][1], f32x2{l[j][0], l[j][1]}, r01, r23, w[j], a2[0][0], a2[0][1], a2[1][0], a2[1][1]);
-      score_2x4(acc[2][0], acc[2][1], acc[3][0], acc[3][1], f32x2{l[j][2], l[j][3]}, r01, r23, w[j], a2[2][0], a2[2][1], a2[3][0], a2[3][1]);
+      const f32x2 r01 = {g.r[j][0], g.r[j][1]}, r23 = {g.r[j][2], g.r[j][3]};
+      score_2x4(acc[0][0], acc[0][1], acc[1][0], acc[1][1], f32x2{g.l[j][0], g.l[j][1]}, r01, r23, g.w[j], a2[0][0], a2[0][1], a2[1][0], a2[1][1]);
+      score_2x4(acc[2][0], acc[2][1], acc[3][0], acc[3][1], f32x2{g.l[j][2], g.l[j][3]}, r01, r23, g.w[j], a2[2][0], a2[2][1], a2[3][0], a2[3][1]);
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      l[j] = ln[j];
-      r[j] = rn[j];
-      w[j] = wn[j];
+  };
+  // two register sets take turns (a rotating copy costs ten v_mov per channel on top of the 24 instructions of the work)
+  Group ga, gb;
+  load(ga, 0);
+  for (int k = 0; k < C; k += 8) {
+    load(gb, k + 4);                 // k + 4 == C: the arrays that follow, unused
+    eval(ga);
+    if (k + 4 < C) {
+      load(ga, k + 8);
+      eval(gb);
     }
   }
 }
