@@ -549,10 +549,10 @@ __global__ __launch_bounds__(256, 4) void gat_proj_bwd_kernel(GatBwdArgs p) {
   float* dxrp = p.dxr + (long)b * GN * p.ldd + hs * C + k0;
   f32x4 xr_next = *reinterpret_cast<const f32x4*>(xrp);
   f32x2 qa[2] = {{0.f, 0.f}, {0.f, 0.f}}, dc[2] = {{0.f, 0.f}, {0.f, 0.f}};
-  for (int c = 0; c < GN; ++c) {
+  auto target = [&](int c) {
     const f32x4 xr4 = xr_next;
-    xrp += a.ld;
-    if (c + 1 < GN) xr_next = *reinterpret_cast<const f32x4*>(xrp);     // one target ahead
+    if (c + 1 < GN) xrp += a.ld;
+    xr_next = *reinterpret_cast<const f32x4*>(xrp);                     // one target ahead; unconditional (the last row twice): no branch
     const f32x2 xr2[2] = {f32x2{xr4[0], xr4[1]} * up, f32x2{xr4[2], xr4[3]} * up};
     const f32x4 g4a = *reinterpret_cast<const f32x4*>(&sG[c * TS + r0]), g4b = *reinterpret_cast<const f32x4*>(&sG[c * TS + r0 + 4]);
     const f32x4 a4a = *reinterpret_cast<const f32x4*>(&sA[c * TS + r0]), a4b = *reinterpret_cast<const f32x4*>(&sA[c * TS + r0 + 4]);
@@ -578,9 +578,15 @@ __global__ __launch_bounds__(256, 4) void gat_proj_bwd_kernel(GatBwdArgs p) {
       o[2 * pp] = at2[pp][0] * d[0];
       o[2 * pp + 1] = at2[pp][1] * d[1];
     }
-    if (q8 == 0) *reinterpret_cast<f32x4*>(dxrp) = o;
+    // every lane of the 8-lane group holds the same sums and stores them (same 16 bytes: one request): a store under `if (q8 == 0)`
+    // is a branch, behind which the compiler can only wait vmcnt(0) for the next target's xr -- i.e. for this store's round trip
+    *reinterpret_cast<f32x4*>(dxrp) = o;
     dxrp += p.ldd;
-  }
+  };
+  // the first target outside the loop: the loop header then sees [load, store] outstanding on both of its edges and waits vmcnt(1)
+  // (with the prologue's loads on the entry edge it waits vmcnt(0): the previous target's store, a memory round trip per target)
+  target(0);
+  for (int c = 1; c < GN; ++c) target(c);
   CTVAE_PH(gat, 2, 2);
   f32x2 dr[2] = {{0.f, 0.f}, {0.f, 0.f}};
   {

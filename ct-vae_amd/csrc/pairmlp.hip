@@ -414,14 +414,13 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
   float* dvp = dV + (long)b * 64 * ldd;
   f32x2 vn = {vp[hca], vp[hcb]};
   f32x2 dwj = {0.f, 0.f};
-  const bool st_ok = (q == 0 && oka) || (q == 1 && okb);
-  const int st_h = q == 0 ? ha : hb;
-  const float st_w = q == 0 ? wv[0] : wv[1];
+  const int st_h = (q & 1) ? hcb : hca;
+  const float st_w = (q & 1) ? wv[1] : wv[0];
   CTVAE_PH(pair, 1, 3);
-  for (int j = 0; j < 64; ++j) {
+  auto column = [&](int j) {
     const f32x2 v2 = vn * f32x2{kStepUp, kStepUp};
-    vp += ld;
-    if (j + 1 < 64) vn = f32x2{vp[hca], vp[hcb]};        // one column ahead
+    if (j + 1 < 64) vp += ld;
+    vn = f32x2{vp[hca], vp[hcb]};                        // one column ahead; unconditional (the last row twice): no branch
     f32x2 bv0 = {0.f, 0.f}, bv1 = {0.f, 0.f};
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
@@ -435,9 +434,14 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
     const float cs = slope * sCS[j];
     const f32x2 dv = f32x2{cs, cs} + f32x2{oms, oms} * bv;
     dwj += v2 * dv;
-    if (st_ok) dvp[st_h] = st_w * (q == 0 ? dv[0] : dv[1]);     // every lane of the quad holds the sums: lane 0 stores ha, lane 1 hb
+    // every lane of the quad holds the sums: even lanes store ha, odd lanes hb -- unconditionally (a predicated store is a branch,
+    // behind which the compiler can only wait vmcnt(0) for the next column's v, i.e. for this store's round trip).  Lanes past H
+    // work on the clamped unit H - 1 and store ITS (correct) value once more.
+    dvp[st_h] = st_w * ((q & 1) ? dv[1] : dv[0]);
     dvp += ldd;
-  }
+  };
+  column(0);                                  // outside the loop: its header then waits vmcnt(1) -- the load, not the previous column's store
+  for (int j = 1; j < 64; ++j) column(j);
   CTVAE_PH(pair, 1, 4);
   f32x2 dwi = {0.f, 0.f};
   float* dup = dU + (long)b * 64 * ldd + (long)i0 * ldd;
