@@ -268,8 +268,13 @@ struct ClsInfo {
   static constexpr int first = CLS == 0 ? 0 : (CLS == 1 ? 1 : (CLS == 2 ? 3 : 5));
 };
 
+// Register budget: ONE wave per SIMD (512 registers: the nine accumulators live in AGPRs, nothing spills).  Cut for two waves
+// (256 registers) the FUSED variant spilled 168 bytes, and every scratch reload in the step loop is a vector-memory operation
+// whose `s_waitcnt vmcnt(0)` also drains the dy / y loads just issued for the next step -- the read-ahead overlapped nothing:
+// 45 -> 27 us at bs = 64 (one workgroup per CU anyway), and still ahead at bs = 256 where a second workgroup per CU is given up
+// (step 1.582 -> 1.567 ms).
 template <bool FUSED>
-__global__ __launch_bounds__(256, 2) void up_wgrad_kernel(const UpArgs a) {
+__global__ __launch_bounds__(256, 1) void up_wgrad_kernel(const UpArgs a) {
   __shared__ __attribute__((aligned(16))) float sA[NP * LDA];   // 42.8 KB
   __shared__ __attribute__((aligned(16))) float sR[4 * C * C];  // 16 KB: cross-wave merge, one tap at a time
   __shared__ float sB[4 * C];
