@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   const f32x4 xf_sh = xf_on ? *reinterpret_cast<const f32x4*>(a.xf_shift + x_c) : f32x4{0.f, 0.f, 0.f, 0.f};
   const float xf_ns = a.xf_act == ACT_LRELU ? kLeaky : (a.xf_act == ACT_RELU ? 0.f : 1.f);
   f32x4 rx[XVEC ? X_V : 1];
+  [[maybe_unused]] float rx_in[XVEC ? X_V : 1];      // 1 where the loaded pixel lies inside the image (the shift applies), else 0
   float rxs[XVEC ? 1 : X_S];
   f32x4 rd[DVEC ? D_V : 1];
   float rds[DVEC ? 1 : D_S];
@@ -116,17 +117,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         int iy = (yx >> 16) + x_dy, ix = (yx & 0xffff) + x_dx;
         bool ok = x_kok && pix >= 0 && (unsigned)iy < (unsigned)g.gH && (unsigned)ix < (unsigned)g.gW;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) {
-          v = *reinterpret_cast<const f32x4*>(a.X + (long)(pix + x_dy * g.gW + x_dx) * gC + x_c);
-          if (xf_on) {   // lazy BatchNorm apply of the previous block (InXform); padding stays 0
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float t = v[e] * xf_sc[e] + xf_sh[e];
-              v[e] = fmaxf(t, t * xf_ns);
-            }
-          }
-        }
+        if (ok) v = *reinterpret_cast<const f32x4*>(a.X + (long)(pix + x_dy * g.gW + x_dx) * gC + x_c);
         rx[j] = v;
+        rx_in[j] = ok ? 1.f : 0.f;      // the lazy BatchNorm apply happens when the chunk is STORED: applied here it consumed every load
+                                        // at once (an s_waitcnt vmcnt(0) behind each of the chunk's loads instead of one chunk of MFMAs later)
       }
     } else {
 #pragma unroll
@@ -167,6 +161,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     float* sX = sXbuf;
     float* sD = sDbuf;
     if constexpr (XVEC) {
+      if (xf_on) {   // lazy BatchNorm apply of the previous block (InXform); padding stays 0
+#pragma unroll
+        for (int j = 0; j < X_V; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = rx[j][e] * xf_sc[e] + xf_sh[e] * rx_in[j];
+            rx[j][e] = fmaxf(t, t * xf_ns);
+          }
+      }
 #pragma unroll
       for (int j = 0; j < X_V; ++j) {
         int r = tid / XQ + (256 / XQ) * j;
