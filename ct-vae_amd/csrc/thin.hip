@@ -91,20 +91,35 @@ __global__ __launch_bounds__(256) void thin_tile_kernel(const ThinArgs a) {
     __syncthreads();                                 // previous tile fully consumed
     // ---- stage the input patch (and dY) ---------------------------------------------------------------
     const int nvec = a.PH * a.PW * LP;
-    for (int e = tid; e < nvec; e += 256) {
-      const int pp = e / LP, c4 = e - pp * LP;
-      const int py = (int)(((unsigned)pp * a.inv_PW) >> 16), px = pp - py * a.PW;   // no integer division in the hot loop
-      const int iy = iy_lo + py, ix = ix_lo + px;
-      const bool ok = (unsigned)iy < (unsigned)g.gH && (unsigned)ix < (unsigned)g.gW;
-      const unsigned off = ok ? (unsigned)(((b * g.gH + iy) * g.gW + ix) * GC + 4 * c4) * 4u : kOOBt;
-      f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, (int)off, 0, 0));
-      if (xform) {
-        const f32x4 tsc = *reinterpret_cast<const f32x4*>(a.in_scale + 4 * c4);
-        const f32x4 tsh = *reinterpret_cast<const f32x4*>(a.in_shift + 4 * c4);
+    // four 16-byte loads per thread are issued before the first is used (one load -> wait -> LDS store per iteration, as this loop
+    // was, is a memory round trip per 4 KB of the patch); a slot past the patch loads the out-of-range offset and is not stored
+    for (int e0 = 0; e0 < nvec; e0 += 4 * 256) {
+      f32x4 v[4];
+      int pp[4], c4[4];
+      bool ok[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = ok ? act_fwd(v[k] * tsc[k] + tsh[k], a.in_act) : 0.f;   // padding stays 0
+      for (int j = 0; j < 4; ++j) {
+        const int e = e0 + tid + 256 * j;
+        pp[j] = e / LP;
+        c4[j] = e - pp[j] * LP;
+        const int py = (int)(((unsigned)pp[j] * a.inv_PW) >> 16), px = pp[j] - py * a.PW;   // no integer division in the hot loop
+        const int iy = iy_lo + py, ix = ix_lo + px;
+        ok[j] = e < nvec && (unsigned)iy < (unsigned)g.gH && (unsigned)ix < (unsigned)g.gW;
+        const unsigned off = ok[j] ? (unsigned)(((b * g.gH + iy) * g.gW + ix) * GC + 4 * c4[j]) * 4u : kOOBt;
+        v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, (int)off, 0, 0));
       }
-      *reinterpret_cast<f32x4*>(&sP[pp * LDP + 4 * c4]) = v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (e0 + tid + 256 * j < nvec) {
+          if (xform) {
+            const f32x4 tsc = *reinterpret_cast<const f32x4*>(a.in_scale + 4 * c4[j]);
+            const f32x4 tsh = *reinterpret_cast<const f32x4*>(a.in_shift + 4 * c4[j]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[j][k] = ok[j] ? act_fwd(v[j][k] * tsc[k] + tsh[k], a.in_act) : 0.f;   // padding stays 0
+          }
+          *reinterpret_cast<f32x4*>(&sP[pp[j] * LDP + 4 * c4[j]]) = v[j];
+        }
+      }
     }
     if constexpr (WGRAD) {
       for (int e = tid; e < NPIX; e += 256) {

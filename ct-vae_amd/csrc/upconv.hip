@@ -124,8 +124,19 @@ __global__ __launch_bounds__(256, 2) void up_fwd_kernel(const UpArgs a) {
   const int OH = 2 * a.H, OW = 2 * a.W;
   const __amdgpu_buffer_rsrc_t rO = rsrc(a.out, (long)a.B * OH * OW * C * 4);
 
-  for (int e = tid; e < NT * C * C / 4; e += 256)
-    reinterpret_cast<f32x4*>(sW)[e] = reinterpret_cast<const f32x4*>(a.Wt)[e];
+  // Every global load of the prologue is issued before the first one is used: the nine 16-byte weight loads per thread, the first
+  // patch, bias and BatchNorm coefficients.  As `for (e = tid; e < N; e += 256) sW[e] = W[e]` the weights were nine load -> wait ->
+  // LDS-store round trips in a row (the trip count depends on tid, so the loop is not unrolled), then three more for the scalars --
+  // a third of this kernel's time at one tile per workgroup.
+  constexpr int NW4 = NT * C * C / 4 / 256;
+  static_assert(NW4 * 256 * 4 == NT * C * C, "weights: a whole number of 16-byte loads per thread");
+  f32x4 wv[NW4];
+#pragma unroll
+  for (int j = 0; j < NW4; ++j) wv[j] = reinterpret_cast<const f32x4*>(a.Wt)[tid + 256 * j];
+  Patch pt;
+  int tile = blockIdx.x;
+  TileXY cur = tile_xy(a, tile < a.ntiles ? tile : 0);
+  if (tile < a.ntiles) patch_load(a, rX, cur, pt);
   const float bv = a.bias != nullptr ? a.bias[li] : 0.f;
   float sn = 0.f, smean = 0.f, sm2 = 0.f;
 
@@ -133,10 +144,8 @@ __global__ __launch_bounds__(256, 2) void up_fwd_kernel(const UpArgs a) {
   const f32x4 xsc = xf ? *reinterpret_cast<const f32x4*>(a.xf_scale + 4 * (tid & 7)) : f32x4{0.f, 0.f, 0.f, 0.f};
   const f32x4 xsh = xf ? *reinterpret_cast<const f32x4*>(a.xf_shift + 4 * (tid & 7)) : f32x4{0.f, 0.f, 0.f, 0.f};
   const float xns = a.xf_act == ACT_LRELU ? kLeaky : (a.xf_act == ACT_RELU ? 0.f : 1.f);
-  Patch pt;
-  int tile = blockIdx.x;
-  TileXY cur = tile_xy(a, tile < a.ntiles ? tile : 0);
-  if (tile < a.ntiles) patch_load(a, rX, cur, pt);
+#pragma unroll
+  for (int j = 0; j < NW4; ++j) reinterpret_cast<f32x4*>(sW)[tid + 256 * j] = wv[j];
   for (; tile < a.ntiles; tile += gridDim.x) {
     if (xf) patch_store_xf(a, cur, pt, sA, xsc, xsh, xns);
     else patch_store(pt, sA);

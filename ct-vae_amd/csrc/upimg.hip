@@ -54,10 +54,21 @@ __global__ __launch_bounds__(256, 2) void upimg_fwd_kernel(UpImgArgs a) {
   const int qy0 = ty * UTH, qx0 = tx * UTW;
 
   // ---- filter matrix -> LDS (transposed) -> registers ----
-  for (int e = tid; e < 48 * 64; e += 256) {
-    const int k = e / 48, n = e - k * 48;                  // reads: 3 contiguous floats per (tap, k)
-    const int t16 = n / 3, c = n - t16 * 3;
-    sWt[n * ULDW + k] = a.Wp[((long)a.wtap[t16] * 64 + k) * 3 + c];
+  {                                                        // all 12 loads of a thread before the first LDS store (they were 12 round trips in a row)
+    float wv[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const int e = tid + 256 * j;
+      const int k = e / 48, n = e - k * 48;                // reads: 3 contiguous floats per (tap, k)
+      const int t16 = n / 3, c = n - t16 * 3;
+      wv[j] = a.Wp[((long)a.wtap[t16] * 64 + k) * 3 + c];
+    }
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const int e = tid + 256 * j;
+      const int k = e / 48, n = e - k * 48;
+      sWt[n * ULDW + k] = wv[j];
+    }
   }
   __syncthreads();
   f32x4 bw[2][8];                                          // B operand: column n = li (+32), k = 32*lh + 4j .. +3
