@@ -348,16 +348,28 @@ __global__ __launch_bounds__(256) void vq_bwd_codebook_posw_kernel(const float* 
   }
   __syncthreads();
   const float sc = (gvq != nullptr ? gvq[0] : 0.f) * 2.f / ((float)P * (float)Dc);
-  for (int e = tid; e < K * Dc; e += 256) {
-    const int k = e / Dc, dd = e - k * Dc;
-    float sx = 0.f, c = 0.f;
+  for (int e0 = 0; e0 < K * Dc; e0 += 8 * 256) {       // the codebook values of eight elements per thread are loaded before the first is used
+    float cbv[8];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      sx += sAcc[((size_t)t * K + k) * 128 + dd];
-      c += sCnt[t * K + k];
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + tid + 256 * u;
+      cbv[u] = e < K * Dc ? cb[(size_t)i * K * Dc + e] : 0.f;
     }
-    const size_t o = ((size_t)i * K + k) * Dc + dd;
-    part[(size_t)blockIdx.x * ((size_t)C * K * Dc) + o] = sc * (c * cb[o] - sx);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + tid + 256 * u;
+      if (e < K * Dc) {
+        const int k = e / Dc, dd = e - k * Dc;
+        float sx = 0.f, c = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          sx += sAcc[((size_t)t * K + k) * 128 + dd];
+          c += sCnt[t * K + k];
+        }
+        const size_t o = ((size_t)i * K + k) * Dc + dd;
+        part[(size_t)blockIdx.x * ((size_t)C * K * Dc) + o] = sc * (c * cbv[u] - sx);
+      }
+    }
   }
 }
 
@@ -366,7 +378,15 @@ __global__ __launch_bounds__(256) void vq_cb_reduce_kernel(const float* __restri
   const int o = blockIdx.x * 256 + threadIdx.x;
   if (o >= n) return;
   float v = accumulate ? dcb[o] : 0.f;
-  for (int z = 0; z < S; ++z) v += part[(size_t)z * n + o];
+  int z = 0;
+  for (; z + 8 <= S; z += 8) {        // eight slabs' loads in flight, added in slab order (the same sum as one by one; as a plain loop
+    float t[8];                       // this was S memory round trips in a row per thread: 31 us for 32 workgroups at S = 128)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = part[(size_t)(z + u) * n + o];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += t[u];
+  }
+  for (; z < S; ++z) v += part[(size_t)z * n + o];
   dcb[o] = v;
 }
 
