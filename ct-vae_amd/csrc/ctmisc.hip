@@ -239,14 +239,38 @@ __global__ __launch_bounds__(256) void ct_mask_fwd_kernel(const float* __restric
   float* sPos = sW + (A + MD) * MD;       // [S][D+1]
   float* sAct = sPos + MD * (MD + 1);     // [D]  bias + W[:, :A] action
   const int tid = threadIdx.x, b = blockIdx.x, In = A + MD;
-  for (int e = tid; e < MD * In; e += 256) {
-    const int d = e / In, i = e - d * In;              // W is [D][A+D] row-major
-    sW[i * MD + d] = W[e];
+  // staging in batches of eight loads per thread (as `for (e = tid; ...; e += 256) s[e] = g[e]` these were 35 memory round trips in a
+  // row -- most of this kernel's 23 us)
+  for (int e0 = 0; e0 < MD * In; e0 += 8 * 256) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + tid + 256 * u;
+      t[u] = e < MD * In ? W[e] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + tid + 256 * u;
+      if (e < MD * In) {
+        const int d = e / In, i = e - d * In;          // W is [D][A+D] row-major
+        sW[i * MD + d] = t[u];
+      }
+    }
   }
-  for (int e = tid; e < MD * MD; e += 256) {
-    const int s = e >> 6, d = e & 63;
-    const float k = keep ? keep[(long)b * MD * MD + e] * scale : 1.f;
-    sPos[s * (MD + 1) + d] = pe[e] * k;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float tp[8], tk[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = tid + 256 * (8 * h + u);
+      tp[u] = pe[e];
+      tk[u] = keep ? keep[(long)b * MD * MD + e] * scale : 1.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = tid + 256 * (8 * h + u);
+      sPos[(e >> 6) * (MD + 1) + (e & 63)] = tp[u] * tk[u];
+    }
   }
   __syncthreads();
   if (tid < MD) {
@@ -306,16 +330,28 @@ __global__ __launch_bounds__(256) void ct_mask_bwd_kernel(const float* __restric
   __shared__ float sPos[MD * (MD + 1)];   // [s][e]
   __shared__ float sCol[MD];
   const int tid = threadIdx.x, b = blockIdx.x;
-  for (int e = tid; e < MD * MD; e += 256) {
-    const int s = e >> 6, d = e & 63;
-    const long r = (long)b * MD + s;
-    const float pi = p_in[r], y1 = soft[r];
-    const float dd = (pi > 1e-4f ? 1.f / pi : 0.f) + ((1.f - pi) > 1e-4f ? 1.f / (1.f - pi) : 0.f);
-    const float dp = g[r] * y1 * (1.f - y1) * dd;                   // straight-through estimator (gumbel_st_bwd_kernel)
-    const float sg = inter[(long)b * MD * MD + e];
-    sDz[s * (MD + 1) + d] = dp * x[(long)b * MD * MD + e] * sg * (1.f - sg);
-    const float k = keep ? keep[(long)b * MD * MD + e] * scale : 1.f;
-    sPos[s * (MD + 1) + d] = pe[e] * k;
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {                                     // four elements' loads in flight per thread (16 round trips in a row before)
+    float pi[4], y1[4], gg[4], sg[4], xv[4], kv[4], pv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + 256 * (4 * h + u);
+      const long r = (long)b * MD + (e >> 6);
+      pi[u] = p_in[r]; y1[u] = soft[r]; gg[u] = g[r];
+      sg[u] = inter[(long)b * MD * MD + e];
+      xv[u] = x[(long)b * MD * MD + e];
+      kv[u] = keep ? keep[(long)b * MD * MD + e] * scale : 1.f;
+      pv[u] = pe[e];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + 256 * (4 * h + u);
+      const int s = e >> 6, d = e & 63;
+      const float dd = (pi[u] > 1e-4f ? 1.f / pi[u] : 0.f) + ((1.f - pi[u]) > 1e-4f ? 1.f / (1.f - pi[u]) : 0.f);
+      const float dp = gg[u] * y1[u] * (1.f - y1[u]) * dd;          // straight-through estimator (gumbel_st_bwd_kernel)
+      sDz[s * (MD + 1) + d] = dp * xv[u] * sg[u] * (1.f - sg[u]);
+      sPos[s * (MD + 1) + d] = pv[u] * kv[u];
+    }
   }
   __syncthreads();
   if (tid < MD) {

@@ -636,10 +636,20 @@ __global__ __launch_bounds__(256) void gat_adj_reduce_kernel(const float* __rest
   for (int i = 0; i < 4; ++i) cnt4[i] = *reinterpret_cast<const f32x4*>(ab + (tr + 16 * i) * GN + 4 * tc);
   const f32x4 av = *reinterpret_cast<const f32x4*>(ab + r * GN + 4 * tc);
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int h = 0; h < Hs; ++h) s += *reinterpret_cast<const f32x4*>(dattr + (((long)b * Hs + h) * GN + r) * GN + 4 * tc);
   float dg = 0.f;
-  if (tid < GN)
-    for (int h = 0; h < Hs; ++h) dg += dattr[(((long)b * Hs + h) * GN + tid) * GN + tid];
+  for (int h0 = 0; h0 < Hs; h0 += 4) {                 // four slots' loads in flight (a plain loop over the slots waits for each), added in slot order
+    f32x4 t[4];
+    float d[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int h = h0 + u < Hs ? h0 + u : Hs - 1;
+      t[u] = *reinterpret_cast<const f32x4*>(dattr + (((long)b * Hs + h) * GN + r) * GN + 4 * tc);
+      d[u] = dattr[(((long)b * Hs + h) * GN + (tid & (GN - 1))) * GN + (tid & (GN - 1))];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (h0 + u < Hs) { s += t[u]; dg += d[u]; }
+  }
   const f32x4 prev = accumulate ? *reinterpret_cast<const f32x4*>(dadj + ((long)b * GN + r) * GN + 4 * tc) : f32x4{0.f, 0.f, 0.f, 0.f};
   float cd[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -98,9 +98,16 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
                                                           float* __restrict__ out, float post_sub, float post_scale) {
   __shared__ double smd[8];
   double s = 0.0, k = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += 256) {
-    s += (double)part[i];
-    k += (double)part[nparts + i];
+  for (int i0 = 0; i0 < nparts; i0 += 4 * 256) {       // four pairs of loads in flight, added in the order of the plain loop
+    float ts[4], tk[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + threadIdx.x + 256 * u;
+      ts[u] = i < nparts ? part[i] : 0.f;
+      tk[u] = i < nparts ? part[nparts + i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s += (double)ts[u]; k += (double)tk[u]; }
   }
   s = wave_sum_d(s);
   k = wave_sum_d(k);

@@ -159,7 +159,16 @@ __global__ __launch_bounds__(64) void vq_loss_finish_kernel(const float* __restr
   float total = 0.f;
   for (int i = 0; i < C; ++i) {
     double s = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += 64) s += (double)part[(size_t)b * C + i];
+    for (int b0 = 0; b0 < nblocks; b0 += 8 * 64) {        // eight loads in flight, added in the order of the plain loop
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = b0 + threadIdx.x + 64 * u;
+        t[u] = b < nblocks ? part[(size_t)b * C + i] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)t[u];
+    }
     s = wave_sum_d(s);
     float mse = (float)(s * inv_n);
     total = total + (mse * beta + mse);
@@ -348,28 +357,16 @@ __global__ __launch_bounds__(256) void vq_bwd_codebook_posw_kernel(const float* 
   }
   __syncthreads();
   const float sc = (gvq != nullptr ? gvq[0] : 0.f) * 2.f / ((float)P * (float)Dc);
-  for (int e0 = 0; e0 < K * Dc; e0 += 8 * 256) {       // the codebook values of eight elements per thread are loaded before the first is used
-    float cbv[8];
+  for (int e = tid; e < K * Dc; e += 256) {
+    const int k = e / Dc, dd = e - k * Dc;
+    float sx = 0.f, c = 0.f;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int e = e0 + tid + 256 * u;
-      cbv[u] = e < K * Dc ? cb[(size_t)i * K * Dc + e] : 0.f;
+    for (int t = 0; t < 4; ++t) {
+      sx += sAcc[((size_t)t * K + k) * 128 + dd];
+      c += sCnt[t * K + k];
     }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int e = e0 + tid + 256 * u;
-      if (e < K * Dc) {
-        const int k = e / Dc, dd = e - k * Dc;
-        float sx = 0.f, c = 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          sx += sAcc[((size_t)t * K + k) * 128 + dd];
-          c += sCnt[t * K + k];
-        }
-        const size_t o = ((size_t)i * K + k) * Dc + dd;
-        part[(size_t)blockIdx.x * ((size_t)C * K * Dc) + o] = sc * (c * cbv[u] - sx);
-      }
-    }
+    const size_t o = ((size_t)i * K + k) * Dc + dd;
+    part[(size_t)blockIdx.x * ((size_t)C * K * Dc) + o] = sc * (c * cb[o] - sx);
   }
 }
 
