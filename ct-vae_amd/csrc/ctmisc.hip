@@ -272,10 +272,13 @@ __global__ __launch_bounds__(256) void ct_mask_fwd_kernel(const float* __restric
       sPos[(e >> 6) * (MD + 1) + (e & 63)] = tp[u] * tk[u];
     }
   }
+  float* sA = sAct + MD;                  // [A] the sample's action row (a serial loop of global loads per output otherwise)
+  if (tid < A) sA[tid] = action[(long)b * A + tid];
+  const float bias_v = tid < MD ? bias[tid] : 0.f;
   __syncthreads();
   if (tid < MD) {
-    float z = bias[tid];
-    for (int a = 0; a < A; ++a) z += sW[a * MD + tid] * action[(long)b * A + a];
+    float z = bias_v;
+    for (int a = 0; a < A; ++a) z += sW[a * MD + tid] * sA[a];
     sAct[tid] = z;
   }
   __syncthreads();
@@ -638,7 +641,7 @@ int launch_ct_mask_forward(const float* x, const float* action, const float* pe,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ct_mask_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  const size_t smem = ((size_t)(A + MD) * MD + MD * (MD + 1) + MD) * sizeof(float);
+  const size_t smem = ((size_t)(A + MD) * MD + MD * (MD + 1) + MD + A) * sizeof(float);
   ProfScope ps("ct_mask_fwd_kernel", st, 2.0 * B * S * D * (A + D), 4.0 * B * S * D * 3.0);
   hipLaunchKernelGGL(ct_mask_fwd_kernel, dim3(B), dim3(256), smem, st, x, action, pe, keep, scale, W, bias, expo, A, inter, p, sample,
                      soft);
