@@ -113,13 +113,15 @@ struct SplitKRaw {
 // r' = cls * Mc + m (m = (b, qy, qx) of a ConvGeom's class grid) -> pixel index in the scattered tensor [B][sH][sW]
 struct RowMap {
   int ncls, Mc, Qh, Qw, sH, sW, os;
-  int py[kMaxCls], px[kMaxCls];
+  unsigned pyp, pxp;     // the classes' parity offsets, 8 bits each: a table indexed by a per-thread class is a LOAD from the kernel
+                         // arguments in front of every row's own load (two dependent round trips per row)
 };
 
 inline RowMap row_map_of(const ConvGeom& g) {
   RowMap m{};
   m.ncls = g.ncls; m.Mc = g.B * g.Qh * g.Qw; m.Qh = g.Qh; m.Qw = g.Qw; m.sH = g.sH; m.sW = g.sW; m.os = g.os;
-  for (int c = 0; c < kMaxCls; ++c) { m.py[c] = g.py[c]; m.px[c] = g.px[c]; }
+  static_assert(kMaxCls <= 4, "RowMap packs four classes");
+  for (int c = 0; c < kMaxCls; ++c) { m.pyp |= (unsigned)(g.py[c] & 0xff) << (8 * c); m.pxp |= (unsigned)(g.px[c] & 0xff) << (8 * c); }
   return m;
 }
 
@@ -127,7 +129,8 @@ __device__ __forceinline__ int row_map_pixel(const RowMap& m, int r) {
   if (m.ncls == 1) return r;
   const int cls = r / m.Mc, mm = r - cls * m.Mc;
   const int qhw = m.Qh * m.Qw, b = mm / qhw, rr = mm - b * qhw, qy = rr / m.Qw, qx = rr - qy * m.Qw;
-  return (b * m.sH + qy * m.os + m.py[cls]) * m.sW + qx * m.os + m.px[cls];
+  const int py = (int)((m.pyp >> (8 * cls)) & 0xffu), px = (int)((m.pxp >> (8 * cls)) & 0xffu);
+  return (b * m.sH + qy * m.os + py) * m.sW + qx * m.os + px;
 }
 
 struct TapGemmPlan {
