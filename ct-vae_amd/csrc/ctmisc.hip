@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void ct_mask_fwd_kernel(const float* __restric
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int e = e0 + tid + 256 * u;
-      t[u] = e < MD * In ? W[e] : 0.f;
+      t[u] = W[e < MD * In ? e : MD * In - 1];          // clamped index: a predicated load is a branch and is waited for on the spot
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {

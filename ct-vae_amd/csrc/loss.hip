@@ -102,9 +102,10 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
     float ts[4], tk[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int i = i0 + threadIdx.x + 256 * u;
-      ts[u] = i < nparts ? part[i] : 0.f;
-      tk[u] = i < nparts ? part[nparts + i] : 0.f;
+      const int i = i0 + threadIdx.x + 256 * u, ic = i < nparts ? i : nparts - 1;      // clamped index, unconditional loads
+      const float vs = part[ic], vk = part[nparts + ic];
+      ts[u] = i < nparts ? vs : 0.f;
+      tk[u] = i < nparts ? vk : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) { s += (double)ts[u]; k += (double)tk[u]; }

@@ -74,32 +74,69 @@ template <int DC>
 __global__ __launch_bounds__(256) void vq_inds_reg_kernel(const float* __restrict__ lat, const float* __restrict__ cb,
                                                           long long* __restrict__ inds, int P, int D, int K, int C, int HW,
                                                           int rows_per_block) {
-  __shared__ __attribute__((aligned(16))) float sX[4][DC];
+  // The code rows reach the lanes through LDS: the workgroup reads the codebook coalesced (K * DC / 256 loads per thread) and lane k
+  // takes row k with conflict-free reads (row stride DC + 1).  Loaded directly, `e[d] = E[k * DC + d]` is DC load instructions of 64
+  // different cache lines each -- 8192 line requests per wave for a 32 KB codebook, most of this kernel's time at 4 rows per wave.
+  __shared__ float sE[64 * (DC + 1)];
+  __shared__ __attribute__((aligned(16))) float sX[4][2][DC];
   const int cbi = blockIdx.y;
   const float* E = cb + (size_t)cbi * K * DC;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float e[DC];
-  float ee = 0.f;
   {
-    const float* row = E + (size_t)(lane < K ? lane : 0) * DC;
+    constexpr int NL = 64 * DC / 256;
+    float t[NL];
 #pragma unroll
-    for (int d = 0; d < DC; ++d) e[d] = row[d];          // (codebooks sit at 4-byte-aligned offsets of the flat buffer)
+    for (int j = 0; j < NL; ++j) {
+      const int e = tid + 256 * j;
+      t[j] = E[e < K * DC ? e : K * DC - 1];               // clamped index, unconditional loads (codebooks sit at 4-byte-aligned offsets)
+    }
 #pragma unroll
-    for (int d = 0; d < DC; ++d) ee += e[d] * e[d];
+    for (int j = 0; j < NL; ++j) {
+      const int e = tid + 256 * j;
+      sE[(e / DC) * (DC + 1) + (e % DC)] = t[j];
+    }
   }
-  float* myX = sX[wave];
+  float* myX = sX[wave][0];
   const int r0 = blockIdx.x * rows_per_block;
   int r1 = r0 + rows_per_block;
   if (r1 > P) r1 = P;
+  // the latent row of the NEXT position is loaded while the current one is scored (two wave-private LDS rows)
+  constexpr int XL = (DC + 63) / 64;
+  float xn[XL];
+  auto load_row = [&](int p) {
+    const float* x = lat + (size_t)(p < r1 ? p : r1 - 1) * D + cbi;      // slice offset i, not i*Dc (reference quirk)
+#pragma unroll
+    for (int j = 0; j < XL; ++j) {
+      const int d = lane + 64 * j;
+      xn[j] = x[d < DC ? d : DC - 1];
+    }
+  };
+  if (r0 + wave < r1) load_row(r0 + wave);
+  __syncthreads();
+  float e[DC];
+  float ee = 0.f;
+  {
+    const float* row = sE + (lane < K ? lane : 0) * (DC + 1);
+#pragma unroll
+    for (int d = 0; d < DC; ++d) e[d] = row[d];
+#pragma unroll
+    for (int d = 0; d < DC; ++d) ee += e[d] * e[d];
+  }
+  int buf = 0;
   for (int p = r0 + wave; p < r1; p += 4) {
-    const float* x = lat + (size_t)p * D + cbi;      // slice offset i, not i*Dc (reference quirk)
-    for (int d = lane; d < DC; d += 64) myX[d] = x[d];
+    float* cx = myX + buf * DC;
+#pragma unroll
+    for (int j = 0; j < XL; ++j) {
+      const int d = lane + 64 * j;
+      if (d < DC) cx[d] = xn[j];
+    }
+    load_row(p + 4);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     float xx = 0.f, dot = 0.f;
 #pragma unroll
     for (int d4 = 0; d4 < DC; d4 += 4) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(myX + d4);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(cx + d4);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         xx += v[u] * v[u];
@@ -114,11 +151,11 @@ __global__ __launch_bounds__(256) void vq_inds_reg_kernel(const float* __restric
       int ok = __shfl_xor(bestk, o, 64);
       if (ob < best || (ob == best && ok < bestk)) { best = ob; bestk = ok; }
     }
-    if (lane == 0) {
-      int b = p / HW, hw = p - b * HW;
+    {                                                      // every lane holds the winner and stores it (same 8 bytes: one request); under
+      int b = p / HW, hw = p - b * HW;                       // `if (lane == 0)` the store is a branch and the next row's load waits for it
       inds[((size_t)b * C + cbi) * HW + hw] = (long long)bestk;
     }
-    __builtin_amdgcn_wave_barrier();
+    buf ^= 1;
   }
 }
 
@@ -164,7 +201,8 @@ __global__ __launch_bounds__(64) void vq_loss_finish_kernel(const float* __restr
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int b = b0 + threadIdx.x + 64 * u;
-        t[u] = b < nblocks ? part[(size_t)b * C + i] : 0.f;
+        const float v = part[(size_t)(b < nblocks ? b : nblocks - 1) * C + i];      // unconditional load of a clamped index: a predicated
+        t[u] = b < nblocks ? v : 0.f;                                               // load is a branch and is waited for on the spot
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += (double)t[u];
@@ -405,8 +443,11 @@ int launch_vq_inds(const float* lat, const float* cb, long long* inds, int B, in
   }
   ProfScope ps("vq_inds_kernel", st, 2.0 * (double)P * K * D, 4.0 * (double)P * D + 8.0 * (double)P * C);
   if (K <= 64 && (Dc == 32 || Dc == 64 || Dc == 128)) {
-    // more, smaller row blocks: nothing is staged per workgroup any more
-    int nb = ceil_div(P, 16);
+    // rows per workgroup: the codebook is staged per workgroup (measured at 16 / 32 / 64 rows: 40.8 / 38.2 / 36.9 us for Dc = 128,
+    // 25.2 / 24.7 / 25.8 us for Dc = 32)
+    static const int rpw_env = [] { const char* e = getenv("CTVAE_VQ_ROWS"); return e ? atoi(e) : 0; }();   // diagnostic override
+    const int rpw = rpw_env ? rpw_env : (Dc == 128 ? 64 : 16);
+    int nb = ceil_div(P, rpw);
     if (nb > 2048) nb = 2048;
     const int rp = ceil_div(P, nb);
     nb = ceil_div(P, rp);
