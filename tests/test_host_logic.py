@@ -283,3 +283,36 @@ def test_clamp_scaling_constants_are_exact_powers_of_two():
         assert float(np.float32(vals[k])) == w, (k, vals[k], w)
     assert float(np.float32(vals["kSatDown"]) * np.float32(vals["kSatUp"])) == 1.0
     assert float(np.float32(vals["kStepDown"]) * np.float32(vals["kStepUp"])) == 1.0
+
+
+def test_hot_kernels_keep_their_loops_free_of_scratch_traffic():
+    """tools/isa_audit.py on the compiler's assembly (hipcc -S, no GPU): a spill reload inside a main loop is a vector-memory
+    operation whose s_waitcnt vmcnt(0) also drains the loads issued ahead for the next iteration -- up_wgrad_kernel ran 45 instead of
+    29 us that way.  The kernels below must have no scratch at all (up_wgrad: register budget of one wave per SIMD) or none inside
+    their loops."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        import pytest
+        pytest.skip("hipcc not available")
+    files = [os.path.join(root, "ct-vae_amd", "csrc", f) for f in ("upconv.hip", "pairmlp.hip")]
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "isa_audit.py")] + files, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-500:]
+    blocks, cur = {}, None
+    for line in out.stdout.splitlines():
+        if not line.startswith("    "):
+            cur = line.split(": ", 1)[1] if ": " in line else line
+            blocks[cur] = []
+        elif cur is not None:
+            blocks[cur].append(line)
+    def block(prefix):
+        hits = [k for k in blocks if k.startswith(prefix)]
+        assert hits, (prefix, list(blocks))
+        return [l for k in hits for l in blocks[k]]
+    for name in ("void up_wgrad_kernel<true>", "void up_wgrad_kernel<false>", "up_fwd_kernel", "void pair_mlp_bwd64_kernel<4>"):
+        lines = block(name)
+        assert any("scratch 0 B" in l for l in lines), (name, lines[:2])
+        assert not any(l.strip().startswith("loop") and l.rstrip().endswith("scratch") for l in lines), (name, lines)

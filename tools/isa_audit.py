@@ -77,8 +77,8 @@ def audit(path):
                 rows.append(f"    loop {lab:11s} {n:5d} lines  mfma {mfma:3d}  loads {loads:3d}  stores {stores:3d}  vmcnt {','.join(waits[:10]) or '-':22s}"
                             f"  scratch {scr:2d}  v_mov {vmov:3d}  {' '.join(flags)}")
         scratch = meta("private_seg_size")
-        if rows or scratch:
-            print(f"{os.path.basename(path)}: {demangle(sym)[:100]}\n    vgpr {meta('num_vgpr')}  agpr {meta('num_agpr')}  scratch {scratch} B")
+        print(f"{os.path.basename(path)}: {demangle(sym)[:100]}\n    vgpr {meta('num_vgpr')}  agpr {meta('num_agpr')}  scratch {scratch} B")
+        if rows:
             print("\n".join(rows))
 
 
