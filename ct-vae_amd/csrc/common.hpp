@@ -60,6 +60,53 @@ __device__ __forceinline__ float block_sum_256(float v, float* sm /* >=4 floats 
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Touch every 64-byte line of the kernel-argument segment with ONE batch of scalar loads.  Kernels with large argument structs
+// (geometry, tap tables, a dozen pointers) read them in the order of use: class index -> per-class counts -> tile constants ->
+// tap table ..., each a dependent round trip to memory behind the launch's cache invalidate -- eight in front of the tile
+// kernel's first operand load, 2.9 us per workgroup of a 9 us launch (tools/phase_probe.py, round 3).  After this batch they
+// are scalar-cache hits (and L2 hits for the lane-indexed table load).  BYTES: explicit arguments; the implicit ones
+// (grid size) follow within the next line.
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warm() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const void* ka = __builtin_amdgcn_kernarg_segment_ptr();
+  unsigned junk;
+  asm volatile(
+      ".set .Lkw_off, 0\n"
+      ".rept %2\n"
+      "s_load_dword %0, %1, .Lkw_off\n"
+      ".set .Lkw_off, .Lkw_off + 64\n"
+      ".endr\n"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(junk)
+      : "s"(ka), "n"((BYTES + 63) / 64 + 1)
+      : "memory");
+#endif
+}
+// The same batch, which also returns the three argument dwords at byte offsets O0, O1, O2 -- the ones the kernel branches on
+// first.  Read as ordinary arguments they are loads the compiler hoists ABOVE the batch (kernel arguments are invariant memory
+// to it): one more round trip in front of it.
+template <int BYTES, int O0, int O1, int O2>
+__device__ __forceinline__ void kernarg_warm_get(int& v0, int& v1, int& v2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const void* ka = __builtin_amdgcn_kernarg_segment_ptr();
+  unsigned junk;
+  asm volatile(
+      "s_load_dword %1, %4, %6\n"
+      "s_load_dword %2, %4, %7\n"
+      "s_load_dword %3, %4, %8\n"
+      ".set .Lkw_off, 0\n"
+      ".rept %5\n"
+      "s_load_dword %0, %4, .Lkw_off\n"
+      ".set .Lkw_off, .Lkw_off + 64\n"
+      ".endr\n"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(junk), "=&s"(v0), "=&s"(v1), "=&s"(v2)
+      : "s"(ka), "n"((BYTES + 63) / 64 + 1), "n"(O0), "n"(O1), "n"(O2)
+      : "memory");
+#endif
+}
+
 // Lazy BatchNorm apply: the operand a kernel gathers is x' = act(x*scale[c] + shift[c]) of the tensor it is given
 // (padding stays 0).  Only the thin (3-output-channel) kernels implement it: they stage every input element once.
 struct InXform {

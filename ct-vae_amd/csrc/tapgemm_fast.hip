@@ -55,7 +55,11 @@ __global__ __launch_bounds__(256) void tapgemm_fast_kernel(const TapGemmArgs a) 
   __shared__ __attribute__((aligned(16))) float sAbuf[(PF == 3 ? 2 : 1) * (WM * TM * 32) * LDK];
   __shared__ __attribute__((aligned(16))) float sBbuf[(PF == 3 ? 2 : 1) * (WT ? (WN * TN * 32) * LDK : KC * (WN * TN * 32))];
   __shared__ __attribute__((aligned(16))) int sOut[WM * TM * 32];
-  const int vbx = blockIdx.x, vby = blockIdx.y, vbz = blockIdx.z, vgx = gridDim.x;
+  PHASE(0);
+  int k_cls_rot, k_mtiles, k_ntiles;
+  kernarg_warm_get<sizeof(TapGemmArgs), offsetof(TapGemmArgs, cls_rot), offsetof(TapGemmArgs, mtiles), offsetof(TapGemmArgs, ntiles)>(
+      k_cls_rot, k_mtiles, k_ntiles);
+  const int vbx = blockIdx.x, vby = blockIdx.y, vbz = blockIdx.z, vgx = k_mtiles * k_ntiles;   // = gridDim.x (launch_fast_cfg)
 #include "tapgemm_fast_body.inc"
 }
 
@@ -77,15 +81,22 @@ __global__ __launch_bounds__(256) void conv_bwd_pair_kernel(const TapGemmArgs a,
   __shared__ unsigned sMsk[2][MC];
   __shared__ unsigned sOutB[2][MC];
   static_assert(2 * 64 * LDK >= MC * 64, "chunk buffers of the weight-gradient kernel fit");
+  // both roles read their arguments behind ONE batch of scalar loads (kernarg_warm); the three the data-gradient role
+  // branches on first come back with it
+  constexpr int kOffW = (sizeof(TapGemmArgs) + 7) / 8 * 8, kOffI = kOffW + sizeof(WgradArgs);
+  static_assert(alignof(TapGemmArgs) == 8 && alignof(WgradArgs) == 8 && sizeof(WgradArgs) % 8 == 0, "kernel-argument layout");
+  int k_nA, k_gxA, k_gyA;
+  kernarg_warm_get<kOffI + 9 * 4, kOffI + 12, kOffI + 16, kOffI + 20>(k_nA, k_gxA, k_gyA);
   const int L = blockIdx.x;
-  if (L < nA) {
+  if (L < k_nA) {
     constexpr int WM = 2, WN = 2, TM = 1, TN = 1, PF = 3;
     constexpr bool WT = true, XF = false;
     constexpr int PD = PDA;
-    const int vbx = L % gxA, vr = L / gxA, vby = vr % gyA, vbz = vr / gyA, vgx = gxA;
+    const int vbx = L % k_gxA, vr = L / k_gxA, vby = vr % k_gyA, vbz = vr / k_gyA, vgx = k_gxA;
+    const int k_cls_rot = a.cls_rot, k_ntiles = a.ntiles;
 #include "tapgemm_fast_body.inc"
   } else {
-    const int Lb = L - nA;
+    const int Lb = L - k_nA;
     // Role-aware XCD placement (round 3).  Workgroups go to the 8 XCDs round-robin by their launch index L.  The data-gradient
     // role gives XCD X a contiguous eighth of its tiles, i.e. of the dY pixel range it gathers; the weight-gradient role used to
     // deal its pixel slices to the XCDs by (slice & 7), so every L2 fetched dY once for each role.  With S % 8 == 0 slices the

@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libctvae_hip.so")
+LIB_PATH = os.environ.get("CTVAE_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libctvae_hip.so")   # override: A/B of two builds in one gpurun call
 
 _c = ctypes
 _fp, _vp, _i, _l, _f, _sz = _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_long, _c.c_float, _c.c_size_t

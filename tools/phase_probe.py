@@ -12,9 +12,10 @@ from ctvae_amd import kernels as K
 lib = native.load()
 lib.ctvae_debug_phase_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
 dev = torch.device("cuda")
-B, Co = 256, 128
-for H, ci, k in [(8, 32, 1), (8, 64, 3), (8, 256, 3), (16, 64, 3)]:
-    spec = K.ConvSpec(K.CONV, ci, Co, k, 1, k // 2, 0, K.ACT_LRELU)
+# shapes "B,H,ci,co,k,stride" on the command line; default: round 1's bs = 256 cases
+shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(256, 8, 32, 128, 1, 1), (256, 8, 64, 128, 3, 1), (256, 8, 256, 128, 3, 1), (256, 16, 64, 128, 3, 1)]
+for B, H, ci, Co, k, stride in shapes:
+    spec = K.ConvSpec(K.CONV, ci, Co, k, stride, k // 2, 0, K.ACT_LRELU)
     x = torch.randn(B, H, H, ci, device=dev)
     w = torch.randn(k, k, ci, Co, device=dev) * 0.05
     b = torch.randn(Co, device=dev)
@@ -26,16 +27,19 @@ for H, ci, k in [(8, 32, 1), (8, 64, 3), (8, 256, 3), (16, 64, 3)]:
     K.conv_forward_raw(x, w, b, spec)
     e1.record()
     torch.cuda.synchronize()
-    nwg = (B * H * H // 64) * (Co // 64)
-    nwg = min(nwg, 8192)
+    nwg = 8192
     buf = np.zeros(8192 * 8, dtype=np.uint64)
     lib.ctvae_debug_phase_read(buf.ctypes.data, buf.size)
-    t = buf.reshape(8192, 8)[:nwg, :6].astype(np.int64)
+    t = buf.reshape(8192, 8)[:nwg][:, [0, 6, 7, 1, 2, 3, 4, 5]].astype(np.int64)
+    t = t[t[:, 0] > t[:, 0].max() - 3000]          # this launch's workgroups (entries of earlier, larger grids are older than 1 ms)
+    nwg = len(t)
     t0 = t[:, 0].min()
+    if (t[:, 6:8] < t0).any():                        # split-K workgroups return before the store marks
+        t[:, 6:8] = t[:, 5:6]
     rel = (t - t0) / 100.0
-    names = ["entry", "prologue done", "first chunk in LDS", "main loop done", "stores issued", "stores retired"]
-    print(f"H={H} Ci={ci} k={k} chunks={k * k * ci // 32} WGs={nwg}  event-timed launch {e0.elapsed_time(e1) * 1e3:.1f} us, "
-          f"span first entry -> last retire {rel[:, 5].max():.1f} us")
+    names = ["entry", "class / tile decoded", "row offsets, sOut", "tap masks (prologue done)", "first chunk in LDS", "main loop done", "stores issued", "stores retired"]
+    print(f"B={B} H={H} Ci={ci} Co={Co} k={k} s={stride} chunks={k * k * ci // 32} WGs={nwg}  event-timed launch {e0.elapsed_time(e1) * 1e3:.1f} us, "
+          f"span first entry -> last retire {rel[:, 7].max():.1f} us")
     for i, n in enumerate(names):
         d = rel[:, i] - (rel[:, i - 1] if i else 0)
         print(f"    {n:20s} at mean {rel[:, i].mean():7.2f} (min {rel[:, i].min():6.2f} max {rel[:, i].max():6.2f})   phase mean {d.mean():6.2f} us")
