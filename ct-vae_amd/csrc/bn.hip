@@ -9,6 +9,7 @@
 //           g_y = gamma*invstd * (g_bn - dbeta/R - xhat*dgamma/R)   (as k1*g_bn + k2*y + k3 per channel)
 // All of these are HBM-bound streaming kernels (roofline: bytes / 8 TB/s): 16-B loads, several in flight per lane.
 #include "common.hpp"
+#include "phase.hpp"
 #include "finish.hpp"
 #include "prof.hpp"
 
@@ -514,11 +515,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // with block reductions in a fixed order, and writes the NHWC rows of its 4 channels as 16-byte stores.  No partial rows,
 // no second pass over memory, bit-reproducible.  The strided 16-byte row accesses touch a line per lane, which is why this
 // form is kept to tensors of a few MB (bn_fused_ok): measured on the 64 x 64 x 3, bs = 64 step.
+CTVAE_PHASE_DECL(bnf)
+#define BNF_PH(I) CTVAE_PH(bnf, (TPB == 1024 ? 0 : (TPB == 256 ? 1 : 2)), I)
+#define BNB_PH(I) CTVAE_PH(bnf, 3, I)   /* backward, any size: the last launch wins */
+
 template <int TPB, int NV>
 __device__ __forceinline__ void block_sum_n(float (&v)[NV], float* sm /* [TPB/64][NV] */) {
   constexpr int NW = TPB / 64;
 #pragma unroll
-  for (int c = 0; c < NV; ++c) v[c] = wave_sum(v[c]);
+  for (int c = 0; c < NV; ++c) v[c] = wave_sum_full(v[c]);
   if constexpr (NW > 1) {
     const int w = threadIdx.x >> 6;
     __syncthreads();
@@ -572,6 +577,7 @@ template <int TPB, int CPW, int SU>
 __global__ __launch_bounds__(TPB) void bn_fused_fwd_kernel(const BnFusedFwd p) {
   typedef float rowv __attribute__((ext_vector_type(CPW)));
   __shared__ float sm[(TPB / 64) * CPW];
+  BNF_PH(0);
   const int tid = threadIdx.x, c0 = fused_group(blockIdx.x, p.C, CPW) * CPW, R = p.R, C = p.C;
   const int r4 = 4 * tid;
   const bool live = r4 < R;
@@ -587,13 +593,16 @@ __global__ __launch_bounds__(TPB) void bn_fused_fwd_kernel(const BnFusedFwd p) {
   }
   const long long nbt0 = (blockIdx.x == 0 && p.nbt != nullptr) ? p.nbt[0] : 0;
   f32x4 v[CPW];
+  BNF_PH(1);
   slice_sum4<CPW, SU>(v, p.part + (long)c0 * R + (live ? r4 : 0), R, (long)C * R, p.S);
 #pragma unroll
   for (int c = 0; c < CPW; ++c) v[c] = live ? v[c] + bsv[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+  BNF_PH(2);
   float s[CPW];
 #pragma unroll
   for (int c = 0; c < CPW; ++c) s[c] = (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);   // rows beyond R hold zeros
   block_sum_n<TPB, CPW>(s, sm);
+  BNF_PH(3);
   float mean[CPW], q[CPW];
 #pragma unroll
   for (int c = 0; c < CPW; ++c) {
@@ -609,6 +618,7 @@ __global__ __launch_bounds__(TPB) void bn_fused_fwd_kernel(const BnFusedFwd p) {
     q[c] = t;
   }
   block_sum_n<TPB, CPW>(q, sm);
+  BNF_PH(4);
   float sc[CPW], sh[CPW];
 #pragma unroll
   for (int c = 0; c < CPW; ++c) {
@@ -645,12 +655,18 @@ __global__ __launch_bounds__(TPB) void bn_fused_fwd_kernel(const BnFusedFwd p) {
       if (p.a != nullptr) *reinterpret_cast<rowv*>(p.a + o) = ar;
     }
   }
+#ifdef CTVAE_PHASES
+  BNF_PH(5);
+  __builtin_amdgcn_s_waitcnt(0);
+  BNF_PH(6);
+#endif
 }
 
 template <int TPB, int CPW, int SU>
 __global__ __launch_bounds__(TPB) void bn_fused_bwd_kernel(const BnFusedBwd p) {
   typedef float rowv __attribute__((ext_vector_type(CPW)));
   __shared__ float sm[(TPB / 64) * 2 * CPW];
+  BNB_PH(0);
   const int tid = threadIdx.x, c0 = fused_group(blockIdx.x, p.C, CPW) * CPW, R = p.R, C = p.C;
   const int r4 = 4 * tid;
   const bool live = r4 < R;
@@ -671,7 +687,9 @@ __global__ __launch_bounds__(TPB) void bn_fused_bwd_kernel(const BnFusedBwd p) {
     dg0[c] = p.accumulate ? p.dgamma[c0 + c] : 0.f;   // requested with the rest: the commit below does not wait for memory
     db0[c] = p.accumulate ? p.dbeta[c0 + c] : 0.f;
   }
+  BNB_PH(1);
   slice_sum4<CPW, SU>(g, p.part + (long)c0 * R + (live ? r4 : 0), R, (long)C * R, p.S);
+  BNB_PH(2);
 #pragma unroll
   for (int c = 0; c < CPW; ++c) {
     if (!live) g[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -687,7 +705,9 @@ __global__ __launch_bounds__(TPB) void bn_fused_bwd_kernel(const BnFusedBwd p) {
     s12[c] = s1;
     s12[CPW + c] = s2;
   }
+  BNB_PH(3);
   block_sum_n<TPB, 2 * CPW>(s12, sm);
+  BNB_PH(4);
   float k1[CPW], k2[CPW], k3[CPW];
 #pragma unroll
   for (int c = 0; c < CPW; ++c) {
@@ -709,6 +729,11 @@ __global__ __launch_bounds__(TPB) void bn_fused_bwd_kernel(const BnFusedBwd p) {
       *reinterpret_cast<rowv*>(p.gy + po[e]) = o;
     }
   }
+#ifdef CTVAE_PHASES
+  BNB_PH(5);
+  __builtin_amdgcn_s_waitcnt(0);
+  BNB_PH(6);
+#endif
 }
 
 // rows / channels the channel-owner kernels take (and the tensor size up to which their strided row accesses pay)

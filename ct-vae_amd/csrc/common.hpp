@@ -42,6 +42,22 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// The same sum for a FULL wave in convergent code, on the DPP data path: four adds inside the 16-lane rows, two row broadcasts,
+// one v_readlane of lane 63 -- seven instructions instead of six dependent ds_bpermute round trips through the LDS crossbar
+// (~130 cycles each: the two block sums of bn_fused_fwd_kernel were 1.2 us apiece, the four-value one of bn_fused_bwd_kernel
+// 3.3 us, in-kernel clocks, round 3).  Fixed summation order; every lane gets the same bits.
+__device__ __forceinline__ float wave_sum_full(float v) {
+  auto bi = [](float x) { return __builtin_bit_cast(int, x); };
+  auto bf = [](int x) { return __builtin_bit_cast(float, x); };
+  v += bf(__builtin_amdgcn_update_dpp(0, bi(v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+  v += bf(__builtin_amdgcn_update_dpp(0, bi(v), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+  v += bf(__builtin_amdgcn_update_dpp(0, bi(v), 0x141, 0xF, 0xF, true));    // row_half_mirror
+  v += bf(__builtin_amdgcn_update_dpp(0, bi(v), 0x140, 0xF, 0xF, true));    // row_mirror: every lane holds its row's sum
+  v += bf(__builtin_amdgcn_update_dpp(0, bi(v), 0x142, 0xA, 0xF, false));   // row_bcast:15 into rows 1 and 3
+  v += bf(__builtin_amdgcn_update_dpp(0, bi(v), 0x143, 0xC, 0xF, false));   // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+  return bf(__builtin_amdgcn_readlane(bi(v), 63));
+}
+
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -50,7 +66,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 // block-wide sum for blockDim.x == 256 (4 waves); result valid in every thread
 __device__ __forceinline__ float block_sum_256(float v, float* sm /* >=4 floats */) {
-  v = wave_sum(v);
+  v = wave_sum_full(v);
   const int w = threadIdx.x >> 6;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) sm[w] = v;
@@ -64,8 +80,8 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // (geometry, tap tables, a dozen pointers) read them in the order of use: class index -> per-class counts -> tile constants ->
 // tap table ..., each a dependent round trip to memory behind the launch's cache invalidate -- eight in front of the tile
 // kernel's first operand load, 2.9 us per workgroup of a 9 us launch (tools/phase_probe.py, round 3).  After this batch they
-// are scalar-cache hits (and L2 hits for the lane-indexed table load).  BYTES: explicit arguments; the implicit ones
-// (grid size) follow within the next line.
+// are scalar-cache hits (and L2 hits for the lane-indexed table load).  BYTES: explicit arguments (every load starts inside
+// them: the implicit arguments behind them exist only in kernels that use them).
 template <int BYTES>
 __device__ __forceinline__ void kernarg_warm() {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -79,7 +95,7 @@ __device__ __forceinline__ void kernarg_warm() {
       ".endr\n"
       "s_waitcnt lgkmcnt(0)"
       : "=&s"(junk)
-      : "s"(ka), "n"((BYTES + 63) / 64 + 1)
+      : "s"(ka), "n"((BYTES + 63) / 64)
       : "memory");
 #endif
 }
@@ -102,7 +118,7 @@ __device__ __forceinline__ void kernarg_warm_get(int& v0, int& v1, int& v2) {
       ".endr\n"
       "s_waitcnt lgkmcnt(0)"
       : "=&s"(junk), "=&s"(v0), "=&s"(v1), "=&s"(v2)
-      : "s"(ka), "n"((BYTES + 63) / 64 + 1), "n"(O0), "n"(O1), "n"(O2)
+      : "s"(ka), "n"((BYTES + 63) / 64), "n"(O0), "n"(O1), "n"(O2)
       : "memory");
 #endif
 }

@@ -199,6 +199,7 @@ __device__ __forceinline__ int tap_dx(const ImgArgs& a, int t) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 3) void img_fwd_kernel(const ImgArgs a) {
+  kernarg_warm<sizeof(ImgArgs)>();
   __shared__ __attribute__((aligned(16))) float sA[NPP * LDA];   // patch; reused for Z [340][33]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const __amdgpu_buffer_rsrc_t rX = rsrc(a.X, (long)a.B * a.H * a.W * C * 4);
@@ -301,6 +302,7 @@ __global__ __launch_bounds__(256, 3) void img_fwd_kernel(const ImgArgs a) {
 // next block is in flight while it multiplies the current one.
 constexpr int LDZ2 = 29;   // odd: the pixel-per-lane gather reads are conflict-free; 4 x 340 x 29 x 4 B = 157.8 KB per CU
 __global__ __launch_bounds__(256, 4) void img_fwd2_kernel(const ImgArgs a) {
+  kernarg_warm<sizeof(ImgArgs)>();
   __shared__ float sZ[NP * LDZ2];
   __shared__ __attribute__((aligned(16))) float sSS[2 * C];   // BatchNorm scale | shift of the lazy apply
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -535,6 +537,7 @@ __global__ __launch_bounds__(256) void img_wgrad_kernel(const ImgArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 // ga [B,H,W,32] from g [B,H,W,3]; optional BatchNorm-backward sums bn_part[blockIdx.x][32][2]
 __global__ __launch_bounds__(256, 4) void img_dgrad_kernel(const ImgArgs a) {
+  kernarg_warm<sizeof(ImgArgs)>();
   __shared__ __attribute__((aligned(16))) float sG[NP * 4];
   __shared__ float sS[4 * C * 2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -645,6 +648,7 @@ __global__ __launch_bounds__(256, 4) void img_dgrad_kernel(const ImgArgs a) {
 // the BatchNorm-backward sums need anyway.  Slabs out[blockIdx.x][wtap*32 + ci][co] and bias partials pbias[blockIdx.x][co] like
 // img_wgrad_kernel; all merges in a fixed order.
 __global__ __launch_bounds__(256, 4) void img_bwd_fused_kernel(const ImgArgs a, float* __restrict__ wpart, float* __restrict__ wpbias) {
+  kernarg_warm<sizeof(ImgArgs) + 16>();
   __shared__ __attribute__((aligned(16))) float sG[NP * 4];
   __shared__ __attribute__((aligned(16))) float sR[4 * 32 * 32];   // end of the launch: the 4 waves' dW accumulators
   __shared__ float sS[4 * C * 2];
@@ -824,6 +828,7 @@ __device__ __forceinline__ void enc_patch_store(const EncPatch& p, float* sX) {
 }
 
 __global__ __launch_bounds__(256, 4) void img_enc_fwd_kernel(const EncArgs a) {
+  kernarg_warm<sizeof(EncArgs)>();
   __shared__ __attribute__((aligned(16))) float sX[ENP * 4];
   __shared__ float sS[4 * C * 3];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -924,6 +929,7 @@ __global__ __launch_bounds__(256, 4) void img_enc_fwd_kernel(const EncArgs a) {
 // straight into the MFMA A operand (128 B per pixel), x comes from the LDS patch.
 template <bool FUSED>
 __global__ __launch_bounds__(256, 4) void img_enc_wgrad_kernel(const EncArgs a) {
+  kernarg_warm<sizeof(EncArgs)>();
   __shared__ __attribute__((aligned(16))) float sX[ENP * 4];
   __shared__ __attribute__((aligned(16))) float sR[4 * 32 * 32];
   __shared__ float sB[4 * C];

@@ -26,6 +26,7 @@ namespace ctvae {
 // Masked / scalar-staging variant (any channel count): used for the 3-channel-input side of the nets.
 template <int WM, int WN, int TM, int TN, bool WT, bool AVEC, bool BVEC>
 __global__ __launch_bounds__(256) void tapgemm_masked_kernel(const TapGemmArgs a) {
+  kernarg_warm<sizeof(TapGemmArgs)>();
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int SA = BM * LDK, SB = WT ? BN * LDK : KC * BN;

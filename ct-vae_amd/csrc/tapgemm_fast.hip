@@ -46,6 +46,9 @@ __device__ unsigned long long g_phase[8 * 8192];
 extern "C" int ctvae_debug_phase_read(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), (size_t)n * 8);
 }
+extern "C" int ctvae_debug_wphase_read(unsigned long long* out, int n) {   // the weight-gradient role of conv_bwd_pair_kernel
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wphase), (size_t)n * 8);
+}
 #else
 #define PHASE(i) do {} while (0)
 #endif

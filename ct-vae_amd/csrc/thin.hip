@@ -41,6 +41,7 @@ constexpr unsigned kOOBt = 0x80000000u;
 // TH x TW tile, LP = gC/4 lanes per pixel.  LDS patch: [PH*PW][gC + 4] floats.
 template <int LP, int NO, int TMAX, int TH, int TW, bool WGRAD>
 __global__ __launch_bounds__(256) void thin_tile_kernel(const ThinArgs a) {
+  kernarg_warm<sizeof(ThinArgs)>();
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int GC = LP * 4, LDP = GC + 4, PPW = 64 / LP, NPIX = TH * TW;
   constexpr int ITERS = NPIX / (4 * PPW);

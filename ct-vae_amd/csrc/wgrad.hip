@@ -19,6 +19,7 @@ namespace ctvae {
 
 template <int WK, int WN, bool XVEC, bool DVEC>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+  kernarg_warm<sizeof(WgradArgs)>();
   constexpr int KT = WK * 32, NT = WN * 32;
   static_assert(WK * WN == 4, "4 waves");
   // single-buffered on purpose: the split-M grid is sized for ~4 workgroups per CU and occupancy hides the
@@ -245,6 +246,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 // ---- lean variant: body in wgrad_fast.hpp (shared with the paired backward launch of tapgemm_fast.hip) --------
 template <int WK, int WN, int TK, int TN, bool XF = false>
 __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradArgs a, int lgQw, int lgQhw, int lgC) {
+  kernarg_warm<sizeof(WgradArgs) + 12>();
   constexpr int KT = WK * TK * 32, NT = WN * TN * 32;
   __shared__ __attribute__((aligned(16))) float sX[MC * KT];
   __shared__ __attribute__((aligned(16))) float sD[MC * NT];
@@ -414,6 +416,7 @@ static DeferCtx& defer_ctx() {
 }
 
 __global__ __launch_bounds__(256) void reduce_multi_kernel(const DeferTable t) {
+  kernarg_warm<sizeof(DeferTable)>();
   __shared__ f32x4 sm[4][64];
   int k = 0;
   while (k + 1 < t.n && (int)blockIdx.x >= t.blk0[k + 1]) ++k;   // workgroup-uniform

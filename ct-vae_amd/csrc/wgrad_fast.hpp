@@ -24,6 +24,14 @@ struct WgradArgs {
 
 constexpr int MC = 32;
 
+#ifdef CTVAE_PHASE_TIMING
+// diagnostic build only (tools/pair_phase_probe.py): per-workgroup timestamps of the weight-gradient role, 100 MHz clock
+static __device__ unsigned long long g_wphase[8 * 8192];
+#define WPHASE(i) do { if (threadIdx.x == 0) g_wphase[((vby * vgx + vbx) & 8191) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define WPHASE(i) do {} while (0)
+#endif
+
 // ---- lean variant (gC % 4 == 0, N % 4 == 0): same tiling, minimal VALU around the MFMAs ---------------------
 // f32 MFMA and VALU share the SIMD's vector datapath on gfx950 (tools/mfma_probe.hip), so address arithmetic is
 // hoisted: a thread's tap / channel offset is constant for the launch, the per-pixel part (byte offset, y/x validity
@@ -47,6 +55,7 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, int lgQw, in
   constexpr int KT = WK * TK * 32, NT = WN * TN * 32;
   static_assert(WK * WN == 4, "4 waves");
 
+  WPHASE(0);
   const ConvGeom& g = a.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave / WN, wn = wave % WN;
@@ -181,6 +190,7 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, int lgQw, in
   float bsum = 0.f;
   const bool do_bias = (a.pbias != nullptr) && (kt0 == 0) && (tid < NT);
 
+  WPHASE(1);
   if (nch > 0) {
     rowinfo(0, 0);
     __syncthreads();
@@ -188,6 +198,7 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, int lgQw, in
     if (nch > 1) rowinfo(1, 1);
     store_chunk();
     __syncthreads();
+    WPHASE(2);
     for (int c = 0; c < nch; ++c) {
       if (c + 1 < nch) load_chunk((c + 1) & 1);
       if (c + 2 < nch) rowinfo(c + 2, c & 1);
@@ -219,6 +230,7 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, int lgQw, in
     }
   }
 
+  WPHASE(3);
 #pragma unroll
   for (int i = 0; i < TK; ++i)
 #pragma unroll
@@ -238,6 +250,11 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, int lgQw, in
       }
     }
   if (do_bias && n0 + tid < N) a.pbias[(long)(split * g.ncls + cls) * N + n0 + tid] = bsum;
+#ifdef CTVAE_PHASE_TIMING
+  WPHASE(4);
+  __builtin_amdgcn_s_waitcnt(0);
+  WPHASE(5);
+#endif
 }
 
 }  // namespace ctvae

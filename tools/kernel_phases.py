@@ -12,8 +12,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ctvae_amd import native  # noqa: E402
 
 name, cases = sys.argv[1], sys.argv[2]
-sys.argv = [sys.argv[0], "--iters", "3", "--cases", cases]
-runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ct_kernels_bench.py"), run_name="__main__")
+if cases.startswith("bench:"):     # e.g. "bench:--no-graph --steps 2 --warmup 1 --no-configs --no-cpu-baseline --no-roofline": the kernels of a whole step
+    sys.argv = [sys.argv[0]] + cases[6:].split()
+    runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"), run_name="__main__")
+else:
+    sys.argv = [sys.argv[0], "--iters", "3", "--cases", cases]
+    runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ct_kernels_bench.py"), run_name="__main__")
 lib = native.load()
 buf = (ctypes.c_longlong * (2 * 4 * 8 * 16))()
 rc = getattr(lib, "ctvae_debug_phases_" + name)(buf)
