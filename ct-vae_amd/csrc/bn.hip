@@ -106,6 +106,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   const int tid = threadIdx.x;
   const int c = blockIdx.x;
   if (c == 0 && tid == 0 && num_batches_tracked != nullptr) num_batches_tracked[0] += 1;   // nn.BatchNorm2d bookkeeping
+  // what the last lines need, requested with the partial rows: behind the merge they were two more memory round trips
+  const float gm = gamma[c], bt = beta[c];
+  const float rm0 = running_mean != nullptr ? running_mean[c] : 0.f, rv0 = running_mean != nullptr ? running_var[c] : 0.f;
   float n = 0.f, mean = 0.f, m2 = 0.f;
   // 8 rows per step: the loads go out together, only the (division-carrying) merges are serial
   for (int b0 = tid; b0 < nparts; b0 += 256 * 8) {
@@ -136,13 +139,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     const float invstd = 1.0f / sqrtf(var + eps);
     save_mean[c] = mean;
     save_invstd[c] = invstd;
-    const float sc = gamma[c] * invstd;
+    const float sc = gm * invstd;
     scale[c] = sc;
-    shift[c] = beta[c] - mean * sc;
+    shift[c] = bt - mean * sc;
     if (running_mean != nullptr) {
       const float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+      running_mean[c] = (1.f - momentum) * rm0 + momentum * mean;
+      running_var[c] = (1.f - momentum) * rv0 + momentum * unbiased;
     }
   }
 }

@@ -58,6 +58,27 @@ __device__ __forceinline__ float wave_sum_full(float v) {
   return bf(__builtin_amdgcn_readlane(bi(v), 63));
 }
 
+// double-precision counterpart of wave_sum_full (two 32-bit DPP moves per step)
+__device__ __forceinline__ double wave_sum_d_full(double v) {
+#define CTVAE_DPP_D(CTRL, RM, BC)                                                                          \
+  {                                                                                                        \
+    const long long b = __builtin_bit_cast(long long, v);                                                  \
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, RM, 0xF, BC);                               \
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, RM, 0xF, BC);                       \
+    v += __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);                                 \
+  }
+  CTVAE_DPP_D(0xB1, 0xF, true)
+  CTVAE_DPP_D(0x4E, 0xF, true)
+  CTVAE_DPP_D(0x141, 0xF, true)
+  CTVAE_DPP_D(0x140, 0xF, true)
+  CTVAE_DPP_D(0x142, 0xA, false)
+  CTVAE_DPP_D(0x143, 0xC, false)
+#undef CTVAE_DPP_D
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

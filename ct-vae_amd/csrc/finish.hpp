@@ -71,34 +71,45 @@ struct BnFinJob {
 
 __device__ __forceinline__ void bn_bwd_finalize_body(const BnFinJob& j, int c, double* sm /* [8] */) {
   const int tid = threadIdx.x, C = j.C;
+  // the operands of the last lines, requested with the partial rows (behind the sums they were two more dependent round trips)
+  const float invstd = j.invstd[c], mean = j.mean[c], gm = j.gamma[c], bt = j.beta[c];
+  const float dg0 = (j.dgamma != nullptr && j.accumulate) ? j.dgamma[c] : 0.f, db0 = (j.dgamma != nullptr && j.accumulate) ? j.dbeta[c] : 0.f;
   double s1 = 0.0, s2 = 0.0;
-#pragma unroll 8
-  for (int b = tid; b < j.nblocks; b += 256) {
-    s1 += (double)j.part[((long)b * C + c) * 2 + 0];
-    s2 += (double)j.part[((long)b * C + c) * 2 + 1];
+  // eight rows of a thread in flight (a loop over `b += 256` with a tid-dependent trip count is one round trip per iteration);
+  // rows beyond the table re-read the thread's first row with weight 0: same summation order as before
+  for (int b0 = tid; b0 < j.nblocks; b0 += 256 * 8) {
+    f32x2 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = b0 + 256 * u;
+      t[u] = *reinterpret_cast<const f32x2*>(j.part + ((long)(b < j.nblocks ? b : b0) * C + c) * 2);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (b0 + 256 * u < j.nblocks) { s1 += (double)t[u][0]; s2 += (double)t[u][1]; }
+    }
   }
-  s1 = wave_sum_d(s1);
-  s2 = wave_sum_d(s2);
+  s1 = wave_sum_d_full(s1);
+  s2 = wave_sum_d_full(s2);
   if ((tid & 63) == 0) { sm[(tid >> 6) * 2] = s1; sm[(tid >> 6) * 2 + 1] = s2; }
   __syncthreads();
   if (tid == 0) {
     s1 = (sm[0] + sm[2]) + (sm[4] + sm[6]);
     s2 = (sm[1] + sm[3]) + (sm[5] + sm[7]);
     const float db = (float)s1, dg = (float)s2;
-    const float invstd = j.invstd[c], mean = j.mean[c];
-    const float k1 = j.gamma[c] * invstd;
+    const float k1 = gm * invstd;
     const float k2 = -k1 * dg / j.R * invstd;
     const float k3 = -k1 * db / j.R - k2 * mean;
     j.coef[c] = k1;
     j.coef[C + c] = k2;
     j.coef[2 * C + c] = k3;
     j.coef[3 * C + c] = k1;
-    j.coef[4 * C + c] = j.beta[c] - mean * k1;
+    j.coef[4 * C + c] = bt - mean * k1;
     j.coef[5 * C + c] = dg;
     j.coef[6 * C + c] = db;
     if (j.dgamma != nullptr) {
-      j.dgamma[c] = (j.accumulate ? j.dgamma[c] : 0.f) + dg;
-      j.dbeta[c] = (j.accumulate ? j.dbeta[c] : 0.f) + db;
+      j.dgamma[c] = dg0 + dg;
+      j.dbeta[c] = db0 + db;
     }
   }
 }
