@@ -11,7 +11,8 @@ namespace ctvae {
 int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
                    const float* mask, int mask_act, float* S, int act, float* bn_part, float* ws, size_t ws_floats,
                    hipStream_t st, const BnBwdFuse* bnb = nullptr, const InXform* xf = nullptr,
-                   const WinoFilters* wf = nullptr, SplitKRaw* raw = nullptr);
+                   const WinoFilters* wf = nullptr, SplitKRaw* raw = nullptr, int out_pix = 0);
+bool out_pix_supported(const ConvGeom& g, size_t ws_floats, int out_pix);
 bool wino_supported(const ConvGeom& g, size_t ws_floats);
 bool wino_enabled();
 int wino_set_enabled(int on);
@@ -225,6 +226,21 @@ int ctvae_conv_forward(int kind, const float* x, const float* w, const float* bi
   const WinoFilters wf{wino_fwd_filters, wino_fwd_filters != nullptr ? nullptr : wino_dgrad_filters_out};
   return launch_tapgemm(g, x, w, bias, add, nullptr, 0, y, act, nullptr, ws, ws_bytes / sizeof(float), (hipStream_t)stream,
                         nullptr, &xf, &wf);
+}
+
+int ctvae_linear_pixmajor_supported(int B, int Ci, int C, int P, size_t ws_bytes) {
+  ConvGeom g;
+  if (B <= 0 || Ci <= 0 || C <= 0 || P <= 1 || conv_geom(g, CTVAE_CONV, 0, B, 1, 1, Ci, C * P, 1, 1, 0, 0)) return 0;
+  return out_pix_supported(g, ws_bytes / sizeof(float), P) ? 1 : 0;
+}
+
+int ctvae_linear_pixmajor_forward(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int C, int P, int act,
+                                  float* ws, size_t ws_bytes, void* stream) {
+  if (!x || !w || !y || !ctvae_linear_pixmajor_supported(B, Ci, C, P, ws_bytes)) return kErrBadArg;
+  ConvGeom g;
+  if (conv_geom(g, CTVAE_CONV, 0, B, 1, 1, Ci, C * P, 1, 1, 0, 0)) return kErrBadArg;
+  return launch_tapgemm(g, x, w, bias, nullptr, nullptr, 0, y, act, nullptr, ws, ws_bytes / sizeof(float), (hipStream_t)stream,
+                        nullptr, nullptr, nullptr, nullptr, P);
 }
 
 int ctvae_wino_filters_batch(int n, const float* const* w, float* const* fwd_filters, float* const* dgrad_filters, const int* Ci,

@@ -636,10 +636,24 @@ int launch_wino_conv(const ConvGeom& g, const float* X, const float* Wp, const f
 
 bool wino_enabled();
 
+// a 1 x 1 layer on a 1 x 1 image (an nn.Linear) that the vector tile kernel runs unsplit: the only launch that honours out_pix
+bool out_pix_supported(const ConvGeom& g, size_t ws_floats, int out_pix) {
+  if (out_pix <= 1 || g.os != 1 || g.ncls != 1 || g.ntaps[0] != 1 || g.sH * g.sW != 1 || g.sC % out_pix != 0 || g.wT != 0) return false;
+  if ((g.gC % KC) != 0 || (g.sC % 4) != 0) return false;
+  TapGemmPlan plan;
+  tapgemm_plan(g, ws_floats, plan);
+  return !plan.thin && plan.BM != 0 && plan.splitk <= 1;
+}
+
 int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const float* bias, const float* add,
                    const float* mask, int mask_act, float* S, int act, float* bn_part, float* ws, size_t ws_floats,
-                   hipStream_t st, const BnBwdFuse* bnb, const InXform* xf, const WinoFilters* wf, SplitKRaw* raw) {
+                   hipStream_t st, const BnBwdFuse* bnb, const InXform* xf, const WinoFilters* wf, SplitKRaw* raw, int out_pix) {
   if (raw != nullptr) raw->splitk = 0;
+  if (out_pix > 1) {   // TapGemmArgs::out_pix: the vector tile kernel's plain epilogue only (see out_pix_supported)
+    if (!out_pix_supported(g, ws != nullptr ? ws_floats : 0, out_pix) || add != nullptr || mask != nullptr || bn_part != nullptr ||
+        (bnb != nullptr && bnb->part != nullptr) || raw != nullptr)
+      return kErrBadArg;
+  }
   // 3x3 / stride 1 / same-padding layers with plain epilogues: Winograd F(2x2,3x3), see wino.hip
   // (the skip operand `add` is taken by the Winograd epilogue; a mask is not)
   if (mask == nullptr && bn_part == nullptr && (bnb == nullptr || bnb->part == nullptr) &&
@@ -664,6 +678,7 @@ int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const floa
   a.g = g;
   a.G = G; a.W = W; a.bias = bias; a.add = add; a.mask = mask; a.S = S;
   a.act = act; a.mask_act = mask_act;
+  a.out_pix = out_pix;
   a.Mc = g.B * g.Qh * g.Qw;
   a.N = g.sC;
   if (a.Mc <= 0 || a.N <= 0) return kErrBadArg;

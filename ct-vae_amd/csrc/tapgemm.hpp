@@ -31,6 +31,8 @@ struct TapGemmArgs {
   const float* xf_scale;
   const float* xf_shift;
   int xf_act;
+  int out_pix;     // P > 1 (dense scatter, no split-K): output column n = c*P + p is stored at column p*(N/P) + c -- an nn.Linear whose
+                   // output is .view(B, C, h, w) (NCHW, vanilla_vae.py:102) leaves the NHWC tensor [B, h, w, C] itself (no layout launch)
   int part_T;      // split-K partials channel-major [splitk][N][B*sH*sW] (SplitKRaw) instead of pixel-major [splitk][B*sH*sW][N]
   int lgQw, lgQhw; // log2(Qw), log2(Qh*Qw) when both are powers of two, else -1 (generic division)
   int act;

@@ -601,6 +601,60 @@ class _ToNHWC(Function):
         return permute_raw(_c(g), B, C, H * W, False).view(B, C, H, W)
 
 
+class LinearToNHWC(Function):
+    """``decoder_input(z).view(-1, C, h, w)`` (vanilla_vae.py:101-102) handed to the decoder as the NHWC tensor [B, h, w, C] by ONE
+    launch: the Linear's GEMM stores output feature c*P + p at column p*C + c (ctvae_linear_pixmajor_forward) instead of a layout
+    launch behind it.  Backward is what ConvAct + _ToNHWC did: the gradient goes back to the Linear's own feature order (summing
+    the consumer's split-K slices on the way when it arrives as slices), then the Linear's paired backward launch."""
+
+    _ok = {}
+    _on = os.environ.get("CTVAE_LINEAR_NHWC", "1") != "0"     # diagnostic: 0 = the two-launch path
+
+    @staticmethod
+    def supported(B, ci, C, P, device):
+        if not LinearToNHWC._on:
+            return False
+        key = (B, ci, C, P)
+        ok = LinearToNHWC._ok.get(key)
+        if ok is None:
+            ws = native.workspace(device)
+            ok = LinearToNHWC._ok[key] = bool(native.load().ctvae_linear_pixmajor_supported(B, ci, C, P, ws.numel() * 4))
+        return ok
+
+    @staticmethod
+    def forward(ctx, x, w, b, spec, C, h, wd):
+        _req_cuda(x, w)
+        x = _c(x)
+        B = x.shape[0]
+        ctx.link_in = link_of(x)
+        ctx.x_slices_ok = bool(getattr(x, "_ctvae_grad_slices_ok", False))
+        ctx.spec, ctx.w, ctx.b, ctx.dims = spec, w, b, (B, C, h, wd)
+        ws = native.workspace(x.device)
+        y = torch.empty((B, h, wd, C), dtype=torch.float32, device=x.device)
+        native.call("ctvae_linear_pixmajor_forward", x.data_ptr(), w.data_ptr(), native.ptr(b), y.data_ptr(), B, spec.ci, C, h * wd,
+                    spec.act, ws.data_ptr(), ws.numel() * 4)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return (None,) * 7
+        (x,) = ctx.saved_tensors
+        B, C, h, wd = ctx.dims
+        spec = ctx.spec
+        if spec.act != ACT_NONE:
+            raise RuntimeError("LinearToNHWC: a fused activation is not differentiated here (decoder_input has none)")
+        lazy = claim_lazy_grad(g) if g.is_contiguous() else None
+        if lazy is not None:       # split-K slices of the consumer's data gradient: summed while the layout changes
+            g_flat = torch.empty((B, 1, 1, C * h * wd), dtype=torch.float32, device=g.device)
+            native.call("ctvae_splitk_permute", lazy[0].data_ptr(), lazy[1], g_flat.data_ptr(), B, C, h * wd)
+        else:
+            g_flat = permute_raw(_c(g), B, C, h * wd, False).view(B, 1, 1, C * h * wd)
+        g_x = wgrad_then_dgrad(x, g_flat, ctx.w, ctx.b, spec, ctx.needs_input_grad[0], ctx.link_in, None, grad_slices=ctx.x_slices_ok)
+        return g_x, None, None, None, None, None, None
+
+
 class _ToNCHW(Function):
     """NHWC contiguous -> NCHW contiguous."""
 

@@ -125,8 +125,12 @@ class VanillaVAE(BaseVAE):
         zr = z.reshape(B, 1, 1, -1)
         if getattr(z, "_ctvae_grad_slices_ok", False):
             K.grad_slices_ok(zr)
-        h = K.ConvAct.apply(zr, self.decoder_input.weight, self.decoder_input.bias, None, self._dec_in_spec)
-        h = K.grad_slices_ok(K._ToNHWC.apply(h.view(B, 512, 2, 2)))      # .view(-1,512,2,2) is NCHW; read by decoder.0 only
+        if K.LinearToNHWC.supported(B, self._dec_in_spec.ci, 512, 4, z.device):
+            # the Linear's own epilogue leaves .view(-1,512,2,2) as the NHWC tensor decoder.0 gathers (one launch less)
+            h = K.grad_slices_ok(K.LinearToNHWC.apply(zr, self.decoder_input.weight, self.decoder_input.bias, self._dec_in_spec, 512, 2, 2))
+        else:
+            h = K.ConvAct.apply(zr, self.decoder_input.weight, self.decoder_input.bias, None, self._dec_in_spec)
+            h = K.grad_slices_ok(K._ToNHWC.apply(h.view(B, 512, 2, 2)))      # .view(-1,512,2,2) is NCHW; read by decoder.0 only
         h = self.decoder(h, last_reader=self.final_layer)                # read by final_layer only (marked by the chain)
         return K.to_nchw_view(self.final_layer(h))
 

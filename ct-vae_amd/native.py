@@ -17,6 +17,8 @@ _fp, _vp, _i, _l, _f, _sz = _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_long, _c.c_
 
 # name -> argtypes (all return int unless listed in _RESTYPES)
 SIGNATURES = {
+    "ctvae_linear_pixmajor_supported": [_i, _i, _i, _i, _sz],
+    "ctvae_linear_pixmajor_forward": [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _sz, _vp],
     "ctvae_conv_forward": [_i, _fp, _fp, _fp, _fp, _fp] + [_i] * 10 + [_fp, _fp, _i, _fp, _fp, _fp, _sz, _vp],
     "ctvae_wino_filters_batch": [_i, _vp, _vp, _vp, _vp, _vp, _vp],
     "ctvae_conv_bn_act_forward": [_i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp] + [_i] * 9

@@ -59,6 +59,14 @@ int ctvae_conv_forward(int kind, const float* x, const float* w, const float* bi
                        int H, int W, int Ci, int Co, int k, int stride, int pad, int out_pad, int act, const float* in_scale,
                        const float* in_shift, int in_act, float* wino_dgrad_filters_out, const float* wino_fwd_filters, float* ws,
                        size_t ws_bytes, void* stream);
+/* nn.Linear(Ci, C*P) followed by .view(-1, C, h, w), h*w = P (decoder_input, vanilla_vae.py:43,101-102): y is written as the
+ * NHWC tensor [B, h, w, C] the next layer gathers -- output feature c*P + p goes to column p*C + c in the GEMM's epilogue, no
+ * layout launch behind it.  x [B, Ci], w the packed [Ci][C*P] block, bias [C*P] or NULL.  _supported: 1 where the layer runs on
+ * the vector tile kernel without a K split (Ci % 32 == 0, enough rows); elsewhere use ctvae_conv_forward + ctvae_permute.
+ * Backward is unchanged: ctvae_permute / ctvae_splitk_permute of the gradient, then ctvae_conv_backward of the Linear. */
+int ctvae_linear_pixmajor_supported(int B, int Ci, int C, int P, size_t ws_bytes);
+int ctvae_linear_pixmajor_forward(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int C, int P, int act,
+                                  float* ws, size_t ws_bytes, void* stream);
 /* Both Winograd filter sets (forward / data gradient, ctvae_conv_wino_filter_floats() floats each) of n 3x3 stride-1 layers
  * in ONE launch: w[l] = the layer's packed weights [9][Ci][Co], Ci, Co multiples of 32.  The residual stacks of MCQ-VAE /
  * CT-MCQ-VAE have 13 / 14 such layers (vq_vae.py:57-70 via mcq_vae.py:182-216); their weights change once per optimizer step.

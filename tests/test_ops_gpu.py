@@ -116,6 +116,48 @@ def test_linear_over_flatten_as_convolution(K, C, k, s, out, B):
     np.testing.assert_allclose(bp.grad.cpu().numpy(), b.grad.numpy(), atol=TOL * max(1.0, float(b.grad.abs().max())), rtol=1e-4)
 
 
+@pytest.mark.parametrize("L,C,h,B", [(128, 512, 2, 64), (128, 512, 2, 256), (128, 512, 2, 7), (64, 32, 3, 130)])
+def test_linear_into_nhwc_view(K, L, C, h, B):
+    """ctvae_linear_pixmajor_forward: nn.Linear(L, C*h*h) + .view(-1, C, h, h) (vanilla_vae.py:101-102) written as the NHWC tensor by
+    the GEMM's epilogue; forward and every gradient vs torch, and bit-equal to the two-launch path (ConvAct + layout change)."""
+    g = torch.Generator().manual_seed(L + C + B)
+    z = torch.randn(B, L, generator=g).requires_grad_(True)
+    w = (torch.randn(C * h * h, L, generator=g) / L ** 0.5).requires_grad_(True)
+    b = torch.randn(C * h * h, generator=g).requires_grad_(True)
+    y = F.linear(z, w, b).view(B, C, h, h)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    dev = torch.device("cuda")
+    spec = K.ConvSpec(K.CONV, L, C * h * h, 1)
+    assert K.LinearToNHWC.supported(B, L, C, h * h, dev)
+    gy_nhwc = gy.permute(0, 2, 3, 1).contiguous().to(dev)
+    outs = []
+    for fused in (True, False):
+        zd = z.detach().view(B, 1, 1, L).to(dev).requires_grad_(True)
+        wp = torch.nn.Parameter(w.detach().t().contiguous().to(dev).t())          # logical [out, in] over memory [in][out]
+        bp = torch.nn.Parameter(b.detach().to(dev))
+        if fused:
+            o = K.LinearToNHWC.apply(zd, wp, bp, spec, C, h, h)
+        else:
+            o = K._ToNHWC.apply(K.ConvAct.apply(zd, wp, bp, None, spec).view(B, C, h, h))
+        assert tuple(o.shape) == (B, h, h, C)
+        o.backward(gy_nhwc)
+        torch.cuda.synchronize()
+        outs.append((o.detach().cpu(), zd.grad.cpu(), wp.grad.cpu(), bp.grad.cpu()))
+    o, gz, gw, gb = outs[0]
+    np.testing.assert_allclose(o.permute(0, 3, 1, 2).numpy(), y.detach().numpy(), atol=TOL, rtol=1e-4)
+    np.testing.assert_allclose(gz.view(B, L).numpy(), z.grad.numpy(), atol=TOL * max(1.0, float(z.grad.abs().max())), rtol=1e-4)
+    np.testing.assert_allclose(gw.numpy(), w.grad.numpy(), atol=TOL * max(1.0, float(w.grad.abs().max())), rtol=1e-4)
+    np.testing.assert_allclose(gb.numpy(), b.grad.numpy(), atol=TOL * max(1.0, float(b.grad.abs().max())), rtol=1e-4)
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a_, b_)
+
+
+def test_linear_into_nhwc_view_says_no_where_the_tile_kernel_does_not_run(K):
+    dev = torch.device("cuda")
+    assert not K.LinearToNHWC.supported(4, 20, 512, 4, dev)          # in_features not a multiple of the 32-wide K chunk
+
+
 @pytest.mark.parametrize("B,C,P", [(5, 3, 64 * 64), (2, 3, 36), (3, 3, 35), (4, 512, 4), (2, 7, 10)])
 def test_permute_both_ways(K, B, C, P):
     """ctvae_permute (NCHW <-> NHWC copies): the 3-channel quad kernel, and the element-wise one for everything else."""
