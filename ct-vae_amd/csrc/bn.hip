@@ -677,12 +677,11 @@ __global__ __launch_bounds__(TPB) void bn_fused_bwd_kernel(const BnFusedBwd p) {
   f32x4 g[CPW];      // [channel] along rows: g_a, then g' = g_a * act'
   long po[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
+  for (int e = 0; e < 4; ++e) po[e] = live ? (long)row_map_pixel(p.rows, r4 + e) * C + c0 : c0;
+  // UNCONDITIONAL loads (threads beyond R read row 0; their g is zeroed below, so the value never counts): under `if (live)` each
+  // load is a branch and the compiler waits for it before the next one -- four memory round trips in a row at the top of the kernel
 #pragma unroll
-    for (int c = 0; c < CPW; ++c) yv[e][c] = 0.f;
-    po[e] = live ? (long)row_map_pixel(p.rows, r4 + e) * C + c0 : 0;
-    if (live) yv[e] = *reinterpret_cast<const rowv*>(p.y + po[e]);
-  }
+  for (int e = 0; e < 4; ++e) yv[e] = *reinterpret_cast<const rowv*>(p.y + po[e]);
   float mean[CPW], invstd[CPW], gm[CPW], bt[CPW], s12[2 * CPW], dg0[CPW], db0[CPW];
 #pragma unroll
   for (int c = 0; c < CPW; ++c) {

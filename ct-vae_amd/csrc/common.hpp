@@ -199,6 +199,8 @@ struct RowMap {
   int ncls, Mc, Qh, Qw, sH, sW, os;
   unsigned pyp, pxp;     // the classes' parity offsets, 8 bits each: a table indexed by a per-thread class is a LOAD from the kernel
                          // arguments in front of every row's own load (two dependent round trips per row)
+  int lgMc, lgQhw, lgQw; // log2 of Mc, Qh*Qw, Qw when ALL THREE are powers of two (the models' shapes), else -1: three integer
+                         // divisions per row were ~100 vector instructions in front of every row's access (bn_fused_*: 16 waves per CU)
 };
 
 inline RowMap row_map_of(const ConvGeom& g) {
@@ -206,13 +208,31 @@ inline RowMap row_map_of(const ConvGeom& g) {
   m.ncls = g.ncls; m.Mc = g.B * g.Qh * g.Qw; m.Qh = g.Qh; m.Qw = g.Qw; m.sH = g.sH; m.sW = g.sW; m.os = g.os;
   static_assert(kMaxCls <= 4, "RowMap packs four classes");
   for (int c = 0; c < kMaxCls; ++c) { m.pyp |= (unsigned)(g.py[c] & 0xff) << (8 * c); m.pxp |= (unsigned)(g.px[c] & 0xff) << (8 * c); }
+  auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (v > 0 && (1 << l) == v) ? l : -1; };
+  m.lgMc = lg2(m.Mc); m.lgQhw = lg2(g.Qh * g.Qw); m.lgQw = lg2(g.Qw);
+  if (m.lgMc < 0 || m.lgQhw < 0 || m.lgQw < 0) m.lgMc = m.lgQhw = m.lgQw = -1;
   return m;
 }
 
 __device__ __forceinline__ int row_map_pixel(const RowMap& m, int r) {
   if (m.ncls == 1) return r;
-  const int cls = r / m.Mc, mm = r - cls * m.Mc;
-  const int qhw = m.Qh * m.Qw, b = mm / qhw, rr = mm - b * qhw, qy = rr / m.Qw, qx = rr - qy * m.Qw;
+  int cls, b, qy, qx;
+  if (m.lgMc >= 0) {
+    cls = r >> m.lgMc;
+    const int mm = r & (m.Mc - 1);
+    b = mm >> m.lgQhw;
+    const int rr = mm & ((1 << m.lgQhw) - 1);
+    qy = rr >> m.lgQw;
+    qx = rr & (m.Qw - 1);
+  } else {
+    cls = r / m.Mc;
+    const int mm = r - cls * m.Mc;
+    const int qhw = m.Qh * m.Qw;
+    b = mm / qhw;
+    const int rr = mm - b * qhw;
+    qy = rr / m.Qw;
+    qx = rr - qy * m.Qw;
+  }
   const int py = (int)((m.pyp >> (8 * cls)) & 0xffu), px = (int)((m.pxp >> (8 * cls)) & 0xffu);
   return (b * m.sH + qy * m.os + py) * m.sW + qx * m.os + px;
 }
