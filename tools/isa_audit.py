@@ -2,7 +2,10 @@
 
     python tools/isa_audit.py [file.hip ...]            (no GPU needed: hipcc -S for gfx950, all of csrc/ by default)
 
-Per kernel: VGPR / AGPR / scratch bytes.  Per loop of a kernel (label to back-branch):
+Per kernel: VGPR / AGPR / scratch bytes, the size of the kernel-argument segment and the number of scalar-load batches (s_load ...
+s_waitcnt lgkmcnt(0)) in front of the first vector load -- with large argument structs each batch is a dependent round trip to memory
+behind the launch's cache invalidate (tile kernels: eight, 2.9 us per workgroup, until common.hpp kernarg_warm fetched all lines at
+once).  Per loop of a kernel (label to back-branch):
   * `scratch` -- spill reloads inside the loop: each is a vector-memory operation, and the `s_waitcnt vmcnt(0)` in front of its use
     also drains every load issued ahead for the next iteration (up_wgrad_kernel: 45 -> 29 us after a budget of one wave per SIMD);
   * `vmcnt(0)` next to global / buffer loads in a loop that also stores -- a predicated store (or load) is a branch, behind which
@@ -48,6 +51,18 @@ def audit(path):
             return int(mm.group(1)) if mm else 0
 
         lines = fn.split("s_endpgm")[0].split("\n")
+        batches, pending, warm = 0, False, False
+        for l in lines:
+            if re.search(r"\b(global|buffer)_load", l):
+                break
+            if ".Lkw_off" in l:
+                warm = True
+            if "s_load" in l:
+                pending = True
+            if "s_waitcnt" in l and "lgkmcnt(0)" in l and pending:
+                batches, pending = batches + 1, False
+        mk = re.search(r"\.kernarg_segment_size: (\d+)\n(?:.*\n){0,40}?\s+\.symbol:\s+" + re.escape(sym) + r"\.kd", txt)
+        karg = int(mk.group(1)) if mk else 0
         rows = []
         for i, l in enumerate(lines):
             mm = re.match(r"^(\.LBB\d+_\d+):.*Loop Header: Depth=(\d+)", l)
@@ -77,7 +92,7 @@ def audit(path):
                 rows.append(f"    loop {lab:11s} {n:5d} lines  mfma {mfma:3d}  loads {loads:3d}  stores {stores:3d}  vmcnt {','.join(waits[:10]) or '-':22s}"
                             f"  scratch {scr:2d}  v_mov {vmov:3d}  {' '.join(flags)}")
         scratch = meta("private_seg_size")
-        print(f"{os.path.basename(path)}: {demangle(sym)[:100]}\n    vgpr {meta('num_vgpr')}  agpr {meta('num_agpr')}  scratch {scratch} B")
+        print(f"{os.path.basename(path)}: {demangle(sym)[:100]}\n    vgpr {meta('num_vgpr')}  agpr {meta('num_agpr')}  scratch {scratch} B   kernarg {karg} B, {batches} scalar-load batches before the first vector load{' (argument lines fetched in one batch)' if warm else ''}")
         if rows:
             print("\n".join(rows))
 
