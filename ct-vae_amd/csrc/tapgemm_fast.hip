@@ -43,6 +43,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long 
 // diagnostic build only (tools/phase_probe.py): per-workgroup timestamps of the kernel phases, 100 MHz clock
 __device__ unsigned long long g_phase[8 * 8192];
 #define PHASE(i) do { if (threadIdx.x == 0 && blockIdx.z == 0) g_phase[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 8 + (i)] = wall_clock64(); } while (0)
+// where the pipelined loop's time goes, summed over the chunks of a workgroup (wave 0, shader clock): [0] waiting for the global
+// loads + LDS stores, [1] issuing the next loads / LDS reads + the first eight MFMAs, [2] the barrier, [3] reads + the last eight MFMAs
+__device__ long long g_loop[4 * 8192];
+#define LOOPT(var) const long long var = clock64()
+#define LOOPACC(i, a, b) loopt_[i] += (b) - (a)
+#define LOOPDECL long long loopt_[4] = {0, 0, 0, 0}
+#define LOOPOUT do { if (threadIdx.x == 0 && blockIdx.z == 0) for (int q_ = 0; q_ < 4; ++q_) g_loop[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 4 + q_] = loopt_[q_]; } while (0)
+extern "C" int ctvae_debug_loop_read(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_loop), (size_t)n * 8); }
 extern "C" int ctvae_debug_phase_read(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), (size_t)n * 8);
 }
@@ -51,6 +59,10 @@ extern "C" int ctvae_debug_wphase_read(unsigned long long* out, int n) {   // th
 }
 #else
 #define PHASE(i) do {} while (0)
+#define LOOPT(var) do {} while (0)
+#define LOOPACC(i, a, b) do {} while (0)
+#define LOOPDECL do {} while (0)
+#define LOOPOUT do {} while (0)
 #endif
 
 template <int WM, int WN, int TM, int TN, bool WT, int PF, bool XF = false, int PD = 1>

@@ -40,6 +40,16 @@ for B, H, ci, Co, k, stride in shapes:
     names = ["entry", "class / tile decoded", "row offsets, sOut", "tap masks (prologue done)", "first chunk in LDS", "main loop done", "stores issued", "stores retired"]
     print(f"B={B} H={H} Ci={ci} Co={Co} k={k} s={stride} chunks={k * k * ci // 32} WGs={nwg}  event-timed launch {e0.elapsed_time(e1) * 1e3:.1f} us, "
           f"span first entry -> last retire {rel[:, 7].max():.1f} us")
+    if hasattr(lib, "ctvae_debug_loop_read"):
+        lib.ctvae_debug_loop_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lb = np.zeros(8192 * 4, dtype=np.int64)
+        lib.ctvae_debug_loop_read(lb.ctypes.data, lb.size)
+        lb = lb.reshape(8192, 4)
+        lb = lb[lb.sum(axis=1) > 0][:nwg]
+        nchunk = max(1, (k * k * ci // 32))
+        print("    pipelined loop, shader cycles per chunk (mean over workgroups; marks cost ~100 cycles each): "
+              f"load wait + LDS store {lb[:, 0].mean() / nchunk:.0f}, issue + 8 MFMA {lb[:, 1].mean() / nchunk:.0f}, "
+              f"barrier {lb[:, 2].mean() / nchunk:.0f}, reads + 8 MFMA {lb[:, 3].mean() / nchunk:.0f}")
     for i, n in enumerate(names):
         d = rel[:, i] - (rel[:, i - 1] if i else 0)
         print(f"    {n:20s} at mean {rel[:, i].mean():7.2f} (min {rel[:, i].min():6.2f} max {rel[:, i].max():6.2f})   phase mean {d.mean():6.2f} us")
