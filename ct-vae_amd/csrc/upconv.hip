@@ -201,10 +201,15 @@ __global__ __launch_bounds__(256, 2) void up_fwd_kernel(const UpArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     };
+    // one scheduling region per tap: the next tap's 20 LDS reads are spread behind the 16 MFMAs of this one (pinned order: an MFMA,
+    // then the reads that issue while it runs) instead of all in front of the first MFMA
 #define UP_STEP(LY, C_, T_, CUR, NXT, NLY, NC, NT_, HAS_NEXT)          \
     if (HAS_NEXT) read_tap(NLY, NC, NT_, NXT);                          \
-    __builtin_amdgcn_sched_barrier(0);                                  \
     mfma_tap(CUR, acc);                                                 \
+    _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                 \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                \
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                \
+    }                                                                   \
     __builtin_amdgcn_sched_barrier(0);
     Frag fa, fb;
 #pragma unroll 1
