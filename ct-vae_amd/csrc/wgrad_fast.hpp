@@ -90,6 +90,7 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, int lgQw, in
   const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)((long)g.B * g.gH * g.gW * gC * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dY), 0, (int)((long)g.B * g.sH * g.sW * N * 4), 0x00020000);
 
+  const int sc_py = g.py[cls], sc_px = g.px[cls];
   auto rowinfo = [&](int c, int buf) {
     if (tid < MC) {
       const int m = (cbeg + c) * MC + tid;
@@ -106,12 +107,15 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, int lgQw, in
         }
         const int iy0 = qy * g.is, ix0 = qx * g.is;
         pixb = (unsigned)(((b * g.gH + iy0) * g.gW + ix0) * gC) * 4u;
-#pragma unroll
-        for (int d = -3; d <= 4; ++d) {
-          if ((unsigned)(iy0 + d) < (unsigned)g.gH) msk |= 1u << (d + 3);
-          if ((unsigned)(ix0 + d) < (unsigned)g.gW) msk |= 1u << (d + 11);
-        }
-        outb = (unsigned)(scatter_pix(g, cls, b, qy, qx) * N) * 4u;
+        // bit (d+3): dy = d allowed, bit (d+11): dx = d allowed, d = -3 .. 4, as two bit ranges (tapgemm_fast_body.inc); the class's
+        // parity offsets are read once per workgroup (sc_py / sc_px), not per chunk: this runs on HALF A WAVE while the other
+        // fifteen half-waves of the workgroup wait for it at the barrier
+        auto range_bits = [](int i0, int n) {
+          const int lo = max(0, 3 - i0), hi = min(7, n + 2 - i0);
+          return hi >= lo ? (2u << hi) - (1u << lo) : 0u;
+        };
+        msk = range_bits(iy0, g.gH) | (range_bits(ix0, g.gW) << 8);
+        outb = (unsigned)(((b * g.sH + qy * g.os + sc_py) * g.sW + qx * g.os + sc_px) * N) * 4u;
       }
       sPix[buf][tid] = pixb; sMsk[buf][tid] = msk; sOutB[buf][tid] = outb;
     }
@@ -148,20 +152,26 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, int lgQw, in
   f32x4 rx[X_V], rd[D_V];
   [[maybe_unused]] float rx_in[X_V];   // XF: 1 where the loaded pixel lies inside the image (the shift applies), else 0
   auto load_chunk = [&](int buf) {
+    // the row table is read first, for every row of the thread: as `ok ? sPix[r] + c : OOB` the table reads sat behind branches,
+    // each with its own wait -- two dependent LDS round trips per load in front of the chunk's MFMAs
+    unsigned mskv[X_V], pixv[X_V], outv[D_V];
 #pragma unroll
     for (int j = 0; j < X_V; ++j) {
       const int r = tid / XQ + (256 / XQ) * j;
-      const unsigned msk = sMsk[buf][r];
-      const bool ok = x_kok && ((msk >> x_sy) & (msk >> x_sx) & 1u) != 0;
-      rx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, (int)(ok ? sPix[buf][r] + x_const : kOOBw), 0, 0));
-      if constexpr (XF) rx_in[j] = (ok && sPix[buf][r] != kOOBw) ? 1.f : 0.f;
+      mskv[j] = sMsk[buf][r];
+      pixv[j] = sPix[buf][r];
     }
 #pragma unroll
-    for (int j = 0; j < D_V; ++j) {
-      const int r = tid / DQ + (256 / DQ) * j;
-      const unsigned ob = sOutB[buf][r];
-      rd[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rD, (int)((ob | d_const) >= kOOBw ? kOOBw : ob + d_const), 0, 0));
+    for (int j = 0; j < D_V; ++j) outv[j] = sOutB[buf][tid / DQ + (256 / DQ) * j];
+#pragma unroll
+    for (int j = 0; j < X_V; ++j) {
+      const bool ok = x_kok && ((mskv[j] >> x_sy) & (mskv[j] >> x_sx) & 1u) != 0;
+      rx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, (int)(ok ? pixv[j] + x_const : kOOBw), 0, 0));
+      if constexpr (XF) rx_in[j] = (ok && pixv[j] != kOOBw) ? 1.f : 0.f;
     }
+#pragma unroll
+    for (int j = 0; j < D_V; ++j)
+      rd[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rD, (int)((outv[j] | d_const) >= kOOBw ? kOOBw : outv[j] + d_const), 0, 0));
   };
   auto store_chunk = [&]() {
     if constexpr (XF) {
@@ -202,17 +212,39 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, int lgQw, in
     for (int c = 0; c < nch; ++c) {
       if (c + 1 < nch) load_chunk((c + 1) & 1);
       if (c + 2 < nch) rowinfo(c + 2, c & 1);
+      // The 16 steps of a chunk in groups of four, fragments one group ahead: as `read; mfma` per step the compiler put every
+      // pair of MFMAs behind the wait for its own LDS reads (~130 cycles of an idle pipe per pair).  The order inside a group is
+      // pinned: an MFMA, then the next group's reads that can issue while it runs.
+      {
+        constexpr int GS = 4, NG = (MC / 2) / GS;
+        float fa[2][GS][TK], fb[2][GS][TN];
+        auto rdg = [&](int g, int set) {
 #pragma unroll
-      for (int s = 0; s < MC / 2; ++s) {
-        float av[TK], bv[TN];
+          for (int q = 0; q < GS; ++q) {
+            const int s = g * GS + q;
 #pragma unroll
-        for (int i = 0; i < TK; ++i) av[i] = sX[(2 * s + lh) * KT + (wk * TK + i) * 32 + li];
+            for (int i = 0; i < TK; ++i) fa[set][q][i] = sX[(2 * s + lh) * KT + (wk * TK + i) * 32 + li];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bv[j] = sD[(2 * s + lh) * NT + (wn * TN + j) * 32 + li];
+            for (int j = 0; j < TN; ++j) fb[set][q][j] = sD[(2 * s + lh) * NT + (wn * TN + j) * 32 + li];
+          }
+        };
+        rdg(0, 0);
 #pragma unroll
-        for (int i = 0; i < TK; ++i)
+        for (int g = 0; g < NG; ++g) {
+          if (g + 1 < NG) rdg(g + 1, (g + 1) & 1);
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+          for (int q = 0; q < GS; ++q)
+#pragma unroll
+            for (int i = 0; i < TK; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][q][i], fb[g & 1][q][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < GS; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, TK * TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TK + TN, 0);
+          }
+        }
       }
       if (do_bias) {
         float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
