@@ -107,21 +107,28 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   [[maybe_unused]] float rx_in[XVEC ? X_V : 1];      // 1 where the loaded pixel lies inside the image (the shift applies), else 0
   float rxs[XVEC ? 1 : X_S];
   f32x4 rd[DVEC ? D_V : 1];
+  [[maybe_unused]] bool rd_ok[DVEC ? D_V : 1];
   float rds[DVEC ? 1 : D_S];
 
   auto load_chunk = [&](int buf) {
     if constexpr (XVEC) {
+      // table reads first, then UNCONDITIONAL loads at a clamped address (the tensor's first pixel for a tap outside the image; the
+      // zero is selected when the chunk is stored): `if (ok) v = load` is a branch per load, behind which the compiler waits
+      // vmcnt(0) -- the chunk's loads went out one memory round trip at a time
+      int pixv[X_V], yxv[X_V];
 #pragma unroll
       for (int j = 0; j < X_V; ++j) {
-        int r = tid / XQ + (256 / XQ) * j;
-        int pix = sRowPix[buf][r], yx = sRowYX[buf][r];
-        int iy = (yx >> 16) + x_dy, ix = (yx & 0xffff) + x_dx;
-        bool ok = x_kok && pix >= 0 && (unsigned)iy < (unsigned)g.gH && (unsigned)ix < (unsigned)g.gW;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) v = *reinterpret_cast<const f32x4*>(a.X + (long)(pix + x_dy * g.gW + x_dx) * gC + x_c);
-        rx[j] = v;
-        rx_in[j] = ok ? 1.f : 0.f;      // the lazy BatchNorm apply happens when the chunk is STORED: applied here it consumed every load
-                                        // at once (an s_waitcnt vmcnt(0) behind each of the chunk's loads instead of one chunk of MFMAs later)
+        const int r = tid / XQ + (256 / XQ) * j;
+        pixv[j] = sRowPix[buf][r];
+        yxv[j] = sRowYX[buf][r];
+      }
+#pragma unroll
+      for (int j = 0; j < X_V; ++j) {
+        const int iy = (yxv[j] >> 16) + x_dy, ix = (yxv[j] & 0xffff) + x_dx;
+        const bool ok = x_kok && pixv[j] >= 0 && (unsigned)iy < (unsigned)g.gH && (unsigned)ix < (unsigned)g.gW;
+        const long off = ok ? (long)(pixv[j] + x_dy * g.gW + x_dx) * gC + x_c : 0L;
+        rx[j] = *reinterpret_cast<const f32x4*>(a.X + off);
+        rx_in[j] = ok ? 1.f : 0.f;      // zero / lazy BatchNorm apply when the chunk is STORED (applied here it consumed every load at once)
       }
     } else {
 #pragma unroll
@@ -134,17 +141,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
       }
     }
     if constexpr (DVEC) {
+      int spv[D_V];
 #pragma unroll
       for (int j = 0; j < D_V; ++j) {
-        int f = tid + 256 * j;
-        int r = f / DQ, nq = f - r * DQ;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r < MC) {
-          int sp = sRowOut[buf][r];
-          int n = n0 + 4 * nq;
-          if (sp >= 0 && n < N) v = *reinterpret_cast<const f32x4*>(a.dY + (long)sp * N + n);
-        }
-        rd[j] = v;
+        const int r = (tid + 256 * j) / DQ;
+        spv[j] = sRowOut[buf][r < MC ? r : 0];
+      }
+#pragma unroll
+      for (int j = 0; j < D_V; ++j) {
+        const int f = tid + 256 * j;
+        const int r = f / DQ, nq = f - r * DQ;
+        const int n = n0 + 4 * nq;
+        const bool ok = r < MC && spv[j] >= 0 && n < N;
+        rd[j] = *reinterpret_cast<const f32x4*>(a.dY + (ok ? (long)spv[j] * N + n : 0L));     // unconditional, clamped (see above)
+        rd_ok[j] = ok;
       }
     } else {
 #pragma unroll
@@ -162,6 +172,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     float* sX = sXbuf;
     float* sD = sDbuf;
     if constexpr (XVEC) {
+#pragma unroll
+      for (int j = 0; j < X_V; ++j)
+        if (rx_in[j] == 0.f) rx[j] = f32x4{0.f, 0.f, 0.f, 0.f};       // tap outside the image / row beyond the tensor (clamped load)
       if (xf_on) {   // lazy BatchNorm apply of the previous block (InXform); padding stays 0
 #pragma unroll
         for (int j = 0; j < X_V; ++j)
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
       for (int j = 0; j < D_V; ++j) {
         int f = tid + 256 * j;
         int r = f / DQ, nq = f - r * DQ;
-        if (r < MC) *reinterpret_cast<f32x4*>(&sD[r * NT + 4 * nq]) = rd[j];
+        if (r < MC) *reinterpret_cast<f32x4*>(&sD[r * NT + 4 * nq]) = rd_ok[j] ? rd[j] : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     } else {
 #pragma unroll
@@ -211,11 +224,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
       const float* sD = sDbuf;
       if (c + 1 < nch) load_chunk((c + 1) & 1);
       if (c + 2 < nch) rowinfo(c + 2, c & 1);
+      {   // fragments one group of four steps ahead, MFMA / LDS-read order pinned (wgrad_fast.hpp)
+        constexpr int GS = 4, NG = (MC / 2) / GS;
+        float fa[2][GS], fb[2][GS];
+        auto rdg = [&](int gi, int set) {
 #pragma unroll
-      for (int s = 0; s < MC / 2; ++s) {
-        float av = sX[(2 * s + lh) * KT + wk * 32 + li];
-        float bv = sD[(2 * s + lh) * NT + wn * 32 + li];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+          for (int q = 0; q < GS; ++q) {
+            const int s = gi * GS + q;
+            fa[set][q] = sX[(2 * s + lh) * KT + wk * 32 + li];
+            fb[set][q] = sD[(2 * s + lh) * NT + wn * 32 + li];
+          }
+        };
+        rdg(0, 0);
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+          if (gi + 1 < NG) rdg(gi + 1, (gi + 1) & 1);
+#pragma unroll
+          for (int q = 0; q < GS; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[gi & 1][q], fb[gi & 1][q], acc, 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < GS; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          }
+        }
       }
       if (do_bias) {
 #pragma unroll 8
