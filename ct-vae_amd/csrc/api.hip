@@ -455,7 +455,7 @@ static int conv_backward_impl(int kind, const float* x, const float* dy, const f
   // diagnostic: CTVAE_IMG_BWD_FUSED=0 keeps the picture-side conv's weight gradient and data gradient as two kernels
   static const int img_fused = [] { const char* e = getenv("CTVAE_IMG_BWD_FUSED"); return e ? atoi(e) : 1; }();
   int rc;
-  if (img_fused && bn && x == bn_y && in_scale != nullptr && in_act == bn_act && mask == nullptr && dy_bn_y == nullptr &&
+  if (img_fused && bn && bn_act != ACT_TANH && x == bn_y && in_scale != nullptr && in_act == bn_act && mask == nullptr && dy_bn_y == nullptr &&
       img_conv_supported(gw) && img_dgrad_supported(gd) && img_backward_fused_ws_floats(gd) <= half_floats) {
     // picture-side conv behind BatchNorm + activation (final_layer.1-3): the data gradient's pass over y also forms the
     // weight gradient (image.hip img_bwd_fused_kernel) -- x of the weight gradient is act(BN(y)), which that pass computes

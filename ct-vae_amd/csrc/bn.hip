@@ -645,13 +645,19 @@ __global__ __launch_bounds__(TPB) void bn_fused_fwd_kernel(const BnFusedFwd p) {
   }
   if (tid == 0 && blockIdx.x == 0 && p.nbt != nullptr) p.nbt[0] = nbt0 + 1;   // nn.BatchNorm2d bookkeeping
   if (live) {
+    const bool atanh_ = p.act == ACT_TANH;
+    const float asl = act_slope(p.act);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       rowv yr, ar;
 #pragma unroll
-      for (int c = 0; c < CPW; ++c) {
-        yr[c] = v[c][e];
-        ar[c] = act_fwd(yr[c] * sc[c] + sh[c], p.act);
+      for (int c = 0; c < CPW; ++c) yr[c] = v[c][e];
+      if (atanh_) {
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) ar[c] = act_fwd(yr[c] * sc[c] + sh[c], ACT_TANH);
+      } else {
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) ar[c] = act_slope_fwd(yr[c] * sc[c] + sh[c], asl);
       }
       const long o = (long)row_map_pixel(p.rows, r4 + e) * C + c0;
       *reinterpret_cast<rowv*>(p.y + o) = yr;
@@ -692,6 +698,8 @@ __global__ __launch_bounds__(TPB) void bn_fused_bwd_kernel(const BnFusedBwd p) {
   BNB_PH(1);
   slice_sum4<CPW, SU>(g, p.part + (long)c0 * R + (live ? r4 : 0), R, (long)C * R, p.S);
   BNB_PH(2);
+  const bool btanh_ = p.act == ACT_TANH;
+  const float bsl_ = act_slope(p.act);
 #pragma unroll
   for (int c = 0; c < CPW; ++c) {
     if (!live) g[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -699,7 +707,8 @@ __global__ __launch_bounds__(TPB) void bn_fused_bwd_kernel(const BnFusedBwd p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float xh = (yv[e][c] - mean[c]) * invstd[c];
-      const float gp = g[c][e] * act_bwd_from_out(act_fwd(gm[c] * xh + bt[c], p.act), p.act);   // rows beyond R: g = 0
+      const float t = gm[c] * xh + bt[c];
+      const float gp = g[c][e] * (btanh_ ? act_bwd_from_out(act_fwd(t, ACT_TANH), ACT_TANH) : act_slope_bwd(t, bsl_));   // rows beyond R: g = 0
       g[c][e] = gp;
       s1 += gp;
       s2 += gp * xh;

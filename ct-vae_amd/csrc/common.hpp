@@ -36,6 +36,14 @@ __device__ __forceinline__ float act_bwd_from_out(float o, int act) {
   }
 }
 
+// Launch-uniform activations in unrolled element loops: `act_fwd(v, act)` per element compiles to a branch tree per element (the
+// tanh code behind it); hot loops decide ONCE -- `if (act == ACT_TANH) { loop with tanh } else { loop with act_slope_fwd }` --
+// and apply identity / LeakyReLU / ReLU as one select: t > 0 ? t : t * slope (slope 1 / 0.01 / 0; ReLU yields -0 for t < 0).
+__device__ __forceinline__ float act_slope(int act) { return act == ACT_LRELU ? kLeaky : (act == ACT_RELU ? 0.f : 1.f); }
+__device__ __forceinline__ float act_slope_fwd(float v, float slope) { return v > 0.f ? v : v * slope; }
+// d act / d t at pre-activation t (equals act_bwd_from_out(act_fwd(t))): t > 0 ? 1 : slope
+__device__ __forceinline__ float act_slope_bwd(float t, float slope) { return t > 0.f ? 1.f : slope; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

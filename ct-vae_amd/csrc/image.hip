@@ -611,12 +611,23 @@ __global__ __launch_bounds__(256, 4) void img_dgrad_kernel(const ImgArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) st1(rO, rowoff + (unsigned)((8 * (r >> 2) + 4 * lh + (r & 3)) * C) * 4u, acc[r]);
       if (bn) {
+        if (a.bn_act == ACT_TANH) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float xh = (yv[r] - bmean) * binv;
-          const float g1 = acc[r] * act_bwd_from_out(act_fwd(bgm * xh + bbt, a.bn_act), a.bn_act);
-          s1 += g1;
-          s2 += g1 * xh;
+          for (int r = 0; r < 16; ++r) {
+            const float xh = (yv[r] - bmean) * binv;
+            const float g1 = acc[r] * act_bwd_from_out(act_fwd(bgm * xh + bbt, ACT_TANH), ACT_TANH);
+            s1 += g1;
+            s2 += g1 * xh;
+          }
+        } else {
+          const float bsl = act_slope(a.bn_act);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float xh = (yv[r] - bmean) * binv;
+            const float g1 = acc[r] * act_slope_bwd(bgm * xh + bbt, bsl);
+            s1 += g1;
+            s2 += g1 * xh;
+          }
         }
       }
     }
@@ -649,6 +660,7 @@ __global__ __launch_bounds__(256, 4) void img_dgrad_kernel(const ImgArgs a) {
 // img_wgrad_kernel; all merges in a fixed order.
 __global__ __launch_bounds__(256, 4) void img_bwd_fused_kernel(const ImgArgs a, float* __restrict__ wpart, float* __restrict__ wpbias) {
   kernarg_warm<sizeof(ImgArgs) + 16>();
+  const float bn_slope = act_slope(a.bn_act);
   __shared__ __attribute__((aligned(16))) float sG[NP * 4];
   __shared__ __attribute__((aligned(16))) float sR[4 * 32 * 32];   // end of the launch: the 4 waves' dW accumulators
   __shared__ float sS[4 * C * 2];
@@ -732,11 +744,13 @@ __global__ __launch_bounds__(256, 4) void img_bwd_fused_kernel(const ImgArgs a, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) st1(rO, rowoff + (unsigned)((8 * (r >> 2) + 4 * lh + (r & 3)) * C) * 4u, acc[r]);
       const float* gw = &sG[ly * PW * 4 + wlane];
+      // the BatchNorm's activation is identity / LeakyReLU / ReLU (host-checked): one select for the value, one for the derivative
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float xh = (yv[r] - bmean) * binv;
-        const float av = act_fwd(bgm * xh + bbt, a.bn_act);
-        const float g1 = acc[r] * act_bwd_from_out(av, a.bn_act);
+        const float t = bgm * xh + bbt;
+        const float av = act_slope_fwd(t, bn_slope);
+        const float g1 = acc[r] * act_slope_bwd(t, bn_slope);
         s1 += g1;
         s2 += g1 * xh;
         wacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, gw[(8 * (r >> 2) + (r & 3)) * 4], wacc, 0, 0, 0);
@@ -848,6 +862,7 @@ __global__ __launch_bounds__(256, 4) void img_enc_fwd_kernel(const EncArgs a) {
     bw[s] = lh ? w1 : w0;
   }
   const float bv = a.bias != nullptr ? a.bias[li] : 0.f;
+  const float out_slope = act_slope(a.act);    // identity / LeakyReLU / ReLU (host-checked)
   float sn = 0.f, smean = 0.f, sm2 = 0.f;   // running (count, mean, M2) of this lane's channel
 
   EncPatch pt;
@@ -875,7 +890,7 @@ __global__ __launch_bounds__(256, 4) void img_enc_fwd_kernel(const EncArgs a) {
       for (int r = 0; r < 16; ++r) {
         acc[r] += bv;
         m1 += acc[r];
-        st1(rO, rowoff + (unsigned)((8 * (r >> 2) + 4 * lh + (r & 3)) * C) * 4u, act_fwd(acc[r], a.act));
+        st1(rO, rowoff + (unsigned)((8 * (r >> 2) + 4 * lh + (r & 3)) * C) * 4u, act_slope_fwd(acc[r], out_slope));
       }
       if (a.bn_part != nullptr) {   // Chan merge of this block's 16 values into the lane's running statistics
         m1 *= (1.f / 16.f);
@@ -1159,6 +1174,7 @@ int launch_img_wgrad(const ConvGeom& g, const float* X, const float* dY, float* 
 // is a = act(BN(bnb->y)).  Slabs [parts][9*32][3] (+ bias partials [parts][3]) into ws, parts = img_dgrad_rows(g).
 int launch_img_backward_fused(const ConvGeom& g, const float* dY, const float* W, float* dX, const BnBwdFuse* bnb, float* ws,
                               float** part_out, float** pbias_out, int* nparts, bool want_bias, hipStream_t st) {
+  if (bnb->act == ACT_TANH) return kErrBadArg;   // the kernel applies the BatchNorm's activation as max-free selects (identity / LeakyReLU / ReLU)
   ImgArgs a{};
   fill(a, g);
   a.dY = dY; a.Wt = W; a.out = dX;

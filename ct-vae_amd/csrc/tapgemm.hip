@@ -664,7 +664,7 @@ int launch_tapgemm(const ConvGeom& g, const float* G, const float* W, const floa
   if (img_dgrad_supported(g) && bias == nullptr && add == nullptr && mask == nullptr && act == ACT_NONE && bn_part == nullptr &&
       (xf == nullptr || xf->scale == nullptr))
     return launch_img_dgrad(g, G, W, S, bnb, st);
-  if (img_enc_supported(g) && add == nullptr && mask == nullptr && (bnb == nullptr || bnb->part == nullptr) &&
+  if (img_enc_supported(g) && act != ACT_TANH && add == nullptr && mask == nullptr && (bnb == nullptr || bnb->part == nullptr) &&
       (xf == nullptr || xf->scale == nullptr))
     return launch_img_enc_forward(g, G, W, bias, S, act, bn_part, st);
   if (upconv_supported(g) && add == nullptr && mask == nullptr && (bnb == nullptr || bnb->part == nullptr))

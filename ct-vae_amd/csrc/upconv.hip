@@ -13,6 +13,7 @@
 //     straight into the MFMA B operand (128 B per pixel) and is reused by every tap of its class, x comes from LDS.
 // Fixed-order merges everywhere: bit-reproducible.
 #include "common.hpp"
+#include "phase.hpp"
 #include <type_traits>
 
 #include "prof.hpp"
@@ -113,8 +114,10 @@ __device__ __forceinline__ void patch_store_xf(const UpArgs& a, const TileXY& t,
   }
 }
 
+CTVAE_PHASE_DECL(up)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void up_fwd_kernel(const UpArgs a) {
+  CTVAE_PH(up, 0, 0);
   kernarg_warm<sizeof(UpArgs)>();
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;               // [297][36]
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(256, 2) void up_fwd_kernel(const UpArgs a) {
   TileXY cur = tile_xy(a, tile < a.ntiles ? tile : 0);
   if (tile < a.ntiles) patch_load(a, rX, cur, pt);
   const float bv = a.bias != nullptr ? a.bias[li] : 0.f;
+  const float out_slope = a.act == ACT_LRELU ? kLeaky : (a.act == ACT_RELU ? 0.f : 1.f);
   float sn = 0.f, smean = 0.f, sm2 = 0.f;
 
   const bool xf = a.xf_scale != nullptr;
@@ -148,9 +152,11 @@ __global__ __launch_bounds__(256, 2) void up_fwd_kernel(const UpArgs a) {
 #pragma unroll
   for (int j = 0; j < NW4; ++j) reinterpret_cast<f32x4*>(sW)[tid + 256 * j] = wv[j];
   for (; tile < a.ntiles; tile += gridDim.x) {
+    CTVAE_PH(up, 0, 1);
     if (xf) patch_store_xf(a, cur, pt, sA, xsc, xsh, xns);
     else patch_store(pt, sA);
     __syncthreads();
+    CTVAE_PH(up, 0, 2);
     const int next = tile + gridDim.x;
     const TileXY nxt = tile_xy(a, next < a.ntiles ? next : 0);
     if (next < a.ntiles) patch_load(a, rX, nxt, pt);
@@ -180,11 +186,22 @@ __global__ __launch_bounds__(256, 2) void up_fwd_kernel(const UpArgs a) {
       // bias, statistics, 128 B per pixel out
       const unsigned rowoff = (unsigned)((((cur.b * OH + 2 * (cur.y0 + ly) + a.cpy[c]) * OW + 2 * cur.x0 + a.cpx[c]) * C + li)) * 4u;
       float m1 = 0.f;
+      // identity / LeakyReLU / ReLU as max(t, t * slope), decided once per launch: `act_fwd(v, a.act)` per element was a branch tree
+      // (with the tanh code behind it) sixteen times per epilogue, 128 per tile -- a fifth of this kernel's cycles
+      if (a.act == ACT_TANH) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        acc[r] += bv;
-        m1 += acc[r];
-        st1(rO, rowoff + (unsigned)((8 * (r >> 2) + 4 * lh + (r & 3)) * 2 * C) * 4u, act_fwd(acc[r], a.act));
+        for (int r = 0; r < 16; ++r) {
+          acc[r] += bv;
+          m1 += acc[r];
+          st1(rO, rowoff + (unsigned)((8 * (r >> 2) + 4 * lh + (r & 3)) * 2 * C) * 4u, act_fwd(acc[r], ACT_TANH));
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc[r] += bv;
+          m1 += acc[r];
+          st1(rO, rowoff + (unsigned)((8 * (r >> 2) + 4 * lh + (r & 3)) * 2 * C) * 4u, fmaxf(acc[r], acc[r] * out_slope));
+        }
       }
       if (a.bn_part != nullptr) {
         m1 *= (1.f / 16.f);
@@ -236,7 +253,9 @@ __global__ __launch_bounds__(256, 2) void up_fwd_kernel(const UpArgs a) {
       epilogue(ly, 3, acc);
     }
 #undef UP_STEP
+    CTVAE_PH(up, 0, 3);
     __syncthreads();
+    CTVAE_PH(up, 0, 4);
     cur = nxt;
   }
   if (a.bn_part != nullptr) {
@@ -316,8 +335,10 @@ __global__ __launch_bounds__(256, 1) void up_wgrad_kernel(const UpArgs a) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float bsum = 0.f;
 
+  CTVAE_PH(up, 1, 0);
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const TileXY cur = tile_xy(a, tile);
+    CTVAE_PH(up, 1, 1);
     // no cross-tile prefetch here: the nine accumulators need the registers (the CU's second workgroup covers the
     // wait); the patch goes through in two rounds of 5 float4 per thread for the same reason
 #pragma unroll
@@ -354,6 +375,7 @@ __global__ __launch_bounds__(256, 1) void up_wgrad_kernel(const UpArgs a) {
     }
     __syncthreads();
 
+    CTVAE_PH(up, 1, 2);
     // one step = (row, class, half row): 8 pixel pairs.  Its dy (and y) loads are issued TWO steps ahead (three register slots):
     // with one wave per SIMD a step of the one-tap class is 8 MFMAs = 0.2 us, far less than a memory round trip
     float dv[3][8], yv[FUSED ? 3 : 1][FUSED ? 8 : 1];
@@ -419,8 +441,10 @@ __global__ __launch_bounds__(256, 1) void up_wgrad_kernel(const UpArgs a) {
     issue(std::integral_constant<int, 1>{});
 #define UPW_STEP(S_) do_step(std::integral_constant<int, S_>{});
     UPW_STEP(0) UPW_STEP(1) UPW_STEP(2) UPW_STEP(3) UPW_STEP(4) UPW_STEP(5) UPW_STEP(6) UPW_STEP(7)
+    CTVAE_PH(up, 1, 3);
     UPW_STEP(8) UPW_STEP(9) UPW_STEP(10) UPW_STEP(11) UPW_STEP(12) UPW_STEP(13) UPW_STEP(14) UPW_STEP(15)
 #undef UPW_STEP
+    CTVAE_PH(up, 1, 4);
     __syncthreads();
   }
   // ---- merge the 4 waves tap by tap (fixed order) into this workgroup's slab [9][32 ci][32 co] ----
@@ -446,6 +470,7 @@ __global__ __launch_bounds__(256, 1) void up_wgrad_kernel(const UpArgs a) {
   merge_tap(a.twt[3][2], acc[7]);
   merge_tap(a.twt[3][3], acc[8]);
   if (a.pbias != nullptr && tid < C) a.pbias[(long)blockIdx.x * C + tid] = ((sB[tid] + sB[C + tid]) + sB[2 * C + tid]) + sB[3 * C + tid];
+  CTVAE_PH(up, 1, 5);
 }
 
 void fill(UpArgs& a, const ConvGeom& g) {

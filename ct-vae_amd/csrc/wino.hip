@@ -464,10 +464,18 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
         const float* ad = a.add + (long)op * N + col;
         s00 += ad[0]; s01 += ad[N]; s10 += ad[(long)a.W * N]; s11 += ad[(long)a.W * N + N];
       }
-      dst[0] = act_fwd(y00 + s00, a.act);
-      dst[N] = act_fwd(y01 + s01, a.act);
-      dst[(long)a.W * N] = act_fwd(y10 + s10, a.act);
-      dst[(long)a.W * N + N] = act_fwd(y11 + s11, a.act);
+      if (a.act == ACT_TANH) {
+        dst[0] = act_fwd(y00 + s00, ACT_TANH);
+        dst[N] = act_fwd(y01 + s01, ACT_TANH);
+        dst[(long)a.W * N] = act_fwd(y10 + s10, ACT_TANH);
+        dst[(long)a.W * N + N] = act_fwd(y11 + s11, ACT_TANH);
+      } else {     // identity / LeakyReLU / ReLU: one select per value, no branch tree per value (common.hpp act_slope_fwd)
+        const float osl = act_slope(a.act);
+        dst[0] = act_slope_fwd(y00 + s00, osl);
+        dst[N] = act_slope_fwd(y01 + s01, osl);
+        dst[(long)a.W * N] = act_slope_fwd(y10 + s10, osl);
+        dst[(long)a.W * N + N] = act_slope_fwd(y11 + s11, osl);
+      }
     }
   }
 }
@@ -720,10 +728,18 @@ __global__ __launch_bounds__(256) void wino_conv_fs_kernel(WinoArgs a) {
         const float* ad = a.add + (long)op * N + col;
         s4[0] += ad[0]; s4[1] += ad[N]; s4[2] += ad[(long)a.W * N]; s4[3] += ad[(long)a.W * N + N];
       }
-      dst[0] = act_fwd(y[0] + s4[0], a.act);
-      dst[N] = act_fwd(y[1] + s4[1], a.act);
-      dst[(long)a.W * N] = act_fwd(y[2] + s4[2], a.act);
-      dst[(long)a.W * N + N] = act_fwd(y[3] + s4[3], a.act);
+      if (a.act == ACT_TANH) {
+        dst[0] = act_fwd(y[0] + s4[0], ACT_TANH);
+        dst[N] = act_fwd(y[1] + s4[1], ACT_TANH);
+        dst[(long)a.W * N] = act_fwd(y[2] + s4[2], ACT_TANH);
+        dst[(long)a.W * N + N] = act_fwd(y[3] + s4[3], ACT_TANH);
+      } else {
+        const float osl = act_slope(a.act);
+        dst[0] = act_slope_fwd(y[0] + s4[0], osl);
+        dst[N] = act_slope_fwd(y[1] + s4[1], osl);
+        dst[(long)a.W * N] = act_slope_fwd(y[2] + s4[2], osl);
+        dst[(long)a.W * N + N] = act_slope_fwd(y[3] + s4[3], osl);
+      }
     }
   }
 }
