@@ -14,6 +14,12 @@
 #include "prof.hpp"
 
 namespace ctvae {
+// d act / d t of a launch-uniform activation at pre-activation t, for element-wise kernels: identity / LeakyReLU / ReLU as one
+// select, tanh behind a branch the caller takes once per vector (common.hpp act_slope_bwd)
+__device__ __forceinline__ float act_dt(float t, int act, float slope) {
+  return act == ACT_TANH ? act_bwd_from_out(act_fwd(t, ACT_TANH), ACT_TANH) : act_slope_bwd(t, slope);
+}
+
 
 constexpr int kBnMaxBlocks = 2048;
 
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float xh = (yv[k] - mean[k]) * invstd[k];
-        float gb = g[k] * act_bwd_from_out(act_fwd(gm[k] * xh + bt[k], act), act);
+        float gb = g[k] * act_dt(gm[k] * xh + bt[k], act, act_slope(act));
         s1[k] += gb;
         s2[k] += gb * xh;
       }
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_apply_kernel(const float*
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      o[k] = k1[k] * (g[k] * act_bwd_from_out(act_fwd(yv[k] * sc[k] + sh[k], act), act)) + k2[k] * yv[k] + k3[k];
+      o[k] = k1[k] * (g[k] * act_dt(yv[k] * sc[k] + sh[k], act, act_slope(act))) + k2[k] * yv[k] + k3[k];
     reinterpret_cast<f32x4*>(gy)[i] = o;
   }
 }
@@ -475,8 +481,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       f32x4 o0, o1;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        o0[k] = k1[k] * (g0[k] * act_bwd_from_out(act_fwd(y0[k] * sc[k] + sh[k], act), act)) + k2[k] * y0[k] + k3[k];
-        o1[k] = k1[k] * (g1[k] * act_bwd_from_out(act_fwd(y1[k] * sc[k] + sh[k], act), act)) + k2[k] * y1[k] + k3[k];
+        o0[k] = k1[k] * (g0[k] * act_dt(y0[k] * sc[k] + sh[k], act, act_slope(act))) + k2[k] * y0[k] + k3[k];
+        o1[k] = k1[k] * (g1[k] * act_dt(y1[k] * sc[k] + sh[k], act, act_slope(act))) + k2[k] * y1[k] + k3[k];
       }
       reinterpret_cast<f32x4*>(gy)[i] = o0;
       reinterpret_cast<f32x4*>(gy)[i + stride] = o1;
@@ -487,7 +493,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       f32x4 o;
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        o[k] = k1[k] * (g[k] * act_bwd_from_out(act_fwd(yv[k] * sc[k] + sh[k], act), act)) + k2[k] * yv[k] + k3[k];
+        o[k] = k1[k] * (g[k] * act_dt(yv[k] * sc[k] + sh[k], act, act_slope(act))) + k2[k] * yv[k] + k3[k];
       reinterpret_cast<f32x4*>(gy)[i] = o;
     }
     return;
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      o[k] = k1[k] * (g[k] * act_bwd_from_out(act_fwd(yv[k] * sc[k] + sh[k], act), act)) + k2[k] * yv[k] + k3[k];
+      o[k] = k1[k] * (g[k] * act_dt(yv[k] * sc[k] + sh[k], act, act_slope(act))) + k2[k] * yv[k] + k3[k];
     reinterpret_cast<f32x4*>(gy)[i] = o;
   }
 }

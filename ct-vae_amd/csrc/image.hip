@@ -284,8 +284,13 @@ __global__ __launch_bounds__(256, 3) void img_fwd_kernel(const ImgArgs a) {
 #pragma unroll
         for (int n = 0; n < NO; ++n) o[n] += z[zoff[t] + n];
       const unsigned off = (unsigned)(((cur.b * a.H + cur.y0 + ly) * a.W + cur.x0 + lx) * NO) * 4u;
+      if (a.act == ACT_TANH) {   // the reference's final layer (vanilla_vae.py:73-75); decided once, not per value
 #pragma unroll
-      for (int n = 0; n < NO; ++n) st1(rO, off + 4u * n, act_fwd(o[n], a.act));
+        for (int n = 0; n < NO; ++n) st1(rO, off + 4u * n, act_fwd(o[n], ACT_TANH));
+      } else {
+#pragma unroll
+        for (int n = 0; n < NO; ++n) st1(rO, off + 4u * n, act_slope_fwd(o[n], act_slope(a.act)));
+      }
     }
     IPHASE(6 + 6 * it);
     __syncthreads();   // Z consumed before the next patch lands
@@ -403,8 +408,13 @@ __global__ __launch_bounds__(256, 4) void img_fwd2_kernel(const ImgArgs a) {
 #pragma unroll
         for (int n = 0; n < NO; ++n) o[n] += z[zoff[t] + n];
       const unsigned off = (unsigned)(((cur.b * a.H + cur.y0 + ly) * a.W + cur.x0 + lx) * NO) * 4u;
+      if (a.act == ACT_TANH) {   // the reference's final layer (vanilla_vae.py:73-75); decided once, not per value
 #pragma unroll
-      for (int n = 0; n < NO; ++n) st1(rO, off + 4u * n, act_fwd(o[n], a.act));
+        for (int n = 0; n < NO; ++n) st1(rO, off + 4u * n, act_fwd(o[n], ACT_TANH));
+      } else {
+#pragma unroll
+        for (int n = 0; n < NO; ++n) st1(rO, off + 4u * n, act_slope_fwd(o[n], act_slope(a.act)));
+      }
     }
     __syncthreads();   // Z consumed before the next tile's blocks land
     cur = nxt;

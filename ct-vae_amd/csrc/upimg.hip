@@ -131,9 +131,16 @@ __global__ __launch_bounds__(256, 2) void upimg_fwd_kernel(UpImgArgs a) {
     const int Y = 2 * qy0 + oy, X = 2 * qx0 + ox;
     if (Y < OH && X < OW) {
       float* dst = a.Y + ((long)(b * OH + Y) * OW + X) * 3;
-      dst[0] = act_fwd(v0, a.act);
-      dst[1] = act_fwd(v1, a.act);
-      dst[2] = act_fwd(v2, a.act);
+      if (a.act == ACT_TANH) {
+        dst[0] = act_fwd(v0, ACT_TANH);
+        dst[1] = act_fwd(v1, ACT_TANH);
+        dst[2] = act_fwd(v2, ACT_TANH);
+      } else {
+        const float osl = act_slope(a.act);
+        dst[0] = act_slope_fwd(v0, osl);
+        dst[1] = act_slope_fwd(v1, osl);
+        dst[2] = act_slope_fwd(v2, osl);
+      }
     }
   }
 }
