@@ -47,9 +47,10 @@ for B, H, ci, Co, k, stride in shapes:
         lb = lb.reshape(8192, 4)
         lb = lb[lb.sum(axis=1) > 0][:nwg]
         nchunk = max(1, (k * k * ci // 32))
-        print("    pipelined loop, shader cycles per chunk (mean over workgroups; marks cost ~100 cycles each): "
-              f"load wait + LDS store {lb[:, 0].mean() / nchunk:.0f}, issue + 8 MFMA {lb[:, 1].mean() / nchunk:.0f}, "
-              f"barrier {lb[:, 2].mean() / nchunk:.0f}, reads + 8 MFMA {lb[:, 3].mean() / nchunk:.0f}")
+        if len(lb):      # only the serial-issue diagnostic build (-DCTVAE_TILE_SERIAL_ISSUE) runs the loop clocks
+            print("    pipelined loop, shader cycles per chunk (mean over workgroups; marks cost ~100 cycles each): "
+                  f"load wait + LDS store {lb[:, 0].mean() / nchunk:.0f}, issue + 8 MFMA {lb[:, 1].mean() / nchunk:.0f}, "
+                  f"barrier {lb[:, 2].mean() / nchunk:.0f}, reads + 8 MFMA {lb[:, 3].mean() / nchunk:.0f}")
     for i, n in enumerate(names):
         d = rel[:, i] - (rel[:, i - 1] if i else 0)
         print(f"    {n:20s} at mean {rel[:, i].mean():7.2f} (min {rel[:, i].min():6.2f} max {rel[:, i].max():6.2f})   phase mean {d.mean():6.2f} us")
