@@ -170,7 +170,10 @@ __device__ __forceinline__ void patch_store(const ImgArgs& a, const Patch& p, fl
       if (xform) {
         const bool ok = (p.ok >> j) & 1u;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = ok ? act_fwd(v[k] * sc[k] + sh[k], a.in_act) : 0.f;   // zero padding stays zero
+        for (int k = 0; k < 4; ++k) {   // zero padding stays zero; the activation is decided once per quad (common.hpp act_slope_fwd)
+          const float t = v[k] * sc[k] + sh[k];
+          v[k] = ok ? (a.in_act == ACT_TANH ? act_fwd(t, ACT_TANH) : act_slope_fwd(t, act_slope(a.in_act))) : 0.f;
+        }
       }
       *reinterpret_cast<f32x4*>(&sA[(e >> 3) * LDA + 4 * (e & 7)]) = v;
     }
@@ -348,6 +351,8 @@ __global__ __launch_bounds__(256, 4) void img_fwd2_kernel(const ImgArgs a) {
     for (int q = 0; q < 4; ++q) v[q] = ld4(rX, ok ? off + 16u * q : kOOBi);
     return ok;
   };
+  const bool in_tanh = a.in_act == ACT_TANH;
+  const float in_slope = act_slope(a.in_act);
   auto blk_mma = [&](int i, const f32x4 (&v)[4], bool ok) {
     f32x16 acc;
 #pragma unroll
@@ -358,8 +363,13 @@ __global__ __launch_bounds__(256, 4) void img_fwd2_kernel(const ImgArgs a) {
       if (xform) {
         const f32x4 sc = *reinterpret_cast<const f32x4*>(&sSS[16 * lh + 4 * q]);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(&sSS[C + 16 * lh + 4 * q]);
+        if (in_tanh) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) x4[k] = ok ? act_fwd(x4[k] * sc[k] + sh[k], a.in_act) : 0.f;     // zero padding stays zero
+          for (int k = 0; k < 4; ++k) x4[k] = ok ? act_fwd(x4[k] * sc[k] + sh[k], ACT_TANH) : 0.f;
+        } else {      // identity / LeakyReLU / ReLU: one select per value between the MFMAs, not a branch tree per value
+#pragma unroll
+          for (int k = 0; k < 4; ++k) x4[k] = ok ? act_slope_fwd(x4[k] * sc[k] + sh[k], in_slope) : 0.f;     // zero padding stays zero
+        }
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x4[k], breg[4 * q + k], acc, 0, 0, 0);

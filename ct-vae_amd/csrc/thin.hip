@@ -116,7 +116,10 @@ __global__ __launch_bounds__(256) void thin_tile_kernel(const ThinArgs a) {
             const f32x4 tsc = *reinterpret_cast<const f32x4*>(a.in_scale + 4 * c4[j]);
             const f32x4 tsh = *reinterpret_cast<const f32x4*>(a.in_shift + 4 * c4[j]);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[j][k] = ok[j] ? act_fwd(v[j][k] * tsc[k] + tsh[k], a.in_act) : 0.f;   // padding stays 0
+            for (int k = 0; k < 4; ++k) {   // padding stays 0
+              const float t = v[j][k] * tsc[k] + tsh[k];
+              v[j][k] = ok[j] ? (a.in_act == ACT_TANH ? act_fwd(t, ACT_TANH) : act_slope_fwd(t, act_slope(a.in_act))) : 0.f;
+            }
           }
           *reinterpret_cast<f32x4*>(&sP[pp[j] * LDP + 4 * c4[j]]) = v[j];
         }
