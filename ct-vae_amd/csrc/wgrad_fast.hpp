@@ -190,6 +190,20 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, int lgQw, in
     for (int j = 0; j < D_V; ++j) *reinterpret_cast<f32x4*>(&sD[(tid / DQ + (256 / DQ) * j) * NT + 4 * (tid % DQ)]) = rd[j];
   };
 
+  // Where this lane's accumulator rows go in the slab, worked out BEFORE the main loop: behind it the tap lookups (a load from
+  // the argument block per row group) and two integer divisions were a dependent tail of every workgroup of the role
+  // that finishes a paired launch.  4 consecutive k rows: same tap when gC % 4 == 0.
+  const int wcr = g.wrs / g.wCo, wtc = g.wts / g.wCo;          // rows between consecutive channels / taps (geom.hpp wts / wrs)
+  int wrow0[TK][4];
+#pragma unroll
+  for (int i = 0; i < TK; ++i)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int k0 = kt0 + (wk * TK + i) * 32 + 8 * q4 + 4 * lh;
+      const int t = k0 < Ktot ? (lgC >= 0 ? (k0 >> lgC) : (k0 / gC)) : 0;
+      const int r0 = g.taps[cls][t].wtap * wtc + (k0 - t * gC) * wcr;
+      wrow0[i][q4] = k0 < Ktot ? r0 : -1;
+    }
   f32x16 acc[TK][TN];
 #pragma unroll
   for (int i = 0; i < TK; ++i)
@@ -270,12 +284,8 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, int lgQw, in
       const int col = n0 + (wn * TN + j) * 32 + li;
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
-        const int k0 = kt0 + (wk * TK + i) * 32 + 8 * q4 + 4 * lh;      // 4 consecutive k rows: same tap when gC % 4 == 0
-        if (k0 < Ktot && col < N) {
-          const int t = lgC >= 0 ? (k0 >> lgC) : (k0 / gC);
-          const int wcr = g.wrs / g.wCo;                                   // rows between consecutive channels (geom.hpp wts / wrs)
-          const int wrow0 = g.taps[cls][t].wtap * (g.wts / g.wCo) + (k0 - t * gC) * wcr;
-          float* dst = a.part + ((long)split * a.rows_total + wrow0) * N + col;
+        if (wrow0[i][q4] >= 0 && col < N) {
+          float* dst = a.part + ((long)split * a.rows_total + wrow0[i][q4]) * N + col;
 #pragma unroll
           for (int q = 0; q < 4; ++q) dst[(long)q * wcr * N] = acc[i][j][4 * q4 + q];
         }
