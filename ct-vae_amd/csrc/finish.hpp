@@ -44,11 +44,11 @@ __device__ __forceinline__ void splitk_finish_body(const SplitKJob& k, int blk) 
     if (k.add != nullptr) v += reinterpret_cast<const f32x4*>(k.add)[i];
     f32x4 o;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = act_fwd(v[q], k.act);
+    for (int q = 0; q < 4; ++q) o[q] = k.act == ACT_TANH ? act_fwd(v[q], ACT_TANH) : act_slope_fwd(v[q], act_slope(k.act));
     if (k.mask != nullptr) {
       f32x4 m = reinterpret_cast<const f32x4*>(k.mask)[i];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) o[q] *= act_bwd_from_out(m[q], k.mask_act);
+      for (int q = 0; q < 4; ++q) o[q] *= k.mask_act == ACT_TANH ? 1.f - m[q] * m[q] : (m[q] > 0.f ? 1.f : act_slope(k.mask_act));
     }
     reinterpret_cast<f32x4*>(k.S)[i] = o;
   }

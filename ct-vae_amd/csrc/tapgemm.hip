@@ -370,6 +370,9 @@ __global__ __launch_bounds__(256) void tapgemm_masked_kernel(const TapGemmArgs a
     const bool cok = col < N;
     const float bv = (a.bias != nullptr && cok) ? a.bias[col] : 0.f;
     const bool plain = (a.add == nullptr) && (a.mask == nullptr);
+    // launch-uniform activations decided once (common.hpp act_slope_fwd): identity / LeakyReLU / ReLU are one select per value
+    const bool o_tanh = a.act == ACT_TANH, m_tanh = a.mask_act == ACT_TANH, b_tanh = a.bnb_act == ACT_TANH;
+    const float o_slope = act_slope(a.act), m_slope = act_slope(a.mask_act), b_slope = act_slope(a.bnb_act);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -384,11 +387,14 @@ __global__ __launch_bounds__(256) void tapgemm_masked_kernel(const TapGemmArgs a
             const unsigned idx = (unsigned)sp * (unsigned)N + (unsigned)col;
             float v = acc[i][j][4 * q4 + q] + bv;
             if (plain) {
-              v = act_fwd(v, a.act);
+              v = o_tanh ? act_fwd(v, ACT_TANH) : act_slope_fwd(v, o_slope);
             } else {
               if (a.add != nullptr) v += a.add[idx];
-              v = act_fwd(v, a.act);
-              if (a.mask != nullptr) v *= act_bwd_from_out(a.mask[idx], a.mask_act);
+              v = o_tanh ? act_fwd(v, ACT_TANH) : act_slope_fwd(v, o_slope);
+              if (a.mask != nullptr) {
+                const float mk = a.mask[idx];
+                v *= m_tanh ? 1.f - mk * mk : (mk > 0.f ? 1.f : m_slope);
+              }
             }
             a.S[idx] = v;
             if (a.bnb_part != nullptr) acc[i][j][4 * q4 + q] = v;   // the stored gradient, for the BN-backward sums
@@ -413,7 +419,8 @@ __global__ __launch_bounds__(256) void tapgemm_masked_kernel(const TapGemmArgs a
         for (int r = 0; r < 16; ++r) {
           const int sp = sOut[(wm * TM + i) * 32 + 8 * (r >> 2) + 4 * lh + (r & 3)];
           const float xh = (yv[r] - bmean) * binv;
-          const float gp = (sp >= 0 && cok) ? acc[i][j][r] * act_bwd_from_out(act_fwd(bgm * xh + bbt, a.bnb_act), a.bnb_act) : 0.f;
+          const float tb = bgm * xh + bbt;
+          const float gp = (sp >= 0 && cok) ? acc[i][j][r] * (b_tanh ? act_bwd_from_out(act_fwd(tb, ACT_TANH), ACT_TANH) : act_slope_bwd(tb, b_slope)) : 0.f;
           s1b += gp;
           s2b += gp * xh;
         }
