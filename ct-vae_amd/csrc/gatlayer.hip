@@ -386,8 +386,17 @@ __global__ __launch_bounds__(256, 2) void gat_layer_bwd_kernel(GatBwdArgs p) {
     for (int i = 0; i < 16; ++i) da[i] = 0.f;
     const float* ap = XL + lh * LS + 32 * mt + ln;
     const float* bp = R2 + lh * LS + 32 * nt + ln;
-#pragma unroll 4
-    for (int k = 0; k < C; k += 2) da = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k * LS], bp[k * LS], da, 0, 0, 0);
+    // four MFMAs per trip with their eight LDS operands read together (`#pragma unroll 4` on the runtime-bounded loop was refused by
+    // the compiler: one ds_read pair -> wait -> MFMA per trip, the matrix pipe idle for an LDS latency fifty times per tile)
+    int k = 0;
+    for (; k + 8 <= C; k += 8) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { av[u] = ap[(k + 2 * u) * LS]; bv[u] = bp[(k + 2 * u) * LS]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) da = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], da, 0, 0, 0);
+    }
+    for (; k < C; k += 2) da = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k * LS], bp[k * LS], da, 0, 0, 0);
   }
   __syncthreads();                                      // alpha is in Ss
   CTVAE_PH(gat, 1, 4);
