@@ -594,7 +594,13 @@ static int choose_splits(const ConvGeom& g, int KT, int NT, size_t ws_floats, in
   int nchunks = ceil_div(Mc, MC);
   int S = target_wgs / (tiles > 0 ? tiles : 1);
   if (S < 1) S = 1;
-  int maxS = ceil_div(nchunks, 4);  // at least 4 chunks per split
+  // at least 8 chunks of 32 pixels per split (4 for pixel ranges below 32 chunks: the Linear layers' rows).  Round 3, after the
+  // kernels' prologues / epilogues got cheaper, the small-batch step prefers half as many, twice as long weight-gradient workgroups
+  // (CTVAE_WGRAD_MIN_CHUNKS 4 / 6 / 8 / 12 / 16 at bs = 64: 0.7355 / 0.7305 / 0.7226 / 0.7304 / 0.7554 ms; bs = 256 and the
+  // Winograd models are bounded by the workgroup target, not by this)
+  static const int min_chunks_env = [] { const char* e = getenv("CTVAE_WGRAD_MIN_CHUNKS"); return e ? atoi(e) : 0; }();   // diagnostic
+  const int min_chunks = min_chunks_env > 0 ? min_chunks_env : (nchunks >= 32 ? 8 : 4);
+  int maxS = ceil_div(nchunks, min_chunks);
   if (maxS < 1) maxS = 1;
   if (S > maxS) S = maxS;
   while (S > 1 && wgrad_workspace_floats(g, S) > ws_floats) --S;
