@@ -316,3 +316,10 @@ def test_hot_kernels_keep_their_loops_free_of_scratch_traffic():
         lines = block(name)
         assert any("scratch 0 B" in l for l in lines), (name, lines[:2])
         assert not any(l.strip().startswith("loop") and l.rstrip().endswith("scratch") for l in lines), (name, lines)
+    # up_fwd_kernel's epilogues decide the launch-uniform activation once: as act_fwd(v, a.act) per value the kernel was ~4 900 lines
+    # with a branch tree per stored value (DESIGN.md 4.8 "Epilogues"); the audit's branch count pins that
+    import re
+    head = [l for l in block("up_fwd_kernel") if " branches" in l][0]
+    nbranch = int(re.search(r"(\d+) branches", head).group(1))
+    ninstr = int(re.search(r"(\d+) instructions", head).group(1))
+    assert nbranch <= 80 and ninstr <= 4200, head

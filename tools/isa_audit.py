@@ -2,7 +2,8 @@
 
     python tools/isa_audit.py [file.hip ...]            (no GPU needed: hipcc -S for gfx950, all of csrc/ by default)
 
-Per kernel: VGPR / AGPR / scratch bytes, the size of the kernel-argument segment and the number of scalar-load batches (s_load ...
+Per kernel: VGPR / AGPR / scratch bytes, instruction and branch counts (an unrolled epilogue that asks `if (a.option)` per value is a
+branch tree per value: 600 branches for the tile kernel's sixteen values, DESIGN.md 4.8 "Epilogues"), the size of the kernel-argument segment and the number of scalar-load batches (s_load ...
 s_waitcnt lgkmcnt(0)) in front of the first vector load -- with large argument structs each batch is a dependent round trip to memory
 behind the launch's cache invalidate (tile kernels: eight, 2.9 us per workgroup, until common.hpp kernarg_warm fetched all lines at
 once).  Per loop of a kernel (label to back-branch):
@@ -61,6 +62,8 @@ def audit(path):
                 pending = True
             if "s_waitcnt" in l and "lgkmcnt(0)" in l and pending:
                 batches, pending = batches + 1, False
+        ninstr = sum(1 for l in lines if l.strip() and not l.strip().startswith((";", ".")) and not l.rstrip().endswith(":"))
+        nbranch = sum("s_cbranch" in l for l in lines)
         mk = re.search(r"\.kernarg_segment_size: (\d+)\n(?:.*\n){0,40}?\s+\.symbol:\s+" + re.escape(sym) + r"\.kd", txt)
         karg = int(mk.group(1)) if mk else 0
         rows = []
@@ -92,7 +95,7 @@ def audit(path):
                 rows.append(f"    loop {lab:11s} {n:5d} lines  mfma {mfma:3d}  loads {loads:3d}  stores {stores:3d}  vmcnt {','.join(waits[:10]) or '-':22s}"
                             f"  scratch {scr:2d}  v_mov {vmov:3d}  {' '.join(flags)}")
         scratch = meta("private_seg_size")
-        print(f"{os.path.basename(path)}: {demangle(sym)[:100]}\n    vgpr {meta('num_vgpr')}  agpr {meta('num_agpr')}  scratch {scratch} B   kernarg {karg} B, {batches} scalar-load batches before the first vector load{' (argument lines fetched in one batch)' if warm else ''}")
+        print(f"{os.path.basename(path)}: {demangle(sym)[:100]}\n    vgpr {meta('num_vgpr')}  agpr {meta('num_agpr')}  scratch {scratch} B   {ninstr} instructions, {nbranch} branches   kernarg {karg} B, {batches} scalar-load batches before the first vector load{' (argument lines fetched in one batch)' if warm else ''}")
         if rows:
             print("\n".join(rows))
 
